@@ -1,0 +1,130 @@
+"""Config system for the RefVSR inference path (model fields + eval flags only).
+
+Mirrors the *surface* of the reference config builders so that `run.py`/`eval.py`
+style callers keep working:
+
+  * global defaults           <- /root/reference/configs/config.py:8-118  (get_config)
+  * per-model overrides       <- /root/reference/configs/config_RefVSR_{small_L1,small_MFID,L1,
+                                 MFID,MFID_8K,small_MFID_8K}.py (model fields: scale, flag_HD_in,
+                                 matching_ksize, num_blocks, mid_channels, reset_branch, frame_num,
+                                 is_amp, network)
+  * RealMCVSR folder layout   <- /root/reference/configs/config.py:120-152 (set_data_path)
+
+Training-only fields (losses, LR schedules, log dirs) are intentionally not reproduced:
+the tier scope is the inference hot path.
+"""
+import os
+
+
+class AttrDict(dict):
+    """Attribute-access dict (stand-in for easydict.EasyDict used by the reference)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+# model-specific fields; values transcribed from the per-model config files cited above.
+_MODELS = {
+    #                         C   blocks  HD     frame_itr  frame_num  reset      amp
+    'config_RefVSR_small_L1':      dict(mid_channels=24, num_blocks=24, flag_HD_in=False, frame_itr_num=26, frame_num=13, reset='itr', is_amp=True),
+    'config_RefVSR_small_MFID':    dict(mid_channels=24, num_blocks=24, flag_HD_in=False, frame_itr_num=9, frame_num=7, reset='itr', is_amp=True),
+    'config_RefVSR_L1':            dict(mid_channels=48, num_blocks=30, flag_HD_in=False, frame_itr_num=26, frame_num=13, reset='itr', is_amp=False),
+    'config_RefVSR_MFID':          dict(mid_channels=48, num_blocks=30, flag_HD_in=False, frame_itr_num=9, frame_num=7, reset='itr', is_amp=False),
+    'config_RefVSR_MFID_8K':       dict(mid_channels=48, num_blocks=30, flag_HD_in=True, frame_itr_num=9, frame_num=7, reset=None, is_amp=False),
+    'config_RefVSR_small_MFID_8K': dict(mid_channels=24, num_blocks=24, flag_HD_in=True, frame_itr_num=9, frame_num=3, reset='itr', is_amp=True),
+}
+
+CONFIG_NAMES = tuple(_MODELS)
+
+
+def base_config(project='', mode='', config_='', data='', LRS='', batch_size=8):
+    """Global defaults (reference configs/config.py:8-118), inference-relevant subset."""
+    c = AttrDict()
+    c.project, c.mode, c.config = project, mode, config_
+    c.is_train = False
+    c.thread_num = batch_size
+    c.cuda = True
+    c.dist = False
+    c.manual_seed = 0
+    c.is_verbose = False
+    c.save_sample = False
+    c.is_amp = False
+    c.device = 'cuda'
+    c.trainer = ''
+    c.network = ''
+    c.batch_size = batch_size
+    c.batch_size_test = 1
+    c.data = 'RealMCVSR'
+    c.data_offset = '/data1/junyonglee'
+    c.LRS = LRS
+    c.wi = None
+    c.win = None
+    c.EVAL = AttrDict(eval_mode='quan_qual', is_qual=False, is_quan=True, is_debug=True,
+                      is_gradio=False, is_replicate=False, data='RealMCVSR', test_set='test',
+                      load_ckpt_by_score=True, ckpt_name=None, ckpt_epoch=None,
+                      ckpt_abs_name=None, low_res=False, ckpt_load_path=None,
+                      HR_data_path=None, LR_data_path=None)
+    c.output_offset = os.path.join('.', 'result')
+    # build-specific knobs (not in the reference)
+    c.cache_windows = True      # de-duplicate flows/matching/ref encodings across sliding windows
+    c.compute_dtype = 'f16'     # storage/MFMA operand type of feature maps on the GPU
+    return c
+
+
+def get_config(project='', mode='', config='', data='', LRS='', batch_size=8):
+    """Same signature as the per-model `get_config` of the reference
+    (configs/config_RefVSR_small_L1.py:8)."""
+    if config not in _MODELS:
+        raise KeyError('unknown RefVSR config %r (known: %s)' % (config, ', '.join(_MODELS)))
+    m = _MODELS[config]
+    c = base_config(project, mode, config, data, LRS, batch_size)
+    c.is_amp = m['is_amp']
+    c.frame_itr_num = m['frame_itr_num']
+    c.frame_num = m['frame_num']
+    c.flag_HD_in = m['flag_HD_in']
+    c.scale = 4
+    c.matching_ksize = 4 if c.scale == 2 else 2          # must be even
+    c.refine_val_lr = 1
+    c.refine_val_hr = 1
+    if c.flag_HD_in:
+        c.matching_ksize *= c.scale
+    c.trainer = 'trainer'
+    c.network = 'RefVSR'
+    c.num_blocks = m['num_blocks']
+    c.mid_channels = m['mid_channels']
+    c.reset_branch = c.frame_itr_num if m['reset'] == 'itr' else None
+    return c
+
+
+def set_data_path(config, data, is_train=False):
+    """RealMCVSR folder layout for evaluation (reference configs/config.py:120-152)."""
+    if data != 'RealMCVSR':
+        return config
+    if not config.flag_HD_in:
+        lr_path = 'LRx2' if config.scale == 2 else 'LRx4'
+        ref_w, ref_t = 'LRx2', 'LRx4'
+    else:
+        lr_path = ref_w = ref_t = 'HR'
+    root = os.path.join(config.data_offset, data, config.EVAL.test_set)
+    config.EVAL.LR_data_path = os.path.join(root, lr_path)
+    config.EVAL.HR_data_path = os.path.join(root, 'HR')
+    config.EVAL.HR_ref_data_W_path = os.path.join(root, ref_w)
+    config.EVAL.HR_ref_data_T_path = os.path.join(root, ref_t)
+    config.EVAL.vid_name = None
+    config.UW_path, config.W_path, config.T_path = 'UW', 'W', 'T'
+    return config

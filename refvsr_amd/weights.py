@@ -1,0 +1,163 @@
+"""State-dict contract of the RefVSR architecture + a deterministic synthetic weight generator.
+
+The key names / shapes restate the module tree of the reference
+(/root/reference/models/archs/RefVSR.py:15-101, SPyNet.py:142-191,
+RefVSR_/attention.py:15-56, RefVSR_/alignment.py:11-32, RefVSR_/common.py:25-109,
+mmedit/models/common/sr_backbone_utils.py:42-66, upsample.py:21-34) so that a released
+`RefVSR_*.pytorch` checkpoint (flat state dict, optionally with a leading `module.` from
+DataParallel, ckpt_manager.py:50-56) loads unchanged.
+
+No pretrained weights exist offline, so parity is established on seeded synthetic weights:
+`make_state_dict(config, seed)` draws every tensor from its own RandomState keyed by
+(seed, crc32(name)), fan-in scaled so that 30-block residual chains stay O(1).
+The same generator feeds the reference (tools/gen_golden.py), the oracle and the HIP build.
+"""
+import collections
+import zlib
+
+import numpy as np
+import torch
+
+VGG_MEAN = (0.485, 0.456, 0.406)
+VGG_STD = (0.229, 0.224, 0.225)
+
+
+def _conv(spec, name, co, ci, k):
+    spec[name + '.weight'] = (co, ci, k, k)
+    spec[name + '.bias'] = (co,)
+
+
+def _resblock(spec, name, c):           # common.py:25-39 / sr_backbone_utils.py:59-62
+    _conv(spec, name + '.conv1', c, c, 3)
+    _conv(spec, name + '.conv2', c, c, 3)
+
+
+def _reslist(spec, name, n, c):         # common.py:64-82
+    for i in range(n):
+        _resblock(spec, '%s.RBs.%d' % (name, i), c)
+    _conv(spec, name + '.conv_tail', c, c, 3)
+
+
+def _aligned_conv(spec, name):          # alignment.py:18-24
+    _conv(spec, name + '.p_conv.0', 32, 64, 5)
+    _resblock(spec, name + '.p_conv.2', 32)
+    _conv(spec, name + '.p_conv.4', 3, 32, 1)
+    _conv(spec, name + '.conv1.0', 32, 3, 5)
+    _resblock(spec, name + '.conv1.2', 32)
+
+
+def state_spec(config):
+    """OrderedDict name -> shape for `SRNet(config).state_dict()` (keys start with `Network.`)."""
+    C = config.mid_channels
+    nb = config.num_blocks
+    hd = bool(config.flag_HD_in)
+    ks = config.matching_ksize
+    s = collections.OrderedDict()
+    P = 'Network.'
+    # SPyNet: 6 pyramid levels x 5 convs 7x7 (SPyNet.py:26-27,152-191)
+    chans = [(32, 8), (64, 32), (32, 64), (16, 32), (2, 16)]
+    for lvl in range(6):
+        for j, (co, ci) in enumerate(chans):
+            _conv(s, P + 'FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j), co, ci, 7)
+    # FeatureMatching (attention.py:28-50)
+    fe = P + 'feature_match.feature_extract.'
+    _conv(s, fe + '0', 64, 3, 3)
+    _conv(s, fe + '2', 64, 64, 3)
+    vgg_range = 7 if (hd or config.scale != 4) else 4
+    if vgg_range == 7:
+        _conv(s, fe + '5', 128, 64, 3)
+        _conv(s, fe + 'map128.0', 16, 128, 1)
+    else:
+        _conv(s, fe + 'map64.0', 16, 64, 1)
+    _conv(s, P + 'feature_match.sub_mean', 3, 3, 1)
+    # AlignedAttention (RefVSR.py:39-40)
+    if ks // 2 > 1:
+        _aligned_conv(s, P + 'aa1.align')
+    _aligned_conv(s, P + 'aa2.align')
+    # reference encoders + RAP fusion stacks (RefVSR.py:42-78)
+    _conv(s, P + 'ref_encoder1.0.0', C, 3, 3)
+    _conv(s, P + 'ref_encoder1.1.0', C, C, 3)
+    _reslist(s, P + 'res1', 4, C)
+    _conv(s, P + 'ref_encoder2.0.0', C, C, 3)
+    _conv(s, P + 'ref_encoder2.1.0', C, C, 3)
+    _reslist(s, P + 'res2', 4, C)
+    for nm in ('conf_fusion', ):
+        _conv(s, P + nm + '.0.0', 16, 2, 3)
+        _conv(s, P + nm + '.1.0', C, 16, 3)
+    _conv(s, P + 'feat_fusion.0.0', C, 2 * C, 3)
+    _conv(s, P + 'feat_fusion.1.0', C, C, 3)
+    _reslist(s, P + 'feat_decoder', 8, C)
+    _conv(s, P + 'conf_fusion2.0.0', 16, 2, 3)
+    _conv(s, P + 'conf_fusion2.1.0', C, 16, 3)
+    _conv(s, P + 'feat_fusion2_1.0.0', C, 2 * C, 3)
+    _conv(s, P + 'feat_fusion2.0.0', C, 2 * C, 3)
+    _conv(s, P + 'feat_fusion2.1.0', C, C, 3)
+    _reslist(s, P + 'feat_decoder2', 4, C)
+    _conv(s, P + 'conf_fusion_BWFW.0.0', 16, 2, 3)
+    _conv(s, P + 'conf_fusion_BWFW.1.0', C, 16, 3)
+    _conv(s, P + 'feat_fusion_BWFW.0.0', C, 2 * C, 3)
+    _conv(s, P + 'feat_fusion_BWFW.1.0', C, C, 3)
+    _reslist(s, P + 'feat_decoder_BWFW', 4, C)
+    # propagation branches (RefVSR.py:81-84,327-350)
+    for br in ('backward_resblocks', 'forward_resblocks'):
+        _conv(s, P + br + '.main.0', C, C + 3, 3)
+        for i in range(nb):
+            _resblock(s, P + '%s.main.2.%d' % (br, i), C)
+    # upsampler (RefVSR.py:87-92)
+    _conv(s, P + 'fusion_UP', C, 2 * C, 1)
+    _conv(s, P + 'upsample1.upsample_conv', 4 * C, C, 3)
+    if config.scale == 4:
+        _conv(s, P + 'upsample2.upsample_conv', 4 * C, C, 3)
+    _conv(s, P + 'conv_hr', C, C, 3)
+    _conv(s, P + 'conv_last', 3, C, 3)
+    return s
+
+
+def num_params(config):
+    return sum(int(np.prod(v)) for v in state_spec(config).values())
+
+
+def _gain(name):
+    """Per-family weight gain: residual bodies are damped so deep chains stay bounded."""
+    if '.main.2.' in name or '.RBs.' in name or '.p_conv.2.' in name or '.conv1.2.' in name:
+        return 0.35
+    if 'FlowNet' in name:
+        return 0.8
+    if name.endswith('p_conv.4.weight'):
+        return 0.6
+    return 1.0
+
+
+def make_state_dict(config, seed=1234, dtype=torch.float32):
+    """Deterministic synthetic weights (fan-in scaled uniform), keyed exactly like the reference."""
+    sd = collections.OrderedDict()
+    for name, shape in state_spec(config).items():
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+        if 'sub_mean' in name:          # MeanShift is a fixed 1x1 conv (common.py:84-94)
+            std = np.asarray(VGG_STD, np.float32)
+            if name.endswith('weight'):
+                a = (np.eye(3, dtype=np.float32) / std[:, None]).reshape(3, 3, 1, 1)
+            else:
+                a = -np.asarray(VGG_MEAN, np.float32) / std
+        elif name.endswith('.bias'):
+            a = rs.uniform(-0.05, 0.05, size=shape).astype(np.float32)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            bound = _gain(name) * np.sqrt(3.0 / fan_in)
+            a = rs.uniform(-bound, bound, size=shape).astype(np.float32)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    return sd
+
+
+def strip_module_prefix(sd):
+    """Accept checkpoints saved from a DataParallel-wrapped net (ckpt_manager.py:50-56)."""
+    if all(k.startswith('module.') for k in sd):
+        return collections.OrderedDict((k[len('module.'):], v) for k, v in sd.items())
+    return sd
+
+
+def spec_checksum(config):
+    h = 0
+    for k, v in state_spec(config).items():
+        h = zlib.crc32(('%s:%s;' % (k, 'x'.join(map(str, v)))).encode(), h)
+    return h

@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REAL reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference does not travel to the GPU box).  The reference
+is imported unmodified; four un-vendored third-party packages it imports (mmcv, torchvision,
+termcolor, easydict -- absent from this image, no network) are replaced by the minimal stand-ins
+in tools/ref_shims/ (SURVEY.md section 8c / appendix B).  Nothing from the reference is copied:
+only input/output tensors are written to tests/golden/*.npz.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz and prints oracle deltas
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools', 'ref_shims'))
+sys.path.insert(0, '/root/reference')
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from refvsr_amd import weights as wts  # noqa: E402
+from refvsr_amd.config import get_config as my_get_config  # noqa: E402
+from oracle import refvsr_oracle as orc  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+SEED_W = 1234
+
+
+def ref_net(name, frame_num, save_sample=True):
+    cfg = importlib.import_module('configs.' + name).get_config('p', 'm', name)
+    cfg.cuda = False
+    cfg.device = 'cpu'
+    cfg.dist = False
+    cfg.frame_num = frame_num
+    cfg.save_sample = save_sample
+    from models.SRNet import SRNet
+    net = SRNet(cfg).eval()
+    mine = my_get_config('p', 'm', name)
+    mine.frame_num = frame_num
+    mine.save_sample = save_sample
+    # the build's config mirror must agree with the reference on every model field
+    for k in ('scale', 'flag_HD_in', 'matching_ksize', 'num_blocks', 'mid_channels', 'reset_branch',
+              'is_amp', 'network'):
+        assert cfg[k] == mine[k], (name, k, cfg[k], mine[k])
+    sd = wts.make_state_dict(mine, SEED_W)
+    ref_sd = net.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()) or set(ref_sd.keys()) == set(sd.keys()), \
+        set(ref_sd.keys()) ^ set(sd.keys())
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    net.load_state_dict(sd, strict=True)
+    return net, cfg, mine, sd
+
+
+def rnd(rs, *shape):
+    return torch.from_numpy(rs.rand(*shape).astype(np.float32))
+
+
+def quant8(x):
+    return torch.round(x * 255.0) / 255.0          # data_loader/utils.py:20,28 (8-bit frames)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('  wrote %-34s %7.1f KB' % (name + '.npz', os.path.getsize(path) / 1024.0))
+
+
+def md(a, b):
+    return float((a - b).abs().max())
+
+
+def gen_ops():
+    """Per-op goldens on the small (S) weights."""
+    print('== per-op goldens (RefVSR_small_L1 weights) ==')
+    net, cfg, mine, sd = ref_net('config_RefVSR_small_L1', 5)
+    N = net.Network
+    rs = np.random.RandomState(7)
+    from models.utils import warp as ref_warp
+    from mmedit.models.common import flow_warp as ref_flow_warp
+    from models.archs.RefVSR_.utils import extract_image_patches
+    with torch.no_grad():
+        # warp (LR form and LR-input / 2x-flow form)
+        x = rnd(rs, 1, 5, 18, 26)
+        fl = (rnd(rs, 1, 2, 18, 26) - 0.5) * 6
+        fl2 = (rnd(rs, 1, 2, 36, 52) - 0.5) * 10
+        w1, w2 = ref_warp(x, fl), ref_warp(x, fl2)
+        print('  warp          ', md(w1, orc.warp(x, fl)), md(w2, orc.warp(x, fl2)))
+        fw = ref_flow_warp(x, fl.permute(0, 2, 3, 1), padding_mode='border')
+        print('  flow_warp     ', md(fw, orc.flow_warp_border(x, fl)))
+        save('op_warp', x=x, flow=fl, flow2=fl2, warp=w1, warp2=w2, flow_warp=fw)
+        # resizes
+        img = rnd(rs, 1, 3, 18, 26)
+        b05 = F.interpolate(img, scale_factor=0.5, mode='bicubic', align_corners=False)
+        b2 = F.interpolate(img, scale_factor=2, mode='bicubic', align_corners=False)
+        b4 = F.interpolate(img, scale_factor=4, mode='bicubic', align_corners=False)
+        up = F.interpolate(fl, scale_factor=2, mode='bilinear', align_corners=True) * 2.0
+        bl = F.interpolate(img, size=(32, 32), mode='bilinear', align_corners=False)
+        bl_back = F.interpolate(bl, size=(18, 26), mode='bilinear', align_corners=False)
+        nn_ = F.interpolate(img, scale_factor=0.5, mode='nearest')
+        print('  bicubic       ', md(b05, orc.bicubic_scale(img, 0.5, False)), md(b2, orc.bicubic_scale(img, 2, False)),
+              md(b4, orc.bicubic_scale(img, 4, False)))
+        print('  bilinear      ', md(up, orc.flow_up2(fl)), md(bl, orc.resize(img, (32, 32), 'bilinear')),
+              md(bl_back, orc.resize(bl, (18, 26), 'bilinear')), md(nn_, orc.resize(img, (9, 13), 'nearest', 2.0)))
+        save('op_resize', img=img, flow=fl, bicubic_half=b05, bicubic_x2=b2, bicubic_x4=b4, flow_up2=up,
+             bilinear_32x32=bl, bilinear_back=bl_back, nearest_half=nn_)
+        # patch extraction
+        f16 = rnd(rs, 1, 4, 10, 12)
+        pt = extract_image_patches(f16, [3, 3], [1, 1], [1, 1], 'same')
+        print('  patches3x3    ', md(pt, orc.patches3x3(f16)))
+        save('op_patches', f=f16, patches=pt)
+        # feature matching
+        lr = quant8(rnd(rs, 1, 3, 20, 28))
+        rf = quant8(rnd(rs, 1, 3, 20, 28))
+        conf, idx = N.feature_match(lr, rf)
+        oc, oi = orc.feature_match(lr, rf, sd, False)
+        print('  feature_match ', md(conf, oc), int((idx != oi).sum()), 'idx mismatches')
+        save('op_match', lr=lr, ref=rf, conf=conf, idx=idx)
+        # block gathers (aa1: s=1 from LR/2 features; aa2: s=2 from LR features)
+        C = mine.mid_channels
+        vd = rnd(rs, 1, C, 10, 14)
+        v = rnd(rs, 1, C, 20, 28)
+        lr_down = F.interpolate(lr, scale_factor=0.5, mode='bicubic', align_corners=False)
+        g1 = N.aa1(lr_down, rf, idx, vd, 'aa1')
+        g2 = N.aa2(lr, rf, idx, v, 'aa2', return_fm=True)
+        g2rgb = N.aa2(lr, rf, idx, rf, 'aa2', return_fm=True)
+        print('  block_gather  ', md(g1, orc.block_gather(vd, idx, 1, (20, 28))),
+              md(g2, orc.block_gather(v, idx, 2, (40, 56))), md(g2rgb, orc.block_gather(rf, idx, 2, (40, 56))))
+        # full aa2 incl. AlignedConv2d
+        a2 = N.aa2(lr, rf, idx, v, 'aa2')
+        oa2 = orc.aligned_conv(orc.block_gather(v, idx, 2, (40, 56)), lr, orc.block_gather(rf, idx, 2, (40, 56)),
+                               sd, 'Network.aa2.align', 2)
+        print('  aa2+align     ', md(a2, oa2))
+        save('op_aa', lr=lr, ref=rf, idx=idx, value_down=vd, value=v, aa1=g1, aa2_fm=g2, aa2_rgb=g2rgb, aa2=a2)
+        # sampler alone with a hand-made affine field (exercises clamping, rotation, scaling)
+        xs = rnd(rs, 1, 3, 12, 16)
+        aff = torch.stack([rnd(rs, 6, 8) * 4 - 1, rnd(rs, 6, 8) * 4 - 1, rnd(rs, 6, 8) * 6 - 3])[None]
+        A = N.aa2.align
+        # drive the reference's own AlignedConv2d.forward with an injected affine field: its encoder is
+        # bypassed (identity) and its predictor replaced by a constant, so only the sampler runs.
+        class _Const(torch.nn.Module):
+            def forward(self, z):
+                return aff - 1.0
+        keep = (A.p_conv, A.conv1)
+        A.p_conv, A.conv1 = _Const(), torch.nn.Identity()
+        smp = A(xs, torch.zeros(1, 3, 6, 8), torch.zeros(1, 3, 12, 16))
+        A.p_conv, A.conv1 = keep
+        print('  aligned_sample', md(smp, orc.aligned_sample(xs, aff.clamp(-3, 3), 2)))
+        save('op_sampler', x=xs, affine=aff.clamp(-3, 3), out=smp)
+        # SPyNet (non-/32 size)
+        a = quant8(rnd(rs, 1, 3, 36, 52))
+        sh = torch.roll(a, shifts=(1, 2), dims=(2, 3))
+        flo = N.FlowNet(a, sh)
+        print('  spynet        ', md(flo, orc.spynet(a, sh, sd)))
+        save('op_spynet', a=a, b=sh, flow=flo)
+        # conv stacks
+        ft = rnd(rs, 1, C, 12, 16) - 0.5
+        rl = N.feat_decoder2(ft)
+        rb = N.backward_resblocks(torch.cat([a[:, :, :12, :16], ft], 1))
+        ps = N.upsample1(ft)
+        print('  reslist/resblocks/pixelshuffle', md(rl, orc.res_list(ft, sd, 'Network.feat_decoder2', 4)),
+              md(rb, orc.resblocks_with_input_conv(torch.cat([a[:, :, :12, :16], ft], 1), sd, 'Network.backward_resblocks', mine.num_blocks)),
+              md(ps, orc.pixel_shuffle_pack(ft, sd, 'Network.upsample1')))
+        save('op_convs', feat=ft, img=a[:, :, :12, :16], res_list=rl, resblocks=rb, pixel_shuffle=ps)
+        # upsampler
+        bw = rnd(rs, 1, C, 12, 16) - 0.5
+        fwd = rnd(rs, 1, C, 12, 16) - 0.5
+        cb, cf = rnd(rs, 1, 1, 6, 8), rnd(rs, 1, 1, 6, 8)
+        base = rnd(rs, 1, 3, 24, 32)
+        cu = N.compute_up(bw, fwd, cb, cf, base)
+        o = orc.OracleNetwork(mine, sd)
+        print('  compute_up    ', md(cu, o._compute_up(bw, fwd, cb, cf, base)))
+        save('op_compute_up', bw=bw, fw=fwd, conf_bw=cb, conf_fw=cf, base=base, out=cu)
+
+
+def synth_clip(rs, nframes, h, w):
+    """Smooth moving texture so flows / matches are non-trivial; 8-bit quantised like read_frame."""
+    H, W = h + 8, w + 8 + nframes
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.zeros((3, H, W), np.float32)
+    for c in range(3):
+        for _ in range(6):
+            fy, fx, ph = rs.uniform(0.05, 0.9), rs.uniform(0.05, 0.9), rs.uniform(0, 6.28)
+            img[c] += rs.uniform(0.3, 1.0) * np.sin(fy * yy + fx * xx + ph)
+    img = (img - img.min()) / (img.max() - img.min()) * 0.9 + 0.05
+    img += rs.uniform(-0.03, 0.03, img.shape).astype(np.float32)
+    lrs, refs = [], []
+    for f in range(nframes):
+        lrs.append(img[:, 4:4 + h, f:f + w])
+        refs.append(img[:, 2:2 + h, f + 3:f + 3 + w][:, ::1, ::1])
+    lr = torch.from_numpy(np.stack(lrs)[None].copy()).clamp(0, 1)
+    rf = torch.from_numpy(np.stack(refs)[None].copy()).clamp(0, 1)
+    return quant8(lr), quant8(rf)
+
+
+def windows(nframes, t):
+    """Sliding windows with edge-frame repetition (data_loader/datasets.py:222-234)."""
+    out = []
+    for f in range(nframes):
+        out.append([min(max(f - t // 2 + k, 0), nframes - 1) for k in range(t)])
+    return out
+
+
+def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep'):
+    print('== end-to-end %s: %s t=%d %dx%d, %d frames ==' % (tag, name, t, h, w, nframes))
+    net, cfg, mine, sd = ref_net(name, t)
+    if reset_override != 'keep':
+        cfg.reset_branch = reset_override
+        mine.reset_branch = reset_override
+        net.Network.max_frame_itr_num = reset_override
+    rs = np.random.RandomState(abs(hash(tag)) % (2 ** 31) if False else sum(map(ord, tag)))
+    lr, rf = synth_clip(rs, nframes, h, w)
+    o = orc.OracleNetwork(mine, sd)
+    arrs = dict(lr=lr, ref=rf, t=np.int64(t), reset_branch=np.int64(-1 if mine.reset_branch is None else mine.reset_branch))
+    with torch.no_grad():
+        for f, win in enumerate(windows(nframes, t)):
+            x, r = lr[:, win], rf[:, win]
+            first = (f == 0)
+            outs = net(x, r, first, is_log=True, is_train=False)
+            tr = {}
+            oo = o.forward(x, r, first, is_log=True, trace=tr)
+            N = net.Network
+            d = dict(result=md(outs['result'], oo['result']),
+                     feat=md(N.forward_feat_prop_prev, o.forward_feat_prop_prev),
+                     feat_up=md(N.forward_feat_prop_UP_prev, o.forward_feat_prop_UP_prev),
+                     conf=md(N.forward_conf_map_prop_prev, o.forward_conf_map_prop_prev),
+                     flow=md(N.forward_flow_prev, o.forward_flow_prev))
+            res = outs['result']
+            sat = float(((res <= 0) | (res >= 1)).float().mean())
+            print('  frame %d first=%s itr=%d  ' % (f, tr['is_first_frame'], N.frame_itr_num) +
+                  ' '.join('%s=%.2e' % kv for kv in d.items()) +
+                  '  | result mean %.3f std %.3f sat %.3f |feat| %.2f |feat_up| %.2f' % (
+                      float(res.mean()), float(res.std()), sat, float(N.forward_feat_prop_prev.abs().mean()),
+                      float(N.forward_feat_prop_UP_prev.abs().mean())))
+            assert N.frame_itr_num == o.frame_itr_num
+            arrs['result_%d' % f] = outs['result']
+            arrs['state_feat_%d' % f] = N.forward_feat_prop_prev
+            arrs['state_feat_up_%d' % f] = N.forward_feat_prop_UP_prev.to(torch.float16) if h * w > 600 else N.forward_feat_prop_UP_prev
+            arrs['state_conf_%d' % f] = N.forward_conf_map_prop_prev
+            arrs['state_flow_%d' % f] = N.forward_flow_prev
+            arrs['itr_%d' % f] = np.int64(N.frame_itr_num)
+            for k, v in outs['eval_vis'].items():
+                arrs['ev_%s_%d' % (k, f)] = v
+    save('e2e_' + tag, **arrs)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_ops()
+    gen_e2e('S_16x16_t3', 'config_RefVSR_small_L1', 3, 16, 16, 4)
+    gen_e2e('S_18x26_t5', 'config_RefVSR_small_L1', 5, 18, 26, 4)
+    gen_e2e('S_24x32_t5_reset3', 'config_RefVSR_small_L1', 5, 24, 32, 5, reset_override=3)
+    gen_e2e('F_16x24_t3', 'config_RefVSR_MFID', 3, 16, 24, 3)
+    gen_e2e('HD_32x48_t3', 'config_RefVSR_small_MFID_8K', 3, 32, 48, 3)
+    # state-dict contract checksums for all six configs
+    sums = {}
+    for name in ('config_RefVSR_small_L1', 'config_RefVSR_small_MFID', 'config_RefVSR_L1', 'config_RefVSR_MFID',
+                 'config_RefVSR_MFID_8K', 'config_RefVSR_small_MFID_8K'):
+        net, cfg, mine, sd = ref_net(name, 3)
+        sums[name + '/nparams'] = np.int64(sum(v.numel() for v in net.state_dict().values()))
+        sums[name + '/ntensors'] = np.int64(len(net.state_dict()))
+        sums[name + '/spec_crc'] = np.int64(wts.spec_checksum(mine))
+        sums[name + '/frame_num'] = np.int64(importlib.import_module('configs.' + name).get_config('p', 'm', name).frame_num)
+    save('state_spec', **sums)
+
+
+if __name__ == '__main__':
+    main()
