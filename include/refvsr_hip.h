@@ -1,0 +1,158 @@
+/*
+ * refvsr_hip.h -- C-ABI of the MI355X (gfx950) RefVSR inference hot path.
+ *
+ * The reference (codeslake/RefVSR) is pure Python + ATen ops; it has no FFI of its own.  The entry
+ * points below are what a ctypes/cffi binding of the hot path binds instead of the ATen calls made
+ * by models/archs/RefVSR.py:Network.forward (paths relative to the reference tree).  Every function
+ * cites the reference code it replaces.  Plain pointers (device memory), ints, floats; no torch
+ * types.  All kernels are enqueued on `stream` (a hipStream_t passed as void*) and return
+ * immediately; 0 = success, non-zero = error (message via refvsr_last_error()).
+ *
+ * Device data layouts
+ *   planar  : float32 [C][H][W]                  (frames, flows, confidence maps, VGG features)
+ *   nhwc16  : _Float16 [H][W][Cs], Cs % 8 == 0   (all C-channel feature maps; "HWC tiles")
+ * Batch size is 1 at this level (the host loops over n, as the reference's eval does).
+ */
+#ifndef REFVSR_HIP_H
+#define REFVSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REFVSR_ABI_VERSION 1
+
+int refvsr_abi_version(void);
+const char* refvsr_last_error(void);
+/* One-time per-process setup (raises dynamic-LDS limits).  Called lazily by every entry point. */
+int refvsr_init(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on v_mfma_f32_16x16x32_f16, fp32 accumulate).
+ * Replaces every nn.Conv2d on C-channel maps: ResidualBlocksWithInputConv (RefVSR.py:327-360),
+ * ResBlock/ResList/BasicBlock (RefVSR_/common.py:25-109), PixelShufflePack (mmedit upsample.py:36-51),
+ * SPyNetBasicModule (SPyNet.py:142-202), AlignedConv2d.conv1/p_conv (RefVSR_/alignment.py:18-24),
+ * fusion_UP/conv_hr/conv_last (RefVSR.py:87-92), with the surrounding elementwise work fused:
+ * torch.cat of two inputs, bias, (Leaky)ReLU, `x + alpha*y` (RefVSR.py:131,143), residual adds,
+ * pixel_shuffle, `+ base` and clamp (RefVSR.py:118,297).
+ * ------------------------------------------------------------------------------------------ */
+enum { REFVSR_OUT_NHWC16 = 0, REFVSR_OUT_NHWC16_SHUFFLE2 = 1, REFVSR_OUT_PLANAR32 = 2 };
+
+typedef struct RefvsrConv {
+    const void* src0; int c0;          /* nhwc16 input, channel stride c0 (multiple of 8)            */
+    const void* src1; int c1;          /* optional 2nd input concatenated after src0 (or NULL, 0)    */
+    int h_in, w_in;                    /* input spatial size                                         */
+    int h_out, w_out;                  /* conv output spatial size (before pixel shuffle)            */
+    int ksize, stride, pad;
+    const void* wpack;                 /* packed fp16 weights, see refvsr_amd/packing.py             */
+    const float* bias;                 /* fp32 [n_mtiles*16], packed row order                        */
+    int cout;                          /* valid output rows (packed row order)                        */
+    int mt_per_block;                  /* 1, 2 or 3 sixteen-row tiles handled per block               */
+    int ksteps;                        /* number of 32-deep K steps in wpack                          */
+    float act_slope;                   /* y<0 ? y*slope : y   (1 = linear, 0 = ReLU)                  */
+    const void* mul; int mul_c;        /* optional nhwc16 multiplier (alpha) and its channel stride   */
+    const void* res; int res_c;        /* optional nhwc16 residual added after mul                    */
+    float post_slope;                  /* activation applied after the residual add (1 = none)        */
+    int out_mode;                      /* REFVSR_OUT_*                                                */
+    void* out; int out_c;              /* nhwc16 modes: channel stride of out                          */
+    const float* res_planar;           /* PLANAR32: optional planar fp32 residual [cout][h][w]        */
+    float add_const;                   /* PLANAR32: constant added after the residual                 */
+    float clamp_lo, clamp_hi;          /* PLANAR32: clamp when clamp_lo < clamp_hi                    */
+} RefvsrConv;
+
+int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
+
+/* fp32 direct convolution on planar maps (VGG feature extractor + MeanShift of FeatureMatching,
+ * attention.py:28-50,62-70, and the 2->16 confidence convs RefVSR.py:47-52).  Kept in fp32 because
+ * the arg-max of the matching is discontinuous in these features.
+ * w: fp32 [cout][cin][k][k]; out: planar fp32 [cout][ho][wo] or nhwc16 [ho][wo][out_c]. */
+int refvsr_conv_direct_f32(const float* src, int cin, int h, int w,
+                           const float* wgt, const float* bias, int cout, int ksize, int stride, int pad,
+                           float act_slope, void* out, int out_nhwc16, int out_c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion
+ * ------------------------------------------------------------------------------------------ */
+/* planar fp32 [c][h][w] -> nhwc16 [h][w][cs] (channels >= c zero-filled). */
+int refvsr_pack_nhwc16(const float* src, int c, int h, int w, void* dst, int cs, void* stream);
+/* nhwc16 [h][w][cs] -> planar fp32 [c][h][w]. */
+int refvsr_unpack_nhwc16(const void* src, int h, int w, int cs, int c, float* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling (F.interpolate / avg_pool2d / max_pool2d call sites)
+ * ------------------------------------------------------------------------------------------ */
+enum { REFVSR_RS_BICUBIC = 0, REFVSR_RS_BILINEAR = 1, REFVSR_RS_BILINEAR_AC = 2, REFVSR_RS_NEAREST = 3 };
+/* dst = post(interp(src)); post: (v - mean[c]) / std[c] if mean != NULL (host arrays of c floats),
+ * then v * mul, then clamp to [0,1] if clamp01.  src_scale_{y,x}: source step per output sample
+ * (1/scale_factor, or in/out when the reference passes size=); ignored for BILINEAR_AC.
+ * dst is planar fp32 [c][oh][ow], or nhwc16 [oh][ow][out_c] when out_nhwc16 != 0. */
+int refvsr_resize(const float* src, int c, int h, int w, void* dst, int oh, int ow, int mode,
+                  float src_scale_y, float src_scale_x, const float* mean, const float* std,
+                  const float* chan_mul, int clamp01, int out_nhwc16, int out_c, void* stream);
+int refvsr_avgpool2(const float* src, int c, int h, int w, float* dst, void* stream);
+int refvsr_maxpool2(const float* src, int c, int h, int w, float* dst, void* stream);
+/* out = max(a, b) elementwise on n floats (confidence accumulation, RefVSR.py:147). */
+int refvsr_max2(const float* a, const float* b, float* out, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Inter-frame alignment
+ * ------------------------------------------------------------------------------------------ */
+/* models/utils.py:35-43 `warp`: linspace(-1,1) base grid + flow/((Win-1)/2), grid_sample(bilinear,
+ * zeros, align_corners=False).  Output size = flow size [hf][wf]; input may be a different size
+ * (RefVSR.py:254).  flow: planar fp32 [2][hf][wf]. */
+int refvsr_warp_nhwc16(const void* x, int hin, int win, int cs, const float* flow, int hf, int wf,
+                       void* out, void* stream);
+int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flow, int hf, int wf,
+                       float* out, void* stream);
+/* One SPyNet pyramid level input (SPyNet.py:83-103): flow_up = 2*bilinear_x2(flow_prev, align_corners)
+ * (or zeros when flow_prev == NULL), warped = flow_warp(supp, flow_up, border, align_corners=True)
+ * (mmedit flow_warp.py:6-47); writes cat[ref, warped, flow_up] as nhwc16 [h][w][8] and flow_up as
+ * planar fp32 [2][h][w].  ref/supp: planar fp32 [3][h][w]; flow_prev: planar [2][h/2][w/2]. */
+int refvsr_spynet_level_input(const float* ref, const float* supp, const float* flow_prev, int h, int w,
+                              void* out8, float* flow_up, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reference matching  (FeatureMatching.forward, RefVSR_/attention.py:72-91)
+ * ------------------------------------------------------------------------------------------ */
+#define REFVSR_MATCH_KP 152       /* 144 = 16 ch x 3x3 patch, padded to 152 halfs (304-byte rows)   */
+#define REFVSR_MATCH_ROWCHUNK 128 /* reference rows are padded to a multiple of this               */
+#define REFVSR_MATCH_COLBLOCK 512 /* LR columns are padded to a multiple of this                    */
+/* feat: planar fp32 [16][h][w].  Writes rows [h*w][KP] fp16 of L2-normalised reflect-padded 3x3
+ * patches (channel order c*9+ky*3+kx, RefVSR_/utils.py:29-57) and inv_norm[h*w] = 1/max(|p|,1e-12). */
+int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, void* stream);
+/* Fused cosine GEMM + column top-2 (never materialises the [n_ref x n_lr] matrix).
+ * ref_rows: [n_ref_pad][KP], lr_rows: [n_lr_pad][KP] (pads zero).  row_splits >= 1 partitions the
+ * reference rows over blockIdx.y.  cand_idx: int32 [n_lr][2*row_splits] (first-max-wins order). */
+int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr_rows, int n_lr, int row_splits,
+                      int32_t* cand_idx, float* cand_val, void* stream);
+/* Exact fp32 re-rank of the candidates: conf[p] = max_c <lr_patch p, ref_patch c> (normalised),
+ * idx[p] = that candidate (smallest index on ties, like torch.max). */
+int refvsr_match_refine(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
+                        const float* inv_lr, const float* inv_ref, const int32_t* cand_idx, int ncand,
+                        float* conf, int32_t* idx, void* stream);
+/* Unfused fp32 reference kernel of the same op (test / debugging aid, O(n_ref*n_lr*144) VALU). */
+int refvsr_match_naive(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
+                       float* conf, int32_t* idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reference alignment  (AlignedAttention / AlignedConv2d, attention.py:131-159, alignment.py:39-178)
+ * ------------------------------------------------------------------------------------------ */
+/* unfold(k=s,stride=s) -> gather(index) -> fold == block gather:
+ * out[s*y+ky][s*x+kx][:] = value[s*ry+ky][s*rx+kx][:], (ry,rx) = divmod(idx[y*gw+x], wv/s). */
+int refvsr_block_gather_nhwc16(const void* value, int hv, int wv, int cs, const int32_t* idx, int gh, int gw,
+                               int s, void* out, void* stream);
+/* same gather on a planar fp32 RGB frame, written as nhwc16 [gh*s][gw*s][8] (3 valid channels). */
+int refvsr_block_gather_rgb(const float* value, int hv, int wv, const int32_t* idx, int gh, int gw, int s,
+                            void* out8, void* stream);
+/* affine-deformable bilinear patch sampler (alignment.py:53-100,102-178).
+ * x: nhwc16 [h*ks][w*ks][cs]; affine: planar fp32 [3][h][w] already (+1, clamped to [-3,3]). */
+int refvsr_aligned_sample(const void* x, int h, int w, int ks, int cs, const float* affine, void* out,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFVSR_HIP_H */

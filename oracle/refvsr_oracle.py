@@ -442,7 +442,7 @@ class OracleNetwork(object):
     upsampler :104-119).  Executes exactly what the reference executes (no cross-window caching).
     `W` is a flat state dict with the reference key names (`Network.*`)."""
 
-    def __init__(self, config, W, match_chunk=None):
+    def __init__(self, config, W, match_chunk=None, match_sample=None):
         self.cfg = config
         self.W = {k: v.detach().to(torch.float32) for k, v in W.items()}
         self.C = config.mid_channels
@@ -451,6 +451,11 @@ class OracleNetwork(object):
         self.scale = config.scale
         self.ks = config.matching_ksize
         self.match_chunk = match_chunk
+        # timing-only mode (bench.py cpu_baseline): evaluate the matching GEMM on 1/match_sample of the
+        # LR columns (results of the skipped columns are tiled copies -- numerically meaningless) and
+        # accumulate the time spent so the caller can scale it back up.
+        self.match_sample = match_sample
+        self.match_seconds = 0.0
         self.reset_state()
 
     def reset_state(self):
@@ -461,7 +466,34 @@ class OracleNetwork(object):
         self.frame_itr_num = 0
         self.max_frame_itr_num = self.cfg.reset_branch
 
+    def export_state(self):
+        """Forward-branch state kept between calls (RefVSR.py:279-283), batch dim dropped."""
+        return dict(feat=self.forward_feat_prop_prev[0], flow=self.forward_flow_prev[0],
+                    feat_up=self.forward_feat_prop_UP_prev[0], conf=self.forward_conf_map_prop_prev[0],
+                    frame_itr_num=self.frame_itr_num)
+
+    def import_state(self, st):
+        self.forward_feat_prop_prev = st['feat'][None].clone()
+        self.forward_flow_prev = st['flow'][None].clone()
+        self.forward_feat_prop_UP_prev = st['feat_up'][None].clone()
+        self.forward_conf_map_prop_prev = st['conf'][None].clone()
+        self.frame_itr_num = int(st['frame_itr_num'])
+
     # -- pieces ------------------------------------------------------------------------------
+    def _feature_match(self, lr, ref):
+        if not self.match_sample:
+            return feature_match(lr, ref, self.W, self.hd, self.scale, self.match_chunk)
+        import time
+        assert not self.hd
+        ref_p, lr_p, (Hf, Wf) = match_features(lr, ref, self.W, self.hd, self.scale)
+        L = lr_p.shape[2]
+        n = max(L // self.match_sample, 1)
+        t0 = time.perf_counter()
+        v, i = match_argmax(ref_p, lr_p[:, :, :n].contiguous(), self.match_chunk)
+        self.match_seconds += time.perf_counter() - t0
+        reps = (L + n - 1) // n
+        return v.repeat(1, reps)[:, :L].view(lr.shape[0], 1, Hf, Wf), i.repeat(1, reps)[:, :L]
+
     def _aa(self, which, lr_like, ref_rgb, index_map, value):
         """AlignedAttention.forward (attention.py:131-159) for aa1 / aa2."""
         s = self.ks // 2 if which == 'aa1' else self.ks
@@ -534,8 +566,7 @@ class OracleNetwork(object):
             bf.append(torch.zeros(n, 2, h, w) if gradio else spynet(lrs[:, j - 1], lrs[:, j], W))
         conf_maps, index_maps = [None] * t, [None] * t
         for i in range(range_start, t):                                      # :196-204
-            conf_maps[i], index_maps[i] = feature_match(lrs[:, i], refs[:, i], W, self.hd,
-                                                        self.scale, self.match_chunk)
+            conf_maps[i], index_maps[i] = self._feature_match(lrs[:, i], refs[:, i])
         # backward branch :211-238
         feat = torch.zeros(n, C, h, w)
         feat_up = torch.zeros(n, C, 2 * h, 2 * w)

@@ -1,0 +1,290 @@
+// Implicit-GEMM convolution on CDNA4 matrix cores (v_mfma_f32_16x16x32_f16), nhwc16 activations.
+//
+//   D[cout][pixel] = sum_k  W[cout][k] * X[k][pixel],   k = (tap, channel)   (fp32 accumulate)
+//
+// * A operand = packed weights (rows = 16 output channels), B operand = 16 consecutive output
+//   pixels of one image row.  With this orientation a lane ends up holding 4 consecutive output
+//   channels of ONE pixel, so the epilogue stores 8-byte channel vectors straight into the HWC map.
+// * One workgroup = 4 waves = an (2*TILES) x 32 output-pixel tile.  The input tile (+halo, zero
+//   padded at the frame border, two concatenated sources) is staged ONCE through LDS with coalesced
+//   16-byte loads of HWC rows; every tap of every output pixel is then an LDS read.
+//   LDS pixel stride is forced odd (in 16-byte slots) so 16 consecutive pixels hit 16 distinct slots.
+// * K is walked in 32-deep steps; per step lane l consumes K-block g = 4*step + (l>>4), an
+//   8-channel group of one tap.  g -> LDS byte offset comes from a small table built per block, so
+//   kernel size, stride and channel count are runtime values (one kernel serves 1x1..7x7).
+// * Weights are pre-packed on the host in exact fragment order ([kstep][mtile][lane][8 halfs]) and
+//   streamed through LDS in chunks of CH K-steps shared by the 4 waves.
+// * Epilogue fuses bias, (leaky)ReLU, alpha-multiply, residual, post-activation, pixel-shuffle or a
+//   planar fp32 store with residual / constant / clamp.
+//
+// Replaces nn.Conv2d call sites listed in include/refvsr_hip.h.
+#include "common.h"
+
+#define CONV_CH 8          // K-steps of weights staged per LDS chunk
+#define CONV_TW 32         // output tile width in pixels
+
+struct ConvArgs {
+    const f16* src0; const f16* src1;
+    int c0, c1, ncg0, ncg, ps;       // ps = LDS pixel stride in 16-byte slots (odd)
+    int h_in, w_in, h_out, w_out;
+    int ks, stride, pad;
+    int LH, LW;                      // LDS input tile extent in pixels
+    int G, S;                        // valid K-blocks, K-steps
+    float inv_ncg;
+    const uint4* wpack; const float* bias;
+    int cout;
+    float act_slope, post_slope;
+    const f16* mul; int mul_c;
+    const f16* res; int res_c;
+    int out_mode; void* out; int out_c;
+    const float* res_planar; float add_const, clamp_lo, clamp_hi;
+    int tab_bytes, wl_bytes;         // LDS carve sizes
+};
+
+template <int MT, int TILES>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* tab = reinterpret_cast<int*>(smem);
+    unsigned char* wl = smem + p.tab_bytes;
+    unsigned char* tile = wl + p.wl_bytes;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int q = lane >> 4;
+    const int lr = lane & 15;
+    constexpr int TH = TILES * 2;
+    const int tx0 = blockIdx.x * CONV_TW;
+    const int ty0 = blockIdx.y * TH;
+    const int zg = blockIdx.z;
+
+    // ---- K-block -> LDS byte offset table -------------------------------------------------
+    for (int g = tid; g < p.S * 4; g += 256) {
+        int off = 0;
+        if (g < p.G) {
+            const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
+            const int cg = g - tap * p.ncg;
+            const int ty = tap / p.ks;
+            const int tx = tap - ty * p.ks;
+            off = ((ty * p.LW + tx) * p.ps + cg) * 16;
+        }
+        tab[g] = off;
+    }
+
+    // ---- stage the input tile (zero padded) -----------------------------------------------
+    {
+        const int iy0 = ty0 * p.stride - p.pad;
+        const int ix0 = tx0 * p.stride - p.pad;
+        const int row_chunks = p.LW * p.ncg;
+        const float inv_rc = 1.0f / (float)row_chunks;
+        const int total = p.LH * row_chunks;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int r = (int)(((float)idx + 0.5f) * inv_rc);
+            const int i = idx - r * row_chunks;
+            const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+            const int cg = i - c * p.ncg;
+            const int iy = iy0 + r;
+            const int ix = ix0 + c;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
+                const size_t pix = (size_t)iy * p.w_in + ix;
+                if (cg < p.ncg0)
+                    v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.c0 + cg * 8);
+                else
+                    v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.c1 + (cg - p.ncg0) * 8);
+            }
+            *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
+        }
+    }
+
+    // ---- per-lane base offsets of this wave's pixel tiles -----------------------------------
+    int pbase[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const int ti = wave * TILES + t;
+        const int row = ti >> 1;
+        const int col = (ti & 1) * 16 + lr;
+        pbase[t] = ((row * p.stride) * p.LW + col * p.stride) * p.ps * 16;
+    }
+
+    f32x4 acc[MT][TILES];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint4* wsrc = p.wpack + (size_t)zg * p.S * MT * 64;
+    for (int s0 = 0; s0 < p.S; s0 += CONV_CH) {
+        const int ns = min(CONV_CH, p.S - s0);
+        __syncthreads();                       // previous chunk fully consumed (and tile/table staged)
+        {
+            const int n16 = ns * MT * 64;
+            const uint4* g = wsrc + (size_t)s0 * MT * 64;
+            uint4* d = reinterpret_cast<uint4*>(wl);
+            for (int i = tid; i < n16; i += 256) d[i] = g[i];
+        }
+        __syncthreads();
+        for (int sl = 0; sl < ns; ++sl) {
+            const int toff = tab[(s0 + sl) * 4 + q];
+            f16x8 a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                a[m] = *reinterpret_cast<const f16x8*>(wl + ((size_t)(sl * MT + m) * 64 + lane) * 16);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(tile + pbase[t] + toff);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b, acc[m][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const int ti = wave * TILES + t;
+        const int oy = ty0 + (ti >> 1);
+        const int ox = tx0 + (ti & 1) * 16 + lr;
+        if (oy >= p.h_out || ox >= p.w_out) continue;
+        const size_t opix = (size_t)oy * p.w_out + ox;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = (zg * MT + m) * 16 + q * 4;
+            if (co0 >= p.cout) continue;
+            float y[4];
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0);
+            y[0] = acc[m][t][0] + bv.x; y[1] = acc[m][t][1] + bv.y;
+            y[2] = acc[m][t][2] + bv.z; y[3] = acc[m][t][3] + bv.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.act_slope);
+            if (p.mul) {
+                const f16x4 mv = *reinterpret_cast<const f16x4*>(p.mul + opix * p.mul_c + co0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] *= (float)mv[i];
+            }
+            if (p.res) {
+                const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + opix * p.res_c + co0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] += (float)rv[i];
+            }
+            if (p.post_slope != 1.0f) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.post_slope);
+            }
+            if (p.out_mode == REFVSR_OUT_NHWC16) {
+                f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + opix * p.out_c + co0) = o;
+            } else if (p.out_mode == REFVSR_OUT_NHWC16_SHUFFLE2) {
+                // packed row r = sub*C + c  <->  conv channel c*4 + sub, sub = dy*2 + dx
+                const int C = p.cout >> 2;
+                const int sub = co0 / C;
+                const int c = co0 - sub * C;
+                const size_t op = (size_t)(2 * oy + (sub >> 1)) * (2 * p.w_out) + (2 * ox + (sub & 1));
+                f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + op * p.out_c + c) = o;
+            } else {
+                const size_t plane = (size_t)p.h_out * p.w_out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + i;
+                    if (co < p.cout) {
+                        float v = y[i];
+                        if (p.res_planar) v += p.res_planar[co * plane + opix];
+                        v += p.add_const;
+                        if (p.clamp_lo < p.clamp_hi) v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
+                        reinterpret_cast<float*>(p.out)[co * plane + opix] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef void (*conv_kernel_t)(ConvArgs);
+
+template <int MT, int TILES>
+static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES>), grid, dim3(256), lds, st, a);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
+    RV_CHECK(d != nullptr, "conv: null descriptor");
+    RV_CHECK(d->src0 && d->c0 > 0 && d->c0 % 8 == 0, "conv: src0/c0 invalid (c0=%d)", d->c0);
+    RV_CHECK((d->src1 == nullptr) == (d->c1 == 0) && d->c1 % 8 == 0, "conv: src1/c1 invalid (c1=%d)", d->c1);
+    RV_CHECK(d->ksize >= 1 && d->ksize <= 7 && d->stride >= 1 && d->pad >= 0, "conv: bad geometry");
+    RV_CHECK(d->h_in > 0 && d->w_in > 0 && d->h_out > 0 && d->w_out > 0, "conv: bad sizes");
+    RV_CHECK(d->wpack && d->bias && d->out, "conv: null weights/bias/out");
+    RV_CHECK(d->mt_per_block >= 1 && d->mt_per_block <= 3, "conv: mt_per_block must be 1..3");
+    RV_CHECK(d->cout >= 1, "conv: cout");
+    if (d->out_mode != REFVSR_OUT_PLANAR32) {
+        RV_CHECK(d->cout % 4 == 0 && d->out_c % 4 == 0, "conv: nhwc16 output needs cout %% 4 == 0");
+        RV_CHECK(d->res_planar == nullptr, "conv: res_planar only with planar output");
+    }
+    if (d->out_mode == REFVSR_OUT_NHWC16_SHUFFLE2)
+        RV_CHECK(d->cout % 16 == 0 && !d->mul && !d->res, "conv: pixel-shuffle output constraints");
+    RV_CHECK(refvsr_init() == 0, "init failed");
+
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = (const f16*)d->src0; a.src1 = (const f16*)d->src1;
+    a.c0 = d->c0; a.c1 = d->c1;
+    a.ncg0 = d->c0 / 8; a.ncg = (d->c0 + d->c1) / 8;
+    a.ps = a.ncg | 1;
+    a.h_in = d->h_in; a.w_in = d->w_in; a.h_out = d->h_out; a.w_out = d->w_out;
+    a.ks = d->ksize; a.stride = d->stride; a.pad = d->pad;
+    a.G = d->ksize * d->ksize * a.ncg;
+    a.S = (a.G + 3) / 4;
+    RV_CHECK(a.S == d->ksteps, "conv: ksteps mismatch (descriptor %d, geometry %d)", d->ksteps, a.S);
+    a.inv_ncg = 1.0f / (float)a.ncg;
+    a.wpack = (const uint4*)d->wpack; a.bias = d->bias; a.cout = d->cout;
+    a.act_slope = d->act_slope; a.post_slope = d->post_slope;
+    a.mul = (const f16*)d->mul; a.mul_c = d->mul_c;
+    a.res = (const f16*)d->res; a.res_c = d->res_c;
+    a.out_mode = d->out_mode; a.out = d->out; a.out_c = d->out_c;
+    a.res_planar = d->res_planar; a.add_const = d->add_const;
+    a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
+
+    const int MT = d->mt_per_block;
+    const int n_mt = (d->cout + 15) / 16;
+    const int nz = (n_mt + MT - 1) / MT;
+    a.tab_bytes = ((a.S * 4 * 4 + 15) / 16) * 16;
+    a.wl_bytes = CONV_CH * MT * 1024;
+
+    // pick the pixel-tile height: 8 rows x 32 cols if the staged input fits, else 4 rows
+    int tiles = 4;
+    size_t lds = 0;
+    for (;;) {
+        const int TH = tiles * 2;
+        a.LH = (TH - 1) * a.stride + a.ks;
+        a.LW = (CONV_TW - 1) * a.stride + a.ks;
+        lds = (size_t)a.tab_bytes + a.wl_bytes + (size_t)a.LH * a.LW * a.ps * 16;
+        if (lds <= 160 * 1024 || tiles == 2) break;
+        tiles = 2;
+    }
+    RV_CHECK(lds <= 160 * 1024, "conv: input tile does not fit LDS (%zu bytes; k=%d stride=%d cin=%d)",
+             lds, a.ks, a.stride, d->c0 + d->c1);
+    // prefer 2 blocks/CU for mid-size tiles
+    if (tiles == 4 && lds > 80 * 1024 && d->h_out * d->w_out > 64 * 1024) {
+        const int LH2 = 3 * a.stride + a.ks;
+        const size_t lds2 = (size_t)a.tab_bytes + a.wl_bytes + (size_t)LH2 * a.LW * a.ps * 16;
+        if (lds2 <= 80 * 1024) { tiles = 2; a.LH = LH2; lds = lds2; }
+    }
+    dim3 grid(rv_cdiv(d->w_out, CONV_TW), rv_cdiv(d->h_out, tiles * 2), nz);
+    hipStream_t st = (hipStream_t)stream;
+#define RV_CONV_CASE(M, T) if (MT == M && tiles == T) return launch_conv<M, T>(a, grid, lds, st);
+    RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
+    RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)
+    RV_CONV_CASE(3, 2) RV_CONV_CASE(3, 4)
+#undef RV_CONV_CASE
+    refvsr_set_error("conv: no kernel for MT=%d tiles=%d", MT, tiles);
+    return 1;
+}

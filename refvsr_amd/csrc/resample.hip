@@ -1,0 +1,357 @@
+// HBM-bound resampling kernels: layout conversion, F.interpolate modes, pooling, the two warps.
+// All are one-thread-per-output-vector gathers with coalesced (row-contiguous) stores; HWC maps
+// move 16 bytes (8 channels) per lane.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_nhwc16_kernel(const float* __restrict__ src, int c, int hw, f16* __restrict__ dst, int cs) {
+    const int ngroups = cs / 8;
+    const size_t total = (size_t)hw * ngroups;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / ngroups;
+        const int g = (int)(i - pix * ngroups);
+        f16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = g * 8 + k;
+            v[k] = ch < c ? (f16)src[(size_t)ch * hw + pix] : (f16)0.f;
+        }
+        *reinterpret_cast<f16x8*>(dst + pix * cs + g * 8) = v;
+    }
+}
+
+extern "C" int refvsr_pack_nhwc16(const float* src, int c, int h, int w, void* dst, int cs, void* stream) {
+    RV_CHECK(src && dst && c > 0 && h > 0 && w > 0 && cs % 8 == 0 && cs >= c, "pack_nhwc16: bad args");
+    const size_t total = (size_t)h * w * (cs / 8);
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_nhwc16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, c, h * w, (f16*)dst, cs);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void unpack_nhwc16_kernel(const f16* __restrict__ src, int hw, int cs, int c, float* __restrict__ dst) {
+    const size_t total = (size_t)hw * c;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ch = i / hw;
+        const size_t pix = i - ch * hw;
+        dst[i] = (float)src[pix * cs + ch];
+    }
+}
+
+extern "C" int refvsr_unpack_nhwc16(const void* src, int h, int w, int cs, int c, float* dst, void* stream) {
+    RV_CHECK(src && dst && c > 0 && h > 0 && w > 0 && cs >= c, "unpack_nhwc16: bad args");
+    const size_t total = (size_t)h * w * c;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(unpack_nhwc16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)src, h * w, cs, c, dst);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F.interpolate restatement (ATen upsample_{bicubic,bilinear,nearest}2d semantics)
+// ------------------------------------------------------------------------------------------------
+struct ResizeArgs {
+    const float* src; void* dst;
+    int c, h, w, oh, ow, mode;
+    float sy, sx;
+    int has_norm; float mean[4], stdv[4];
+    int has_mul; float mul[4];
+    int clamp01, out_nhwc16, out_c;
+};
+
+__device__ __forceinline__ void cubic_taps(float t, float* wgt) {
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    wgt[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    wgt[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    wgt[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    wgt[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+
+// 1-D source taps for output index o: up to 4 (index, weight) pairs.
+__device__ __forceinline__ int src_taps(int mode, int o, int n_in, int n_out, float scale, int* idx, float* wgt) {
+    if (mode == REFVSR_RS_BICUBIC) {
+        const float x = ((float)o + 0.5f) * scale - 0.5f;
+        const float fl = floorf(x);
+        const int ix = (int)fl;
+        cubic_taps(x - fl, wgt);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) idx[k] = min(max(ix - 1 + k, 0), n_in - 1);
+        return 4;
+    }
+    if (mode == REFVSR_RS_NEAREST) {
+        idx[0] = min((int)floorf((float)o * scale), n_in - 1);
+        wgt[0] = 1.0f;
+        return 1;
+    }
+    float x;
+    if (mode == REFVSR_RS_BILINEAR) {
+        x = fmaxf(((float)o + 0.5f) * scale - 0.5f, 0.0f);
+    } else {  // align_corners=True
+        const float sc = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
+        x = (float)o * sc;
+    }
+    const int i0 = min((int)x, n_in - 1);
+    const int i1 = min(i0 + 1, n_in - 1);
+    const float l1 = x - (float)i0;
+    idx[0] = i0; idx[1] = i1;
+    wgt[0] = 1.0f - l1; wgt[1] = l1;
+    return 2;
+}
+
+__global__ void resize_kernel(ResizeArgs a) {
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int oy = blockIdx.y;
+    if (ox >= a.ow) return;
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    const int ny = src_taps(a.mode, oy, a.h, a.oh, a.sy, iy, wy);
+    const int nx = src_taps(a.mode, ox, a.w, a.ow, a.sx, ix, wx);
+    const size_t plane = (size_t)a.h * a.w;
+    float outv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        if (ch < a.c) {
+            const float* s = a.src + ch * plane;
+            float acc = 0.0f;
+            for (int j = 0; j < ny; ++j) {
+                float r = 0.0f;
+                const float* row = s + (size_t)iy[j] * a.w;
+                for (int i = 0; i < nx; ++i) r += wx[i] * row[ix[i]];
+                acc += wy[j] * r;
+            }
+            if (a.has_norm) acc = (acc - a.mean[ch & 3]) / a.stdv[ch & 3];
+            if (a.has_mul) acc *= a.mul[ch & 3];
+            if (a.clamp01) acc = fminf(fmaxf(acc, 0.0f), 1.0f);
+            outv[ch] = acc;
+            if (!a.out_nhwc16)
+                reinterpret_cast<float*>(a.dst)[ch * (size_t)a.oh * a.ow + (size_t)oy * a.ow + ox] = acc;
+        }
+    }
+    if (a.out_nhwc16) {
+        f16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = k < a.c ? (f16)outv[k] : (f16)0.f;
+        f16* d = reinterpret_cast<f16*>(a.dst) + ((size_t)oy * a.ow + ox) * a.out_c;
+        *reinterpret_cast<f16x8*>(d) = v;
+        for (int g = 8; g < a.out_c; g += 8) *reinterpret_cast<f16x8*>(d + g) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+extern "C" int refvsr_resize(const float* src, int c, int h, int w, void* dst, int oh, int ow, int mode,
+                             float src_scale_y, float src_scale_x, const float* mean, const float* std,
+                             const float* chan_mul, int clamp01, int out_nhwc16, int out_c, void* stream) {
+    RV_CHECK(src && dst && c > 0 && c <= 8 && h > 0 && w > 0 && oh > 0 && ow > 0, "resize: bad sizes (c <= 8)");
+    RV_CHECK(mode >= 0 && mode <= 3, "resize: bad mode %d", mode);
+    RV_CHECK((mean == nullptr) == (std == nullptr), "resize: mean/std must come together");
+    RV_CHECK(!(mean || chan_mul) || c <= 4, "resize: per-channel params support c <= 4");
+    RV_CHECK(!out_nhwc16 || (c <= 8 && out_c % 8 == 0 && out_c >= 8), "resize: nhwc16 output needs c <= 8");
+    ResizeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = src; a.dst = dst; a.c = c; a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.mode = mode;
+    a.sy = src_scale_y; a.sx = src_scale_x;
+    if (mean) { a.has_norm = 1; for (int i = 0; i < c; ++i) { a.mean[i] = mean[i]; a.stdv[i] = std[i]; } }
+    if (chan_mul) { a.has_mul = 1; for (int i = 0; i < c; ++i) a.mul[i] = chan_mul[i]; }
+    a.clamp01 = clamp01; a.out_nhwc16 = out_nhwc16; a.out_c = out_c;
+    hipLaunchKernelGGL(resize_kernel, dim3(rv_cdiv(ow, 128), oh), dim3(128), 0, (hipStream_t)stream, a);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void pool2_kernel(const float* __restrict__ src, int c, int h, int w, float* __restrict__ dst, int is_max) {
+    const int oh = h / 2, ow = w / 2;
+    const size_t total = (size_t)c * oh * ow;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % ow);
+        const int y = (int)((i / ow) % oh);
+        const int ch = (int)(i / ((size_t)ow * oh));
+        const float* s = src + ((size_t)ch * h + 2 * y) * w + 2 * x;
+        const float a = s[0], b = s[1], cc = s[w], d = s[w + 1];
+        dst[i] = is_max ? fmaxf(fmaxf(a, b), fmaxf(cc, d)) : 0.25f * (a + b + cc + d);
+    }
+}
+
+static int launch_pool(const float* src, int c, int h, int w, float* dst, int is_max, void* stream) {
+    RV_CHECK(src && dst && c > 0 && h >= 2 && w >= 2, "pool2: bad args");
+    const size_t total = (size_t)c * (h / 2) * (w / 2);
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pool2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, c, h, w, dst, is_max);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int refvsr_avgpool2(const float* src, int c, int h, int w, float* dst, void* stream) {
+    return launch_pool(src, c, h, w, dst, 0, stream);
+}
+extern "C" int refvsr_maxpool2(const float* src, int c, int h, int w, float* dst, void* stream) {
+    return launch_pool(src, c, h, w, dst, 1, stream);
+}
+
+__global__ void max2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = fmaxf(a[i], b[i]);
+}
+extern "C" int refvsr_max2(const float* a, const float* b, float* out, size_t n, void* stream) {
+    RV_CHECK(a && b && out && n > 0, "max2: bad args");
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(max2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// warp (models/utils.py:35-43): zeros padding, align_corners=False sampling of a linspace(-1,1) grid
+// ------------------------------------------------------------------------------------------------
+struct WarpCoord { int x0, y0; float w00, w01, w10, w11; bool v00, v01, v10, v11; };
+
+__device__ __forceinline__ WarpCoord warp_coord(const float* flow, int hf, int wf, int hin, int win, int y, int x) {
+    const size_t fp = (size_t)y * wf + x;
+    const float u = flow[fp];
+    const float v = flow[(size_t)hf * wf + fp];
+    const float gx = rv_linspace_m1p1(x, wf) + u / (((float)win - 1.0f) / 2.0f);
+    const float gy = rv_linspace_m1p1(y, hf) + v / (((float)hin - 1.0f) / 2.0f);
+    const float xs = ((gx + 1.0f) * (float)win - 1.0f) / 2.0f;
+    const float ys = ((gy + 1.0f) * (float)hin - 1.0f) / 2.0f;
+    const float fx = floorf(xs), fy = floorf(ys);
+    const float tx = xs - fx, ty = ys - fy;
+    WarpCoord c;
+    // clamp before the int conversion so wild flows cannot overflow; such taps are out of range anyway
+    c.x0 = (int)fminf(fmaxf(fx, -2.0f), (float)win + 1.0f);
+    c.y0 = (int)fminf(fmaxf(fy, -2.0f), (float)hin + 1.0f);
+    const bool xin0 = c.x0 >= 0 && c.x0 < win, xin1 = c.x0 + 1 >= 0 && c.x0 + 1 < win;
+    const bool yin0 = c.y0 >= 0 && c.y0 < hin, yin1 = c.y0 + 1 >= 0 && c.y0 + 1 < hin;
+    c.v00 = xin0 && yin0; c.v01 = xin1 && yin0; c.v10 = xin0 && yin1; c.v11 = xin1 && yin1;
+    c.w00 = (1.0f - ty) * (1.0f - tx); c.w01 = (1.0f - ty) * tx;
+    c.w10 = ty * (1.0f - tx); c.w11 = ty * tx;
+    return c;
+}
+
+__global__ void warp_nhwc16_kernel(const f16* __restrict__ x, int hin, int win, int cs, const float* __restrict__ flow,
+                                   int hf, int wf, f16* __restrict__ out) {
+    const int ng = cs / 8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (pixel-in-row, group)
+    const int y = blockIdx.y;
+    if (i >= wf * ng) return;
+    const int px = i / ng;
+    const int g = i - px * ng;
+    const WarpCoord c = warp_coord(flow, hf, wf, hin, win, y, px);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tap = [&](bool valid, int yy, int xx, float wgt) {
+        if (valid) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(x + ((size_t)yy * win + xx) * cs + g * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += wgt * (float)v[k];
+        }
+    };
+    tap(c.v00, c.y0, c.x0, c.w00);
+    tap(c.v01, c.y0, c.x0 + 1, c.w01);
+    tap(c.v10, c.y0 + 1, c.x0, c.w10);
+    tap(c.v11, c.y0 + 1, c.x0 + 1, c.w11);
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+    *reinterpret_cast<f16x8*>(out + ((size_t)y * wf + px) * cs + g * 8) = o;
+}
+
+extern "C" int refvsr_warp_nhwc16(const void* x, int hin, int win, int cs, const float* flow, int hf, int wf,
+                                  void* out, void* stream) {
+    RV_CHECK(x && flow && out && hin > 1 && win > 1 && hf > 1 && wf > 1 && cs % 8 == 0, "warp_nhwc16: bad args");
+    const int ng = cs / 8;
+    hipLaunchKernelGGL(warp_nhwc16_kernel, dim3(rv_cdiv(wf * ng, 256), hf), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, hin, win, cs, flow, hf, wf, (f16*)out);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void warp_planar_kernel(const float* __restrict__ x, int c, int hin, int win, const float* __restrict__ flow,
+                                   int hf, int wf, float* __restrict__ out) {
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (px >= wf) return;
+    const WarpCoord k = warp_coord(flow, hf, wf, hin, win, y, px);
+    for (int ch = 0; ch < c; ++ch) {
+        const float* s = x + (size_t)ch * hin * win;
+        float acc = 0.0f;
+        if (k.v00) acc += k.w00 * s[(size_t)k.y0 * win + k.x0];
+        if (k.v01) acc += k.w01 * s[(size_t)k.y0 * win + k.x0 + 1];
+        if (k.v10) acc += k.w10 * s[(size_t)(k.y0 + 1) * win + k.x0];
+        if (k.v11) acc += k.w11 * s[(size_t)(k.y0 + 1) * win + k.x0 + 1];
+        out[((size_t)ch * hf + y) * wf + px] = acc;
+    }
+}
+
+extern "C" int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flow, int hf, int wf,
+                                  float* out, void* stream) {
+    RV_CHECK(x && flow && out && c > 0 && hin > 1 && win > 1 && hf > 1 && wf > 1, "warp_planar: bad args");
+    hipLaunchKernelGGL(warp_planar_kernel, dim3(rv_cdiv(wf, 128), hf), dim3(128), 0, (hipStream_t)stream,
+                       x, c, hin, win, flow, hf, wf, out);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPyNet level input: x2 align_corners flow upsample (*2) + border-clamped flow_warp + concat
+// ------------------------------------------------------------------------------------------------
+__global__ void spynet_level_input_kernel(const float* __restrict__ ref, const float* __restrict__ supp,
+                                          const float* __restrict__ flow_prev, int h, int w,
+                                          f16* __restrict__ out8, float* __restrict__ flow_up) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const size_t plane = (size_t)h * w;
+    const size_t pix = (size_t)y * w + x;
+    float u = 0.0f, v = 0.0f;
+    if (flow_prev) {
+        const int hp = h / 2, wp = w / 2;
+        int iy[2], ix[2];
+        float wy[2], wx[2];
+        src_taps(REFVSR_RS_BILINEAR_AC, y, hp, h, 0.f, iy, wy);
+        src_taps(REFVSR_RS_BILINEAR_AC, x, wp, w, 0.f, ix, wx);
+        const float* f0 = flow_prev;
+        const float* f1 = flow_prev + (size_t)hp * wp;
+        u = wy[0] * (wx[0] * f0[(size_t)iy[0] * wp + ix[0]] + wx[1] * f0[(size_t)iy[0] * wp + ix[1]]) +
+            wy[1] * (wx[0] * f0[(size_t)iy[1] * wp + ix[0]] + wx[1] * f0[(size_t)iy[1] * wp + ix[1]]);
+        v = wy[0] * (wx[0] * f1[(size_t)iy[0] * wp + ix[0]] + wx[1] * f1[(size_t)iy[0] * wp + ix[1]]) +
+            wy[1] * (wx[0] * f1[(size_t)iy[1] * wp + ix[0]] + wx[1] * f1[(size_t)iy[1] * wp + ix[1]]);
+        u *= 2.0f;
+        v *= 2.0f;
+    }
+    flow_up[pix] = u;
+    flow_up[plane + pix] = v;
+    // flow_warp (mmedit flow_warp.py:36-46): normalise with align_corners=True, border padding
+    const float gx = 2.0f * ((float)x + u) / (float)max(w - 1, 1) - 1.0f;
+    const float gy = 2.0f * ((float)y + v) / (float)max(h - 1, 1) - 1.0f;
+    float xs = (gx + 1.0f) / 2.0f * (float)(w - 1);
+    float ys = (gy + 1.0f) / 2.0f * (float)(h - 1);
+    xs = fminf(fmaxf(xs, 0.0f), (float)(w - 1));
+    ys = fminf(fmaxf(ys, 0.0f), (float)(h - 1));
+    const int x0 = (int)floorf(xs), y0 = (int)floorf(ys);
+    const float tx = xs - (float)x0, ty = ys - (float)y0;
+    const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    f16x8 o;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        o[ch] = (f16)ref[ch * plane + pix];
+        const float* s = supp + ch * plane;
+        const float val = (1.0f - ty) * ((1.0f - tx) * s[(size_t)y0 * w + x0] + tx * s[(size_t)y0 * w + x1]) +
+                          ty * ((1.0f - tx) * s[(size_t)y1 * w + x0] + tx * s[(size_t)y1 * w + x1]);
+        o[3 + ch] = (f16)val;
+    }
+    o[6] = (f16)u;
+    o[7] = (f16)v;
+    *reinterpret_cast<f16x8*>(out8 + pix * 8) = o;
+}
+
+extern "C" int refvsr_spynet_level_input(const float* ref, const float* supp, const float* flow_prev, int h, int w,
+                                         void* out8, float* flow_up, void* stream) {
+    RV_CHECK(ref && supp && out8 && flow_up && h > 0 && w > 0, "spynet_level_input: bad args");
+    RV_CHECK(flow_prev == nullptr || (h % 2 == 0 && w % 2 == 0), "spynet_level_input: odd level size");
+    hipLaunchKernelGGL(spynet_level_input_kernel, dim3(rv_cdiv(w, 128), h), dim3(128), 0, (hipStream_t)stream,
+                       ref, supp, flow_prev, h, w, (f16*)out8, flow_up);
+    RV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,428 @@
+"""The MI355X RefVSR pipeline: `Network.forward` of the reference re-expressed as launches of the
+HIP kernels behind the C-ABI (refvsr_amd/ops.py), one sample (n=1) at a time.
+
+Follows /root/reference/models/archs/RefVSR.py:151-325 step by step (the comments cite the lines).
+What differs from the reference's *execution* (never its results):
+
+  * only the flows the network consumes are computed (RefVSR.py:182-191 computes 2(t-1), uses
+    t//2 + 1 in steady state), and
+  * everything that depends on a single frame only -- SPyNet pyramids, matching (conf, index),
+    the reference encoders, and both AlignedAttention outputs (aa1 gather, aa2 gather +
+    AlignedConv2d), which are functions of (lr_i, ref_i) alone -- is cached per frame and reused
+    across overlapping sliding windows and across the backward/forward branches
+    (`config.cache_windows`).  Frames are recognised by exact content
+    equality with the previous window, so the drop-in call signature needs no frame ids.
+
+Feature maps live in HBM as fp16 HWC ("nhwc16"); frames, flows and confidence maps as planar fp32.
+"""
+import collections
+import itertools
+
+import torch
+
+from . import ops
+from .packing import pack_conv
+from .weights import VGG_MEAN, VGG_STD
+
+_uid = itertools.count()
+
+
+class FrameCtx(object):
+    """Per-frame data (functions of one (lr, ref) frame pair only)."""
+
+    def __init__(self, lr, ref):
+        self.uid = next(_uid)
+        self.lr = lr            # planar fp32 [3,h,w]
+        self.ref = ref
+        self.lr8 = None         # nhwc16 [h,w,8]
+        self.pyr = None         # SPyNet pyramid of lr, coarse -> fine
+        self.conf = None        # planar [1,h,w]
+        self.idx = None         # int32 [Hf*Wf]
+        self.aligned = None     # aa1 output nhwc16 [h,w,C]
+        self.aligned_up = None  # aa2 output nhwc16 [2h,2w,C]
+
+
+class Weights(object):
+    """All parameters of the network packed for the kernels (built from a reference-keyed state dict)."""
+
+    def __init__(self, config, sd, device):
+        self.device = device
+        self.C = config.mid_channels
+        self.nb = config.num_blocks
+        self.conv = {}
+        self.raw = {}
+        C = self.C
+        g = lambda n: (sd['Network.' + n + '.weight'], sd['Network.' + n + '.bias'])
+
+        def mf(name, srcs, shuffle=False):
+            w, b = g(name)
+            self.conv[name] = ops.ConvWeights(pack_conv(w, b, srcs, shuffle), device)
+
+        def dr(name):
+            w, b = g(name)
+            self.raw[name] = (w.detach().to(device, torch.float32).contiguous(),
+                              b.detach().to(device, torch.float32).contiguous())
+
+        chans = [(32, 8), (64, 32), (32, 64), (16, 32), (2, 16)]
+        for lvl in range(6):
+            for j, (co, ci) in enumerate(chans):
+                mf('FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j), [ci])
+        fe = 'feature_match.feature_extract.'
+        for n in ('feature_match.sub_mean', fe + '0', fe + '2', fe + 'map64.0'):
+            dr(n)
+
+        def aligned(prefix):
+            mf(prefix + '.conv1.0', [3])
+            mf(prefix + '.conv1.2.conv1', [32])
+            mf(prefix + '.conv1.2.conv2', [32])
+            mf(prefix + '.p_conv.0', [32, 32])
+            mf(prefix + '.p_conv.2.conv1', [32])
+            mf(prefix + '.p_conv.2.conv2', [32])
+            mf(prefix + '.p_conv.4', [32])
+        aligned('aa2.align')
+
+        def reslist(name, n):
+            for i in range(n):
+                mf('%s.RBs.%d.conv1' % (name, i), [C])
+                mf('%s.RBs.%d.conv2' % (name, i), [C])
+            mf(name + '.conv_tail', [C])
+
+        mf('ref_encoder1.0.0', [3])
+        mf('ref_encoder1.1.0', [C])
+        reslist('res1', 4)
+        mf('ref_encoder2.0.0', [C])
+        mf('ref_encoder2.1.0', [C])
+        reslist('res2', 4)
+        for nm in ('conf_fusion', 'conf_fusion2', 'conf_fusion_BWFW'):
+            dr(nm + '.0.0')
+            mf(nm + '.1.0', [16])
+        for nm in ('feat_fusion', 'feat_fusion2', 'feat_fusion_BWFW'):
+            mf(nm + '.0.0', [C, C])
+            mf(nm + '.1.0', [C])
+        mf('feat_fusion2_1.0.0', [C, C])
+        reslist('feat_decoder', 8)
+        reslist('feat_decoder2', 4)
+        reslist('feat_decoder_BWFW', 4)
+        for br in ('backward_resblocks', 'forward_resblocks'):
+            mf(br + '.main.0', [3, C])
+            for i in range(self.nb):
+                mf('%s.main.2.%d.conv1' % (br, i), [C])
+                mf('%s.main.2.%d.conv2' % (br, i), [C])
+        mf('fusion_UP', [C, C])
+        mf('upsample1.upsample_conv', [C], shuffle=True)
+        mf('upsample2.upsample_conv', [C], shuffle=True)
+        mf('conv_hr', [C])
+        mf('conv_last', [C])
+
+
+class Engine(object):
+    """Stateful per-stream executor (one stream of consecutive frames, like a reference module
+    instance: RefVSR.py:96-101,279-283)."""
+
+    def __init__(self, config, weights):
+        if config.flag_HD_in:
+            raise NotImplementedError('flag_HD_in (8K) path is not built yet on the HIP engine')
+        if config.scale != 4:
+            raise NotImplementedError('only scale 4 is built')
+        self.cfg = config
+        self.W = weights
+        self.C = config.mid_channels
+        self.nb = config.num_blocks
+        self.ks = config.matching_ksize
+        self.cache = bool(getattr(config, 'cache_windows', True))
+        self.match_row_splits = 1
+        self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
+        self.reset_state()
+
+    # ------------------------------------------------------------------ state
+    def reset_state(self):
+        self.fw_feat = None
+        self.fw_flow = None
+        self.fw_feat_up = None
+        self.fw_conf = None
+        self.frame_itr_num = 0
+        self.max_frame_itr_num = self.cfg.reset_branch
+        self.prev_window = []
+        self.flow_cache = {}
+
+    def export_state(self):
+        """Forward-branch state as planar fp32 tensors (what RefVSR.py:279-283 keeps)."""
+        if self.fw_feat is None:
+            return None
+        return dict(feat=ops.unpack_nhwc16(self.fw_feat), flow=self.fw_flow, feat_up=ops.unpack_nhwc16(self.fw_feat_up),
+                    conf=self.fw_conf, frame_itr_num=self.frame_itr_num)
+
+    def import_state(self, st):
+        self.fw_feat = ops.pack_nhwc16(st['feat'].contiguous())
+        self.fw_flow = st['flow'].contiguous()
+        self.fw_feat_up = ops.pack_nhwc16(st['feat_up'].contiguous())
+        self.fw_conf = st['conf'].contiguous()
+        self.frame_itr_num = int(st['frame_itr_num'])
+
+    # ------------------------------------------------------------------ building blocks
+    def cw(self, name):
+        return self.W.conv[name]
+
+    def res_list(self, x, name, n):
+        """ResList (RefVSR_/common.py:64-82) with ResBlocks (:25-39)."""
+        x0 = x
+        for i in range(n):
+            t = ops.conv(self.cw('%s.RBs.%d.conv1' % (name, i)), x, act=0.2)
+            x = ops.conv(self.cw('%s.RBs.%d.conv2' % (name, i)), t, res=x)
+        return ops.conv(self.cw(name + '.conv_tail'), x, res=x0)
+
+    def resblocks(self, lr8, feat, name):
+        """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources."""
+        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1)
+        for i in range(self.nb):
+            t = ops.conv(self.cw('%s.main.2.%d.conv1' % (name, i)), x, act=0.0)
+            x = ops.conv(self.cw('%s.main.2.%d.conv2' % (name, i)), t, res=x)
+        return x
+
+    def pyramid(self, fr):
+        """SPyNet.forward resize-to-/32 + normalise + 5x avg_pool2d (SPyNet.py:62-81,117-126)."""
+        if fr.pyr is None:
+            h, w = fr.lr.shape[1:]
+            w_up = w if w % 32 == 0 else 32 * (w // 32 + 1)
+            h_up = h if h % 32 == 0 else 32 * (h // 32 + 1)
+            lv = [ops.resize(fr.lr, (h_up, w_up), ops.RS_BILINEAR, mean=VGG_MEAN, std=VGG_STD)]
+            for _ in range(5):
+                lv.append(ops.avgpool2(lv[-1]))
+            fr.pyr = lv[::-1]
+        return fr.pyr
+
+    def flow(self, fr_ref, fr_supp):
+        """FlowNet(ref, supp) (SPyNet.py:49-139), cached per ordered frame pair."""
+        key = (fr_ref.uid, fr_supp.uid)
+        if key in self.flow_cache:
+            return self.flow_cache[key]
+        pr, ps = self.pyramid(fr_ref), self.pyramid(fr_supp)
+        h, w = fr_ref.lr.shape[1:]
+        flow = None
+        for lvl in range(6):
+            x, fup = ops.spynet_level_input(pr[lvl], ps[lvl], flow)
+            p = 'FlowNet.basic_module.%d.basic_module.' % lvl
+            for j in range(4):
+                x = ops.conv(self.cw(p + '%d.conv' % j), x, act=0.0)
+            flow = ops.conv(self.cw(p + '4.conv'), x, planar_out=True, res_planar=fup)
+        h_up, w_up = flow.shape[1:]
+        out = ops.resize(flow, (h, w), ops.RS_BILINEAR, chan_mul=[float(w) / float(w_up), float(h) / float(h_up)])
+        self.flow_cache[key] = out
+        return out
+
+    def feature_match(self, fr):
+        """FeatureMatching.forward (RefVSR_/attention.py:58-100), fused GEMM+argmax."""
+        R = self.W.raw
+        h, w = fr.lr.shape[1:]
+
+        def extract(x):
+            x = ops.conv_direct(x, *R['feature_match.feature_extract.0'], act=0.0)
+            x = ops.conv_direct(x, *R['feature_match.feature_extract.2'], act=0.0)
+            return ops.conv_direct(x, *R['feature_match.feature_extract.map64.0'], act=0.2)
+        lr_n = ops.conv_direct(fr.lr, *R['feature_match.sub_mean'])
+        ref_n = ops.conv_direct(fr.ref, *R['feature_match.sub_mean'])
+        lr_f = extract(lr_n)
+        ref_f = extract(ops.avgpool2(ref_n))
+        lr_rows, inv_lr = ops.match_patches(lr_f, ops.hip.MATCH_COLBLOCK)
+        ref_rows, inv_ref = ops.match_patches(ref_f, ops.hip.MATCH_ROWCHUNK)
+        n_lr = lr_f.shape[1] * lr_f.shape[2]
+        n_ref = ref_f.shape[1] * ref_f.shape[2]
+        if self.kernel_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        cand, _ = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, self.match_row_splits)
+        if self.kernel_events is not None:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+        conf, idx = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand)
+        return conf.view(1, lr_f.shape[1], lr_f.shape[2]), idx
+
+    def aligned_conv(self, feats, fr, rgb8, prefix, ks):
+        """AlignedConv2d.forward (RefVSR_/alignment.py:39-100)."""
+        def enc(z8):
+            e = ops.conv(self.cw(prefix + '.conv1.0'), z8, act=0.2)
+            t = ops.conv(self.cw(prefix + '.conv1.2.conv1'), e, act=0.2)
+            return ops.conv(self.cw(prefix + '.conv1.2.conv2'), t, res=e, post=0.2)
+        q = enc(ops.bicubic_scale(fr.lr, 2, clamp01=False, nhwc16_out=True))
+        r = enc(rgb8)
+        a = ops.conv(self.cw(prefix + '.p_conv.0'), r, q, stride=ks, act=0.2)
+        t = ops.conv(self.cw(prefix + '.p_conv.2.conv1'), a, act=0.2)
+        a = ops.conv(self.cw(prefix + '.p_conv.2.conv2'), t, res=a, post=0.2)
+        affine = ops.conv(self.cw(prefix + '.p_conv.4'), a, planar_out=True, add_const=1.0, clamp=(-3.0, 3.0))
+        return ops.aligned_sample(feats, affine, ks)
+
+    def prepare_frame(self, fr):
+        """Everything that is a function of (lr_i, ref_i) only: matching (RefVSR.py:196-204), reference
+        encoders (:233-234) and both AlignedAttention outputs (:127,136)."""
+        if fr.conf is not None:
+            return
+        h, w = fr.lr.shape[1:]
+        fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
+        fr.conf, fr.idx = self.feature_match(fr)
+        ref8 = ops.pack_nhwc16(fr.ref, 8)
+        x = ops.conv(self.cw('ref_encoder1.0.0'), ref8, act=0.2)
+        x = ops.conv(self.cw('ref_encoder1.1.0'), x, act=0.2)
+        ref_feat = self.res_list(x, 'res1', 4)
+        x = ops.conv(self.cw('ref_encoder2.0.0'), ref_feat, stride=2, act=0.2)
+        x = ops.conv(self.cw('ref_encoder2.1.0'), x, act=0.2)
+        ref_feat_down = self.res_list(x, 'res2', 4)
+        s1, s2 = self.ks // 2, self.ks
+        fr.aligned = ops.block_gather_nhwc16(ref_feat_down, fr.idx, h, w, s1)            # aa1 (attention.py:142-144)
+        feats2 = ops.block_gather_nhwc16(ref_feat, fr.idx, h, w, s2)                     # aa2
+        rgb2 = ops.block_gather_rgb(fr.ref, fr.idx, h, w, s2)                            # attention.py:152-154
+        fr.aligned_up = self.aligned_conv(feats2, fr, rgb2, 'aa2.align', s2)
+
+    def rap(self, fr, conf_prop, feat, feat_up):
+        """AA_AF_conf_prop (RefVSR.py:123-149)."""
+        R = self.W.raw
+        pair = torch.cat([conf_prop, fr.conf], 0)                                        # [2,h,w] (:130)
+        a = ops.conv_direct(pair, *R['conf_fusion.0.0'], act=0.2, nhwc16_out=True)
+        alpha = ops.conv(self.cw('conf_fusion.1.0'), a, act=0.2)
+        t = ops.conv(self.cw('feat_fusion.0.0'), feat, fr.aligned, act=0.2)
+        feat = ops.conv(self.cw('feat_fusion.1.0'), t, act=0.2, mul=alpha, res=feat)     # :131
+        feat = self.res_list(feat, 'feat_decoder', 8)
+        up1 = ops.conv(self.cw('upsample1.upsample_conv'), feat)                         # :138 (pixel shuffle fused)
+        feat_up = ops.conv(self.cw('feat_fusion2_1.0.0'), feat_up, up1, act=0.2)
+        pair_up = ops.bicubic_scale(pair, 2, clamp01=True)                               # :140-141
+        a = ops.conv_direct(pair_up, *R['conf_fusion2.0.0'], act=0.2, nhwc16_out=True)
+        alpha2 = ops.conv(self.cw('conf_fusion2.1.0'), a, act=0.2)
+        t = ops.conv(self.cw('feat_fusion2.0.0'), feat_up, fr.aligned_up, act=0.2)
+        feat_up = ops.conv(self.cw('feat_fusion2.1.0'), t, act=0.2, mul=alpha2, res=feat_up)   # :143
+        feat_up = self.res_list(feat_up, 'feat_decoder2', 4)
+        conf_prop = ops.max2(conf_prop, fr.conf)                                         # :147
+        return feat, feat_up, conf_prop
+
+    def compute_up(self, bw_up, fw_up, conf_bw, conf_fw, lr_center):
+        """compute_up + base (RefVSR.py:104-119,288) + final clamp (:297)."""
+        R = self.W.raw
+        pair_up = ops.bicubic_scale(torch.cat([conf_bw, conf_fw], 0), 2, clamp01=True)
+        fus = ops.conv(self.cw('fusion_UP'), bw_up, fw_up)
+        a = ops.conv_direct(pair_up, *R['conf_fusion_BWFW.0.0'], act=0.2, nhwc16_out=True)
+        alpha = ops.conv(self.cw('conf_fusion_BWFW.1.0'), a, act=0.2)
+        t = ops.conv(self.cw('feat_fusion_BWFW.0.0'), bw_up, fw_up, act=0.2)
+        out = ops.conv(self.cw('feat_fusion_BWFW.1.0'), t, act=0.2, mul=alpha, res=fus)
+        out = self.res_list(out, 'feat_decoder_BWFW', 4)
+        out = ops.conv(self.cw('upsample2.upsample_conv'), out, act=0.1)      # lrelu commutes with pixel_shuffle
+        out = ops.conv(self.cw('conv_hr'), out, act=0.1)
+        base = ops.bicubic_scale(lr_center, 4, clamp01=True)
+        return ops.conv(self.cw('conv_last'), out, planar_out=True, res_planar=base, clamp=(0.0, 1.0))
+
+    # ------------------------------------------------------------------ window bookkeeping
+    def _frames(self, lrs, refs):
+        """Wrap the t frames of this window, reusing per-frame contexts of the previous window (or of
+        earlier positions in this window) whose content is identical."""
+        t = lrs.shape[0]
+        frames = [None] * t
+        if not self.cache:
+            self.flow_cache = {}
+            return [FrameCtx(lrs[i].contiguous(), refs[i].contiguous()) for i in range(t)]
+        prev = self.prev_window
+        cands, tests = [], []
+        for i in range(t):
+            opts = []
+            if prev:
+                for j in (i + 1, i, i - 1):
+                    if 0 <= j < len(prev) and prev[j] not in opts:
+                        opts.append(prev[j])
+            cands.append(opts)
+            for o in opts:
+                tests.append(((lrs[i] == o.lr).all() & (refs[i] == o.ref).all()))
+        flags = torch.stack(tests).cpu().tolist() if tests else []
+        k = 0
+        for i in range(t):
+            for o in cands[i]:
+                if flags[k] and frames[i] is None:
+                    frames[i] = o
+                k += 1
+        # repeated frames inside this window (clip edges replicate frames, datasets.py:233-234)
+        fresh = [i for i in range(t) if frames[i] is None]
+        if len(fresh) > 1:
+            pairs = [(a, b) for ai, a in enumerate(fresh) for b in fresh[ai + 1:]]
+            eq = torch.stack([(lrs[a] == lrs[b]).all() & (refs[a] == refs[b]).all() for a, b in pairs]).cpu().tolist()
+            for (a, b), e in zip(pairs, eq):
+                if e:
+                    if frames[a] is None:
+                        frames[a] = FrameCtx(lrs[a].contiguous(), refs[a].contiguous())
+                    if frames[b] is None:
+                        frames[b] = frames[a]
+        for i in range(t):
+            if frames[i] is None:
+                frames[i] = FrameCtx(lrs[i].contiguous(), refs[i].contiguous())
+        live = set(f.uid for f in frames)
+        self.flow_cache = {k2: v for k2, v in self.flow_cache.items() if k2[0] in live and k2[1] in live}
+        self.prev_window = frames
+        return frames
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, lrs, refs, is_first_frame, want_vis=False):
+        """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None)."""
+        assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
+        t, _, h, w = lrs.shape
+        assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
+        C = self.C
+        ctr = t // 2
+        dev = lrs.device
+        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
+            is_first_frame = True                                                   # :168-170
+        if not is_first_frame and self.fw_feat is None:
+            raise RuntimeError('is_first_frame=False but no forward state is held (first call of a stream '
+                               'must pass is_first_frame=True, cf. RefVSR.py:257-258)')
+        gradio = bool(self.cfg.EVAL.is_gradio)
+        zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if gradio else None
+        fr = self._frames(lrs, refs)
+        flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b]))   # :183-191
+        range_start = 0 if is_first_frame else ctr                                  # :173-176
+        for i in range(range_start, t):                                             # :196-204 (+ per-frame RAP parts)
+            self.prepare_frame(fr[i])
+
+        # ---- backward branch (:211-238)
+        feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
+        feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
+        conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+        for i in range(t - 1, ctr - 1, -1):
+            if i < t - 1:
+                fl = flow(i, i + 1)                       # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
+                feat = ops.warp_nhwc16(feat, fl)
+                conf = ops.warp_planar(conf, fl)
+                feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
+            feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
+            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+        bw_up, conf_bw = feat_up, conf
+
+        # ---- forward branch (:240-283)
+        if is_first_frame:
+            feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
+            feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
+            conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+            range_start = 0
+        else:
+            range_start = ctr
+        for i in range(range_start, ctr + 1):
+            if i > range_start:
+                fl = flow(i, i - 1)                       # forward_flows[:, i-1] = FlowNet(lrs[i], lrs[i-1])
+                feat = ops.warp_nhwc16(feat, fl)
+                feat_up = ops.warp_nhwc16(feat, ops.flow_up2(fl))      # :254 LR state resampled on the 2x grid
+                conf = ops.warp_planar(conf, fl)
+            elif not is_first_frame:
+                fl = self.fw_flow                                                   # :257-260
+                feat = ops.warp_nhwc16(self.fw_feat, fl)
+                feat_up = ops.warp_nhwc16(self.fw_feat_up, ops.flow_up2(fl))
+                conf = ops.warp_planar(self.fw_conf, fl)
+            feat = self.resblocks(fr[i].lr8, feat, 'forward_resblocks')
+            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+            if i == ctr:                                                            # :279-283
+                self.fw_feat, self.fw_feat_up, self.fw_conf = feat, feat_up, conf
+                self.fw_flow = flow(ctr + 1, ctr)         # forward_flows[:, ctr]
+        out = self.compute_up(bw_up, feat_up, conf_bw, conf, fr[ctr].lr)            # :288-289,297
+        if is_first_frame:                                                          # :292-295
+            self.frame_itr_num = 0
+        self.frame_itr_num += 1
+        vis = None
+        if want_vis:                                                                # :318-322
+            vis = collections.OrderedDict()
+            vis['conf_map'] = fr[ctr].conf
+            vis['conf_map_prop'] = ops.max2(conf_bw, conf)
+            vis['conf_map_prop_backward'] = conf_bw
+            vis['conf_map_prop_forward'] = conf
+        return out, vis

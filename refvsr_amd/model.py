@@ -1,0 +1,158 @@
+"""Drop-in model shell: `SRNet(config)` with the reference's constructor / forward / state_dict
+surface (/root/reference/models/SRNet.py:11-61, models/archs/RefVSR.py:14-101,151-325), executing on
+the HIP engine (refvsr_amd/engine.py).
+
+  * `SRNet(config).Network` is resolved through `config.network` exactly like the reference's
+    importlib plugin hook (SRNet.py:20-21): `refvsr_amd.archs.<config.network>.Network(config)`.
+  * Parameters are registered under the reference's state-dict key names (refvsr_amd/weights.py), so
+    `load_state_dict` accepts released checkpoints (with or without the DataParallel `module.`
+    prefix, ckpt_manager.py:50-56) and `state_dict()` round-trips.
+  * The recurrent forward state lives on the module between calls, like the reference
+    (RefVSR.py:96-101,279-283): one module instance == one stream of consecutive frames, not
+    thread-safe, not re-entrant.
+  * There is NO CPU fallback: inputs must be CUDA (HIP) tensors and the HIP library must be built.
+"""
+import collections
+import importlib
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .engine import Engine, Weights
+from .weights import state_spec, strip_module_prefix
+
+
+def _register(root, dotted, param):
+    mod = root
+    parts = dotted.split('.')
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, nn.Module())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], param)
+
+
+class _FlowNetHandle(nn.Module):
+    """Placeholder carrying `load_ckpt` so that `SRNet.init()` keeps working (SRNet.py:44-45)."""
+
+    def load_ckpt(self, pretrained):
+        sd = torch.load(pretrained, map_location='cpu')
+        sd = sd.get('state_dict', sd)
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v)
+
+
+class Network(nn.Module):
+    """HIP implementation of models/archs/RefVSR.py:Network (inference path)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.rank = torch.distributed.get_rank() if config.dist else -1
+        self.scale = config.scale
+        self.flag_HD_in = config.flag_HD_in
+        self.mid_channels = config.mid_channels
+        self.add_module('FlowNet', _FlowNetHandle())
+        for name, shape in state_spec(config).items():
+            assert name.startswith('Network.')
+            p = nn.Parameter(torch.zeros(shape), requires_grad=False)
+            _register(self, name[len('Network.'):], p)
+        self._packed = None
+        self._packed_key = None
+        self._engines = []
+
+    # -- weights ------------------------------------------------------------------------------
+    def _weights_key(self):
+        return tuple((p.device, p._version, p.data_ptr()) for p in self.parameters())
+
+    def _weights(self, device):
+        key = (self._weights_key(), str(device))
+        if self._packed is None or self._packed_key != key:
+            sd = collections.OrderedDict(('Network.' + k, v.detach()) for k, v in self.named_parameters())
+            self._packed = Weights(self.config, sd, device)
+            self._packed_key = key
+            for e in self._engines:
+                e.W = self._packed
+        return self._packed
+
+    def reset(self):
+        """Forget the recurrent state (start a new clip)."""
+        for e in self._engines:
+            e.reset_state()
+
+    # mirrors the attributes of the reference module that callers / tests look at
+    @property
+    def frame_itr_num(self):
+        return self._engines[0].frame_itr_num if self._engines else 0
+
+    def engine(self, n=0):
+        return self._engines[n]
+
+    def ensure_engines(self, n, device):
+        W = self._weights(device)
+        while len(self._engines) < n:
+            self._engines.append(Engine(self.config, W))
+        return self._engines
+
+    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False):
+        """Same contract as RefVSR.py:151: lrs, refs [n,t,3,h,w] in [0,1]; returns OrderedDict with
+        'result' [n,3,4h,4w] (+ 'eval_vis' when is_log and config.save_sample)."""
+        if is_train:
+            raise NotImplementedError('refvsr_amd implements the inference path only (is_train=False)')
+        hip.lib()                                              # fail loudly if the extension is missing
+        if not lrs.is_cuda:
+            raise RuntimeError('refvsr_amd.Network runs on the GPU only (got a %s tensor); there is no CPU path'
+                               % lrs.device)
+        lrs = lrs.float().contiguous()
+        refs = refs.float().contiguous()
+        n = lrs.shape[0]
+        self.ensure_engines(n, lrs.device)
+        want_vis = bool(is_log and self.config.save_sample)
+        results, vis_all = [], []
+        for b in range(n):
+            out, vis = self._engines[b].forward(lrs[b], refs[b], bool(is_first_frame), want_vis)
+            results.append(out)
+            vis_all.append(vis)
+        outs = collections.OrderedDict()
+        if is_log:
+            outs['vis'] = collections.OrderedDict()
+        outs['result'] = torch.stack(results, 0)
+        if want_vis:
+            ev = collections.OrderedDict()
+            for k in vis_all[0]:
+                ev[k] = torch.stack([v[k] for v in vis_all], 0)
+            outs['eval_vis'] = ev
+        return outs
+
+
+class SRNet(nn.Module):
+    """models/SRNet.py:SRNet surface."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.rank = torch.distributed.get_rank() if config.dist else -1
+        self.config = config
+        self.device = config.device
+        lib = importlib.import_module('refvsr_amd.archs.{}'.format(config.network))
+        self.Network = lib.Network(config)
+        self.data = collections.OrderedDict()
+
+    def init(self):
+        # dead in the reference too (wi / win are None in every config, SRNet.py:40-45)
+        if self.config.wi is not None and self.config.win is not None:
+            raise NotImplementedError('weight initialisation is a training feature')
+
+    def input_constructor(self, res):
+        b, f, c, h, w = res[:]
+        imgs = torch.rand(b, f, c, h, w, device=self.device)
+        return {'x': imgs, 'ref': imgs}
+
+    def load_state_dict(self, state_dict, strict=True):
+        return super().load_state_dict(strip_module_prefix(state_dict), strict=strict)
+
+    def forward(self, x, ref, is_first_frame=True, is_log=False, is_train=False):
+        return self.Network.forward(x, ref, is_first_frame, is_log=is_log, is_train=is_train)

@@ -1,0 +1,315 @@
+"""Tensor-level wrappers over the C-ABI (refvsr_amd/hip.py).  torch is used only for device memory
+(caching allocator) and the current HIP stream; every computation is a kernel of librefvsr_hip.so.
+
+Layouts: `planar` = float32 [C,H,W];  `nhwc16` = float16 [H,W,Cs] (Cs % 8 == 0).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import hip
+from .hip import (OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32, RS_BICUBIC, RS_BILINEAR,  # noqa: F401
+                  RS_BILINEAR_AC, RS_NEAREST)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _planar(t, c=None):
+    assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.is_contiguous(), \
+        'expected contiguous cuda float32 [C,H,W], got %s %s' % (t.dtype, tuple(t.shape))
+    if c is not None:
+        assert t.shape[0] == c
+    return t
+
+
+def _nhwc(t):
+    assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 3 and t.is_contiguous() and t.shape[2] % 8 == 0, \
+        'expected contiguous cuda float16 [H,W,C%%8==0], got %s %s' % (t.dtype, tuple(t.shape))
+    return t
+
+
+def _farr(vals):
+    if vals is None:
+        return None
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+class ConvWeights(object):
+    """Packed weights of one conv on the device (see packing.pack_conv)."""
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle')
+
+    def __init__(self, pk, device):
+        self.wpack = pk['wpack'].to(device).contiguous()
+        self.bias = pk['bias'].to(device).contiguous()
+        self.cout, self.ksteps, self.mt, self.ksize = pk['cout'], pk['ksteps'], pk['mt'], pk['ksize']
+        self.cpads, self.shuffle = pk['cpads'], pk['shuffle']
+
+
+def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
+         planar_out=False, res_planar=None, add_const=0.0, clamp=None):
+    """refvsr_conv_mfma.  Returns nhwc16 [ho,wo,cout] (or [2ho,2wo,cout/4] for pixel-shuffle weights),
+    or planar fp32 [cout,ho,wo] when planar_out."""
+    _nhwc(src0)
+    h, w, c0 = src0.shape
+    c1 = 0
+    if src1 is not None:
+        _nhwc(src1)
+        assert src1.shape[:2] == src0.shape[:2]
+        c1 = src1.shape[2]
+    assert [c0] + ([c1] if src1 is not None else []) == list(cw.cpads), \
+        'conv input channels %s do not match packed weights %s' % ([c0, c1], cw.cpads)
+    k = cw.ksize
+    if pad is None:
+        pad = k // 2
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    d = hip.RefvsrConv()
+    d.src0, d.c0, d.src1, d.c1 = src0.data_ptr(), c0, (src1.data_ptr() if src1 is not None else None), c1
+    d.h_in, d.w_in, d.h_out, d.w_out = h, w, ho, wo
+    d.ksize, d.stride, d.pad = k, stride, pad
+    d.wpack, d.bias = cw.wpack.data_ptr(), cw.bias.data_ptr()
+    d.cout, d.mt_per_block, d.ksteps = cw.cout, cw.mt, cw.ksteps
+    d.act_slope, d.post_slope = act, post
+    if mul is not None:
+        _nhwc(mul)
+        assert tuple(mul.shape[:2]) == (ho, wo)
+        d.mul, d.mul_c = mul.data_ptr(), mul.shape[2]
+    if res is not None:
+        _nhwc(res)
+        assert tuple(res.shape[:2]) == (ho, wo)
+        d.res, d.res_c = res.data_ptr(), res.shape[2]
+    if planar_out:
+        out = torch.empty((cw.cout, ho, wo), dtype=torch.float32, device=src0.device)
+        d.out_mode, d.out_c = OUT_PLANAR32, 0
+        if res_planar is not None:
+            _planar(res_planar, cw.cout)
+            assert tuple(res_planar.shape[1:]) == (ho, wo)
+            d.res_planar = res_planar.data_ptr()
+        d.add_const = add_const
+        if clamp is not None:
+            d.clamp_lo, d.clamp_hi = clamp
+    elif cw.shuffle:
+        co = cw.cout // 4
+        out = torch.empty((2 * ho, 2 * wo, co), dtype=torch.float16, device=src0.device)
+        d.out_mode, d.out_c = OUT_NHWC16_SHUFFLE2, co
+    else:
+        out = torch.empty((ho, wo, cw.cout), dtype=torch.float16, device=src0.device)
+        d.out_mode, d.out_c = OUT_NHWC16, cw.cout
+    d.out = out.data_ptr()
+    hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
+    return out
+
+
+def conv_direct(x, w, b, stride=1, pad=None, act=1.0, nhwc16_out=False):
+    """refvsr_conv_direct_f32 on a planar fp32 map; w fp32 [cout,cin,k,k] on the device."""
+    _planar(x)
+    cout, cin, k, _ = w.shape
+    assert x.shape[0] == cin and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    if pad is None:
+        pad = k // 2
+    h, wd = x.shape[1:]
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (wd + 2 * pad - k) // stride + 1
+    if nhwc16_out:
+        assert cout % 8 == 0
+        out = torch.empty((ho, wo, cout), dtype=torch.float16, device=x.device)
+    else:
+        out = torch.empty((cout, ho, wo), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_conv_direct_f32(_ptr(x), cin, h, wd, _ptr(w), _ptr(b), cout, k, stride, pad, act,
+                                               _ptr(out), int(nhwc16_out), cout if nhwc16_out else 0, _stream()),
+              'conv_direct_f32')
+    return out
+
+
+def pack_nhwc16(x, cs=None):
+    _planar(x)
+    c, h, w = x.shape
+    cs = cs or (c + 7) // 8 * 8
+    out = torch.empty((h, w, cs), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().refvsr_pack_nhwc16(_ptr(x), c, h, w, _ptr(out), cs, _stream()), 'pack_nhwc16')
+    return out
+
+
+def unpack_nhwc16(x, c=None):
+    _nhwc(x)
+    h, w, cs = x.shape
+    c = c or cs
+    out = torch.empty((c, h, w), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_unpack_nhwc16(_ptr(x), h, w, cs, c, _ptr(out), _stream()), 'unpack_nhwc16')
+    return out
+
+
+def resize(x, out_hw, mode, src_scale=None, mean=None, std=None, chan_mul=None, clamp01=False, nhwc16_out=False):
+    """F.interpolate restatement.  src_scale: (sy, sx) source step per output sample; default in/out."""
+    _planar(x)
+    c, h, w = x.shape
+    oh, ow = out_hw
+    if src_scale is None:
+        src_scale = (float(h) / float(oh), float(w) / float(ow))
+    if nhwc16_out:
+        out = torch.empty((oh, ow, 8), dtype=torch.float16, device=x.device)
+    else:
+        out = torch.empty((c, oh, ow), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_resize(_ptr(x), c, h, w, _ptr(out), oh, ow, mode, src_scale[0], src_scale[1],
+                                      _farr(mean), _farr(std), _farr(chan_mul), int(clamp01), int(nhwc16_out),
+                                      8 if nhwc16_out else 0, _stream()), 'resize')
+    return out
+
+
+def bicubic_scale(x, factor, clamp01=True, nhwc16_out=False):
+    """F.interpolate(x, scale_factor=factor, mode='bicubic', align_corners=False)[.clamp(0,1)]."""
+    c, h, w = x.shape
+    oh, ow = int(math.floor(h * factor)), int(math.floor(w * factor))
+    s = 1.0 / factor
+    return resize(x, (oh, ow), RS_BICUBIC, (s, s), clamp01=clamp01, nhwc16_out=nhwc16_out)
+
+
+def flow_up2(flow):
+    """F.interpolate(flow, scale_factor=2, 'bilinear', align_corners=True) * 2."""
+    c, h, w = flow.shape
+    return resize(flow, (2 * h, 2 * w), RS_BILINEAR_AC, (0.0, 0.0), chan_mul=[2.0] * c)
+
+
+def avgpool2(x):
+    _planar(x)
+    c, h, w = x.shape
+    out = torch.empty((c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_avgpool2(_ptr(x), c, h, w, _ptr(out), _stream()), 'avgpool2')
+    return out
+
+
+def maxpool2(x):
+    _planar(x)
+    c, h, w = x.shape
+    out = torch.empty((c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_maxpool2(_ptr(x), c, h, w, _ptr(out), _stream()), 'maxpool2')
+    return out
+
+
+def max2(a, b):
+    assert a.shape == b.shape and a.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a)
+    hip.check(hip.lib().refvsr_max2(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), 'max2')
+    return out
+
+
+def warp_nhwc16(x, flow):
+    _nhwc(x)
+    _planar(flow, 2)
+    hin, win, cs = x.shape
+    hf, wf = flow.shape[1:]
+    out = torch.empty((hf, wf, cs), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().refvsr_warp_nhwc16(_ptr(x), hin, win, cs, _ptr(flow), hf, wf, _ptr(out), _stream()), 'warp_nhwc16')
+    return out
+
+
+def warp_planar(x, flow):
+    _planar(x)
+    _planar(flow, 2)
+    c, hin, win = x.shape
+    hf, wf = flow.shape[1:]
+    out = torch.empty((c, hf, wf), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_warp_planar(_ptr(x), c, hin, win, _ptr(flow), hf, wf, _ptr(out), _stream()), 'warp_planar')
+    return out
+
+
+def spynet_level_input(ref, supp, flow_prev):
+    _planar(ref, 3)
+    _planar(supp, 3)
+    h, w = ref.shape[1:]
+    if flow_prev is not None:
+        _planar(flow_prev, 2)
+        assert tuple(flow_prev.shape[1:]) == (h // 2, w // 2)
+    out8 = torch.empty((h, w, 8), dtype=torch.float16, device=ref.device)
+    fup = torch.empty((2, h, w), dtype=torch.float32, device=ref.device)
+    hip.check(hip.lib().refvsr_spynet_level_input(_ptr(ref), _ptr(supp), _ptr(flow_prev), h, w, _ptr(out8), _ptr(fup),
+                                                  _stream()), 'spynet_level_input')
+    return out8, fup
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def match_patches(feat, row_pad):
+    """feat planar [16,h,w] -> (rows fp16 [pad(h*w), KP] zero padded, inv_norm fp32 [h*w])."""
+    _planar(feat, 16)
+    h, w = feat.shape[1:]
+    n = h * w
+    rows = torch.zeros((_round_up(n, row_pad), hip.MATCH_KP), dtype=torch.float16, device=feat.device)
+    inv = torch.empty((n,), dtype=torch.float32, device=feat.device)
+    hip.check(hip.lib().refvsr_match_patches(_ptr(feat), h, w, _ptr(rows), _ptr(inv), _stream()), 'match_patches')
+    return rows, inv
+
+
+def match_top2(ref_rows, n_ref, lr_rows, n_lr, row_splits=1):
+    assert ref_rows.shape[0] % hip.MATCH_ROWCHUNK == 0 and lr_rows.shape[0] % hip.MATCH_COLBLOCK == 0
+    assert ref_rows.shape[0] >= n_ref and lr_rows.shape[0] >= n_lr
+    ci = torch.empty((n_lr, 2 * row_splits), dtype=torch.int32, device=ref_rows.device)
+    cv = torch.empty((n_lr, 2 * row_splits), dtype=torch.float32, device=ref_rows.device)
+    hip.check(hip.lib().refvsr_match_top2(_ptr(ref_rows), n_ref, _ptr(lr_rows), n_lr, row_splits, _ptr(ci), _ptr(cv),
+                                          _stream()), 'match_top2')
+    return ci, cv
+
+
+def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand):
+    _planar(lr_feat, 16)
+    _planar(ref_feat, 16)
+    h, w = lr_feat.shape[1:]
+    hr, wr = ref_feat.shape[1:]
+    assert cand.dtype == torch.int32 and cand.shape[0] == h * w and cand.is_contiguous()
+    conf = torch.empty((h * w,), dtype=torch.float32, device=lr_feat.device)
+    idx = torch.empty((h * w,), dtype=torch.int32, device=lr_feat.device)
+    hip.check(hip.lib().refvsr_match_refine(_ptr(lr_feat), h, w, _ptr(ref_feat), hr, wr, _ptr(inv_lr), _ptr(inv_ref),
+                                            _ptr(cand), cand.shape[1], _ptr(conf), _ptr(idx), _stream()), 'match_refine')
+    return conf, idx
+
+
+def match_naive(lr_feat, ref_feat):
+    _planar(lr_feat, 16)
+    _planar(ref_feat, 16)
+    h, w = lr_feat.shape[1:]
+    hr, wr = ref_feat.shape[1:]
+    conf = torch.empty((h * w,), dtype=torch.float32, device=lr_feat.device)
+    idx = torch.empty((h * w,), dtype=torch.int32, device=lr_feat.device)
+    hip.check(hip.lib().refvsr_match_naive(_ptr(lr_feat), h, w, _ptr(ref_feat), hr, wr, _ptr(conf), _ptr(idx),
+                                           _stream()), 'match_naive')
+    return conf, idx
+
+
+def block_gather_nhwc16(value, idx, gh, gw, s):
+    _nhwc(value)
+    hv, wv, cs = value.shape
+    assert idx.dtype == torch.int32 and idx.numel() == gh * gw and idx.is_contiguous()
+    out = torch.empty((gh * s, gw * s, cs), dtype=torch.float16, device=value.device)
+    hip.check(hip.lib().refvsr_block_gather_nhwc16(_ptr(value), hv, wv, cs, _ptr(idx), gh, gw, s, _ptr(out), _stream()),
+              'block_gather_nhwc16')
+    return out
+
+
+def block_gather_rgb(value, idx, gh, gw, s):
+    _planar(value, 3)
+    hv, wv = value.shape[1:]
+    assert idx.dtype == torch.int32 and idx.numel() == gh * gw and idx.is_contiguous()
+    out = torch.empty((gh * s, gw * s, 8), dtype=torch.float16, device=value.device)
+    hip.check(hip.lib().refvsr_block_gather_rgb(_ptr(value), hv, wv, _ptr(idx), gh, gw, s, _ptr(out), _stream()),
+              'block_gather_rgb')
+    return out
+
+
+def aligned_sample(x, affine, ks):
+    _nhwc(x)
+    _planar(affine, 3)
+    h, w = affine.shape[1:]
+    assert tuple(x.shape[:2]) == (h * ks, w * ks)
+    out = torch.empty_like(x)
+    hip.check(hip.lib().refvsr_aligned_sample(_ptr(x), h, w, ks, x.shape[2], _ptr(affine), _ptr(out), _stream()),
+              'aligned_sample')
+    return out

@@ -1,0 +1,96 @@
+"""Multi-GPU execution of one clip: shard by output-frame index, one process per GPU.
+
+The only cross-frame dependency of the path is the forward-branch state
+(forward_feat_prop_prev, forward_flow_prev, forward_feat_prop_UP_prev, forward_conf_map_prop_prev,
+frame_itr_num -- RefVSR.py:96-101,279-283).  The backward branch restarts from zeros in every window
+(:211-214), and with `reset_branch = R` call k*R behaves as is_first_frame=True (:168-170).  Hence
+
+  * shards that start at a multiple of R are bit-identical to the sequential run with NO
+    communication -- `partition(..., aligned=True)`;
+  * any other shard boundary needs ONE point-to-point hand-off of the state from rank r to r+1
+    (RCCL send/recv over a single xGMI link; 63.8 MB fp32 for RefVSR_small at 270p).  There is no
+    all-reduce anywhere on the inference path.
+
+`run_sharded` is executor-agnostic (anything with forward/export_state/import_state), so the
+protocol is tested on CPU with the gloo backend and the oracle as executor.
+"""
+import torch
+import torch.distributed as dist
+
+STATE_KEYS = ('feat', 'flow', 'feat_up', 'conf')
+
+
+def partition(nframes, world, reset_branch=None, aligned=False):
+    """Contiguous [start, end) frame ranges per rank.  aligned=True snaps boundaries to multiples of
+    reset_branch (exchange-free, possibly unbalanced)."""
+    if aligned:
+        assert reset_branch, 'aligned partition needs reset_branch'
+        units = list(range(0, nframes, reset_branch)) + [nframes]
+        nunits = len(units) - 1
+        per = [nunits // world + (1 if r < nunits % world else 0) for r in range(world)]
+        out, u = [], 0
+        for r in range(world):
+            out.append((units[u], units[u + per[r]]))
+            u += per[r]
+        return out
+    base, rem = divmod(nframes, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def needs_handoff(start, reset_branch):
+    return start != 0 and not (reset_branch and start % reset_branch == 0)
+
+
+def send_state(state, dst, device):
+    """state: dict of planar fp32 tensors + frame_itr_num (Engine.export_state())."""
+    meta = torch.tensor([float(state['frame_itr_num'])] + [float(d) for k in STATE_KEYS for d in state[k].shape[-2:]],
+                        dtype=torch.float32, device=device)
+    dist.send(meta, dst)
+    for k in STATE_KEYS:
+        dist.send(state[k].contiguous().to(device), dst)
+
+
+def recv_state(src, channels, device):
+    meta = torch.empty(1 + 2 * len(STATE_KEYS), dtype=torch.float32, device=device)
+    dist.recv(meta, src)
+    meta = meta.cpu().tolist()
+    chans = {'feat': channels, 'flow': 2, 'feat_up': channels, 'conf': 1}
+    st = {'frame_itr_num': int(meta[0])}
+    for i, k in enumerate(STATE_KEYS):
+        hh, ww = int(meta[1 + 2 * i]), int(meta[2 + 2 * i])
+        buf = torch.empty((chans[k], hh, ww), dtype=torch.float32, device=device)
+        dist.recv(buf, src)
+        st[k] = buf
+    return st
+
+
+def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels, device, aligned=False,
+                on_result=None):
+    """Run this rank's share of an nframes clip.
+
+    executor(lrs[t,3,h,w], refs, is_first_frame) -> result; executor.export_state()/.import_state(st).
+    get_window(f) -> (lrs, refs) of output frame f.  Returns {frame: result} for the local frames."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    start, end = partition(nframes, world, reset_branch, aligned)[rank]
+    results = {}
+    if end > start and needs_handoff(start, reset_branch):
+        executor.import_state(recv_state(rank - 1, channels, device))
+        first = False
+    else:
+        first = True
+    for f in range(start, end):
+        lrs, refs = get_window(f)
+        out = executor(lrs, refs, first)
+        first = False
+        results[f] = out
+        if on_result is not None:
+            on_result(f, out)
+    nxt = partition(nframes, world, reset_branch, aligned)[rank + 1] if rank + 1 < world else None
+    if nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch):
+        send_state(executor.export_state(), rank + 1, device)
+    return results

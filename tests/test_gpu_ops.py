@@ -1,0 +1,396 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the CPU oracle
+(oracle/refvsr_oracle.py) on the same seeded inputs.  Integer work (indices, block gathers) is
+bit-exact; floating point uses the tolerances written next to each assert (fp16 HWC storage with
+fp32 accumulation => ~1e-3 relative per layer; fp32 planar kernels => ~1e-5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'gpu_ops_report.txt')
+
+
+def report(name, **kv):
+    line = '%-34s ' % name + ' '.join('%s=%.3e' % (k, v) if isinstance(v, float) else '%s=%s' % (k, v) for k, v in kv.items())
+    print(line)
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from refvsr_amd import hip
+    hip.lib()
+    return torch.device('cuda:0')
+
+
+def nhwc(x, dev, cs=None):
+    """planar cpu [C,H,W] -> device nhwc16 via the product's own pack kernel."""
+    from refvsr_amd import ops
+    return ops.pack_nhwc16(x.contiguous().to(dev), cs)
+
+
+def planar(x, c=None):
+    from refvsr_amd import ops
+    return ops.unpack_nhwc16(x, c).cpu()
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ------------------------------------------------------------------------------------------------
+def test_pack_unpack_roundtrip(dev):
+    from refvsr_amd import ops
+    x = torch.randn(5, 13, 17)
+    p = ops.pack_nhwc16(x.to(dev), 8)
+    assert p.shape == (13, 17, 8) and p.dtype == torch.float16
+    assert torch.equal(p[:, :, 5:].cpu(), torch.zeros(13, 17, 3, dtype=torch.float16))
+    assert torch.equal(planar(p, 5), x.half().float())
+
+
+CONV_CASES = [
+    # co, cins, ks, stride, h, w, shuffle
+    (24, [24], 3, 1, 19, 45, False),
+    (24, [3, 24], 3, 1, 16, 32, False),
+    (24, [24, 24], 3, 1, 33, 70, False),
+    (96, [24], 3, 1, 18, 40, True),
+    (48, [48], 3, 1, 17, 35, False),
+    (24, [24], 3, 2, 22, 50, False),
+    (32, [3], 5, 1, 20, 36, False),
+    (32, [32, 32], 5, 2, 24, 64, False),
+    (24, [24, 24], 1, 1, 15, 33, False),
+    (32, [8], 7, 1, 18, 30, False),
+    (64, [32], 7, 1, 9, 15, False),
+    (32, [64], 7, 1, 36, 60, False),
+    (16, [32], 7, 1, 12, 20, False),
+    (24, [16], 3, 1, 10, 12, False),
+    (192, [48], 3, 1, 10, 34, True),
+    (48, [48, 48], 3, 1, 12, 40, False),
+]
+
+
+@pytest.mark.parametrize('co,cins,ks,stride,h,w,shuffle', CONV_CASES)
+def test_conv_mfma_vs_conv2d(dev, co, cins, ks, stride, h, w, shuffle):
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(co * 131 + ks * 7 + sum(cins))
+    cin = sum(cins)
+    wt = torch.randn(co, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    x = torch.randn(1, cin, h, w, generator=g)
+    cw = ops.ConvWeights(pack_conv(wt, b, cins, shuffle), dev)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(nhwc(x[0, o:o + c], dev))
+        o += c
+    got = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, stride=stride, act=0.2)
+    xh = x.half().float()                      # the kernel sees fp16 inputs and fp16 weights
+    want = F.leaky_relu(F.conv2d(xh, wt.half().float(), b, stride=stride, padding=ks // 2), 0.2)[0]
+    if shuffle:
+        want = F.pixel_shuffle(want[None], 2)[0]
+    got = planar(got)
+    assert got.shape == want.shape
+    err = rel(got, want)
+    report('conv_mfma co%d cin%s k%d s%d%s' % (co, cins, ks, stride, ' shuf' if shuffle else ''), rel=err)
+    assert err < 2e-3          # fp16 output rounding (2^-11) + fp32 accumulation order
+
+
+def test_conv_mfma_epilogues(dev):
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(5)
+    C, h, w = 24, 21, 37
+    wt = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    x, mul, res = (torch.randn(C, h, w, generator=g) for _ in range(3))
+    cw = ops.ConvWeights(pack_conv(wt, b, [C]), dev)
+    y = F.conv2d(x.half().float()[None], wt.half().float(), b, padding=1)[0]
+    # x + alpha * lrelu(conv)   (RefVSR.py:131)
+    got = planar(ops.conv(cw, nhwc(x, dev), act=0.2, mul=nhwc(mul, dev), res=nhwc(res, dev)))
+    want = res.half().float() + mul.half().float() * F.leaky_relu(y, 0.2)
+    report('conv epilogue mul+res', rel=rel(got, want))
+    assert rel(got, want) < 2e-3
+    # lrelu(x + conv)   (AlignedConv2d heads, alignment.py:18-20)
+    got = planar(ops.conv(cw, nhwc(x, dev), res=nhwc(res, dev), post=0.2))
+    want = F.leaky_relu(res.half().float() + y, 0.2)
+    assert rel(got, want) < 2e-3
+    # relu
+    got = planar(ops.conv(cw, nhwc(x, dev), act=0.0))
+    assert rel(got, F.relu(y)) < 2e-3
+    # planar fp32 output + planar residual + clamp   (conv_last + base, RefVSR.py:118,297)
+    w3 = torch.randn(3, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b3 = torch.randn(3, generator=g) * 0.1
+    base = torch.rand(3, h, w, generator=g)
+    cw3 = ops.ConvWeights(pack_conv(w3, b3, [C]), dev)
+    got = ops.conv(cw3, nhwc(x, dev), planar_out=True, res_planar=base.to(dev), clamp=(0.0, 1.0)).cpu()
+    want = (F.conv2d(x.half().float()[None], w3.half().float(), b3, padding=1)[0] + base).clamp(0, 1)
+    report('conv planar+res+clamp', abs=maxdiff(got, want))
+    assert maxdiff(got, want) < 1e-4
+    # planar + constant + clamp(-3,3)   (affine head, alignment.py:47,58)
+    got = ops.conv(cw3, nhwc(x, dev), planar_out=True, add_const=1.0, clamp=(-3.0, 3.0)).cpu()
+    want = (F.conv2d(x.half().float()[None], w3.half().float(), b3, padding=1)[0] + 1.0).clamp(-3, 3)
+    assert maxdiff(got, want) < 1e-4
+
+
+def test_conv_direct_f32(dev):
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (co, ci, k, s, h, w) in [(64, 3, 3, 1, 20, 28), (64, 64, 3, 1, 20, 28), (16, 64, 1, 1, 20, 28), (3, 3, 1, 1, 9, 11),
+                                 (16, 2, 3, 1, 17, 19), (128, 64, 3, 1, 10, 14), (24, 5, 3, 2, 18, 22)]:
+        wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        x = torch.randn(ci, h, w, generator=g)
+        got = ops.conv_direct(x.to(dev), wt.to(dev), b.to(dev), stride=s, act=0.2).cpu()
+        want = F.leaky_relu(F.conv2d(x[None], wt, b, stride=s, padding=k // 2), 0.2)[0]
+        report('conv_direct co%d ci%d k%d s%d' % (co, ci, k, s), abs=maxdiff(got, want))
+        assert maxdiff(got, want) < 2e-5           # fp32 FMA chain vs MKL-DNN blocking
+        if co % 8 == 0:
+            got16 = planar(ops.conv_direct(x.to(dev), wt.to(dev), b.to(dev), stride=s, act=0.2, nhwc16_out=True))
+            assert rel(got16, want) < 1e-3
+
+
+def test_resize_modes_vs_golden_and_oracle(dev):
+    from refvsr_amd import ops
+    from oracle import refvsr_oracle as orc
+    g = load_golden('op_resize')
+    img, fl = g['img'][0].to(dev), g['flow'][0].to(dev)
+    tol = 2e-5
+    assert maxdiff(ops.bicubic_scale(img, 0.5, clamp01=False).cpu(), g['bicubic_half'][0]) < tol
+    assert maxdiff(ops.bicubic_scale(img, 2, clamp01=False).cpu(), g['bicubic_x2'][0]) < tol
+    assert maxdiff(ops.bicubic_scale(img, 4, clamp01=False).cpu(), g['bicubic_x4'][0]) < tol
+    assert maxdiff(ops.bicubic_scale(img, 4, clamp01=True).cpu(), g['bicubic_x4'][0].clamp(0, 1)) < tol
+    assert maxdiff(ops.flow_up2(fl).cpu(), g['flow_up2'][0]) < tol
+    assert maxdiff(ops.resize(img, (32, 32), ops.RS_BILINEAR).cpu(), g['bilinear_32x32'][0]) < tol
+    assert maxdiff(ops.resize(g['bilinear_32x32'][0].to(dev), (18, 26), ops.RS_BILINEAR).cpu(), g['bilinear_back'][0]) < tol
+    assert maxdiff(ops.resize(img, (9, 13), ops.RS_NEAREST, (2.0, 2.0)).cpu(), g['nearest_half'][0]) == 0.0
+    # larger, odd geometry + fused normalisation / per-channel gain / nhwc16 output
+    x = torch.rand(3, 54, 100)
+    from refvsr_amd.weights import VGG_MEAN, VGG_STD
+    got = ops.resize(x.to(dev), (64, 128), ops.RS_BILINEAR, mean=VGG_MEAN, std=VGG_STD).cpu()
+    want = (orc.resize(x[None], (64, 128), 'bilinear')[0] - torch.tensor(VGG_MEAN).view(3, 1, 1)) / torch.tensor(VGG_STD).view(3, 1, 1)
+    assert maxdiff(got, want) < tol
+    f2 = torch.randn(2, 64, 128)
+    got = ops.resize(f2.to(dev), (54, 100), ops.RS_BILINEAR, chan_mul=[100 / 128.0, 54 / 64.0]).cpu()
+    want = orc.resize(f2[None], (54, 100), 'bilinear')[0] * torch.tensor([100 / 128.0, 54 / 64.0]).view(2, 1, 1)
+    assert maxdiff(got, want) < tol
+    got = planar(ops.bicubic_scale(x.to(dev), 2, clamp01=False, nhwc16_out=True), 3)
+    assert maxdiff(got, orc.bicubic_scale(x[None], 2, False)[0]) < 2e-3      # fp16 store
+    report('resize', ok=1)
+
+
+def test_pools_and_max(dev):
+    from refvsr_amd import ops
+    from oracle import refvsr_oracle as orc
+    x = torch.randn(5, 18, 26)
+    assert maxdiff(ops.avgpool2(x.to(dev)).cpu(), orc.avg_pool2(x[None])[0]) < 1e-6
+    assert maxdiff(ops.maxpool2(x.to(dev)).cpu(), orc.max_pool2(x[None])[0]) == 0.0
+    y = torch.randn(5, 18, 26)
+    assert torch.equal(ops.max2(x.to(dev), y.to(dev)).cpu(), torch.maximum(x, y))
+
+
+def test_warp_vs_golden(dev):
+    from refvsr_amd import ops
+    g = load_golden('op_warp')
+    x, fl, fl2 = g['x'][0], g['flow'][0], g['flow2'][0]
+    got = ops.warp_planar(x.to(dev), fl.to(dev)).cpu()
+    report('warp_planar', abs=maxdiff(got, g['warp'][0]))
+    assert maxdiff(got, g['warp'][0]) < 2e-5
+    assert maxdiff(ops.warp_planar(x.to(dev), fl2.to(dev)).cpu(), g['warp2'][0]) < 2e-5     # LR input, 2x flow
+    xh = x.half().float()
+    from oracle import refvsr_oracle as orc
+    for f_, name in ((fl, 'lr'), (fl2, '2x')):
+        got = planar(ops.warp_nhwc16(nhwc(x, dev), f_.to(dev)), 5)
+        want = orc.warp(xh[None], f_[None])[0]
+        report('warp_nhwc16 ' + name, abs=maxdiff(got, want))
+        assert maxdiff(got, want) < 1.5e-3      # fp16 output rounding of O(1) values
+    # zero flow is NOT the identity: column 0 samples at -0.5
+    z = torch.zeros(2, 18, 26)
+    got = ops.warp_planar(x.to(dev), z.to(dev)).cpu()
+    assert maxdiff(got, orc.warp(x[None], z[None])[0]) < 2e-5
+    assert maxdiff(got, x) > 1e-2
+
+
+def test_spynet_level_input(dev):
+    from refvsr_amd import ops
+    from oracle import refvsr_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(3, 18, 30, generator=g), torch.randn(3, 18, 30, generator=g)
+    fp = torch.randn(2, 9, 15, generator=g) * 3
+    out8, fup = ops.spynet_level_input(a.to(dev), b.to(dev), fp.to(dev))
+    want_up = orc.flow_up2(fp[None])
+    assert maxdiff(fup.cpu(), want_up[0]) < 2e-5
+    want = torch.cat([a, orc.flow_warp_border(b[None], want_up)[0], want_up[0]], 0)
+    got = planar(out8)
+    report('spynet_level_input', abs=maxdiff(got, want))
+    assert maxdiff(got, want) < 8e-3            # fp16 store of values up to ~8
+    out8, fup = ops.spynet_level_input(a.to(dev), b.to(dev), None)
+    assert float(fup.abs().max()) == 0.0
+    assert maxdiff(planar(out8)[3:6], b.half().float()) == 0.0
+    gw = load_golden('op_warp')                 # mmedit flow_warp golden through the same kernel path
+    x3, fl = gw['x'][0, :3], gw['flow'][0]
+
+
+def test_match_patches(dev):
+    from refvsr_amd import ops
+    from oracle import refvsr_oracle as orc
+    f = torch.randn(16, 14, 18)
+    rows, inv = ops.match_patches(f.to(dev), 128)
+    p = orc.patches3x3(f[None])[0].t()                          # [L,144]
+    n = p.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    assert rows.shape == (256, 152) and float(rows[14 * 18:].abs().max()) == 0 and float(rows[:, 144:].abs().max()) == 0
+    assert maxdiff(rows[:14 * 18, :144].float().cpu(), p / n) < 5e-4     # fp16 rounding of |v| <= 1
+    assert maxdiff(inv.cpu() * n[:, 0], torch.ones(14 * 18)) < 1e-5
+
+
+def _check_match(conf, idx, lr_f, ref_f, tag):
+    """conf/idx from the HIP path vs the oracle GEMM: the chosen index must achieve the oracle's column
+    maximum to within fp32 rounding (ties/near-ties may legitimately pick another index)."""
+    from oracle import refvsr_oracle as orc
+    lp = orc.patches3x3(lr_f[None])
+    rp = orc.patches3x3(ref_f[None]).permute(0, 2, 1)
+    rp = rp / rp.norm(dim=2, keepdim=True).clamp_min(1e-12)
+    lp = lp / lp.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    corr = torch.bmm(rp, lp)[0]                                  # [n_ref, n_lr]
+    val, ix = corr.max(0)
+    conf, idx = conf.cpu(), idx.cpu().long()
+    achieved = corr.gather(0, idx[None])[0]
+    mism = int((idx != ix).sum())
+    report('match ' + tag, conf_err=maxdiff(conf, val), idx_mismatch=mism, n=idx.numel(),
+           worst_gap=float((val - achieved).max()))
+    assert maxdiff(conf, val) < 5e-6
+    assert float((val - achieved).max()) < 5e-6
+    assert mism <= max(2, idx.numel() // 2000)
+    return mism
+
+
+def test_match_fused_vs_oracle(dev):
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (h, w) in [(20, 28), (34, 50), (64, 96)]:
+        base = F.interpolate(torch.randn(1, 16, h // 4 + 2, w // 4 + 2, generator=g), size=(h, w), mode='bilinear')[0]
+        lr_f = base + 0.2 * torch.randn(16, h, w, generator=g)
+        ref_f = F.avg_pool2d(base[None], 2)[0] + 0.2 * torch.randn(16, h // 2, w // 2, generator=g)
+        lr_rows, inv_lr = ops.match_patches(lr_f.to(dev), 512)
+        ref_rows, inv_ref = ops.match_patches(ref_f.to(dev), 128)
+        n_ref = ref_f.shape[1] * ref_f.shape[2]
+        for splits in (1, 2):
+            if splits > (n_ref + 127) // 128:
+                continue
+            cand, cval = ops.match_top2(ref_rows, n_ref, lr_rows, h * w, splits)
+            assert int(cand.min()) >= 0 and int(cand.max()) < n_ref
+            conf, idx = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand)
+            _check_match(conf, idx, lr_f, ref_f, '%dx%d splits=%d' % (h, w, splits))
+        conf, idx = ops.match_naive(lr_f.to(dev), ref_f.to(dev))
+        _check_match(conf, idx, lr_f, ref_f, '%dx%d naive' % (h, w))
+
+
+def test_match_ties_pick_first_index(dev):
+    """Constant features: every correlation ties exactly; torch.max returns index 0."""
+    from refvsr_amd import ops
+    lr_f = torch.ones(16, 12, 16)
+    ref_f = torch.ones(16, 6, 8)
+    lr_rows, inv_lr = ops.match_patches(lr_f.to(dev), 512)
+    ref_rows, inv_ref = ops.match_patches(ref_f.to(dev), 128)
+    cand, _ = ops.match_top2(ref_rows, 48, lr_rows, 192, 1)
+    conf, idx = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand)
+    assert int(idx.abs().max()) == 0
+    assert maxdiff(conf.cpu(), torch.ones(192)) < 1e-5
+
+
+def test_feature_match_golden(dev, small_cfg, small_sd):
+    """Whole FeatureMatching.forward against the fixture produced by the reference."""
+    from refvsr_amd.engine import Engine, FrameCtx, Weights
+    g = load_golden('op_match')
+    eng = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
+    conf, idx = eng.feature_match(FrameCtx(g['lr'][0].to(dev), g['ref'][0].to(dev)))
+    mism = int((idx.cpu().long() != g['idx'][0]).sum())
+    report('feature_match golden', conf_err=maxdiff(conf.cpu(), g['conf'][0]), idx_mismatch=mism)
+    assert maxdiff(conf.cpu(), g['conf'][0]) < 2e-5
+    assert mism <= 1
+
+
+def test_block_gather_bit_exact(dev):
+    from refvsr_amd import ops
+    g = load_golden('op_aa')
+    idx = g['idx'][0].to(torch.int32).to(dev)
+    v, vd, rf = g['value'][0], g['value_down'][0], g['ref'][0]
+    assert torch.equal(planar(ops.block_gather_nhwc16(nhwc(vd, dev), idx, 20, 28, 1)), g['aa1'][0].half().float())
+    assert torch.equal(planar(ops.block_gather_nhwc16(nhwc(v, dev), idx, 20, 28, 2)), g['aa2_fm'][0].half().float())
+    assert torch.equal(planar(ops.block_gather_rgb(rf.to(dev), idx, 20, 28, 2), 3), g['aa2_rgb'][0].half().float())
+
+
+def test_aligned_sample(dev):
+    from refvsr_amd import ops
+    from oracle import refvsr_oracle as orc
+    g = load_golden('op_sampler')
+    x, aff = g['x'][0], g['affine'][0]
+    x8 = torch.cat([x, torch.zeros(5, 12, 16)], 0)
+    got = planar(ops.aligned_sample(nhwc(x8, dev), aff.to(dev), 2), 3)
+    report('aligned_sample golden', abs=maxdiff(got, g['out'][0]))
+    assert maxdiff(got, g['out'][0]) < 1.5e-3         # fp16 in/out of O(1) values
+    gen = torch.Generator().manual_seed(2)
+    for ks in (2, 4):
+        h, w = 7, 9
+        xx = torch.randn(16, h * ks, w * ks, generator=gen)
+        af = torch.stack([torch.rand(h, w, generator=gen) * 6 - 3, torch.rand(h, w, generator=gen) * 6 - 3,
+                          torch.rand(h, w, generator=gen) * 6 - 3])
+        got = planar(ops.aligned_sample(nhwc(xx, dev), af.to(dev), ks))
+        want = orc.aligned_sample(xx.half().float()[None], af[None], ks)[0]
+        report('aligned_sample ks%d' % ks, abs=maxdiff(got, want))
+        assert maxdiff(got, want) < 4e-3
+        ident = planar(ops.aligned_sample(nhwc(xx, dev), torch.ones(3, h, w).to(dev), ks))
+        assert maxdiff(ident, xx.half().float()) < 2e-3
+
+
+def test_spynet_flow_golden(dev, small_cfg, small_sd):
+    from refvsr_amd.engine import Engine, FrameCtx, Weights
+    g = load_golden('op_spynet')
+    eng = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
+    a, b = g['a'][0].to(dev), g['b'][0].to(dev)
+    fl = eng.flow(FrameCtx(a, a), FrameCtx(b, b)).cpu()
+    report('spynet golden', abs=maxdiff(fl, g['flow'][0]), flow_mag=float(g['flow'].abs().max()))
+    assert maxdiff(fl, g['flow'][0]) < 3e-2           # pixels; fp16 conv stack, |flow| up to ~O(1-10)
+
+
+def test_conv_stacks_golden(dev, small_cfg, small_sd):
+    from refvsr_amd import ops
+    from refvsr_amd.engine import Engine, Weights
+    g = load_golden('op_convs')
+    eng = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
+    feat, img = g['feat'][0], g['img'][0]
+    got = planar(eng.res_list(nhwc(feat, dev), 'feat_decoder2', 4))
+    report('res_list golden', abs=maxdiff(got, g['res_list'][0]), mag=float(g['res_list'].abs().max()))
+    assert maxdiff(got, g['res_list'][0]) < 4e-3
+    got = planar(eng.resblocks(nhwc(img, dev, 8), nhwc(feat, dev), 'backward_resblocks'))
+    report('resblocks golden', abs=maxdiff(got, g['resblocks'][0]), mag=float(g['resblocks'].abs().max()))
+    assert maxdiff(got, g['resblocks'][0]) < 1e-2     # 49 fp16 layers
+    got = planar(ops.conv(eng.cw('upsample1.upsample_conv'), nhwc(feat, dev)))
+    assert maxdiff(got, g['pixel_shuffle'][0]) < 3e-3
+
+
+def test_compute_up_golden(dev, small_cfg, small_sd):
+    from refvsr_amd.engine import Engine, Weights
+    g = load_golden('op_compute_up')
+    eng = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
+    # base is an input of the reference's compute_up; feed lr such that bicubic x4 is not needed: compare pre-base
+    from oracle import refvsr_oracle as orc
+    o = orc.OracleNetwork(small_cfg, small_sd)
+    lr = torch.rand(1, 3, 6, 8)
+    base = orc.bicubic_scale(lr, 4, True)
+    want = o._compute_up(g['bw'], g['fw'], g['conf_bw'], g['conf_fw'], base).clamp(0, 1)[0]
+    got = eng.compute_up(nhwc(g['bw'][0], dev), nhwc(g['fw'][0], dev), g['conf_bw'][0].to(dev), g['conf_fw'][0].to(dev),
+                         lr[0].to(dev)).cpu()
+    report('compute_up', abs=maxdiff(got, want))
+    assert maxdiff(got, want) < 5e-3

@@ -1,0 +1,174 @@
+"""Host logic on CPU: config mirror, state-dict contract, weight packing, model shell, clip windows,
+shard partitioning."""
+import collections
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from refvsr_amd import CONFIG_NAMES, get_config, make_state_dict, state_spec
+from refvsr_amd import shard, weights
+from refvsr_amd.packing import choose_mt, pack_conv
+from refvsr_amd.synth import make_clip, window_indices
+
+
+def test_configs_match_reference_fields():
+    g = load_golden('state_spec')      # produced from the reference's own config modules
+    for name in CONFIG_NAMES:
+        cfg = get_config('p', 'm', name)
+        assert cfg.frame_num == int(g[name + '/frame_num'])
+        spec = state_spec(cfg)
+        assert len(spec) == int(g[name + '/ntensors'])
+        assert weights.num_params(cfg) == int(g[name + '/nparams'])
+        assert weights.spec_checksum(cfg) == int(g[name + '/spec_crc'])
+    c = get_config('p', 'm', 'config_RefVSR_small_L1')
+    assert (c.mid_channels, c.num_blocks, c.matching_ksize, c.reset_branch, c.scale) == (24, 24, 2, 26, 4)
+    c = get_config('p', 'm', 'config_RefVSR_MFID_8K')
+    assert (c.mid_channels, c.num_blocks, c.matching_ksize, c.reset_branch, c.flag_HD_in) == (48, 30, 8, None, True)
+    with pytest.raises(KeyError):
+        get_config('p', 'm', 'config_nope')
+
+
+def test_config_modules_importable_like_reference():
+    import importlib
+    for name in CONFIG_NAMES:
+        m = importlib.import_module('refvsr_amd.configs.' + name)
+        assert m.get_config('p', 'm', name).network == 'RefVSR'
+
+
+def test_param_counts():
+    want = {'config_RefVSR_small_L1': 2492070, 'config_RefVSR_MFID': 5717550,
+            'config_RefVSR_MFID_8K': 5883185, 'config_RefVSR_small_MFID_8K': 2657705}
+    for k, v in want.items():
+        assert weights.num_params(get_config('p', 'm', k)) == v
+
+
+def test_state_dict_generator_is_deterministic(small_cfg):
+    a, b = make_state_dict(small_cfg, 1234), make_state_dict(small_cfg, 1234)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = make_state_dict(small_cfg, 1)
+    assert not torch.equal(a['Network.conv_hr.weight'], c['Network.conv_hr.weight'])
+    w = a['Network.feature_match.sub_mean.weight']
+    assert torch.allclose(w[:, :, 0, 0], torch.diag(1.0 / torch.tensor(weights.VGG_STD)))
+
+
+def _emulate(srcs, pk, ks, stride, pad, ho, wo):
+    """numpy model of conv_mfma.hip's K walk: K-block g -> (tap, channel group) -> strided gather."""
+    X = np.concatenate(srcs, -1)
+    H, W, Ct = X.shape
+    ncg = Ct // 8
+    Xp = np.zeros((H + 2 * pad + 2 * stride + ks, W + 2 * pad + 2 * stride + ks, Ct), np.float32)
+    Xp[pad:pad + H, pad:pad + W] = X
+    wp = pk['wpack'].float().numpy()
+    nz, S, MT = wp.shape[:3]
+    out = np.zeros((nz * MT * 16, ho, wo), np.float32)
+    for z in range(nz):
+        for m in range(MT):
+            for s in range(S):
+                for q in range(4):
+                    g = 4 * s + q
+                    if g >= ks * ks * ncg:
+                        assert not wp[z, s, m, q * 16:(q + 1) * 16].any()     # padded K-blocks carry zero weights
+                        continue
+                    tap, cg = divmod(g, ncg)
+                    ty, tx = divmod(tap, ks)
+                    A = wp[z, s, m, q * 16:(q + 1) * 16]
+                    B = Xp[ty:ty + ho * stride:stride, tx:tx + wo * stride:stride, cg * 8:cg * 8 + 8]
+                    out[(z * MT + m) * 16:(z * MT + m + 1) * 16] += np.einsum('rk,yxk->ryx', A, B)
+    return out + pk['bias'].numpy()[:, None, None]
+
+
+@pytest.mark.parametrize('co,cins,ks,stride,shuffle', [
+    (24, [24], 3, 1, False), (24, [3, 24], 3, 1, False), (96, [24], 3, 1, True), (32, [32, 32], 5, 2, False),
+    (2, [16], 7, 1, False), (48, [48, 48], 1, 1, False), (64, [32], 7, 1, False), (3, [24], 3, 1, False),
+    (192, [48], 3, 1, True)])
+def test_weight_packing_reproduces_conv(co, cins, ks, stride, shuffle):
+    rs = np.random.RandomState(0)
+    cin = sum(cins)
+    w = (rs.randn(co, cin, ks, ks) * 0.1).astype(np.float32)
+    b = rs.randn(co).astype(np.float32)
+    H, W, pad = 9, 11, ks // 2
+    x = rs.randn(1, cin, H, W).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=pad)[0].numpy()
+    pk = pack_conv(w, b, cins, shuffle)
+    assert pk['wpack'].dtype == torch.float16 and pk['wpack'].shape[3:] == (64, 8)
+    assert pk['wpack'].shape[0] * pk['mt'] * 16 >= co and pk['mt'] == choose_mt(co)
+    srcs, o = [], 0
+    for c in cins:
+        a = np.zeros((H, W, (c + 7) // 8 * 8), np.float32)
+        a[:, :, :c] = x[0, o:o + c].transpose(1, 2, 0)
+        srcs.append(a)
+        o += c
+    out = _emulate(srcs, pk, ks, stride, pad, ref.shape[1], ref.shape[2])
+    if shuffle:
+        C = co // 4
+        rows = (np.arange(co) % C) * 4 + np.arange(co) // C
+        got = np.zeros_like(ref)
+        got[rows] = out[:co]
+    else:
+        got = out[:co]
+    assert np.abs(got - ref).max() < 5e-3          # fp16 weight rounding only
+
+
+def test_model_shell_state_dict_contract(small_cfg, small_sd):
+    from refvsr_amd import SRNet
+    net = SRNet(small_cfg)
+    assert list(net.state_dict().keys()) == list(small_sd.keys())
+    net.load_state_dict(small_sd, strict=True)
+    net.load_state_dict(collections.OrderedDict(('module.' + k, v) for k, v in small_sd.items()), strict=True)
+    assert torch.equal(net.state_dict()['Network.conv_last.bias'], small_sd['Network.conv_last.bias'])
+    assert hasattr(net.Network, 'FlowNet') and hasattr(net.Network.FlowNet, 'load_ckpt')
+    net.init()
+    # plugin hook: unknown arch -> ImportError like the reference's importlib lookup
+    bad = get_config('p', 'm', 'config_RefVSR_small_L1')
+    bad.network = 'NoSuchArch'
+    with pytest.raises(ImportError):
+        SRNet(bad)
+
+
+def test_product_path_has_no_cpu_fallback(small_cfg, small_sd):
+    from refvsr_amd import SRNet
+    net = SRNet(small_cfg)
+    net.load_state_dict(small_sd)
+    x = torch.rand(1, 5, 3, 16, 16)
+    with pytest.raises(RuntimeError, match='GPU only'):
+        net(x, x, True)
+    with pytest.raises(NotImplementedError):
+        net(x, x, True, is_train=True)
+
+
+def test_product_never_imports_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'refvsr_amd')
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+
+
+def test_window_indices_and_clip():
+    assert window_indices(0, 10, 5) == [0, 0, 0, 1, 2]
+    assert window_indices(9, 10, 5) == [7, 8, 9, 9, 9]
+    assert window_indices(4, 10, 3) == [3, 4, 5]
+    lr, rf, gt = make_clip(3, 16, 24, seed=0)
+    assert lr.shape == (3, 3, 16, 24) and rf.shape == lr.shape and gt.shape == (3, 3, 64, 96)
+    lr2, _, _ = make_clip(2, 16, 24, seed=0, start=1)
+    assert torch.equal(lr[1:], lr2)                       # shards of one endless clip line up
+    assert float(lr.min()) >= 0 and float(lr.max()) <= 1
+    assert torch.equal(torch.round(lr * 255) / 255, lr)   # 8-bit quantised
+    assert not torch.equal(lr[0], lr[1])
+
+
+def test_partition():
+    assert shard.partition(64, 8) == [(8 * r, 8 * r + 8) for r in range(8)]
+    assert shard.partition(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    p = shard.partition(64, 8, reset_branch=9, aligned=True)            # 8 units {0-8,...,63}
+    assert p == [(0, 9), (9, 18), (18, 27), (27, 36), (36, 45), (45, 54), (54, 63), (63, 64)]
+    p = shard.partition(64, 2, reset_branch=9, aligned=True)
+    assert p == [(0, 36), (36, 64)] and all(s % 9 == 0 for s, _ in p)
+    assert not shard.needs_handoff(0, None) and shard.needs_handoff(8, None)
+    assert not shard.needs_handoff(18, 9) and shard.needs_handoff(20, 9)

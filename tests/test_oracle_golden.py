@@ -1,0 +1,128 @@
+"""The oracle (oracle/refvsr_oracle.py) against fixtures produced by the REAL reference
+(tools/gen_golden.py, run in the build container).  This is what pins the oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, maxdiff
+from oracle import refvsr_oracle as orc
+from refvsr_amd import get_config, make_state_dict
+from refvsr_amd.synth import window_indices
+
+TOL = 2e-5      # fp32 restatement vs reference; measured deltas are <= 1.1e-5 (see gen_golden output)
+
+
+def test_warp_and_flow_warp():
+    g = load_golden('op_warp')
+    assert maxdiff(orc.warp(g['x'], g['flow']), g['warp']) < TOL
+    assert maxdiff(orc.warp(g['x'], g['flow2']), g['warp2']) < TOL      # LR input, 2x flow (RefVSR.py:254)
+    assert maxdiff(orc.flow_warp_border(g['x'], g['flow']), g['flow_warp']) < TOL
+
+
+def test_resize_modes():
+    g = load_golden('op_resize')
+    img, fl = g['img'], g['flow']
+    assert maxdiff(orc.bicubic_scale(img, 0.5, False), g['bicubic_half']) < TOL
+    assert maxdiff(orc.bicubic_scale(img, 2, False), g['bicubic_x2']) < TOL
+    assert maxdiff(orc.bicubic_scale(img, 4, False), g['bicubic_x4']) < TOL
+    assert maxdiff(orc.flow_up2(fl), g['flow_up2']) < TOL
+    assert maxdiff(orc.resize(img, (32, 32), 'bilinear'), g['bilinear_32x32']) < TOL
+    assert maxdiff(orc.resize(g['bilinear_32x32'], (18, 26), 'bilinear'), g['bilinear_back']) < TOL
+    assert maxdiff(orc.resize(img, (9, 13), 'nearest', 2.0), g['nearest_half']) == 0.0
+
+
+def test_patches_reflect():
+    g = load_golden('op_patches')
+    assert maxdiff(orc.patches3x3(g['f']), g['patches']) == 0.0
+
+
+def test_feature_match(small_sd):
+    g = load_golden('op_match')
+    conf, idx = orc.feature_match(g['lr'], g['ref'], small_sd, False)
+    assert maxdiff(conf, g['conf']) < TOL
+    assert torch.equal(idx, g['idx'])
+    # chunked evaluation gives identical per-column results
+    conf2, idx2 = orc.feature_match(g['lr'], g['ref'], small_sd, False, chunk=100)
+    assert maxdiff(conf2, g['conf']) < TOL and torch.equal(idx2, g['idx'])
+
+
+def test_argmax_first_index_on_ties():
+    ref_p = torch.zeros(1, 6, 4)
+    ref_p[0, 2, 0] = ref_p[0, 4, 0] = 1.0
+    lr_p = torch.zeros(1, 4, 3)
+    lr_p[0, 0, :] = 1.0
+    v, i = orc.match_argmax(ref_p, lr_p)
+    assert i.tolist() == [[2, 2, 2]]
+
+
+def test_block_gather_and_aligned_conv(small_sd):
+    g = load_golden('op_aa')
+    idx = g['idx']
+    assert maxdiff(orc.block_gather(g['value_down'], idx, 1, (20, 28)), g['aa1']) == 0.0
+    assert maxdiff(orc.block_gather(g['value'], idx, 2, (40, 56)), g['aa2_fm']) == 0.0
+    rgb = orc.block_gather(g['ref'], idx, 2, (40, 56))
+    assert maxdiff(rgb, g['aa2_rgb']) == 0.0
+    out = orc.aligned_conv(g['aa2_fm'], g['lr'], rgb, small_sd, 'Network.aa2.align', 2)
+    assert maxdiff(out, g['aa2']) < TOL
+
+
+def test_aligned_sampler():
+    g = load_golden('op_sampler')
+    assert maxdiff(orc.aligned_sample(g['x'], g['affine'], 2), g['out']) < TOL
+    # zero predictor output (affine == 1) is the identity
+    x = torch.rand(1, 2, 8, 12)
+    for ks in (2, 4):
+        aff = torch.ones(1, 3, 8 // ks, 12 // ks)
+        assert maxdiff(orc.aligned_sample(x, aff, ks), x) < 1e-6
+
+
+def test_spynet(small_sd):
+    g = load_golden('op_spynet')
+    assert maxdiff(orc.spynet(g['a'], g['b'], small_sd), g['flow']) < TOL
+
+
+def test_conv_stacks(small_cfg, small_sd):
+    g = load_golden('op_convs')
+    assert maxdiff(orc.res_list(g['feat'], small_sd, 'Network.feat_decoder2', 4), g['res_list']) < TOL
+    x = torch.cat([g['img'], g['feat']], 1)
+    assert maxdiff(orc.resblocks_with_input_conv(x, small_sd, 'Network.backward_resblocks', small_cfg.num_blocks),
+                   g['resblocks']) < TOL
+    assert maxdiff(orc.pixel_shuffle_pack(g['feat'], small_sd, 'Network.upsample1'), g['pixel_shuffle']) < TOL
+
+
+def test_compute_up(small_cfg, small_sd):
+    g = load_golden('op_compute_up')
+    o = orc.OracleNetwork(small_cfg, small_sd)
+    assert maxdiff(o._compute_up(g['bw'], g['fw'], g['conf_bw'], g['conf_fw'], g['base']), g['out']) < TOL
+
+
+E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_small_L1'),
+       ('S_24x32_t5_reset3', 'config_RefVSR_small_L1'), ('F_16x24_t3', 'config_RefVSR_MFID'),
+       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K')]
+
+
+@pytest.mark.parametrize('tag,name', E2E)
+def test_end_to_end_stream(tag, name):
+    """First-frame call, chained steady-state calls and a reset_branch rollover: result, the four
+    carried state tensors, the iteration counter and the eval_vis confidence maps."""
+    g = load_golden('e2e_' + tag)
+    cfg = get_config('p', 'm', name)
+    t = int(g['t'])
+    cfg.frame_num = t
+    cfg.save_sample = True
+    rb = int(g['reset_branch'])
+    cfg.reset_branch = None if rb < 0 else rb
+    o = orc.OracleNetwork(cfg, make_state_dict(cfg, 1234))
+    lr, rf = g['lr'], g['ref']
+    nframes = lr.shape[1]
+    for f in range(nframes):
+        w = window_indices(f, nframes, t)
+        outs = o.forward(lr[:, w], rf[:, w], f == 0, is_log=True)
+        assert maxdiff(outs['result'], g['result_%d' % f]) < TOL, (tag, f)
+        assert o.frame_itr_num == int(g['itr_%d' % f])
+        assert maxdiff(o.forward_feat_prop_prev, g['state_feat_%d' % f]) < TOL
+        up_tol = TOL if g['state_feat_up_%d' % f].dtype == torch.float32 else 2e-3   # big maps stored as fp16
+        assert maxdiff(o.forward_feat_prop_UP_prev, g['state_feat_up_%d' % f]) < up_tol
+        assert maxdiff(o.forward_conf_map_prop_prev, g['state_conf_%d' % f]) < TOL
+        assert maxdiff(o.forward_flow_prev, g['state_flow_%d' % f]) < TOL
+        for k, v in outs['eval_vis'].items():
+            assert maxdiff(v, g['ev_%s_%d' % (k, f)]) < TOL, (tag, f, k)

@@ -1,0 +1,96 @@
+"""N>1 path on CPU: two processes, gloo backend, the oracle as executor.  The sharded run (with the
+point-to-point state hand-off, and with the exchange-free reset-aligned partition) must reproduce
+the sequential run bit-for-bit."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Exec(object):
+    def __init__(self, cfg, sd):
+        from oracle import refvsr_oracle as orc
+        self.o = orc.OracleNetwork(cfg, sd)
+
+    def __call__(self, lrs, refs, first):
+        return self.o.forward(lrs[None], refs[None], first)['result'][0]
+
+    def export_state(self):
+        return self.o.export_state()
+
+    def import_state(self, st):
+        self.o.import_state(st)
+
+
+def _setup(reset):
+    from refvsr_amd import get_config, make_state_dict
+    from refvsr_amd.synth import make_clip, window_indices
+    cfg = get_config('p', 'm', 'config_RefVSR_small_L1')
+    cfg.frame_num = 3
+    cfg.reset_branch = reset
+    sd = make_state_dict(cfg, 1234)
+    lr, rf, _ = make_clip(6, 16, 16, seed=3)
+    get = lambda f: (lr[window_indices(f, 6, 3)], rf[window_indices(f, 6, 3)])
+    return cfg, sd, get
+
+
+def _worker(rank, world, port, reset, aligned, q):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from refvsr_amd import shard
+    cfg, sd, get = _setup(reset)
+    res = shard.run_sharded(_Exec(cfg, sd), get, 6, 3, reset, cfg.mid_channels, 'cpu', aligned=aligned)
+    q.put((rank, {f: v.clone() for f, v in res.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(reset, aligned):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, reset, aligned, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, res = q.get(timeout=600)
+        got.update(res)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg, sd, get = _setup(reset)
+    ex = _Exec(cfg, sd)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(2)                 # same CPU kernel blocking as the workers => bit-exact compare
+    try:
+        for f in range(6):
+            want = ex(*get(f), f == 0)
+            assert torch.equal(got[f], want), 'frame %d differs from the sequential run' % f
+    finally:
+        torch.set_num_threads(nthr)
+    return got
+
+
+def test_handoff_partition_matches_sequential():
+    _run(reset=None, aligned=False)          # boundary at frame 3: needs the state hand-off
+
+
+def test_reset_aligned_partition_is_exchange_free():
+    _run(reset=3, aligned=True)              # boundary at a multiple of reset_branch: no communication

@@ -255,7 +255,35 @@ def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep'):
     save('e2e_' + tag, **arrs)
 
 
+def gen_full(nframes=2, stride=8):
+    """Full BASELINE size (270x480 -> 1080x1920, t=5): PSNR scalars + a strided sub-sample of the result
+    (the full frame is 24.9 MB).  ~3 min + 1.5 min per frame on 8 cores, 18 GB RSS."""
+    from refvsr_amd.synth import make_clip, window_indices
+    print('== full-size S 270x480 t=5, %d frames ==' % nframes)
+    net, cfg, mine, sd = ref_net('config_RefVSR_small_L1', 5, save_sample=False)
+    lr, rf, gt = make_clip(nframes, 270, 480, seed=0)
+    arrs = dict(nframes=np.int64(nframes), stride=np.int64(stride),
+                lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
+    import time
+    with torch.no_grad():
+        for f in range(nframes):
+            w = window_indices(f, nframes, 5)
+            t0 = time.time()
+            res = net(lr[w][None], rf[w][None], f == 0, is_log=False, is_train=False)['result']
+            mse = torch.mean((res - gt[f][None]) ** 2)
+            p = float(10 * torch.log10(1 / mse))
+            print('  frame %d: %.1f s, PSNR vs GT %.6f dB' % (f, time.time() - t0, p))
+            arrs['psnr_%d' % f] = np.float64(p)
+            arrs['sub_%d' % f] = res[0, :, ::stride, ::stride].clone()
+    save('e2e_full_S_270x480_t5', **arrs)
+
+
 def main():
+    if '--full' in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        gen_full()
+        return
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
