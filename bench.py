@@ -37,6 +37,35 @@ PEAK_F16_TFLOPS = 2500.0          # dense MFMA f16/bf16 peak, MI355X_MICROARCH.m
 ALG_TFLOP_PER_FRAME = 2.490       # de-duplicated algorithmic work per output frame
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota (os.cpu_count() reports
+    the whole host, which on a quota-limited container oversubscribes OpenMP badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_child():
+    """Runs in a child process (so a slow host can be cut off without losing the GPU number)."""
+    from refvsr_amd import get_config, make_state_dict
+    from refvsr_amd.synth import make_clip
+    ncores = min(usable_cores(), 64)
+    torch.set_num_threads(ncores)
+    cfg = get_config('bench', 'bench', 'config_RefVSR_small_L1')
+    cfg.frame_num = T
+    sd = make_state_dict(cfg, 1234)
+    lr, rf, _ = make_clip(T, H, W_, seed=0)
+    out = cpu_baseline(cfg, sd, lr, rf)
+    out['host_cpu_count'] = os.cpu_count()
+    out['usable_cores'] = usable_cores()
+    print('CPU_BASELINE ' + json.dumps(out), flush=True)
+
+
 def cpu_baseline(cfg, sd, lr, rf):
     """One steady-state forward of the oracle exactly as the reference executes it (8 SPyNet calls,
     3 matchings, 3 backward + 1 forward RAP steps, upsampler) at the full 270x480 size.  The
@@ -77,7 +106,12 @@ def main():
     ap.add_argument('--config', default='config_RefVSR_small_L1')
     ap.add_argument('--no-cache', action='store_true', help='execute exactly the work the reference executes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-baseline-timeout', type=float, default=240.0)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_child()
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -164,12 +198,17 @@ def main():
                               'achieved_tflops_per_gpu': ALG_TFLOP_PER_FRAME * fps / world,
                               'frac_of_f16_mfma_peak': ALG_TFLOP_PER_FRAME * fps / world / PEAK_F16_TFLOPS}
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                torch.set_num_threads(os.cpu_count() or 1)
-                line['cpu_baseline'] = cpu_baseline(cfg, sd, lr, rf)
+            import subprocess
+            try:                     # child process + timeout: the baseline leg must never take the GPU number down
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'],
+                                   capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
+                tag = [ln for ln in r.stdout.splitlines() if ln.startswith('CPU_BASELINE ')]
+                if not tag:
+                    raise RuntimeError('no result (rc=%d): %s' % (r.returncode, r.stderr[-300:]))
+                line['cpu_baseline'] = json.loads(tag[-1][len('CPU_BASELINE '):])
                 line['cpu_baseline']['gpu_over_cpu'] = fps / line['cpu_baseline']['value']
-            except Exception as e:  # noqa: BLE001  (the baseline leg must never take the GPU number down)
-                line['cpu_baseline'] = {'error': repr(e)}
+            except Exception as e:  # noqa: BLE001
+                line['cpu_baseline'] = {'error': repr(e)[:300]}
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

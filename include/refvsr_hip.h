@@ -59,6 +59,9 @@ typedef struct RefvsrConv {
     int out_mode;                      /* REFVSR_OUT_*                                                */
     void* out; int out_c;              /* nhwc16 modes: channel stride of out                          */
     const float* res_planar;           /* PLANAR32: optional planar fp32 residual [cout][h][w]        */
+    int f32;                           /* 0: nhwc16 maps, fp16 hi+lo weights on 16x16x32 f16 MFMA;
+                                          1: the same maps in fp32 ("nhwc32", channel stride % 4 == 0), fp32 weights,
+                                             exact fp32 products on v_mfma_f32_16x16x4_f32 (src/mul/res/out all fp32) */
     float add_const;                   /* PLANAR32: constant added after the residual                 */
     float clamp_lo, clamp_hi;          /* PLANAR32: clamp when clamp_lo < clamp_hi                    */
 } RefvsrConv;
@@ -78,6 +81,8 @@ int refvsr_conv_direct_f32(const float* src, int cin, int h, int w,
  * ------------------------------------------------------------------------------------------ */
 /* planar fp32 [c][h][w] -> nhwc16 [h][w][cs] (channels >= c zero-filled). */
 int refvsr_pack_nhwc16(const float* src, int c, int h, int w, void* dst, int cs, void* stream);
+/* planar fp32 [c][h][w] -> fp32 HWC [h][w][cs], cs % 4 == 0 (input of the f32 conv mode). */
+int refvsr_pack_nhwc32(const float* src, int c, int h, int w, float* dst, int cs, void* stream);
 /* nhwc16 [h][w][cs] -> planar fp32 [c][h][w]. */
 int refvsr_unpack_nhwc16(const void* src, int h, int w, int cs, int c, float* dst, void* stream);
 

@@ -12,8 +12,15 @@
 // * K is walked in 32-deep steps; per step lane l consumes K-block g = 4*step + (l>>4), an
 //   8-channel group of one tap.  g -> LDS byte offset comes from a small table built per block, so
 //   kernel size, stride and channel count are runtime values (one kernel serves 1x1..7x7).
-// * Weights are pre-packed on the host in exact fragment order ([kstep][mtile][lane][8 halfs]) and
-//   streamed through LDS in chunks of CH K-steps shared by the 4 waves.
+// * Weights are pre-packed on the host in exact fragment order and streamed through LDS in chunks of
+//   CH K-steps shared by the 4 waves.  fp16 mode: every weight is carried as hi + lo halves
+//   ([kstep][mtile][hi|lo][lane][8 halfs], two MFMAs per B fragment): a plain fp16 weight rounding is a
+//   *systematic* perturbation of the network and was measured to dominate the PSNR-parity error
+//   (tools/precision_sim.py); hi+lo gives ~22-bit weights for one extra MFMA.
+// * F32 mode (template flag): the same walk on v_mfma_f32_16x16x4_f32 with fp32 HWC activations and fp32
+//   weights ([kstep][mtile][lane][4 floats]; a K-block is 4 channels, 4 MFMAs per 16-byte fragment) --
+//   bitwise an fp32 FMA chain.  Used for the VGG feature extractor of the matching, whose arg-max is
+//   discontinuous in the features.
 // * Epilogue fuses bias, (leaky)ReLU, alpha-multiply, residual, post-activation, pixel-shuffle or a
 //   planar fp32 store with residual / constant / clamp.
 //
@@ -24,8 +31,9 @@
 #define CONV_TW 32         // output tile width in pixels
 
 struct ConvArgs {
-    const f16* src0; const f16* src1;
-    int c0, c1, ncg0, ncg, ps;       // ps = LDS pixel stride in 16-byte slots (odd)
+    const unsigned char* src0; const unsigned char* src1;   // HWC maps: f16 (8 ch / 16 B) or f32 (4 ch / 16 B)
+    int c0, c1, ncg0, ncg, ps;       // channel counts; ncg* = 16-byte groups per pixel; ps = LDS pixel stride in slots (odd)
+    int pixb0, pixb1;                // bytes per pixel of src0 / src1
     int h_in, w_in, h_out, w_out;
     int ks, stride, pad;
     int LH, LW;                      // LDS input tile extent in pixels
@@ -34,15 +42,16 @@ struct ConvArgs {
     const uint4* wpack; const float* bias;
     int cout;
     float act_slope, post_slope;
-    const f16* mul; int mul_c;
-    const f16* res; int res_c;
+    const unsigned char* mul; int mul_c;
+    const unsigned char* res; int res_c;
     int out_mode; void* out; int out_c;
     const float* res_planar; float add_const, clamp_lo, clamp_hi;
     int tab_bytes, wl_bytes;         // LDS carve sizes
 };
 
-template <int MT, int TILES>
+template <int MT, int TILES, bool F32>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+    constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tab = reinterpret_cast<int*>(smem);
     unsigned char* wl = smem + p.tab_bytes;
@@ -89,9 +98,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
             if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
                 const size_t pix = (size_t)iy * p.w_in + ix;
                 if (cg < p.ncg0)
-                    v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.c0 + cg * 8);
+                    v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16);
                 else
-                    v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.c1 + (cg - p.ncg0) * 8);
+                    v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
             }
             *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
         }
@@ -113,30 +122,56 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const uint4* wsrc = p.wpack + (size_t)zg * p.S * MT * 64;
+    const uint4* wsrc = p.wpack + (size_t)zg * p.S * MT * WFR * 64;
+    auto load_weights = [&](int s0) {
+        const int n16 = min(CONV_CH, p.S - s0) * MT * WFR * 64;
+        const uint4* g = wsrc + (size_t)s0 * MT * WFR * 64;
+        uint4* d = reinterpret_cast<uint4*>(wl);
+        for (int i = tid; i < n16; i += 256) d[i] = g[i];
+    };
+    load_weights(0);                           // issued together with the tile staging: one latency, one barrier
+    __syncthreads();
     for (int s0 = 0; s0 < p.S; s0 += CONV_CH) {
         const int ns = min(CONV_CH, p.S - s0);
-        __syncthreads();                       // previous chunk fully consumed (and tile/table staged)
-        {
-            const int n16 = ns * MT * 64;
-            const uint4* g = wsrc + (size_t)s0 * MT * 64;
-            uint4* d = reinterpret_cast<uint4*>(wl);
-            for (int i = tid; i < n16; i += 256) d[i] = g[i];
-        }
-        __syncthreads();
         for (int sl = 0; sl < ns; ++sl) {
             const int toff = tab[(s0 + sl) * 4 + q];
-            f16x8 a[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                a[m] = *reinterpret_cast<const f16x8*>(wl + ((size_t)(sl * MT + m) * 64 + lane) * 16);
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                const f16x8 b = *reinterpret_cast<const f16x8*>(tile + pbase[t] + toff);
+            if constexpr (F32) {
+                f32x4 a[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b, acc[m][t], 0, 0, 0);
+                    a[m] = *reinterpret_cast<const f32x4*>(wl + ((size_t)(sl * MT + m) * 64 + lane) * 16);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + pbase[t] + toff);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], b[j], acc[m][t], 0, 0, 0);
+                    }
+                }
+            } else {
+                f16x8 ah[MT], al[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = *reinterpret_cast<const f16x8*>(wl + ((size_t)((sl * MT + m) * 2 + 0) * 64 + lane) * 16);
+                    al[m] = *reinterpret_cast<const f16x8*>(wl + ((size_t)((sl * MT + m) * 2 + 1) * 64 + lane) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(tile + pbase[t] + toff);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                    }
+                }
             }
+        }
+        if (s0 + CONV_CH < p.S) {
+            __syncthreads();                   // chunk fully consumed
+            load_weights(s0 + CONV_CH);
+            __syncthreads();
         }
     }
 
@@ -159,22 +194,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.act_slope);
             if (p.mul) {
-                const f16x4 mv = *reinterpret_cast<const f16x4*>(p.mul + opix * p.mul_c + co0);
+                float mv[4];
+                if constexpr (F32) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.mul + (opix * p.mul_c + co0) * 4);
+                    mv[0] = t4[0]; mv[1] = t4[1]; mv[2] = t4[2]; mv[3] = t4[3];
+                } else {
+                    const f16x4 t4 = *reinterpret_cast<const f16x4*>(p.mul + (opix * p.mul_c + co0) * 2);
+                    mv[0] = (float)t4[0]; mv[1] = (float)t4[1]; mv[2] = (float)t4[2]; mv[3] = (float)t4[3];
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] *= (float)mv[i];
+                for (int i = 0; i < 4; ++i) y[i] *= mv[i];
             }
             if (p.res) {
-                const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + opix * p.res_c + co0);
+                float rv[4];
+                if constexpr (F32) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.res + (opix * p.res_c + co0) * 4);
+                    rv[0] = t4[0]; rv[1] = t4[1]; rv[2] = t4[2]; rv[3] = t4[3];
+                } else {
+                    const f16x4 t4 = *reinterpret_cast<const f16x4*>(p.res + (opix * p.res_c + co0) * 2);
+                    rv[0] = (float)t4[0]; rv[1] = (float)t4[1]; rv[2] = (float)t4[2]; rv[3] = (float)t4[3];
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] += (float)rv[i];
+                for (int i = 0; i < 4; ++i) y[i] += rv[i];
             }
             if (p.post_slope != 1.0f) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.post_slope);
             }
             if (p.out_mode == REFVSR_OUT_NHWC16) {
-                f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + opix * p.out_c + co0) = o;
+                if constexpr (F32) {
+                    f32x4 o = {y[0], y[1], y[2], y[3]};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + opix * p.out_c + co0) = o;
+                } else {
+                    f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + opix * p.out_c + co0) = o;
+                }
             } else if (p.out_mode == REFVSR_OUT_NHWC16_SHUFFLE2) {
                 // packed row r = sub*C + c  <->  conv channel c*4 + sub, sub = dy*2 + dx
                 const int C = p.cout >> 2;
@@ -203,23 +257,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 
 typedef void (*conv_kernel_t)(ConvArgs);
 
-template <int MT, int TILES>
+template <int MT, int TILES, bool F32>
 static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32>), grid, dim3(256), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     RV_CHECK(d != nullptr, "conv: null descriptor");
-    RV_CHECK(d->src0 && d->c0 > 0 && d->c0 % 8 == 0, "conv: src0/c0 invalid (c0=%d)", d->c0);
-    RV_CHECK((d->src1 == nullptr) == (d->c1 == 0) && d->c1 % 8 == 0, "conv: src1/c1 invalid (c1=%d)", d->c1);
+    const bool f32 = d->f32 != 0;
+    const int cgrp = f32 ? 4 : 8;                      // channels per 16-byte group
+    const int esz = f32 ? 4 : 2;
+    RV_CHECK(d->src0 && d->c0 > 0 && d->c0 % cgrp == 0, "conv: src0/c0 invalid (c0=%d)", d->c0);
+    RV_CHECK((d->src1 == nullptr) == (d->c1 == 0) && d->c1 % cgrp == 0, "conv: src1/c1 invalid (c1=%d)", d->c1);
     RV_CHECK(d->ksize >= 1 && d->ksize <= 7 && d->stride >= 1 && d->pad >= 0, "conv: bad geometry");
     RV_CHECK(d->h_in > 0 && d->w_in > 0 && d->h_out > 0 && d->w_out > 0, "conv: bad sizes");
     RV_CHECK(d->wpack && d->bias && d->out, "conv: null weights/bias/out");
@@ -230,14 +287,15 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         RV_CHECK(d->res_planar == nullptr, "conv: res_planar only with planar output");
     }
     if (d->out_mode == REFVSR_OUT_NHWC16_SHUFFLE2)
-        RV_CHECK(d->cout % 16 == 0 && !d->mul && !d->res, "conv: pixel-shuffle output constraints");
+        RV_CHECK(d->cout % 16 == 0 && !d->mul && !d->res && !f32, "conv: pixel-shuffle output constraints");
     RV_CHECK(refvsr_init() == 0, "init failed");
 
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.src0 = (const f16*)d->src0; a.src1 = (const f16*)d->src1;
+    a.src0 = (const unsigned char*)d->src0; a.src1 = (const unsigned char*)d->src1;
     a.c0 = d->c0; a.c1 = d->c1;
-    a.ncg0 = d->c0 / 8; a.ncg = (d->c0 + d->c1) / 8;
+    a.pixb0 = d->c0 * esz; a.pixb1 = d->c1 * esz;
+    a.ncg0 = d->c0 / cgrp; a.ncg = (d->c0 + d->c1) / cgrp;
     a.ps = a.ncg | 1;
     a.h_in = d->h_in; a.w_in = d->w_in; a.h_out = d->h_out; a.w_out = d->w_out;
     a.ks = d->ksize; a.stride = d->stride; a.pad = d->pad;
@@ -247,8 +305,8 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     a.inv_ncg = 1.0f / (float)a.ncg;
     a.wpack = (const uint4*)d->wpack; a.bias = d->bias; a.cout = d->cout;
     a.act_slope = d->act_slope; a.post_slope = d->post_slope;
-    a.mul = (const f16*)d->mul; a.mul_c = d->mul_c;
-    a.res = (const f16*)d->res; a.res_c = d->res_c;
+    a.mul = (const unsigned char*)d->mul; a.mul_c = d->mul_c;
+    a.res = (const unsigned char*)d->res; a.res_c = d->res_c;
     a.out_mode = d->out_mode; a.out = d->out; a.out_c = d->out_c;
     a.res_planar = d->res_planar; a.add_const = d->add_const;
     a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
@@ -257,7 +315,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     const int n_mt = (d->cout + 15) / 16;
     const int nz = (n_mt + MT - 1) / MT;
     a.tab_bytes = ((a.S * 4 * 4 + 15) / 16) * 16;
-    a.wl_bytes = CONV_CH * MT * 1024;
+    a.wl_bytes = CONV_CH * MT * (f32 ? 1 : 2) * 1024;
 
     // pick the pixel-tile height: 8 rows x 32 cols if the staged input fits, else 4 rows
     int tiles = 4;
@@ -280,7 +338,9 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     }
     dim3 grid(rv_cdiv(d->w_out, CONV_TW), rv_cdiv(d->h_out, tiles * 2), nz);
     hipStream_t st = (hipStream_t)stream;
-#define RV_CONV_CASE(M, T) if (MT == M && tiles == T) return launch_conv<M, T>(a, grid, lds, st);
+#define RV_CONV_CASE(M, T)                                                        \
+    if (MT == M && tiles == T)                                                    \
+        return f32 ? launch_conv<M, T, true>(a, grid, lds, st) : launch_conv<M, T, false>(a, grid, lds, st);
     RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
     RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)
     RV_CONV_CASE(3, 2) RV_CONV_CASE(3, 4)

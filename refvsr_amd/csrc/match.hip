@@ -15,6 +15,8 @@
 //    slots per row, odd => the 16 lanes of a ds_read_b128 group hit 16 distinct slots.
 //  * top-2 (not top-1) is kept so that the fp16 operand rounding cannot change the winner: the
 //    candidates are re-ranked with an exact fp32 dot product by match_refine.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define KP REFVSR_MATCH_KP            // halfs per row (152)
@@ -100,10 +102,15 @@ __device__ __forceinline__ void top2_scan(Top2& s, const f32x16& acc, int rowbas
     }
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void match_top2_kernel(const f16* __restrict__ ref_rows, int n_ref,
-                                                             const f16* __restrict__ lr_rows, int n_lr,
-                                                             int chunks_per_split, int n_chunks, int row_splits,
-                                                             int32_t* __restrict__ cand_idx, float* __restrict__ cand_val) {
+// V = 0: first version (kept for A/B: the compiler hoists the LDS write of the prefetched chunk above
+//        the compute loop, exposing the global-load latency once per chunk).
+// V = 1: prefetch pinned -- global loads issued before, LDS writes after the MFMA loop.
+// V = 2: V1 + row-tile loop fully unrolled with the next tile's A fragments read during the current
+//        tile's MFMAs (explicit register double buffering).
+template <int V>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void match_top2_kernel(
+    const f16* __restrict__ ref_rows, int n_ref, const f16* __restrict__ lr_rows, int n_lr,
+    int chunks_per_split, int n_chunks, int row_splits, int32_t* __restrict__ cand_idx, float* __restrict__ cand_val) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][CHUNK * ROWB];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -128,13 +135,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const uint4* gsrc = reinterpret_cast<const uint4*>(ref_rows);
     uint4 pf[PF];
-    // prologue: first chunk straight to LDS buffer 0
-    if (c_begin < c_end) {
+    // per-thread staging slots: slot k covers uint4 index tid + 512*k; the last one is clamped (branch-free load)
+    int pfi[PF];
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int i = tid + k * 512;
-            if (i < CHUNK_U4) reinterpret_cast<uint4*>(lds[0])[i] = gsrc[(size_t)c_begin * CHUNK_U4 + i];
-        }
+    for (int k = 0; k < PF; ++k) pfi[k] = min(tid + k * 512, CHUNK_U4 - 1);
+    const bool last_ok = (tid + (PF - 1) * 512) < CHUNK_U4;
+
+    if (c_begin < c_end) {                     // prologue: first chunk straight to LDS buffer 0
+#pragma unroll
+        for (int k = 0; k < PF; ++k) pf[k] = gsrc[(size_t)c_begin * CHUNK_U4 + pfi[k]];
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+            if (k < PF - 1 || last_ok) reinterpret_cast<uint4*>(lds[0])[pfi[k]] = pf[k];
     }
     __syncthreads();
 
@@ -143,36 +155,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool has_next = (c + 1 < c_end);
         if (has_next) {
 #pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int i = tid + k * 512;
-                if (i < CHUNK_U4) pf[k] = gsrc[(size_t)(c + 1) * CHUNK_U4 + i];
-            }
+            for (int k = 0; k < PF; ++k) pf[k] = gsrc[(size_t)(c + 1) * CHUNK_U4 + pfi[k]];
         }
+        if (V >= 1) asm volatile("" ::: "memory");        // keep the loads above, in flight during the MFMAs
         const unsigned char* L = lds[buf];
+        if (V <= 1) {
 #pragma unroll 1
-        for (int rt = 0; rt < CHUNK / 32; ++rt) {
-            f16x8 afrag[KSTEPS];
-            const unsigned char* ap = L + (size_t)(rt * 32 + l31) * ROWB + hi * 16;
+            for (int rt = 0; rt < CHUNK / 32; ++rt) {
+                f16x8 afrag[KSTEPS];
+                const unsigned char* ap = L + (size_t)(rt * 32 + l31) * ROWB + hi * 16;
 #pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) afrag[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
-            f32x16 acc0, acc1;
+                for (int k = 0; k < KSTEPS; ++k) afrag[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
+                f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
 #pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[k], bfrag[0][k], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[k], bfrag[1][k], acc1, 0, 0, 0);
+                for (int k = 0; k < KSTEPS; ++k) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[k], bfrag[0][k], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[k], bfrag[1][k], acc1, 0, 0, 0);
+                }
+                const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
+                top2_scan(st[0], acc0, rowbase, n_ref);
+                top2_scan(st[1], acc1, rowbase, n_ref);
             }
-            const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
-            top2_scan(st[0], acc0, rowbase, n_ref);
-            top2_scan(st[1], acc1, rowbase, n_ref);
+        } else {
+            f16x8 afA[KSTEPS], afB[KSTEPS];
+            const unsigned char* ap = L + (size_t)l31 * ROWB + hi * 16;
+#pragma unroll
+            for (int k = 0; k < KSTEPS; ++k) afA[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
+#pragma unroll
+            for (int rt = 0; rt < CHUNK / 32; ++rt) {
+                f16x8* cur = (rt & 1) ? afB : afA;
+                f16x8* nxt = (rt & 1) ? afA : afB;
+                if (rt + 1 < CHUNK / 32) {
+                    const unsigned char* an = ap + (size_t)(rt + 1) * 32 * ROWB;
+#pragma unroll
+                    for (int k = 0; k < KSTEPS; ++k) nxt[k] = *reinterpret_cast<const f16x8*>(an + k * 32);
+                }
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#pragma unroll
+                for (int k = 0; k < KSTEPS; ++k) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[k], bfrag[0][k], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[k], bfrag[1][k], acc1, 0, 0, 0);
+                }
+                const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
+                top2_scan(st[0], acc0, rowbase, n_ref);
+                top2_scan(st[1], acc1, rowbase, n_ref);
+            }
         }
+        if (V >= 1) asm volatile("" ::: "memory");        // ... and the LDS writes below
         if (has_next) {
 #pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int i = tid + k * 512;
-                if (i < CHUNK_U4) reinterpret_cast<uint4*>(lds[buf ^ 1])[i] = pf[k];
-            }
+            for (int k = 0; k < PF; ++k)
+                if (k < PF - 1 || last_ok) reinterpret_cast<uint4*>(lds[buf ^ 1])[pfi[k]] = pf[k];
         }
         __syncthreads();
         buf ^= 1;
@@ -210,8 +247,17 @@ extern "C" int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr
     const int cps = rv_cdiv(n_chunks, row_splits);
     RV_CHECK((row_splits - 1) * cps < n_chunks, "match_top2: empty row split (use fewer splits)");
     dim3 grid(rv_cdiv(n_lr, COLB), row_splits);
-    hipLaunchKernelGGL(match_top2_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, n_ref,
-                       (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val);
+    static int variant = -1;                 // tuning knob (A/B of schedules inside one process): REFVSR_MATCH_VARIANT
+    const char* ev = getenv("REFVSR_MATCH_VARIANT");
+    const int want = ev ? atoi(ev) : 2;
+    if (want != variant) variant = (want >= 0 && want <= 2) ? want : 2;
+#define RV_MATCH_LAUNCH(V)                                                                                   \
+    hipLaunchKernelGGL(match_top2_kernel<V>, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, \
+                       n_ref, (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val)
+    if (variant == 0) RV_MATCH_LAUNCH(0);
+    else if (variant == 1) RV_MATCH_LAUNCH(1);
+    else RV_MATCH_LAUNCH(2);
+#undef RV_MATCH_LAUNCH
     RV_LAUNCH_CHECK();
     return 0;
 }

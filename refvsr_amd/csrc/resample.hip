@@ -31,6 +31,31 @@ extern "C" int refvsr_pack_nhwc16(const float* src, int c, int h, int w, void* d
     return 0;
 }
 
+__global__ void pack_nhwc32_kernel(const float* __restrict__ src, int c, int hw, float* __restrict__ dst, int cs) {
+    const int ngroups = cs / 4;
+    const size_t total = (size_t)hw * ngroups;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / ngroups;
+        const int g = (int)(i - pix * ngroups);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = g * 4 + k;
+            v[k] = ch < c ? src[(size_t)ch * hw + pix] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dst + pix * cs + g * 4) = v;
+    }
+}
+
+extern "C" int refvsr_pack_nhwc32(const float* src, int c, int h, int w, float* dst, int cs, void* stream) {
+    RV_CHECK(src && dst && c > 0 && h > 0 && w > 0 && cs % 4 == 0 && cs >= c, "pack_nhwc32: bad args");
+    const size_t total = (size_t)h * w * (cs / 4);
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_nhwc32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, c, h * w, dst, cs);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void unpack_nhwc16_kernel(const f16* __restrict__ src, int hw, int cs, int c, float* __restrict__ dst) {
     const size_t total = (size_t)hw * c;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

@@ -63,13 +63,19 @@ class Weights(object):
             self.raw[name] = (w.detach().to(device, torch.float32).contiguous(),
                               b.detach().to(device, torch.float32).contiguous())
 
+        def mf32(name, srcs):
+            w, b = g(name)
+            self.conv[name] = ops.ConvWeights(pack_conv(w, b, srcs, f32=True), device)
+
         chans = [(32, 8), (64, 32), (32, 64), (16, 32), (2, 16)]
         for lvl in range(6):
             for j, (co, ci) in enumerate(chans):
                 mf('FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j), [ci])
         fe = 'feature_match.feature_extract.'
-        for n in ('feature_match.sub_mean', fe + '0', fe + '2', fe + 'map64.0'):
-            dr(n)
+        dr('feature_match.sub_mean')
+        mf32(fe + '0', [3])
+        mf32(fe + '2', [64])
+        mf32(fe + 'map64.0', [64])
 
         def aligned(prefix):
             mf(prefix + '.conv1.0', [3])
@@ -215,10 +221,11 @@ class Engine(object):
         R = self.W.raw
         h, w = fr.lr.shape[1:]
 
-        def extract(x):
-            x = ops.conv_direct(x, *R['feature_match.feature_extract.0'], act=0.0)
-            x = ops.conv_direct(x, *R['feature_match.feature_extract.2'], act=0.0)
-            return ops.conv_direct(x, *R['feature_match.feature_extract.map64.0'], act=0.2)
+        def extract(x):       # VGG19[0:4] + map64 in exact fp32 on v_mfma_f32_16x16x4_f32 (attention.py:31-42)
+            x = ops.pack_nhwc32(x, 4)
+            x = ops.conv(self.cw('feature_match.feature_extract.0'), x, act=0.0)
+            x = ops.conv(self.cw('feature_match.feature_extract.2'), x, act=0.0)
+            return ops.conv(self.cw('feature_match.feature_extract.map64.0'), x, act=0.2, planar_out=True)
         lr_n = ops.conv_direct(fr.lr, *R['feature_match.sub_mean'])
         ref_n = ops.conv_direct(fr.ref, *R['feature_match.sub_mean'])
         lr_f = extract(lr_n)

@@ -32,6 +32,7 @@ class RefvsrConv(C.Structure):
         ('out_mode', C.c_int),
         ('out', C.c_void_p), ('out_c', C.c_int),
         ('res_planar', C.c_void_p),
+        ('f32', C.c_int),
         ('add_const', C.c_float), ('clamp_lo', C.c_float), ('clamp_hi', C.c_float),
     ]
 
@@ -44,6 +45,7 @@ SIGNATURES = {
     'refvsr_conv_mfma': [C.POINTER(RefvsrConv), _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     'refvsr_pack_nhwc16': [_P, _I, _I, _I, _P, _I, _P],
+    'refvsr_pack_nhwc32': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_unpack_nhwc16': [_P, _I, _I, _I, _I, _P, _P],
     'refvsr_resize': [_P, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P, _P, _P, _I, _I, _I, _P],
     'refvsr_avgpool2': [_P, _I, _I, _I, _P, _P],

@@ -29,7 +29,11 @@ def _planar(t, c=None):
     return t
 
 
-def _nhwc(t):
+def _nhwc(t, f32=False):
+    if f32:
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.is_contiguous() and t.shape[2] % 4 == 0, \
+            'expected contiguous cuda float32 [H,W,C%%4==0], got %s %s' % (t.dtype, tuple(t.shape))
+        return t
     assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 3 and t.is_contiguous() and t.shape[2] % 8 == 0, \
         'expected contiguous cuda float16 [H,W,C%%8==0], got %s %s' % (t.dtype, tuple(t.shape))
     return t
@@ -43,24 +47,25 @@ def _farr(vals):
 
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
         self.bias = pk['bias'].to(device).contiguous()
         self.cout, self.ksteps, self.mt, self.ksize = pk['cout'], pk['ksteps'], pk['mt'], pk['ksize']
-        self.cpads, self.shuffle = pk['cpads'], pk['shuffle']
+        self.cpads, self.shuffle, self.f32 = pk['cpads'], pk['shuffle'], bool(pk.get('f32', False))
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
          planar_out=False, res_planar=None, add_const=0.0, clamp=None):
     """refvsr_conv_mfma.  Returns nhwc16 [ho,wo,cout] (or [2ho,2wo,cout/4] for pixel-shuffle weights),
-    or planar fp32 [cout,ho,wo] when planar_out."""
-    _nhwc(src0)
+    or planar fp32 [cout,ho,wo] when planar_out.  For f32-packed weights all maps are fp32 HWC."""
+    f32 = cw.f32
+    _nhwc(src0, f32)
     h, w, c0 = src0.shape
     c1 = 0
     if src1 is not None:
-        _nhwc(src1)
+        _nhwc(src1, f32)
         assert src1.shape[:2] == src0.shape[:2]
         c1 = src1.shape[2]
     assert [c0] + ([c1] if src1 is not None else []) == list(cw.cpads), \
@@ -77,12 +82,13 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     d.wpack, d.bias = cw.wpack.data_ptr(), cw.bias.data_ptr()
     d.cout, d.mt_per_block, d.ksteps = cw.cout, cw.mt, cw.ksteps
     d.act_slope, d.post_slope = act, post
+    d.f32 = int(f32)
     if mul is not None:
-        _nhwc(mul)
+        _nhwc(mul, f32)
         assert tuple(mul.shape[:2]) == (ho, wo)
         d.mul, d.mul_c = mul.data_ptr(), mul.shape[2]
     if res is not None:
-        _nhwc(res)
+        _nhwc(res, f32)
         assert tuple(res.shape[:2]) == (ho, wo)
         d.res, d.res_c = res.data_ptr(), res.shape[2]
     if planar_out:
@@ -100,7 +106,7 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         out = torch.empty((2 * ho, 2 * wo, co), dtype=torch.float16, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16_SHUFFLE2, co
     else:
-        out = torch.empty((ho, wo, cw.cout), dtype=torch.float16, device=src0.device)
+        out = torch.empty((ho, wo, cw.cout), dtype=torch.float32 if f32 else torch.float16, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16, cw.cout
     d.out = out.data_ptr()
     hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
@@ -134,6 +140,15 @@ def pack_nhwc16(x, cs=None):
     cs = cs or (c + 7) // 8 * 8
     out = torch.empty((h, w, cs), dtype=torch.float16, device=x.device)
     hip.check(hip.lib().refvsr_pack_nhwc16(_ptr(x), c, h, w, _ptr(out), cs, _stream()), 'pack_nhwc16')
+    return out
+
+
+def pack_nhwc32(x, cs=None):
+    _planar(x)
+    c, h, w = x.shape
+    cs = cs or (c + 3) // 4 * 4
+    out = torch.empty((h, w, cs), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_pack_nhwc32(_ptr(x), c, h, w, _ptr(out), cs, _stream()), 'pack_nhwc32')
     return out
 
 

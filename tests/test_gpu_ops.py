@@ -96,15 +96,15 @@ def test_conv_mfma_vs_conv2d(dev, co, cins, ks, stride, h, w, shuffle):
         srcs.append(nhwc(x[0, o:o + c], dev))
         o += c
     got = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, stride=stride, act=0.2)
-    xh = x.half().float()                      # the kernel sees fp16 inputs and fp16 weights
-    want = F.leaky_relu(F.conv2d(xh, wt.half().float(), b, stride=stride, padding=ks // 2), 0.2)[0]
+    xh = x.half().float()                      # the kernel sees fp16 activations; weights are hi+lo (~fp32)
+    want = F.leaky_relu(F.conv2d(xh, wt, b, stride=stride, padding=ks // 2), 0.2)[0]
     if shuffle:
         want = F.pixel_shuffle(want[None], 2)[0]
     got = planar(got)
     assert got.shape == want.shape
     err = rel(got, want)
     report('conv_mfma co%d cin%s k%d s%d%s' % (co, cins, ks, stride, ' shuf' if shuffle else ''), rel=err)
-    assert err < 2e-3          # fp16 output rounding (2^-11) + fp32 accumulation order
+    assert err < 1e-3          # fp16 output rounding (2^-11 relative) + fp32 accumulation order
 
 
 def test_conv_mfma_epilogues(dev):
@@ -116,7 +116,7 @@ def test_conv_mfma_epilogues(dev):
     b = torch.randn(C, generator=g) * 0.1
     x, mul, res = (torch.randn(C, h, w, generator=g) for _ in range(3))
     cw = ops.ConvWeights(pack_conv(wt, b, [C]), dev)
-    y = F.conv2d(x.half().float()[None], wt.half().float(), b, padding=1)[0]
+    y = F.conv2d(x.half().float()[None], wt, b, padding=1)[0]
     # x + alpha * lrelu(conv)   (RefVSR.py:131)
     got = planar(ops.conv(cw, nhwc(x, dev), act=0.2, mul=nhwc(mul, dev), res=nhwc(res, dev)))
     want = res.half().float() + mul.half().float() * F.leaky_relu(y, 0.2)
@@ -135,13 +135,33 @@ def test_conv_mfma_epilogues(dev):
     base = torch.rand(3, h, w, generator=g)
     cw3 = ops.ConvWeights(pack_conv(w3, b3, [C]), dev)
     got = ops.conv(cw3, nhwc(x, dev), planar_out=True, res_planar=base.to(dev), clamp=(0.0, 1.0)).cpu()
-    want = (F.conv2d(x.half().float()[None], w3.half().float(), b3, padding=1)[0] + base).clamp(0, 1)
+    want = (F.conv2d(x.half().float()[None], w3, b3, padding=1)[0] + base).clamp(0, 1)
     report('conv planar+res+clamp', abs=maxdiff(got, want))
     assert maxdiff(got, want) < 1e-4
     # planar + constant + clamp(-3,3)   (affine head, alignment.py:47,58)
     got = ops.conv(cw3, nhwc(x, dev), planar_out=True, add_const=1.0, clamp=(-3.0, 3.0)).cpu()
-    want = (F.conv2d(x.half().float()[None], w3.half().float(), b3, padding=1)[0] + 1.0).clamp(-3, 3)
+    want = (F.conv2d(x.half().float()[None], w3, b3, padding=1)[0] + 1.0).clamp(-3, 3)
     assert maxdiff(got, want) < 1e-4
+
+
+def test_conv_mfma_f32_mode(dev):
+    """Exact-fp32 MFMA mode (v_mfma_f32_16x16x4_f32) used for the VGG feature extractor."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(21)
+    for (co, ci, k, h, w) in [(64, 3, 3, 20, 28), (64, 64, 3, 35, 50), (16, 64, 1, 20, 28), (64, 64, 3, 70, 130)]:
+        wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        x = torch.randn(ci, h, w, generator=g)
+        cw = ops.ConvWeights(pack_conv(wt, b, [ci], f32=True), dev)
+        xin = ops.pack_nhwc32(x.to(dev))
+        want = F.relu(F.conv2d(x[None], wt, b, padding=k // 2))[0]
+        got = ops.conv(cw, xin, act=0.0)                      # fp32 HWC out
+        assert got.dtype == torch.float32 and got.shape == (h, w, co)
+        e1 = maxdiff(got.permute(2, 0, 1).cpu(), want)
+        got_p = ops.conv(cw, xin, act=0.0, planar_out=True).cpu()
+        report('conv_mfma f32 co%d ci%d k%d' % (co, ci, k), abs=e1, abs_planar=maxdiff(got_p, want))
+        assert e1 < 2e-5 and maxdiff(got_p, want) < 2e-5      # fp32 FMA chain vs MKL-DNN summation order
 
 
 def test_conv_direct_f32(dev):
@@ -164,30 +184,33 @@ def test_conv_direct_f32(dev):
 def test_resize_modes_vs_golden_and_oracle(dev):
     from refvsr_amd import ops
     from oracle import refvsr_oracle as orc
+    from refvsr_amd.weights import VGG_MEAN, VGG_STD
     g = load_golden('op_resize')
     img, fl = g['img'][0].to(dev), g['flow'][0].to(dev)
-    tol = 2e-5
-    assert maxdiff(ops.bicubic_scale(img, 0.5, clamp01=False).cpu(), g['bicubic_half'][0]) < tol
-    assert maxdiff(ops.bicubic_scale(img, 2, clamp01=False).cpu(), g['bicubic_x2'][0]) < tol
-    assert maxdiff(ops.bicubic_scale(img, 4, clamp01=False).cpu(), g['bicubic_x4'][0]) < tol
-    assert maxdiff(ops.bicubic_scale(img, 4, clamp01=True).cpu(), g['bicubic_x4'][0].clamp(0, 1)) < tol
-    assert maxdiff(ops.flow_up2(fl).cpu(), g['flow_up2'][0]) < tol
-    assert maxdiff(ops.resize(img, (32, 32), ops.RS_BILINEAR).cpu(), g['bilinear_32x32'][0]) < tol
-    assert maxdiff(ops.resize(g['bilinear_32x32'][0].to(dev), (18, 26), ops.RS_BILINEAR).cpu(), g['bilinear_back'][0]) < tol
-    assert maxdiff(ops.resize(img, (9, 13), ops.RS_NEAREST, (2.0, 2.0)).cpu(), g['nearest_half'][0]) == 0.0
+    errs = {}
+    errs['bicubic_half'] = maxdiff(ops.bicubic_scale(img, 0.5, clamp01=False).cpu(), g['bicubic_half'][0])
+    errs['bicubic_x2'] = maxdiff(ops.bicubic_scale(img, 2, clamp01=False).cpu(), g['bicubic_x2'][0])
+    errs['bicubic_x4'] = maxdiff(ops.bicubic_scale(img, 4, clamp01=False).cpu(), g['bicubic_x4'][0])
+    errs['bicubic_x4_clamp'] = maxdiff(ops.bicubic_scale(img, 4, clamp01=True).cpu(), g['bicubic_x4'][0].clamp(0, 1))
+    errs['flow_up2'] = maxdiff(ops.flow_up2(fl).cpu(), g['flow_up2'][0]) / 6.0          # values up to ~6
+    errs['bilinear_up'] = maxdiff(ops.resize(img, (32, 32), ops.RS_BILINEAR).cpu(), g['bilinear_32x32'][0])
+    errs['bilinear_back'] = maxdiff(ops.resize(g['bilinear_32x32'][0].to(dev), (18, 26), ops.RS_BILINEAR).cpu(), g['bilinear_back'][0])
+    errs['nearest'] = maxdiff(ops.resize(img, (9, 13), ops.RS_NEAREST, (2.0, 2.0)).cpu(), g['nearest_half'][0])
     # larger, odd geometry + fused normalisation / per-channel gain / nhwc16 output
     x = torch.rand(3, 54, 100)
-    from refvsr_amd.weights import VGG_MEAN, VGG_STD
     got = ops.resize(x.to(dev), (64, 128), ops.RS_BILINEAR, mean=VGG_MEAN, std=VGG_STD).cpu()
     want = (orc.resize(x[None], (64, 128), 'bilinear')[0] - torch.tensor(VGG_MEAN).view(3, 1, 1)) / torch.tensor(VGG_STD).view(3, 1, 1)
-    assert maxdiff(got, want) < tol
+    errs['bilinear_norm'] = maxdiff(got, want) / 3.0
     f2 = torch.randn(2, 64, 128)
     got = ops.resize(f2.to(dev), (54, 100), ops.RS_BILINEAR, chan_mul=[100 / 128.0, 54 / 64.0]).cpu()
     want = orc.resize(f2[None], (54, 100), 'bilinear')[0] * torch.tensor([100 / 128.0, 54 / 64.0]).view(2, 1, 1)
-    assert maxdiff(got, want) < tol
+    errs['bilinear_mul'] = maxdiff(got, want) / 3.0
     got = planar(ops.bicubic_scale(x.to(dev), 2, clamp01=False, nhwc16_out=True), 3)
-    assert maxdiff(got, orc.bicubic_scale(x[None], 2, False)[0]) < 2e-3      # fp16 store
-    report('resize', ok=1)
+    errs['bicubic_nhwc16'] = maxdiff(got, orc.bicubic_scale(x[None], 2, False)[0]) / 50.0    # fp16 store: 1e-3 allowed
+    report('resize', **errs)
+    assert errs.pop('nearest') == 0.0
+    for k, v in errs.items():
+        assert v < 2e-5, (k, v)                     # fp32 interpolation arithmetic
 
 
 def test_pools_and_max(dev):
@@ -237,9 +260,12 @@ def test_spynet_level_input(dev):
     assert maxdiff(got, want) < 8e-3            # fp16 store of values up to ~8
     out8, fup = ops.spynet_level_input(a.to(dev), b.to(dev), None)
     assert float(fup.abs().max()) == 0.0
-    assert maxdiff(planar(out8)[3:6], b.half().float()) == 0.0
-    gw = load_golden('op_warp')                 # mmedit flow_warp golden through the same kernel path
+    # zero flow: the normalise/unnormalise round trip of flow_warp leaves ~1e-5 of interpolation
+    assert maxdiff(planar(out8)[3:6], orc.flow_warp_border(b[None], torch.zeros(1, 2, 18, 30))[0]) < 4e-3
+    gw = load_golden('op_warp')                 # mmedit flow_warp fixture (produced by the reference) through the kernel
     x3, fl = gw['x'][0, :3], gw['flow'][0]
+    out8, _ = ops.spynet_level_input(x3.to(dev), x3.to(dev), (fl[:, ::2, ::2] * 0).contiguous().to(dev))
+    assert maxdiff(planar(out8)[3:6], x3) < 2e-3
 
 
 def test_match_patches(dev):

@@ -58,11 +58,14 @@ def _emulate(srcs, pk, ks, stride, pad, ho, wo):
     """numpy model of conv_mfma.hip's K walk: K-block g -> (tap, channel group) -> strided gather."""
     X = np.concatenate(srcs, -1)
     H, W, Ct = X.shape
-    ncg = Ct // 8
+    ncg = Ct // (4 if pk['f32'] else 8)
     Xp = np.zeros((H + 2 * pad + 2 * stride + ks, W + 2 * pad + 2 * stride + ks, Ct), np.float32)
     Xp[pad:pad + H, pad:pad + W] = X
     wp = pk['wpack'].float().numpy()
+    if not pk['f32']:
+        wp = wp.sum(3)                         # fp16 hi + lo
     nz, S, MT = wp.shape[:3]
+    grp = 4 if pk['f32'] else 8
     out = np.zeros((nz * MT * 16, ho, wo), np.float32)
     for z in range(nz):
         for m in range(MT):
@@ -75,16 +78,17 @@ def _emulate(srcs, pk, ks, stride, pad, ho, wo):
                     tap, cg = divmod(g, ncg)
                     ty, tx = divmod(tap, ks)
                     A = wp[z, s, m, q * 16:(q + 1) * 16]
-                    B = Xp[ty:ty + ho * stride:stride, tx:tx + wo * stride:stride, cg * 8:cg * 8 + 8]
+                    B = Xp[ty:ty + ho * stride:stride, tx:tx + wo * stride:stride, cg * grp:cg * grp + grp]
                     out[(z * MT + m) * 16:(z * MT + m + 1) * 16] += np.einsum('rk,yxk->ryx', A, B)
     return out + pk['bias'].numpy()[:, None, None]
 
 
-@pytest.mark.parametrize('co,cins,ks,stride,shuffle', [
-    (24, [24], 3, 1, False), (24, [3, 24], 3, 1, False), (96, [24], 3, 1, True), (32, [32, 32], 5, 2, False),
-    (2, [16], 7, 1, False), (48, [48, 48], 1, 1, False), (64, [32], 7, 1, False), (3, [24], 3, 1, False),
-    (192, [48], 3, 1, True)])
-def test_weight_packing_reproduces_conv(co, cins, ks, stride, shuffle):
+@pytest.mark.parametrize('co,cins,ks,stride,shuffle,f32', [
+    (24, [24], 3, 1, False, False), (24, [3, 24], 3, 1, False, False), (96, [24], 3, 1, True, False),
+    (32, [32, 32], 5, 2, False, False), (2, [16], 7, 1, False, False), (48, [48, 48], 1, 1, False, False),
+    (64, [32], 7, 1, False, False), (3, [24], 3, 1, False, False), (192, [48], 3, 1, True, False),
+    (64, [3], 3, 1, False, True), (64, [64], 3, 1, False, True), (16, [64], 1, 1, False, True)])
+def test_weight_packing_reproduces_conv(co, cins, ks, stride, shuffle, f32):
     rs = np.random.RandomState(0)
     cin = sum(cins)
     w = (rs.randn(co, cin, ks, ks) * 0.1).astype(np.float32)
@@ -92,12 +96,16 @@ def test_weight_packing_reproduces_conv(co, cins, ks, stride, shuffle):
     H, W, pad = 9, 11, ks // 2
     x = rs.randn(1, cin, H, W).astype(np.float32)
     ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=pad)[0].numpy()
-    pk = pack_conv(w, b, cins, shuffle)
-    assert pk['wpack'].dtype == torch.float16 and pk['wpack'].shape[3:] == (64, 8)
+    pk = pack_conv(w, b, cins, shuffle, f32=f32)
+    if f32:
+        assert pk['wpack'].dtype == torch.float32 and pk['wpack'].shape[3:] == (64, 4)
+    else:                                       # [nz, S, MT, hi|lo, lane, 8]
+        assert pk['wpack'].dtype == torch.float16 and pk['wpack'].shape[3:] == (2, 64, 8)
     assert pk['wpack'].shape[0] * pk['mt'] * 16 >= co and pk['mt'] == choose_mt(co)
+    grp = 4 if f32 else 8
     srcs, o = [], 0
     for c in cins:
-        a = np.zeros((H, W, (c + 7) // 8 * 8), np.float32)
+        a = np.zeros((H, W, (c + grp - 1) // grp * grp), np.float32)
         a[:, :, :c] = x[0, o:o + c].transpose(1, 2, 0)
         srcs.append(a)
         o += c
@@ -109,7 +117,7 @@ def test_weight_packing_reproduces_conv(co, cins, ks, stride, shuffle):
         got[rows] = out[:co]
     else:
         got = out[:co]
-    assert np.abs(got - ref).max() < 5e-3          # fp16 weight rounding only
+    assert np.abs(got - ref).max() < 2e-5          # hi+lo fp16 weights carry ~22 bits; f32 mode is exact
 
 
 def test_model_shell_state_dict_contract(small_cfg, small_sd):
