@@ -68,6 +68,15 @@ typedef struct RefvsrConv {
 
 int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
 
+/* Fused residual block  out = post( x + conv2( act( conv1(x) ) ) ),  3x3, C -> C, stride 1 (one launch; the
+ * intermediate map lives in LDS): ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97) and ResBlock
+ * (RefVSR_/common.py:25-39).  w1/w2: fp16 hi+lo packed weights of the two convs, b1/b2 packed biases.
+ * refvsr_resblock_fits(c) tells whether the fused kernel supports c channels (LDS budget). */
+int refvsr_resblock_fits(int c);
+int refvsr_resblock_mfma(const void* src, int c, int h, int w, const void* w1, const float* b1,
+                         const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
+                         void* out, void* stream);
+
 /* fp32 direct convolution on planar maps (VGG feature extractor + MeanShift of FeatureMatching,
  * attention.py:28-50,62-70, and the 2->16 confidence convs RefVSR.py:47-52).  Kept in fp32 because
  * the arg-max of the matching is discontinuous in these features.

@@ -1,0 +1,263 @@
+// Fused residual block on CDNA4 matrix cores:  out = x + conv2( act( conv1(x) ) ),  both 3x3, C -> C,
+// stride 1, zero padding -- ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97, act = ReLU) and ResBlock
+// (RefVSR_/common.py:25-39, act = LeakyReLU 0.2).  ~70% of all convolutions of the network sit in such
+// pairs; as two launches each pair costs two launch boundaries, two input stagings and an HBM round trip
+// of the intermediate map.  Here one workgroup owns a 16x32 output tile:
+//
+//   stage   x tile (20 x 36 px, zero padded)            global -> LDS   (coalesced 16-byte HWC loads)
+//           both packed weight sets (hi + lo fp16)      global -> LDS
+//   phase 1 t = act(conv1(x) + b1) on the 18 x 34 halo region (612 px = 39 sixteen-pixel MFMA tiles,
+//           flattened; positions outside the frame are forced to 0 = conv2's zero padding)  -> LDS (fp16)
+//   phase 2 out = x + conv2(t) + b2 on the 16 x 32 tile; the residual x is re-read from the LDS tile
+//           -> global (8-byte HWC channel vectors)
+//
+// Same MFMA orientation / K walk as conv_mfma.hip (D[cout][pixel], K-block = (tap, 8-channel group),
+// v_mfma_f32_16x16x32_f16, hi+lo weights).  8 waves per workgroup (2 per SIMD).
+#include "common.h"
+
+#define RB_TH 16
+#define RB_TW 32
+#define RB_XH (RB_TH + 4)
+#define RB_XW (RB_TW + 4)
+#define RB_IH (RB_TH + 2)
+#define RB_IW (RB_TW + 2)
+#define RB_NI (RB_IH * RB_IW)            // 612 intermediate pixels
+#define RB_T1 ((RB_NI + 15) / 16)        // 39 phase-1 tiles
+#define RB_T1W ((RB_T1 + 7) / 8)         // 5 per wave
+#define RB_T2W (RB_TH * 2 / 8)           // 4 per wave
+
+struct ResBlockArgs {
+    const f16* src; f16* out;
+    int c, ncg, ps, h, w;
+    int G, S;
+    float inv_ncg;
+    const uint4* w1; const float* b1;
+    const uint4* w2; const float* b2;
+    float act_slope, post_slope;
+    int tab_bytes, w_bytes, x_bytes;     // LDS carve
+};
+
+template <int MT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_mfma_kernel(ResBlockArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* tab1 = reinterpret_cast<int*>(smem);                    // K-block -> offset in the x tile
+    int* tab2 = tab1 + p.S * 4;                                   // K-block -> offset in the t tile
+    unsigned char* wl1 = smem + p.tab_bytes;
+    unsigned char* wl2 = wl1 + p.w_bytes;
+    unsigned char* xt = wl2 + p.w_bytes;                          // [RB_XH][RB_XW][ps*16]
+    unsigned char* tt = xt + p.x_bytes;                           // [RB_IH][RB_IW][ps*16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int q = lane >> 4;
+    const int lr = lane & 15;
+    const int tx0 = blockIdx.x * RB_TW;
+    const int ty0 = blockIdx.y * RB_TH;
+    const int psb = p.ps * 16;
+
+    for (int g = tid; g < p.S * 4; g += 512) {
+        int o1 = 0, o2 = 0;
+        if (g < p.G) {
+            const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
+            const int cg = g - tap * p.ncg;
+            const int ty = tap / 3;
+            const int tx = tap - ty * 3;
+            o1 = ((ty * RB_XW + tx) * p.ps + cg) * 16;
+            o2 = ((ty * RB_IW + tx) * p.ps + cg) * 16;
+        }
+        tab1[g] = o1;
+        tab2[g] = o2;
+    }
+    {   // x tile, zero padded at the frame border
+        const int row_chunks = RB_XW * p.ncg;
+        const float inv_rc = 1.0f / (float)row_chunks;
+        const int total = RB_XH * row_chunks;
+        for (int idx = tid; idx < total; idx += 512) {
+            const int r = (int)(((float)idx + 0.5f) * inv_rc);
+            const int i = idx - r * row_chunks;
+            const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+            const int cg = i - c * p.ncg;
+            const int iy = ty0 - 2 + r, ix = tx0 - 2 + c;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+                v = *reinterpret_cast<const uint4*>(p.src + ((size_t)iy * p.w + ix) * p.c + cg * 8);
+            *reinterpret_cast<uint4*>(xt + (size_t)(r * RB_XW + c) * psb + cg * 16) = v;
+        }
+        const int n16 = p.S * MT * 2 * 64;
+        for (int i = tid; i < n16; i += 512) {
+            reinterpret_cast<uint4*>(wl1)[i] = p.w1[i];
+            reinterpret_cast<uint4*>(wl2)[i] = p.w2[i];
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 1: t = act(conv1(x) + b1) on the halo region -------------------------
+    {
+        int pb[RB_T1W], pp[RB_T1W];
+#pragma unroll
+        for (int t = 0; t < RB_T1W; ++t) {
+            int pix = (wave * RB_T1W + t) * 16 + lr;
+            pix = min(pix, RB_NI - 1);
+            const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RB_IW));
+            const int c = pix - r * RB_IW;
+            pp[t] = pix;
+            pb[t] = (r * RB_XW + c) * psb;
+        }
+        f32x4 acc[MT][RB_T1W];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < RB_T1W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.S; ++s) {
+            const int toff = tab1[s * 4 + q];
+            f16x8 ah[MT], al[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
+                al[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < RB_T1W; ++t) {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(xt + pb[t] + toff);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RB_T1W; ++t) {
+            const int tile = wave * RB_T1W + t;
+            const int pix = tile * 16 + lr;
+            if (tile >= RB_T1 || pix >= RB_NI) continue;
+            const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RB_IW));
+            const int c = pix - r * RB_IW;
+            const int iy = ty0 - 1 + r, ix = tx0 - 1 + c;
+            const bool inside = (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + q * 4;
+                if (co0 >= p.c) continue;
+                const float4 bv = *reinterpret_cast<const float4*>(p.b1 + co0);
+                f16x4 o;
+                o[0] = (f16)(inside ? rv_lrelu(acc[m][t][0] + bv.x, p.act_slope) : 0.f);
+                o[1] = (f16)(inside ? rv_lrelu(acc[m][t][1] + bv.y, p.act_slope) : 0.f);
+                o[2] = (f16)(inside ? rv_lrelu(acc[m][t][2] + bv.z, p.act_slope) : 0.f);
+                o[3] = (f16)(inside ? rv_lrelu(acc[m][t][3] + bv.w, p.act_slope) : 0.f);
+                *reinterpret_cast<f16x4*>(tt + (size_t)pix * psb + co0 * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: out = x + conv2(t) + b2 ------------------------------------------------
+    {
+        int pb[RB_T2W];
+#pragma unroll
+        for (int t = 0; t < RB_T2W; ++t) {
+            const int ti = wave * RB_T2W + t;
+            const int row = ti >> 1;
+            const int col = (ti & 1) * 16 + lr;
+            pb[t] = (row * RB_IW + col) * psb;
+        }
+        f32x4 acc[MT][RB_T2W];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < RB_T2W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.S; ++s) {
+            const int toff = tab2[s * 4 + q];
+            f16x8 ah[MT], al[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
+                al[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < RB_T2W; ++t) {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(tt + pb[t] + toff);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RB_T2W; ++t) {
+            const int ti = wave * RB_T2W + t;
+            const int row = ti >> 1;
+            const int col = (ti & 1) * 16 + lr;
+            const int oy = ty0 + row, ox = tx0 + col;
+            if (oy >= p.h || ox >= p.w) continue;
+            const unsigned char* xr = xt + (size_t)((row + 2) * RB_XW + (col + 2)) * psb;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + q * 4;
+                if (co0 >= p.c) continue;
+                const float4 bv = *reinterpret_cast<const float4*>(p.b2 + co0);
+                const f16x4 xv = *reinterpret_cast<const f16x4*>(xr + co0 * 2);
+                float y[4] = {acc[m][t][0] + bv.x + (float)xv[0], acc[m][t][1] + bv.y + (float)xv[1],
+                              acc[m][t][2] + bv.z + (float)xv[2], acc[m][t][3] + bv.w + (float)xv[3]};
+                if (p.post_slope != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.post_slope);
+                }
+                f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                *reinterpret_cast<f16x4*>(p.out + ((size_t)oy * p.w + ox) * p.c + co0) = o;
+            }
+        }
+    }
+}
+
+template <int MT>
+static int launch_resblock(const ResBlockArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_mfma_kernel<MT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((resblock_mfma_kernel<MT>), grid, dim3(512), lds, st, a);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int refvsr_resblock_fits(int c) {
+    if (c <= 0 || c % 8 != 0) return 0;
+    const int ncg = c / 8, ps = ncg | 1;
+    const int S = (9 * ncg + 3) / 4;
+    const int MT = (c + 15) / 16;
+    if (MT > 2) return 0;
+    const size_t lds = (size_t)((S * 4 * 2 * 4 + 15) / 16 * 16) + 2 * (size_t)S * MT * 2 * 1024 +
+                       (size_t)RB_XH * RB_XW * ps * 16 + (size_t)RB_IH * RB_IW * ps * 16;
+    return lds <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int refvsr_resblock_mfma(const void* src, int c, int h, int w, const void* w1, const float* b1,
+                                    const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
+                                    void* out, void* stream) {
+    RV_CHECK(src && out && w1 && w2 && b1 && b2 && h > 0 && w > 0, "resblock: bad args");
+    RV_CHECK(src != out, "resblock: in-place operation is not supported (neighbouring tiles read the input halo)");
+    RV_CHECK(refvsr_resblock_fits(c), "resblock: channel count %d not supported by the fused kernel", c);
+    RV_CHECK(refvsr_init() == 0, "init failed");
+    ResBlockArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = (const f16*)src; a.out = (f16*)out;
+    a.c = c; a.ncg = c / 8; a.ps = a.ncg | 1; a.h = h; a.w = w;
+    a.G = 9 * a.ncg; a.S = (a.G + 3) / 4;
+    RV_CHECK(a.S == ksteps, "resblock: ksteps mismatch (%d vs %d)", ksteps, a.S);
+    a.inv_ncg = 1.0f / (float)a.ncg;
+    a.w1 = (const uint4*)w1; a.b1 = b1; a.w2 = (const uint4*)w2; a.b2 = b2;
+    a.act_slope = act_slope; a.post_slope = post_slope;
+    const int MT = (c + 15) / 16;
+    a.tab_bytes = (a.S * 4 * 2 * 4 + 15) / 16 * 16;
+    a.w_bytes = a.S * MT * 2 * 1024;
+    a.x_bytes = RB_XH * RB_XW * a.ps * 16;
+    const size_t lds = (size_t)a.tab_bytes + 2 * (size_t)a.w_bytes + a.x_bytes + (size_t)RB_IH * RB_IW * a.ps * 16;
+    dim3 grid(rv_cdiv(w, RB_TW), rv_cdiv(h, RB_TH));
+    if (MT == 1) return launch_resblock<1>(a, grid, lds, (hipStream_t)stream);
+    return launch_resblock<2>(a, grid, lds, (hipStream_t)stream);
+}

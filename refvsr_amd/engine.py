@@ -137,6 +137,7 @@ class Engine(object):
         self.ks = config.matching_ksize
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
+        self.fuse_resblocks = bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.reset_state()
 
@@ -173,16 +174,24 @@ class Engine(object):
         """ResList (RefVSR_/common.py:64-82) with ResBlocks (:25-39)."""
         x0 = x
         for i in range(n):
-            t = ops.conv(self.cw('%s.RBs.%d.conv1' % (name, i)), x, act=0.2)
-            x = ops.conv(self.cw('%s.RBs.%d.conv2' % (name, i)), t, res=x)
+            c1, c2 = self.cw('%s.RBs.%d.conv1' % (name, i)), self.cw('%s.RBs.%d.conv2' % (name, i))
+            if self.fuse_resblocks:
+                x = ops.resblock(c1, c2, x, act=0.2)
+            else:
+                t = ops.conv(c1, x, act=0.2)
+                x = ops.conv(c2, t, res=x)
         return ops.conv(self.cw(name + '.conv_tail'), x, res=x0)
 
     def resblocks(self, lr8, feat, name):
         """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources."""
         x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1)
         for i in range(self.nb):
-            t = ops.conv(self.cw('%s.main.2.%d.conv1' % (name, i)), x, act=0.0)
-            x = ops.conv(self.cw('%s.main.2.%d.conv2' % (name, i)), t, res=x)
+            c1, c2 = self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i))
+            if self.fuse_resblocks:
+                x = ops.resblock(c1, c2, x, act=0.0)
+            else:
+                t = ops.conv(c1, x, act=0.0)
+                x = ops.conv(c2, t, res=x)
         return x
 
     def pyramid(self, fr):

@@ -43,6 +43,8 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     'refvsr_init': [],
     'refvsr_conv_mfma': [C.POINTER(RefvsrConv), _P],
+    'refvsr_resblock_fits': [_I],
+    'refvsr_resblock_mfma': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     'refvsr_pack_nhwc16': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_pack_nhwc32': [_P, _I, _I, _I, _P, _I, _P],

@@ -113,6 +113,22 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     return out
 
 
+def resblock_fits(c):
+    return bool(hip.lib().refvsr_resblock_fits(int(c)))
+
+
+def resblock(cw1, cw2, x, act, post=1.0):
+    """refvsr_resblock_mfma: post(x + conv2(act(conv1(x)))) in one launch (3x3, C->C)."""
+    _nhwc(x)
+    h, w, c = x.shape
+    assert cw1.cpads == [c] and cw2.cpads == [c] and cw1.cout == c and cw2.cout == c and cw1.ksize == 3
+    assert not cw1.f32 and not cw1.shuffle and cw1.wpack.shape[0] == 1
+    out = torch.empty_like(x)
+    hip.check(hip.lib().refvsr_resblock_mfma(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
+                                             _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_mfma')
+    return out
+
+
 def conv_direct(x, w, b, stride=1, pad=None, act=1.0, nhwc16_out=False):
     """refvsr_conv_direct_f32 on a planar fp32 map; w fp32 [cout,cin,k,k] on the device."""
     _planar(x)

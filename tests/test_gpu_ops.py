@@ -144,6 +144,34 @@ def test_conv_mfma_epilogues(dev):
     assert maxdiff(got, want) < 1e-4
 
 
+@pytest.mark.parametrize('C,h,w,act', [(24, 16, 32, 0.0), (24, 45, 83, 0.2), (24, 270, 480, 0.0), (16, 19, 33, 0.2)])
+def test_resblock_fused(dev, C, h, w, act):
+    """Fused conv-act-conv+residual launch vs the same block as two conv launches and vs torch."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    if not ops.resblock_fits(C):
+        pytest.skip('fused kernel does not support C=%d' % C)
+    g = torch.Generator().manual_seed(C + h)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    x = torch.randn(C, h, w, generator=g)
+    c1, c2 = ops.ConvWeights(pack_conv(w1, b1, [C]), dev), ops.ConvWeights(pack_conv(w2, b2, [C]), dev)
+    xin = nhwc(x, dev)
+    fused = ops.resblock(c1, c2, xin, act=act)
+    two = ops.conv(c2, ops.conv(c1, xin, act=act), res=xin)
+    xh = x.half().float()
+    t = F.leaky_relu(F.conv2d(xh[None], w1, b1, padding=1), act).half().float()       # intermediate is fp16 in both paths
+    want = xh + F.conv2d(t, w2, b2, padding=1)[0]
+    e_f, e_t = rel(planar(fused), want), rel(planar(two), want)
+    same = maxdiff(planar(fused), planar(two))
+    report('resblock fused C%d %dx%d act%.1f' % (C, h, w, act), rel_fused=e_f, rel_two=e_t, fused_vs_two=same)
+    assert e_f < 1e-3 and e_t < 1e-3
+    assert same < 4e-3            # both round the intermediate and the output to fp16; summation order differs
+    fused_p = ops.resblock(c1, c2, xin, act=act, post=0.2)
+    assert rel(planar(fused_p), F.leaky_relu(want, 0.2)) < 1e-3
+
+
 def test_conv_mfma_f32_mode(dev):
     """Exact-fp32 MFMA mode (v_mfma_f32_16x16x4_f32) used for the VGG feature extractor."""
     from refvsr_amd import ops
