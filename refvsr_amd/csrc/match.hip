@@ -107,6 +107,29 @@ __device__ __forceinline__ void top2_scan(Top2& s, const f32x16& acc, int rowbas
 // V = 1: prefetch pinned -- global loads issued before, LDS writes after the MFMA loop.
 // V = 2: V1 + row-tile loop fully unrolled with the next tile's A fragments read during the current
 //        tile's MFMAs (explicit register double buffering).
+// V = 3: V2 + accumulator double buffering: the 18 MFMAs of row tile rt+1 are issued BEFORE the column
+//        reduction of tile rt, so the VALU max-trees run under the matrix pipe; the two per-column-tile
+//        slow paths share one (rare) branch.
+__device__ __forceinline__ float acc_max(const f32x16& a) {
+    float t0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), t1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+    float t2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), t3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+    return fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+}
+
+__device__ __forceinline__ void top2_insert(Top2& s, const f32x16& acc, int rowbase, int n_ref) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                      // increasing r == increasing row index; branch-free selects
+        const int row = rowbase + (r & 3) + 8 * (r >> 2);
+        const float v = (row < n_ref) ? acc[r] : -INFINITY;
+        const bool g1 = v > s.m1;
+        const bool g2 = v > s.m2;
+        s.m2 = g1 ? s.m1 : (g2 ? v : s.m2);
+        s.i2 = g1 ? s.i1 : (g2 ? row : s.i2);
+        s.m1 = g1 ? v : s.m1;
+        s.i1 = g1 ? row : s.i1;
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void match_top2_kernel(
     const f16* __restrict__ ref_rows, int n_ref, const f16* __restrict__ lr_rows, int n_lr,
@@ -159,7 +182,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (V >= 1) asm volatile("" ::: "memory");        // keep the loads above, in flight during the MFMAs
         const unsigned char* L = lds[buf];
-        if (V <= 1) {
+        if (V == 3) {
+            constexpr int NRT = CHUNK / 32;
+            f16x8 afA[KSTEPS], afB[KSTEPS];
+            const unsigned char* ap = L + (size_t)l31 * ROWB + hi * 16;
+#pragma unroll
+            for (int k = 0; k < KSTEPS; ++k) afA[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
+            f32x16 accA0, accA1, accB0, accB1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA0[r] = 0.0f; accA1[r] = 0.0f; }
+#pragma unroll
+            for (int k = 0; k < KSTEPS; ++k) {
+                accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[0][k], accA0, 0, 0, 0);
+                accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[1][k], accA1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                f32x16& c0 = (rt & 1) ? accB0 : accA0;           // finished tile
+                f32x16& c1 = (rt & 1) ? accB1 : accA1;
+                f32x16& n0 = (rt & 1) ? accA0 : accB0;           // tile in flight
+                f32x16& n1 = (rt & 1) ? accA1 : accB1;
+                f16x8* nf = (rt & 1) ? afA : afB;
+                if (rt + 1 < NRT) {
+                    const unsigned char* an = ap + (size_t)(rt + 1) * 32 * ROWB;
+#pragma unroll
+                    for (int k = 0; k < KSTEPS; ++k) nf[k] = *reinterpret_cast<const f16x8*>(an + k * 32);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { n0[r] = 0.0f; n1[r] = 0.0f; }
+#pragma unroll
+                    for (int k = 0; k < KSTEPS; ++k) {
+                        n0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(nf[k], bfrag[0][k], n0, 0, 0, 0);
+                        n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(nf[k], bfrag[1][k], n1, 0, 0, 0);
+                    }
+                }
+                const float t0 = acc_max(c0), t1 = acc_max(c1);
+                if (t0 > st[0].m2 || t1 > st[1].m2) {
+                    const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
+                    if (t0 > st[0].m2) top2_insert(st[0], c0, rowbase, n_ref);
+                    if (t1 > st[1].m2) top2_insert(st[1], c1, rowbase, n_ref);
+                }
+            }
+        } else if (V <= 1) {
 #pragma unroll 1
             for (int rt = 0; rt < CHUNK / 32; ++rt) {
                 f16x8 afrag[KSTEPS];
@@ -249,14 +312,15 @@ extern "C" int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr
     dim3 grid(rv_cdiv(n_lr, COLB), row_splits);
     static int variant = -1;                 // tuning knob (A/B of schedules inside one process): REFVSR_MATCH_VARIANT
     const char* ev = getenv("REFVSR_MATCH_VARIANT");
-    const int want = ev ? atoi(ev) : 2;
-    if (want != variant) variant = (want >= 0 && want <= 2) ? want : 2;
+    const int want = ev ? atoi(ev) : 3;
+    if (want != variant) variant = (want >= 0 && want <= 3) ? want : 3;
 #define RV_MATCH_LAUNCH(V)                                                                                   \
     hipLaunchKernelGGL(match_top2_kernel<V>, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, \
                        n_ref, (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val)
     if (variant == 0) RV_MATCH_LAUNCH(0);
     else if (variant == 1) RV_MATCH_LAUNCH(1);
-    else RV_MATCH_LAUNCH(2);
+    else if (variant == 2) RV_MATCH_LAUNCH(2);
+    else RV_MATCH_LAUNCH(3);
 #undef RV_MATCH_LAUNCH
     RV_LAUNCH_CHECK();
     return 0;

@@ -17,6 +17,7 @@ Feature maps live in HBM as fp16 HWC ("nhwc16"); frames, flows and confidence ma
 """
 import collections
 import itertools
+import os
 
 import torch
 
@@ -137,7 +138,8 @@ class Engine(object):
         self.ks = config.matching_ksize
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
-        self.fuse_resblocks = bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
+        self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
+                               and not os.environ.get('REFVSR_NO_FUSE'))
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.reset_state()
 

@@ -46,7 +46,7 @@ def bench_match():
     n_lr, n_ref = h * w, (h // 2) * (w // 2)
     flops = 2.0 * n_lr * n_ref * 144
     base = None
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3):
         os.environ['REFVSR_MATCH_VARIANT'] = str(v)
         ci, cv = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1)
         if base is None:
@@ -55,7 +55,7 @@ def bench_match():
         us = timeit(lambda: ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1), iters=10)
         emit('match_top2 variant %d: %.1f us  %.1f TFLOP/s  (%.1f%% of 2.5 PF)  identical=%s' %
              (v, us, flops / us / 1e6, flops / us / 1e6 / 25.0, same))
-    os.environ['REFVSR_MATCH_VARIANT'] = '2'
+    os.environ['REFVSR_MATCH_VARIANT'] = '3'
     us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0]), iters=10)
     emit('match_refine: %.1f us' % us)
     us = timeit(lambda: ops.match_patches(lr_f, 512), iters=10)
@@ -93,11 +93,22 @@ def bench_conv():
         for c in cins:
             x = torch.randn(c, h, w, generator=g).to(dev)
             srcs.append(ops.pack_nhwc32(x) if f32 else ops.pack_nhwc16(x))
-        fn = lambda: ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, stride=st, act=0.2)
+        fn = lambda: ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, stride=st, act=0.2, planar_out=(co % 4 != 0))
         us = timeit(fn)
         ho, wo = (h + st - 1) // st, (w + st - 1) // st
         fl = 2.0 * ho * wo * co * cin * ks * ks
         emit('conv %-28s %8.1f us  %7.1f TFLOP/s (useful)' % (name, us, fl / us / 1e6))
+    # fused residual block vs two launches
+    for name, h, w in (('LR', 270, 480), ('LR/2', 135, 240), ('2x', 540, 960)):
+        C = 24
+        w1 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        c1 = ops.ConvWeights(pack_conv(w1, torch.zeros(C), [C]), dev)
+        c2 = ops.ConvWeights(pack_conv(w1.flip(0), torch.zeros(C), [C]), dev)
+        x = ops.pack_nhwc16(torch.randn(C, h, w, generator=g).to(dev))
+        us_f = timeit(lambda: ops.resblock(c1, c2, x, act=0.0))
+        us_t = timeit(lambda: ops.conv(c2, ops.conv(c1, x, act=0.0), res=x))
+        fl = 2 * 2.0 * h * w * C * C * 9
+        emit('resblock %-5s fused %7.1f us (%6.1f TFLOP/s useful)   two launches %7.1f us' % (name, us_f, fl / us_f / 1e6, us_t))
     # launch floor: smallest possible conv
     wt = torch.randn(24, 24, 3, 3) * 0.1
     cw = ops.ConvWeights(pack_conv(wt, torch.zeros(24), [24]), dev)
