@@ -108,6 +108,9 @@ int refvsr_resize(const float* src, int c, int h, int w, void* dst, int oh, int 
                   const float* chan_mul, int clamp01, int out_nhwc16, int out_c, void* stream);
 int refvsr_avgpool2(const float* src, int c, int h, int w, float* dst, void* stream);
 int refvsr_maxpool2(const float* src, int c, int h, int w, float* dst, void* stream);
+/* *flag &= (a[0..n_words) == b[0..n_words)) bitwise on 32-bit words; the caller presets *flag = 1.
+ * Keys the per-frame cache (frames of consecutive sliding windows are recognised by content). */
+int refvsr_buffers_equal(const void* a, const void* b, size_t n_words, int32_t* flag, void* stream);
 /* out = max(a, b) elementwise on n floats (confidence accumulation, RefVSR.py:147). */
 int refvsr_max2(const float* a, const float* b, float* out, size_t n, void* stream);
 
@@ -132,7 +135,7 @@ int refvsr_spynet_level_input(const float* ref, const float* supp, const float* 
  * Reference matching  (FeatureMatching.forward, RefVSR_/attention.py:72-91)
  * ------------------------------------------------------------------------------------------ */
 #define REFVSR_MATCH_KP 152       /* 144 = 16 ch x 3x3 patch, padded to 152 halfs (304-byte rows)   */
-#define REFVSR_MATCH_ROWCHUNK 128 /* reference rows are padded to a multiple of this               */
+#define REFVSR_MATCH_ROWCHUNK 256 /* reference rows are padded to a multiple of this               */
 #define REFVSR_MATCH_COLBLOCK 512 /* LR columns are padded to a multiple of this                    */
 /* feat: planar fp32 [16][h][w].  Writes rows [h*w][KP] fp16 of L2-normalised reflect-padded 3x3
  * patches (channel order c*9+ky*3+kx, RefVSR_/utils.py:29-57) and inv_norm[h*w] = 1/max(|p|,1e-12). */

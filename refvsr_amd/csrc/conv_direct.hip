@@ -4,9 +4,8 @@
 // inputs are fp32 confidence maps (RefVSR.py:47-52).
 //
 // One workgroup = 16x16 output pixels x CO_T output channels.  Input channels are walked in groups
-// of CI_T: the (16*stride + k - 1)^2 x CI_T input patch is staged in LDS; the weights are
-// wave-uniform, so the compiler fetches them with scalar loads and the inner loop is pure
-// v_fma_f32 with an SGPR operand.
+// of CI_T: the (16*stride + k - 1)^2 x CI_T input patch and the matching weight slab are staged in
+// LDS; weights are read back as 16-byte LDS broadcasts (4 output channels per ds_read_b128).
 #include "common.h"
 
 #define CD_T 16
@@ -21,7 +20,7 @@ struct DirectArgs {
 };
 
 __global__ __launch_bounds__(256) void conv_direct_kernel(DirectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float patch[];   // [CD_CI][PH][PW]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int ox = blockIdx.x * CD_T + tx, oy = blockIdx.y * CD_T + ty;
     const int co0 = blockIdx.z * CD_CO;
@@ -30,6 +29,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectArgs a) {
     const int ix0 = blockIdx.x * CD_T * a.stride - a.pad;
     const size_t plane = (size_t)a.h * a.w;
     const int kk = a.ks * a.ks;
+    float* patch = smem;                               // [CD_CI][PH][PW]
+    float* wl = smem + CD_CI * PH * PW;                // [CD_CI][kk][CD_CO]  (co fastest: one 64-byte broadcast row per tap)
 
     float acc[CD_CO];
 #pragma unroll
@@ -47,16 +48,27 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectArgs a) {
             if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) v = a.src[(ci0 + ci) * plane + (size_t)iy * a.w + ix];
             patch[i] = v;
         }
+        for (int i = threadIdx.x; i < nci * kk * CD_CO; i += 256) {
+            const int c = i % CD_CO;
+            const int t = (i / CD_CO) % kk;
+            const int ci = i / (CD_CO * kk);
+            wl[i] = (co0 + c < a.cout) ? a.wgt[((size_t)(co0 + c) * a.cin + (ci0 + ci)) * kk + t] : 0.0f;
+        }
         __syncthreads();
         for (int ci = 0; ci < nci; ++ci) {
             const float* pp = patch + ci * PH * PW + (ty * a.stride) * PW + tx * a.stride;
+            const float* wc = wl + ci * kk * CD_CO;
             for (int ky = 0; ky < a.ks; ++ky) {
                 for (int kx = 0; kx < a.ks; ++kx) {
                     const float xv = pp[ky * PW + kx];
-                    const float* wp = a.wgt + ((size_t)co0 * a.cin + (ci0 + ci)) * kk + ky * a.ks + kx;
+                    const f32x4* w4 = reinterpret_cast<const f32x4*>(wc + (ky * a.ks + kx) * CD_CO);
 #pragma unroll
-                    for (int c = 0; c < CD_CO; ++c) {
-                        if (co0 + c < a.cout) acc[c] = fmaf(xv, wp[(size_t)c * a.cin * kk], acc[c]);
+                    for (int c4 = 0; c4 < CD_CO / 4; ++c4) {
+                        const f32x4 wv = w4[c4];            // same address in every lane: LDS broadcast
+                        acc[c4 * 4 + 0] = fmaf(xv, wv[0], acc[c4 * 4 + 0]);
+                        acc[c4 * 4 + 1] = fmaf(xv, wv[1], acc[c4 * 4 + 1]);
+                        acc[c4 * 4 + 2] = fmaf(xv, wv[2], acc[c4 * 4 + 2]);
+                        acc[c4 * 4 + 3] = fmaf(xv, wv[3], acc[c4 * 4 + 3]);
                     }
                 }
             }
@@ -66,9 +78,20 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectArgs a) {
     const size_t opix = (size_t)oy * a.wo + ox;
     if (a.out_nhwc16) {
         f16* o = reinterpret_cast<f16*>(a.out) + opix * a.out_c + co0;
+        if (co0 + CD_CO <= a.cout) {
+            f16x8 v0, v1;
 #pragma unroll
-        for (int c = 0; c < CD_CO; ++c)
-            if (co0 + c < a.cout) o[c] = (f16)rv_lrelu(acc[c] + a.bias[co0 + c], a.slope);
+            for (int c = 0; c < 8; ++c) {
+                v0[c] = (f16)rv_lrelu(acc[c] + a.bias[co0 + c], a.slope);
+                v1[c] = (f16)rv_lrelu(acc[8 + c] + a.bias[co0 + 8 + c], a.slope);
+            }
+            *reinterpret_cast<f16x8*>(o) = v0;
+            *reinterpret_cast<f16x8*>(o + 8) = v1;
+        } else {
+#pragma unroll
+            for (int c = 0; c < CD_CO; ++c)
+                if (co0 + c < a.cout) o[c] = (f16)rv_lrelu(acc[c] + a.bias[co0 + c], a.slope);
+        }
     } else {
         float* o = reinterpret_cast<float*>(a.out);
 #pragma unroll
@@ -91,7 +114,8 @@ extern "C" int refvsr_conv_direct_f32(const float* src, int cin, int h, int w,
     a.wo = (w + 2 * pad - ksize) / stride + 1;
     a.slope = act_slope; a.out_nhwc16 = out_nhwc16; a.out_c = out_c;
     const int PH = (CD_T - 1) * stride + ksize;
-    const size_t lds = (size_t)CD_CI * PH * PH * sizeof(float);
+    const size_t lds = ((size_t)CD_CI * PH * PH + (size_t)CD_CI * ksize * ksize * CD_CO) * sizeof(float);
+    RV_CHECK(!out_nhwc16 || out_c % 8 == 0, "conv_direct: nhwc16 output needs out_c %% 8 == 0");
     dim3 grid(rv_cdiv(a.wo, CD_T), rv_cdiv(a.ho, CD_T), rv_cdiv(cout, CD_CO));
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK();

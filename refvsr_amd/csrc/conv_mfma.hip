@@ -23,6 +23,10 @@
 //   discontinuous in the features.
 // * Epilogue fuses bias, (leaky)ReLU, alpha-multiply, residual, post-activation, pixel-shuffle or a
 //   planar fp32 store with residual / constant / clamp.
+// * Gather mode (runtime flag, chosen when the staged tile would not fit LDS, i.e. the stride-4/8 5x5
+//   offset predictors of the HD configs, alignment.py:20 with stride = ks): windows of neighbouring output
+//   pixels do not overlap there, so B fragments are read straight from global memory (16 bytes per lane,
+//   zero for out-of-frame taps) and only the weights go through LDS.
 //
 // Replaces nn.Conv2d call sites listed in include/refvsr_hip.h.
 #include "common.h"
@@ -47,6 +51,7 @@ struct ConvArgs {
     int out_mode; void* out; int out_c;
     const float* res_planar; float add_const, clamp_lo, clamp_hi;
     int tab_bytes, wl_bytes;         // LDS carve sizes
+    int gather;                      // 1: no LDS input tile, B fragments gathered from global memory
 };
 
 template <int MT, int TILES, bool F32>
@@ -69,19 +74,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 
     // ---- K-block -> LDS byte offset table -------------------------------------------------
     for (int g = tid; g < p.S * 4; g += 256) {
-        int off = 0;
+        int off = p.gather ? -1 : 0;
         if (g < p.G) {
             const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
             const int cg = g - tap * p.ncg;
             const int ty = tap / p.ks;
             const int tx = tap - ty * p.ks;
-            off = ((ty * p.LW + tx) * p.ps + cg) * 16;
+            off = p.gather ? (ty | (tx << 8) | (cg << 16)) : ((ty * p.LW + tx) * p.ps + cg) * 16;
         }
         tab[g] = off;
     }
 
     // ---- stage the input tile (zero padded) -----------------------------------------------
-    {
+    if (!p.gather) {
         const int iy0 = ty0 * p.stride - p.pad;
         const int ix0 = tx0 * p.stride - p.pad;
         const int row_chunks = p.LW * p.ncg;
@@ -107,14 +112,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     }
 
     // ---- per-lane base offsets of this wave's pixel tiles -----------------------------------
-    int pbase[TILES];
+    int pbase[TILES];        // tile mode: LDS byte offset of the pixel's window origin; gather mode: packed (iy0, ix0)
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
         const int ti = wave * TILES + t;
         const int row = ti >> 1;
         const int col = (ti & 1) * 16 + lr;
-        pbase[t] = ((row * p.stride) * p.LW + col * p.stride) * p.ps * 16;
+        if (p.gather) {
+            const int iy = (ty0 + row) * p.stride - p.pad + 4096, ix = (tx0 + col) * p.stride - p.pad + 4096;
+            pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
+        } else {
+            pbase[t] = ((row * p.stride) * p.LW + col * p.stride) * p.ps * 16;
+        }
     }
+    auto load_b = [&](int pb, int toff) -> uint4 {
+        if (!p.gather) return *reinterpret_cast<const uint4*>(tile + pb + toff);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (toff >= 0) {
+            const int iy = (pb >> 16) - 4096 + (toff & 0xff);
+            const int ix = (pb & 0xffff) - 4096 + ((toff >> 8) & 0xff);
+            const int cg = toff >> 16;
+            if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
+                const size_t pix = (size_t)iy * p.w_in + ix;
+                v = (cg < p.ncg0) ? *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16)
+                                  : *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
+            }
+        }
+        return v;
+    };
 
     f32x4 acc[MT][TILES];
 #pragma unroll
@@ -142,7 +167,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     a[m] = *reinterpret_cast<const f32x4*>(wl + ((size_t)(sl * MT + m) * 64 + lane) * 16);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + pbase[t] + toff);
+                    const uint4 braw = load_b(pbase[t], toff);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&braw);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -159,7 +185,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 }
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    const f16x8 b = *reinterpret_cast<const f16x8*>(tile + pbase[t] + toff);
+                    const uint4 braw = load_b(pbase[t], toff);
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(&braw);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
@@ -328,10 +355,15 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         if (lds <= 160 * 1024 || tiles == 2) break;
         tiles = 2;
     }
-    RV_CHECK(lds <= 160 * 1024, "conv: input tile does not fit LDS (%zu bytes; k=%d stride=%d cin=%d)",
-             lds, a.ks, a.stride, d->c0 + d->c1);
+    if (lds > 160 * 1024) {                        // strided predictor convs: gather B fragments from global memory
+        a.gather = 1;
+        tiles = 4;
+        a.LH = a.LW = 0;
+        lds = (size_t)a.tab_bytes + a.wl_bytes;
+        RV_CHECK(d->h_in < 60000 && d->w_in < 60000, "conv: frame too large for gather-mode coordinates");
+    }
     // prefer 2 blocks/CU for mid-size tiles
-    if (tiles == 4 && lds > 80 * 1024 && d->h_out * d->w_out > 64 * 1024) {
+    if (!a.gather && tiles == 4 && lds > 80 * 1024 && d->h_out * d->w_out > 64 * 1024) {
         const int LH2 = 3 * a.stride + a.ks;
         const size_t lds2 = (size_t)a.tab_bytes + a.wl_bytes + (size_t)LH2 * a.LW * a.ps * 16;
         if (lds2 <= 80 * 1024) { tiles = 2; a.LH = LH2; lds = lds2; }

@@ -228,6 +228,25 @@ extern "C" int refvsr_max2(const float* a, const float* b, float* out, size_t n,
     return 0;
 }
 
+// bit-exact equality of two float buffers -> flag (1 = equal).  Used to key the per-frame cache: frames of
+// consecutive sliding windows are recognised by content, so the drop-in forward() needs no frame ids.
+__global__ void buffers_equal_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n,
+                                     int* __restrict__ flag) {
+    bool diff = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        diff |= (a[i] != b[i]);
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
+extern "C" int refvsr_buffers_equal(const void* a, const void* b, size_t n_words, int32_t* flag, void* stream) {
+    RV_CHECK(a && b && flag && n_words > 0, "buffers_equal: bad args");
+    const int grid = (int)((n_words + 255) / 256 > 1024 ? 1024 : (n_words + 255) / 256);
+    hipLaunchKernelGGL(buffers_equal_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)a,
+                       (const uint32_t*)b, n_words, flag);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // warp (models/utils.py:35-43): zeros padding, align_corners=False sampling of a linspace(-1,1) grid
 // ------------------------------------------------------------------------------------------------

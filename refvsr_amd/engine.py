@@ -73,10 +73,15 @@ class Weights(object):
             for j, (co, ci) in enumerate(chans):
                 mf('FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j), [ci])
         fe = 'feature_match.feature_extract.'
+        self.hd = bool(config.flag_HD_in)
         dr('feature_match.sub_mean')
         mf32(fe + '0', [3])
         mf32(fe + '2', [64])
-        mf32(fe + 'map64.0', [64])
+        if self.hd:                       # VGG19[0:7] + map128 (attention.py:33-40)
+            mf32(fe + '5', [64])
+            mf32(fe + 'map128.0', [128])
+        else:
+            mf32(fe + 'map64.0', [64])
 
         def aligned(prefix):
             mf(prefix + '.conv1.0', [3])
@@ -87,6 +92,8 @@ class Weights(object):
             mf(prefix + '.p_conv.2.conv2', [32])
             mf(prefix + '.p_conv.4', [32])
         aligned('aa2.align')
+        if config.matching_ksize // 2 > 1:     # RefVSR.py:39 -- aa1 aligns only when its patch is larger than 1 px
+            aligned('aa1.align')
 
         def reslist(name, n):
             for i in range(n):
@@ -127,8 +134,6 @@ class Engine(object):
     instance: RefVSR.py:96-101,279-283)."""
 
     def __init__(self, config, weights):
-        if config.flag_HD_in:
-            raise NotImplementedError('flag_HD_in (8K) path is not built yet on the HIP engine')
         if config.scale != 4:
             raise NotImplementedError('only scale 4 is built')
         self.cfg = config
@@ -136,6 +141,7 @@ class Engine(object):
         self.C = config.mid_channels
         self.nb = config.num_blocks
         self.ks = config.matching_ksize
+        self.hd = bool(config.flag_HD_in)
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
@@ -232,13 +238,25 @@ class Engine(object):
         R = self.W.raw
         h, w = fr.lr.shape[1:]
 
-        def extract(x):       # VGG19[0:4] + map64 in exact fp32 on v_mfma_f32_16x16x4_f32 (attention.py:31-42)
+        fe = 'feature_match.feature_extract.'
+
+        def extract(x):       # VGG19 head + 1x1 map in exact fp32 on v_mfma_f32_16x16x4_f32 (attention.py:31-42)
             x = ops.pack_nhwc32(x, 4)
-            x = ops.conv(self.cw('feature_match.feature_extract.0'), x, act=0.0)
-            x = ops.conv(self.cw('feature_match.feature_extract.2'), x, act=0.0)
-            return ops.conv(self.cw('feature_match.feature_extract.map64.0'), x, act=0.2, planar_out=True)
+            x = ops.conv(self.cw(fe + '0'), x, act=0.0)
+            if not self.hd:
+                x = ops.conv(self.cw(fe + '2'), x, act=0.0)
+                return ops.conv(self.cw(fe + 'map64.0'), x, act=0.2, planar_out=True)
+            x = ops.conv(self.cw(fe + '2'), x, act=0.0, planar_out=True)
+            x = ops.pack_nhwc32(ops.maxpool2(x))                                   # VGG19[4]
+            x = ops.conv(self.cw(fe + '5'), x, act=0.0)
+            return ops.conv(self.cw(fe + 'map128.0'), x, act=0.2, planar_out=True)
         lr_n = ops.conv_direct(fr.lr, *R['feature_match.sub_mean'])
         ref_n = ops.conv_direct(fr.ref, *R['feature_match.sub_mean'])
+        if self.hd:                                                                # attention.py:65-67
+            f = 1.0 / (self.cfg.scale // 2)
+            oh, ow = int(h * f), int(w * f)
+            lr_n = ops.resize(lr_n, (oh, ow), ops.RS_NEAREST, (1.0 / f, 1.0 / f))
+            ref_n = ops.resize(ref_n, (oh, ow), ops.RS_NEAREST, (1.0 / f, 1.0 / f))
         lr_f = extract(lr_n)
         ref_f = extract(ops.avgpool2(ref_n))
         lr_rows, inv_lr = ops.match_patches(lr_f, ops.hip.MATCH_COLBLOCK)
@@ -253,15 +271,19 @@ class Engine(object):
             e1.record()
             self.kernel_events.append((e0, e1))
         conf, idx = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand)
-        return conf.view(1, lr_f.shape[1], lr_f.shape[2]), idx
+        conf = conf.view(1, lr_f.shape[1], lr_f.shape[2])
+        grid = (lr_f.shape[1], lr_f.shape[2])
+        if grid[0] != h:                                                           # attention.py:96-98 (HD)
+            conf = ops.bicubic_scale(conf, float(h) / grid[0], clamp01=True)
+        return conf, idx, grid
 
-    def aligned_conv(self, feats, fr, rgb8, prefix, ks):
-        """AlignedConv2d.forward (RefVSR_/alignment.py:39-100)."""
+    def aligned_conv(self, feats, query, rgb8, prefix, ks):
+        """AlignedConv2d.forward (RefVSR_/alignment.py:39-100); query: planar fp32 [3,.,.] (bicubic x2 inside)."""
         def enc(z8):
             e = ops.conv(self.cw(prefix + '.conv1.0'), z8, act=0.2)
             t = ops.conv(self.cw(prefix + '.conv1.2.conv1'), e, act=0.2)
             return ops.conv(self.cw(prefix + '.conv1.2.conv2'), t, res=e, post=0.2)
-        q = enc(ops.bicubic_scale(fr.lr, 2, clamp01=False, nhwc16_out=True))
+        q = enc(ops.bicubic_scale(query, 2, clamp01=False, nhwc16_out=True))
         r = enc(rgb8)
         a = ops.conv(self.cw(prefix + '.p_conv.0'), r, q, stride=ks, act=0.2)
         t = ops.conv(self.cw(prefix + '.p_conv.2.conv1'), a, act=0.2)
@@ -276,7 +298,7 @@ class Engine(object):
             return
         h, w = fr.lr.shape[1:]
         fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
-        fr.conf, fr.idx = self.feature_match(fr)
+        fr.conf, fr.idx, (gh, gw) = self.feature_match(fr)
         ref8 = ops.pack_nhwc16(fr.ref, 8)
         x = ops.conv(self.cw('ref_encoder1.0.0'), ref8, act=0.2)
         x = ops.conv(self.cw('ref_encoder1.1.0'), x, act=0.2)
@@ -285,10 +307,18 @@ class Engine(object):
         x = ops.conv(self.cw('ref_encoder2.1.0'), x, act=0.2)
         ref_feat_down = self.res_list(x, 'res2', 4)
         s1, s2 = self.ks // 2, self.ks
-        fr.aligned = ops.block_gather_nhwc16(ref_feat_down, fr.idx, h, w, s1)            # aa1 (attention.py:142-144)
-        feats2 = ops.block_gather_nhwc16(ref_feat, fr.idx, h, w, s2)                     # aa2
-        rgb2 = ops.block_gather_rgb(fr.ref, fr.idx, h, w, s2)                            # attention.py:152-154
-        fr.aligned_up = self.aligned_conv(feats2, fr, rgb2, 'aa2.align', s2)
+        # aa1 (RefVSR.py:127, attention.py:142-157): gather of LR/2 reference features; with a patch > 1 px (HD)
+        # also the affine AlignedConv2d, queried by bicubic x0.5 of the LR frame (RefVSR.py:125)
+        feats1 = ops.block_gather_nhwc16(ref_feat_down, fr.idx, gh, gw, s1)
+        if s1 > 1:
+            rgb1 = ops.block_gather_rgb(fr.ref, fr.idx, gh, gw, s1)
+            lr_down = ops.bicubic_scale(fr.lr, 0.5, clamp01=True)
+            fr.aligned = self.aligned_conv(feats1, lr_down, rgb1, 'aa1.align', s1)
+        else:
+            fr.aligned = feats1
+        feats2 = ops.block_gather_nhwc16(ref_feat, fr.idx, gh, gw, s2)                   # aa2 (RefVSR.py:136)
+        rgb2 = ops.block_gather_rgb(fr.ref, fr.idx, gh, gw, s2)                          # attention.py:152-154
+        fr.aligned_up = self.aligned_conv(feats2, fr.lr, rgb2, 'aa2.align', s2)
 
     def rap(self, fr, conf_prop, feat, feat_up):
         """AA_AF_conf_prop (RefVSR.py:123-149)."""
@@ -335,30 +365,24 @@ class Engine(object):
             self.flow_cache = {}
             return [FrameCtx(lrs[i].contiguous(), refs[i].contiguous()) for i in range(t)]
         prev = self.prev_window
-        cands, tests = [], []
-        for i in range(t):
-            opts = []
-            if prev:
-                for j in (i + 1, i, i - 1):
-                    if 0 <= j < len(prev) and prev[j] not in opts:
-                        opts.append(prev[j])
-            cands.append(opts)
-            for o in opts:
-                tests.append(((lrs[i] == o.lr).all() & (refs[i] == o.ref).all()))
-        flags = torch.stack(tests).cpu().tolist() if tests else []
-        k = 0
-        for i in range(t):
-            for o in cands[i]:
-                if flags[k] and frames[i] is None:
-                    frames[i] = o
-                k += 1
+        if prev:
+            # candidates in order of likelihood: the window slid by one (i+1), did not move (i), slid back (i-1).
+            # Each round is one batch of compare kernels + one D2H sync; steady state resolves t-1 frames in round 1.
+            for shift in (1, 0, -1):
+                todo = [i for i in range(t) if frames[i] is None and 0 <= i + shift < len(prev)]
+                if not todo:
+                    continue
+                flags = ops.buffers_equal([x for i in todo for x in ((lrs[i], prev[i + shift].lr), (refs[i], prev[i + shift].ref))])
+                for n_, i in enumerate(todo):
+                    if flags[2 * n_] and flags[2 * n_ + 1]:
+                        frames[i] = prev[i + shift]
         # repeated frames inside this window (clip edges replicate frames, datasets.py:233-234)
         fresh = [i for i in range(t) if frames[i] is None]
         if len(fresh) > 1:
-            pairs = [(a, b) for ai, a in enumerate(fresh) for b in fresh[ai + 1:]]
-            eq = torch.stack([(lrs[a] == lrs[b]).all() & (refs[a] == refs[b]).all() for a, b in pairs]).cpu().tolist()
-            for (a, b), e in zip(pairs, eq):
-                if e:
+            pp = [(a, b) for ai, a in enumerate(fresh) for b in fresh[ai + 1:]]
+            eq = ops.buffers_equal([x for a, b in pp for x in ((lrs[a], lrs[b]), (refs[a], refs[b]))])
+            for n_, (a, b) in enumerate(pp):
+                if eq[2 * n_] and eq[2 * n_ + 1]:
                     if frames[a] is None:
                         frames[a] = FrameCtx(lrs[a].contiguous(), refs[a].contiguous())
                     if frames[b] is None:
@@ -378,6 +402,7 @@ class Engine(object):
         assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
         t, _, h, w = lrs.shape
         assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
+        assert not self.hd or (h % 8 == 0 and w % 8 == 0), 'flag_HD_in needs h, w divisible by 8'
         C = self.C
         ctr = t // 2
         dev = lrs.device

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
-MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 128, 512
+MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
 ABI_VERSION = 1
 
 
@@ -53,6 +53,7 @@ SIGNATURES = {
     'refvsr_avgpool2': [_P, _I, _I, _I, _P, _P],
     'refvsr_maxpool2': [_P, _I, _I, _I, _P, _P],
     'refvsr_max2': [_P, _P, _P, _Z, _P],
+    'refvsr_buffers_equal': [_P, _P, _Z, _P, _P],
     'refvsr_warp_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_warp_planar': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_spynet_level_input': [_P, _P, _P, _I, _I, _P, _P, _P],

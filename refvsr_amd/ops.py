@@ -231,6 +231,18 @@ def max2(a, b):
     return out
 
 
+def buffers_equal(pairs):
+    """pairs: list of (a, b) float32 tensors of equal shape.  Returns a python list of bools (one D2H sync)."""
+    if not pairs:
+        return []
+    flags = torch.ones(len(pairs), dtype=torch.int32, device=pairs[0][0].device)
+    for i, (a, b) in enumerate(pairs):
+        assert a.shape == b.shape and a.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+        hip.check(hip.lib().refvsr_buffers_equal(_ptr(a), _ptr(b), a.numel(), C.c_void_p(flags.data_ptr() + 4 * i),
+                                                 _stream()), 'buffers_equal')
+    return [bool(v) for v in flags.cpu().tolist()]
+
+
 def warp_nhwc16(x, flow):
     _nhwc(x)
     _planar(flow, 2)

@@ -107,6 +107,24 @@ def test_conv_mfma_vs_conv2d(dev, co, cins, ks, stride, h, w, shuffle):
     assert err < 1e-3          # fp16 output rounding (2^-11 relative) + fp32 accumulation order
 
 
+def test_conv_mfma_gather_mode_strided(dev):
+    """5x5 stride-4 / stride-8 offset predictors of the HD configs (alignment.py:20): the staged tile cannot fit
+    LDS, the kernel switches to gathering B fragments from global memory."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(77)
+    for stride, h, w in ((4, 64, 96), (8, 128, 192), (8, 72, 200)):
+        wt = torch.randn(32, 64, 5, 5, generator=g) / (64 * 25) ** 0.5
+        b = torch.randn(32, generator=g) * 0.1
+        x = torch.randn(1, 64, h, w, generator=g)
+        cw = ops.ConvWeights(pack_conv(wt, b, [32, 32]), dev)
+        got = planar(ops.conv(cw, nhwc(x[0, :32], dev), nhwc(x[0, 32:], dev), stride=stride, act=0.2))
+        want = F.leaky_relu(F.conv2d(x.half().float(), wt, b, stride=stride, padding=2), 0.2)[0]
+        assert got.shape == want.shape
+        report('conv gather 5x5 s%d %dx%d' % (stride, h, w), rel=rel(got, want))
+        assert rel(got, want) < 1e-3
+
+
 def test_conv_mfma_epilogues(dev):
     from refvsr_amd import ops
     from refvsr_amd.packing import pack_conv
@@ -300,7 +318,7 @@ def test_match_patches(dev):
     from refvsr_amd import ops
     from oracle import refvsr_oracle as orc
     f = torch.randn(16, 14, 18)
-    rows, inv = ops.match_patches(f.to(dev), 128)
+    rows, inv = ops.match_patches(f.to(dev), 256)
     p = orc.patches3x3(f[None])[0].t()                          # [L,144]
     n = p.norm(dim=1, keepdim=True).clamp_min(1e-12)
     assert rows.shape == (256, 152) and float(rows[14 * 18:].abs().max()) == 0 and float(rows[:, 144:].abs().max()) == 0
@@ -337,10 +355,10 @@ def test_match_fused_vs_oracle(dev):
         lr_f = base + 0.2 * torch.randn(16, h, w, generator=g)
         ref_f = F.avg_pool2d(base[None], 2)[0] + 0.2 * torch.randn(16, h // 2, w // 2, generator=g)
         lr_rows, inv_lr = ops.match_patches(lr_f.to(dev), 512)
-        ref_rows, inv_ref = ops.match_patches(ref_f.to(dev), 128)
+        ref_rows, inv_ref = ops.match_patches(ref_f.to(dev), 256)
         n_ref = ref_f.shape[1] * ref_f.shape[2]
         for splits in (1, 2):
-            if splits > (n_ref + 127) // 128:
+            if splits > (n_ref + 255) // 256:
                 continue
             cand, cval = ops.match_top2(ref_rows, n_ref, lr_rows, h * w, splits)
             assert int(cand.min()) >= 0 and int(cand.max()) < n_ref
@@ -356,7 +374,7 @@ def test_match_ties_pick_first_index(dev):
     lr_f = torch.ones(16, 12, 16)
     ref_f = torch.ones(16, 6, 8)
     lr_rows, inv_lr = ops.match_patches(lr_f.to(dev), 512)
-    ref_rows, inv_ref = ops.match_patches(ref_f.to(dev), 128)
+    ref_rows, inv_ref = ops.match_patches(ref_f.to(dev), 256)
     cand, _ = ops.match_top2(ref_rows, 48, lr_rows, 192, 1)
     conf, idx = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand)
     assert int(idx.abs().max()) == 0
@@ -368,7 +386,7 @@ def test_feature_match_golden(dev, small_cfg, small_sd):
     from refvsr_amd.engine import Engine, FrameCtx, Weights
     g = load_golden('op_match')
     eng = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
-    conf, idx = eng.feature_match(FrameCtx(g['lr'][0].to(dev), g['ref'][0].to(dev)))
+    conf, idx, _ = eng.feature_match(FrameCtx(g['lr'][0].to(dev), g['ref'][0].to(dev)))
     mism = int((idx.cpu().long() != g['idx'][0]).sum())
     report('feature_match golden', conf_err=maxdiff(conf.cpu(), g['conf'][0]), idx_mismatch=mism)
     assert maxdiff(conf.cpu(), g['conf'][0]) < 2e-5

@@ -42,11 +42,11 @@ def bench_match():
     lr_f = torch.randn(16, h, w, generator=g).to(dev)
     ref_f = torch.randn(16, h // 2, w // 2, generator=g).to(dev)
     lr_rows, inv_lr = ops.match_patches(lr_f, 512)
-    ref_rows, inv_ref = ops.match_patches(ref_f, 128)
+    ref_rows, inv_ref = ops.match_patches(ref_f, 256)
     n_lr, n_ref = h * w, (h // 2) * (w // 2)
     flops = 2.0 * n_lr * n_ref * 144
     base = None
-    for v in (0, 1, 2, 3):
+    for v in (0, 3, 4):
         os.environ['REFVSR_MATCH_VARIANT'] = str(v)
         ci, cv = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1)
         if base is None:
@@ -55,7 +55,7 @@ def bench_match():
         us = timeit(lambda: ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1), iters=10)
         emit('match_top2 variant %d: %.1f us  %.1f TFLOP/s  (%.1f%% of 2.5 PF)  identical=%s' %
              (v, us, flops / us / 1e6, flops / us / 1e6 / 25.0, same))
-    os.environ['REFVSR_MATCH_VARIANT'] = '3'
+    os.environ["REFVSR_MATCH_VARIANT"] = "4"
     us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0]), iters=10)
     emit('match_refine: %.1f us' % us)
     us = timeit(lambda: ops.match_patches(lr_f, 512), iters=10)

@@ -11,7 +11,7 @@ h, w = 270, 480
 lr_f = torch.randn(16, h, w, generator=g).to(dev)
 ref_f = torch.randn(16, h // 2, w // 2, generator=g).to(dev)
 lr_rows, _ = ops.match_patches(lr_f, 512)
-ref_rows, _ = ops.match_patches(ref_f, 128)
+ref_rows, _ = ops.match_patches(ref_f, 256)
 for _ in range(4):
     ops.match_top2(ref_rows, (h // 2) * (w // 2), lr_rows, h * w, 1)
 torch.cuda.synchronize()
