@@ -108,9 +108,11 @@ int refvsr_resize(const float* src, int c, int h, int w, void* dst, int oh, int 
                   const float* chan_mul, int clamp01, int out_nhwc16, int out_c, void* stream);
 int refvsr_avgpool2(const float* src, int c, int h, int w, float* dst, void* stream);
 int refvsr_maxpool2(const float* src, int c, int h, int w, float* dst, void* stream);
-/* *flag &= (a[0..n_words) == b[0..n_words)) bitwise on 32-bit words; the caller presets *flag = 1.
+/* flags[i] &= (a[i][0..n_bytes) == b[i][0..n_bytes)) for i < n_pairs (<= 32) in one launch; the caller presets
+ * flags to 1.  a, b: HOST arrays of device pointers (16-byte aligned buffers, n_bytes % 16 == 0).
  * Keys the per-frame cache (frames of consecutive sliding windows are recognised by content). */
-int refvsr_buffers_equal(const void* a, const void* b, size_t n_words, int32_t* flag, void* stream);
+int refvsr_buffers_equal(const void* const* a, const void* const* b, int n_pairs, size_t n_bytes,
+                         int32_t* flags, void* stream);
 /* out = max(a, b) elementwise on n floats (confidence accumulation, RefVSR.py:147). */
 int refvsr_max2(const float* a, const float* b, float* out, size_t n, void* stream);
 

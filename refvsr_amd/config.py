@@ -126,6 +126,7 @@ def set_data_path(config, data, is_train=False):
     config.EVAL.HR_data_path = os.path.join(root, 'HR')
     config.EVAL.HR_ref_data_W_path = os.path.join(root, ref_w)
     config.EVAL.HR_ref_data_T_path = os.path.join(root, ref_t)
-    config.EVAL.vid_name = None
+    if 'vid_name' not in config.EVAL:       # the reference resets it here (configs/config.py:146), which defeats --vid_name
+        config.EVAL.vid_name = None
     config.UW_path, config.W_path, config.T_path = 'UW', 'W', 'T'
     return config

@@ -54,7 +54,7 @@ struct ConvArgs {
     int gather;                      // 1: no LDS input tile, B fragments gathered from global memory
 };
 
-template <int MT, int TILES, bool F32>
+template <int MT, int TILES, bool F32, bool GATHER>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -74,19 +74,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 
     // ---- K-block -> LDS byte offset table -------------------------------------------------
     for (int g = tid; g < p.S * 4; g += 256) {
-        int off = p.gather ? -1 : 0;
+        int off = GATHER ? -1 : 0;
         if (g < p.G) {
             const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
             const int cg = g - tap * p.ncg;
             const int ty = tap / p.ks;
             const int tx = tap - ty * p.ks;
-            off = p.gather ? (ty | (tx << 8) | (cg << 16)) : ((ty * p.LW + tx) * p.ps + cg) * 16;
+            off = GATHER ? (ty | (tx << 8) | (cg << 16)) : ((ty * p.LW + tx) * p.ps + cg) * 16;
         }
         tab[g] = off;
     }
 
     // ---- stage the input tile (zero padded) -----------------------------------------------
-    if (!p.gather) {
+    if constexpr (!GATHER) {
         const int iy0 = ty0 * p.stride - p.pad;
         const int ix0 = tx0 * p.stride - p.pad;
         const int row_chunks = p.LW * p.ncg;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         const int ti = wave * TILES + t;
         const int row = ti >> 1;
         const int col = (ti & 1) * 16 + lr;
-        if (p.gather) {
+        if constexpr (GATHER) {
             const int iy = (ty0 + row) * p.stride - p.pad + 4096, ix = (tx0 + col) * p.stride - p.pad + 4096;
             pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
         } else {
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         }
     }
     auto load_b = [&](int pb, int toff) -> uint4 {
-        if (!p.gather) return *reinterpret_cast<const uint4*>(tile + pb + toff);
+        if constexpr (!GATHER) return *reinterpret_cast<const uint4*>(tile + pb + toff);
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (toff >= 0) {
+        if (GATHER && toff >= 0) {
             const int iy = (pb >> 16) - 4096 + (toff & 0xff);
             const int ix = (pb & 0xffff) - 4096 + ((toff >> 8) & 0xff);
             const int cg = toff >> 16;
@@ -284,15 +284,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 
 typedef void (*conv_kernel_t)(ConvArgs);
 
-template <int MT, int TILES, bool F32>
+template <int MT, int TILES, bool F32, bool GATHER>
 static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER>), grid, dim3(256), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -370,9 +370,15 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     }
     dim3 grid(rv_cdiv(d->w_out, CONV_TW), rv_cdiv(d->h_out, tiles * 2), nz);
     hipStream_t st = (hipStream_t)stream;
+    if (a.gather) {                                // only the fp16 strided predictors need it
+        RV_CHECK(!f32, "conv: gather mode is built for the fp16 path only");
+        if (MT == 1) return launch_conv<1, 4, false, true>(a, grid, lds, st);
+        if (MT == 2) return launch_conv<2, 4, false, true>(a, grid, lds, st);
+        return launch_conv<3, 4, false, true>(a, grid, lds, st);
+    }
 #define RV_CONV_CASE(M, T)                                                        \
     if (MT == M && tiles == T)                                                    \
-        return f32 ? launch_conv<M, T, true>(a, grid, lds, st) : launch_conv<M, T, false>(a, grid, lds, st);
+        return f32 ? launch_conv<M, T, true, false>(a, grid, lds, st) : launch_conv<M, T, false, false>(a, grid, lds, st);
     RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
     RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)
     RV_CONV_CASE(3, 2) RV_CONV_CASE(3, 4)

@@ -230,19 +230,35 @@ extern "C" int refvsr_max2(const float* a, const float* b, float* out, size_t n,
 
 // bit-exact equality of two float buffers -> flag (1 = equal).  Used to key the per-frame cache: frames of
 // consecutive sliding windows are recognised by content, so the drop-in forward() needs no frame ids.
-__global__ void buffers_equal_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n,
-                                     int* __restrict__ flag) {
+#define EQ_MAX_PAIRS 32
+struct EqArgs { const uint4* a[EQ_MAX_PAIRS]; const uint4* b[EQ_MAX_PAIRS]; size_t n16; int* flags; };
+
+__global__ void buffers_equal_kernel(EqArgs e) {
+    const uint4* a = e.a[blockIdx.y];
+    const uint4* b = e.b[blockIdx.y];
     bool diff = false;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        diff |= (a[i] != b[i]);
-    if (__any(diff) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < e.n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 x = a[i], y = b[i];
+        diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicAnd(e.flags + blockIdx.y, 0);
 }
 
-extern "C" int refvsr_buffers_equal(const void* a, const void* b, size_t n_words, int32_t* flag, void* stream) {
-    RV_CHECK(a && b && flag && n_words > 0, "buffers_equal: bad args");
-    const int grid = (int)((n_words + 255) / 256 > 1024 ? 1024 : (n_words + 255) / 256);
-    hipLaunchKernelGGL(buffers_equal_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)a,
-                       (const uint32_t*)b, n_words, flag);
+extern "C" int refvsr_buffers_equal(const void* const* a, const void* const* b, int n_pairs, size_t n_bytes,
+                                    int32_t* flags, void* stream) {
+    RV_CHECK(a && b && flags && n_pairs > 0 && n_pairs <= EQ_MAX_PAIRS, "buffers_equal: 1..%d pairs per call", EQ_MAX_PAIRS);
+    RV_CHECK(n_bytes > 0 && n_bytes % 16 == 0, "buffers_equal: size must be a multiple of 16 bytes");
+    EqArgs e;
+    memset(&e, 0, sizeof(e));
+    for (int i = 0; i < n_pairs; ++i) {
+        RV_CHECK(a[i] && b[i] && ((uintptr_t)a[i] % 16 == 0) && ((uintptr_t)b[i] % 16 == 0), "buffers_equal: unaligned buffer");
+        e.a[i] = (const uint4*)a[i];
+        e.b[i] = (const uint4*)b[i];
+    }
+    e.n16 = n_bytes / 16;
+    e.flags = flags;
+    const int gx = (int)((e.n16 + 255) / 256 > 256 ? 256 : (e.n16 + 255) / 256);
+    hipLaunchKernelGGL(buffers_equal_kernel, dim3(gx, n_pairs), dim3(256), 0, (hipStream_t)stream, e);
     RV_LAUNCH_CHECK();
     return 0;
 }

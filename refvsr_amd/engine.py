@@ -366,16 +366,13 @@ class Engine(object):
             return [FrameCtx(lrs[i].contiguous(), refs[i].contiguous()) for i in range(t)]
         prev = self.prev_window
         if prev:
-            # candidates in order of likelihood: the window slid by one (i+1), did not move (i), slid back (i-1).
-            # Each round is one batch of compare kernels + one D2H sync; steady state resolves t-1 frames in round 1.
-            for shift in (1, 0, -1):
-                todo = [i for i in range(t) if frames[i] is None and 0 <= i + shift < len(prev)]
-                if not todo:
-                    continue
-                flags = ops.buffers_equal([x for i in todo for x in ((lrs[i], prev[i + shift].lr), (refs[i], prev[i + shift].ref))])
-                for n_, i in enumerate(todo):
-                    if flags[2 * n_] and flags[2 * n_ + 1]:
-                        frames[i] = prev[i + shift]
+            # candidates in order of likelihood: the window slid by one (i+1), did not move (i), slid back (i-1);
+            # all candidate pairs are compared by ONE kernel launch + one D2H sync
+            cand = [(i, i + sh) for sh in (1, 0, -1) for i in range(t) if 0 <= i + sh < len(prev)]
+            flags = ops.buffers_equal([x for i, j in cand for x in ((lrs[i], prev[j].lr), (refs[i], prev[j].ref))])
+            for n_, (i, j) in enumerate(cand):
+                if frames[i] is None and flags[2 * n_] and flags[2 * n_ + 1]:
+                    frames[i] = prev[j]
         # repeated frames inside this window (clip edges replicate frames, datasets.py:233-234)
         fresh = [i for i in range(t) if frames[i] is None]
         if len(fresh) > 1:

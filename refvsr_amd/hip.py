@@ -53,7 +53,7 @@ SIGNATURES = {
     'refvsr_avgpool2': [_P, _I, _I, _I, _P, _P],
     'refvsr_maxpool2': [_P, _I, _I, _I, _P, _P],
     'refvsr_max2': [_P, _P, _P, _Z, _P],
-    'refvsr_buffers_equal': [_P, _P, _Z, _P, _P],
+    'refvsr_buffers_equal': [_P, _P, _I, _Z, _P, _P],
     'refvsr_warp_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_warp_planar': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_spynet_level_input': [_P, _P, _P, _I, _I, _P, _P, _P],

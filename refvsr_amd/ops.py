@@ -232,13 +232,20 @@ def max2(a, b):
 
 
 def buffers_equal(pairs):
-    """pairs: list of (a, b) float32 tensors of equal shape.  Returns a python list of bools (one D2H sync)."""
+    """pairs: list of (a, b) float32 tensors of one common shape.  Returns a python list of bools
+    (one launch per 32 pairs, one D2H sync)."""
     if not pairs:
         return []
+    nbytes = pairs[0][0].numel() * 4
     flags = torch.ones(len(pairs), dtype=torch.int32, device=pairs[0][0].device)
-    for i, (a, b) in enumerate(pairs):
-        assert a.shape == b.shape and a.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
-        hip.check(hip.lib().refvsr_buffers_equal(_ptr(a), _ptr(b), a.numel(), C.c_void_p(flags.data_ptr() + 4 * i),
+    for s0 in range(0, len(pairs), 32):
+        chunk = pairs[s0:s0 + 32]
+        for a, b in chunk:
+            assert a.shape == b.shape and a.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+            assert a.numel() * 4 == nbytes
+        pa = (C.c_void_p * len(chunk))(*[a.data_ptr() for a, _ in chunk])
+        pb = (C.c_void_p * len(chunk))(*[b.data_ptr() for _, b in chunk])
+        hip.check(hip.lib().refvsr_buffers_equal(pa, pb, len(chunk), nbytes, C.c_void_p(flags.data_ptr() + 4 * s0),
                                                  _stream()), 'buffers_equal')
     return [bool(v) for v in flags.cpu().tolist()]
 
