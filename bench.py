@@ -120,11 +120,15 @@ def main():
         raise SystemExit('--gpus %d needs a torch.distributed.run launch with --nproc-per-node %d' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # REFVSR_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box (all ranks share GPU 0);
+    # the real multi-GPU run uses nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get('REFVSR_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from refvsr_amd import SRNet, get_config, make_state_dict
     from refvsr_amd.synth import make_clip, window_indices
@@ -163,7 +167,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(out).all())

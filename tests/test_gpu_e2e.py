@@ -177,3 +177,69 @@ def test_full_size_against_reference_fixture(dev):
                ref_psnr=float(g['psnr_%d' % f]), dPSNR=float(abs(p - float(g['psnr_%d' % f]))))
         assert maxdiff(sub, g['sub_%d' % f]) < 3e-2
         assert abs(p - float(g['psnr_%d' % f])) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 with the real engine: two processes share the one GPU of the test box (gloo for the hand-off)
+# ------------------------------------------------------------------------------------------------
+class _HipExec(object):
+    def __init__(self, reset):
+        self.net, self.cfg, self.sd = make_net('config_RefVSR_small_L1', 3, torch.device('cuda:0'), reset=reset,
+                                               save_sample=False)
+        self.eng = self.net.Network.ensure_engines(1, torch.device('cuda:0'))[0]
+
+    def __call__(self, lrs, refs, first):
+        return self.net(lrs[None].cuda(), refs[None].cuda(), first)['result'][0].cpu()
+
+    def export_state(self):
+        st = self.eng.export_state()
+        return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+
+    def import_state(self, st):
+        self.eng.import_state({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in st.items()})
+
+
+def _shard_worker(rank, world, port, reset, aligned, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from refvsr_amd import shard
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, _ = make_clip(6, 32, 48, seed=3)
+    get = lambda f: (lr[window_indices(f, 6, 3)], rf[window_indices(f, 6, 3)])
+    ex = _HipExec(reset)
+    res = shard.run_sharded(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu', aligned=aligned)
+    q.put((rank, {f: v.clone() for f, v in res.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('reset,aligned', [(None, False), (3, True)])
+def test_two_process_sharding_matches_sequential(dev, reset, aligned):
+    """Frame sharding across two ranks (state hand-off, and the exchange-free reset-aligned partition) must
+    reproduce the single-process stream bit-for-bit on the HIP engine."""
+    import socket
+    import torch.multiprocessing as mp
+    from refvsr_amd.synth import make_clip, window_indices
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, reset, aligned, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        _, res = q.get(timeout=600)
+        got.update(res)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    lr, rf, _ = make_clip(6, 32, 48, seed=3)
+    ex = _HipExec(reset)
+    for f in range(6):
+        w = window_indices(f, 6, 3)
+        assert torch.equal(got[f], ex(lr[w], rf[w], f == 0)), 'frame %d differs from the sequential run' % f
