@@ -83,6 +83,7 @@ def base_config(project='', mode='', config_='', data='', LRS='', batch_size=8):
     # build-specific knobs (not in the reference)
     c.cache_windows = True      # de-duplicate flows/matching/ref encodings across sliding windows
     c.compute_dtype = 'f16'     # storage/MFMA operand type of feature maps on the GPU
+    c.overlap_streams = True    # forward-branch step on a side HIP stream, concurrent with the new frame's preparation
     c.fuse_resblocks = True     # conv-act-conv+residual pairs in one launch where the LDS budget allows
     return c
 

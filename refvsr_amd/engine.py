@@ -146,6 +146,8 @@ class Engine(object):
         self.match_row_splits = 1
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
+        self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
+        self._side = None
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.reset_state()
 
@@ -392,45 +394,14 @@ class Engine(object):
         self.prev_window = frames
         return frames
 
-    # ------------------------------------------------------------------ forward
-    @torch.no_grad()
-    def forward(self, lrs, refs, is_first_frame, want_vis=False):
-        """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None)."""
-        assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
-        t, _, h, w = lrs.shape
-        assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
-        assert not self.hd or (h % 8 == 0 and w % 8 == 0), 'flag_HD_in needs h, w divisible by 8'
-        C = self.C
-        ctr = t // 2
-        dev = lrs.device
-        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
-            is_first_frame = True                                                   # :168-170
-        if not is_first_frame and self.fw_feat is None:
-            raise RuntimeError('is_first_frame=False but no forward state is held (first call of a stream '
-                               'must pass is_first_frame=True, cf. RefVSR.py:257-258)')
-        gradio = bool(self.cfg.EVAL.is_gradio)
-        zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if gradio else None
-        fr = self._frames(lrs, refs)
-        flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b]))   # :183-191
-        range_start = 0 if is_first_frame else ctr                                  # :173-176
-        for i in range(range_start, t):                                             # :196-204 (+ per-frame RAP parts)
-            self.prepare_frame(fr[i])
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
-        # ---- backward branch (:211-238)
-        feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
-        feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
-        conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
-        for i in range(t - 1, ctr - 1, -1):
-            if i < t - 1:
-                fl = flow(i, i + 1)                       # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
-                feat = ops.warp_nhwc16(feat, fl)
-                conf = ops.warp_planar(conf, fl)
-                feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
-            feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
-            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
-        bw_up, conf_bw = feat_up, conf
-
-        # ---- forward branch (:240-283)
+    def _forward_branch(self, fr, flow, t, h, w, is_first_frame):
+        """Forward propagation branch (RefVSR.py:240-283); updates the carried state.  Runs on the current stream."""
+        C, ctr, dev = self.C, t // 2, fr[0].lr.device
         if is_first_frame:
             feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
             feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
@@ -454,6 +425,68 @@ class Engine(object):
             if i == ctr:                                                            # :279-283
                 self.fw_feat, self.fw_feat_up, self.fw_conf = feat, feat_up, conf
                 self.fw_flow = flow(ctr + 1, ctr)         # forward_flows[:, ctr]
+        return feat, feat_up, conf
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, lrs, refs, is_first_frame, want_vis=False):
+        """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None)."""
+        assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
+        t, _, h, w = lrs.shape
+        assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
+        assert not self.hd or (h % 8 == 0 and w % 8 == 0), 'flag_HD_in needs h, w divisible by 8'
+        C = self.C
+        ctr = t // 2
+        dev = lrs.device
+        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
+            is_first_frame = True                                                   # :168-170
+        if not is_first_frame and self.fw_feat is None:
+            raise RuntimeError('is_first_frame=False but no forward state is held (first call of a stream '
+                               'must pass is_first_frame=True, cf. RefVSR.py:257-258)')
+        gradio = bool(self.cfg.EVAL.is_gradio)
+        zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if gradio else None
+        fr = self._frames(lrs, refs)
+        flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b]))   # :183-191
+        range_start = 0 if is_first_frame else ctr                                  # :173-176
+        # Two-stream overlap (steady state): the forward-branch step depends only on cached per-frame data and
+        # the carried state, not on this window's new frame, so it runs on a side stream while the main stream
+        # prepares the new frame (matching, encoders, alignment) and walks the backward branch.
+        main = torch.cuda.current_stream()
+        overlap = (self.overlap and not is_first_frame and fr[ctr].conf is not None)
+        if overlap:
+            for i in range(ctr, t):
+                self.pyramid(fr[i])                        # shared by both streams: build on main before the fork
+            side = self._side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
+                    x.record_stream(side)
+                fw = self._forward_branch(fr, flow, t, h, w, False)
+        for i in range(range_start, t):                                             # :196-204 (+ per-frame RAP parts)
+            self.prepare_frame(fr[i])
+
+        # ---- backward branch (:211-238)
+        feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
+        feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
+        conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+        for i in range(t - 1, ctr - 1, -1):
+            if i < t - 1:
+                fl = flow(i, i + 1)                       # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
+                feat = ops.warp_nhwc16(feat, fl)
+                conf = ops.warp_planar(conf, fl)
+                feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
+            feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
+            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+        bw_up, conf_bw = feat_up, conf
+
+        # ---- forward branch (:240-283)
+        if overlap:
+            main.wait_stream(side)
+            for x in fw:
+                x.record_stream(main)
+        else:
+            fw = self._forward_branch(fr, flow, t, h, w, is_first_frame)
+        feat, feat_up, conf = fw
         out = self.compute_up(bw_up, feat_up, conf_bw, conf, fr[ctr].lr)            # :288-289,297
         if is_first_frame:                                                          # :292-295
             self.frame_itr_num = 0

@@ -210,7 +210,7 @@ def _shard_worker(rank, world, port, reset, aligned, q):
     get = lambda f: (lr[window_indices(f, 6, 3)], rf[window_indices(f, 6, 3)])
     ex = _HipExec(reset)
     res = shard.run_sharded(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu', aligned=aligned)
-    q.put((rank, {f: v.clone() for f, v in res.items()}))
+    q.put((rank, {f: v.clone().numpy() for f, v in res.items()}))     # by value: no fd passing after exit
     dist.barrier()
     dist.destroy_process_group()
 
@@ -234,7 +234,7 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned):
     got = {}
     for _ in range(2):
         _, res = q.get(timeout=600)
-        got.update(res)
+        got.update({f: torch.from_numpy(v) for f, v in res.items()})
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

@@ -48,7 +48,7 @@ def _worker(rank, world, port, reset, aligned, q):
     from refvsr_amd import shard
     cfg, sd, get = _setup(reset)
     res = shard.run_sharded(_Exec(cfg, sd), get, 6, 3, reset, cfg.mid_channels, 'cpu', aligned=aligned)
-    q.put((rank, {f: v.clone() for f, v in res.items()}))
+    q.put((rank, {f: v.clone().numpy() for f, v in res.items()}))     # by value: no fd passing after exit
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,7 +71,7 @@ def _run(reset, aligned):
     got = {}
     for _ in range(2):
         rank, res = q.get(timeout=600)
-        got.update(res)
+        got.update({f: torch.from_numpy(v) for f, v in res.items()})
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
