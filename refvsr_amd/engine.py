@@ -147,6 +147,7 @@ class Engine(object):
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
+        self.overlap_prepare = not os.environ.get('REFVSR_NO_OVERLAP_PREPARE')
         self._side = None
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.reset_state()
@@ -293,6 +294,16 @@ class Engine(object):
         affine = ops.conv(self.cw(prefix + '.p_conv.4'), a, planar_out=True, add_const=1.0, clamp=(-3.0, 3.0))
         return ops.aligned_sample(feats, affine, ks)
 
+    def _ref_encoders(self, fr):
+        """ref_feat = res1(ref_encoder1(ref)), ref_feat_down = res2(ref_encoder2(ref_feat))  (RefVSR.py:233-234)."""
+        ref8 = ops.pack_nhwc16(fr.ref, 8)
+        x = ops.conv(self.cw('ref_encoder1.0.0'), ref8, act=0.2)
+        x = ops.conv(self.cw('ref_encoder1.1.0'), x, act=0.2)
+        ref_feat = self.res_list(x, 'res1', 4)
+        x = ops.conv(self.cw('ref_encoder2.0.0'), ref_feat, stride=2, act=0.2)
+        x = ops.conv(self.cw('ref_encoder2.1.0'), x, act=0.2)
+        return ref_feat, self.res_list(x, 'res2', 4)
+
     def prepare_frame(self, fr):
         """Everything that is a function of (lr_i, ref_i) only: matching (RefVSR.py:196-204), reference
         encoders (:233-234) and both AlignedAttention outputs (:127,136)."""
@@ -300,14 +311,22 @@ class Engine(object):
             return
         h, w = fr.lr.shape[1:]
         fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
+        # the reference encoders do not depend on the matching: with stream overlap they run on a second side
+        # stream underneath the (MFMA-bound, 1 workgroup / CU) matching kernel
+        main = torch.cuda.current_stream()
+        par = self.overlap and self.overlap_prepare
+        if par:
+            side = self._side_stream(fr.lr.device, 1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ref_feat, ref_feat_down = self._ref_encoders(fr)
         fr.conf, fr.idx, (gh, gw) = self.feature_match(fr)
-        ref8 = ops.pack_nhwc16(fr.ref, 8)
-        x = ops.conv(self.cw('ref_encoder1.0.0'), ref8, act=0.2)
-        x = ops.conv(self.cw('ref_encoder1.1.0'), x, act=0.2)
-        ref_feat = self.res_list(x, 'res1', 4)
-        x = ops.conv(self.cw('ref_encoder2.0.0'), ref_feat, stride=2, act=0.2)
-        x = ops.conv(self.cw('ref_encoder2.1.0'), x, act=0.2)
-        ref_feat_down = self.res_list(x, 'res2', 4)
+        if par:
+            main.wait_stream(side)
+            ref_feat.record_stream(main)
+            ref_feat_down.record_stream(main)
+        else:
+            ref_feat, ref_feat_down = self._ref_encoders(fr)
         s1, s2 = self.ks // 2, self.ks
         # aa1 (RefVSR.py:127, attention.py:142-157): gather of LR/2 reference features; with a patch > 1 px (HD)
         # also the affine AlignedConv2d, queried by bicubic x0.5 of the LR frame (RefVSR.py:125)
@@ -394,10 +413,10 @@ class Engine(object):
         self.prev_window = frames
         return frames
 
-    def _side_stream(self, dev):
-        if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-        return self._side
+    def _side_stream(self, dev, k=0):
+        if self._side is None or self._side[0].device != dev:
+            self._side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        return self._side[k]
 
     def _forward_branch(self, fr, flow, t, h, w, is_first_frame):
         """Forward propagation branch (RefVSR.py:240-283); updates the carried state.  Runs on the current stream."""
