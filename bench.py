@@ -192,10 +192,18 @@ def main():
             n_lr, n_ref = H * W_, (H // 2) * (W_ // 2)
             flops = 2.0 * n_lr * n_ref * 144
             ach = flops / (mean_ms * 1e-3) / 1e12
+            traffic, tsrc = None, None
+            pj = os.path.join(ROOT, 'profiles', 'pmc_match_top2.json')
+            if os.path.exists(pj):           # HBM bytes per launch from the PMC passes (tools/pmc_to_json.py); not live
+                try:
+                    traffic = json.load(open(pj))['traffic_bytes_per_launch']
+                    tsrc = 'profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
+                except Exception:  # noqa: BLE001
+                    traffic = None
             line['roofline'] = {'kernel': 'match_top2_kernel (fused cosine GEMM + column top-2)', 'bound': 'mfma',
                                 'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
-                                'traffic': None, 'launches_timed': len(ms), 'mean_launch_ms': mean_ms,
-                                'flops_per_launch': flops}
+                                'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': len(ms),
+                                'mean_launch_ms': mean_ms, 'flops_per_launch': flops}
         else:
             line['roofline'] = None
         line['whole_path'] = {'algorithmic_tflop_per_frame_dedup': ALG_TFLOP_PER_FRAME,

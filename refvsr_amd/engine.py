@@ -147,7 +147,8 @@ class Engine(object):
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
-        self.overlap_prepare = not os.environ.get('REFVSR_NO_OVERLAP_PREPARE')
+        # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
+        self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
         self._side = None
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.reset_state()

@@ -99,6 +99,23 @@ def test_midsize_against_live_oracle_and_cache_equivalence(dev):
         assert d_psnr < 1e-3          # north-star parity bar: |PSNR(build,GT) - PSNR(oracle,GT)| <= 1e-3 dB
 
 
+def test_hd_midsize_against_live_oracle(dev):
+    """flag_HD_in path (RefVSR_small_MFID_8K geometry) at 128x192 -> 512x768: exercises the stride-4/8 gather-mode
+    predictor convs, aa1 alignment and the VGG conv2_1 + max-pool matching branch at a non-toy size."""
+    from oracle import refvsr_oracle as orc
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, gt = make_clip(2, 128, 192, seed=9)
+    net, cfg, sd = make_net('config_RefVSR_small_MFID_8K', 3, dev)
+    o = orc.OracleNetwork(cfg, sd)
+    for f in range(2):
+        w = window_indices(f, 2, 3)
+        a = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+        want = o.forward(lr[w][None], rf[w][None], f == 0)['result']
+        d_psnr = abs(psnr(a, gt[f][None]) - psnr(want, gt[f][None]))
+        report('e2e HD 128x192 f%d' % f, res=maxdiff(a, want), psnr_vs_oracle=float(psnr(a, want)), dPSNR_vs_gt=float(d_psnr))
+        assert a.shape == (1, 3, 512, 768) and maxdiff(a, want) < 2e-2 and psnr(a, want) > 55.0 and d_psnr < 1e-3
+
+
 def test_batch_and_api_contract(dev):
     from refvsr_amd.synth import make_clip, window_indices
     lr, rf, _ = make_clip(2, 32, 48, seed=1)
