@@ -13,6 +13,11 @@
 //
 // Same MFMA orientation / K walk as conv_mfma.hip (D[cout][pixel], K-block = (tap, 8-channel group),
 // v_mfma_f32_16x16x32_f16, hi+lo weights).  8 waves per workgroup (2 per SIMD).
+//
+// Workgroups are persistent: at most one per CU, each walking tiles  blockIdx.x, +gridDim.x, ...  The weights
+// are fetched once per workgroup; the x tile is double buffered and the NEXT tile is prefetched into registers
+// while the current one is in the matrix pipe (at LR there is one tile per CU and the loop runs once; on the
+// 2x maps four tiles per workgroup hide three of four staging latencies and three of four weight loads).
 #include "common.h"
 
 #define RB_TH 16
@@ -35,7 +40,10 @@ struct ResBlockArgs {
     const uint4* w2; const float* b2;
     float act_slope, post_slope;
     int tab_bytes, w_bytes, x_bytes;     // LDS carve
+    int tiles_x, n_tiles;
 };
+
+#define RB_XCH_MAX 5                      // uint4 prefetch registers per thread for one x tile (20*36*ncg / 512, ncg <= 3)
 
 template <int MT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_mfma_kernel(ResBlockArgs p) {
@@ -44,16 +52,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int* tab2 = tab1 + p.S * 4;                                   // K-block -> offset in the t tile
     unsigned char* wl1 = smem + p.tab_bytes;
     unsigned char* wl2 = wl1 + p.w_bytes;
-    unsigned char* xt = wl2 + p.w_bytes;                          // [RB_XH][RB_XW][ps*16]
-    unsigned char* tt = xt + p.x_bytes;                           // [RB_IH][RB_IW][ps*16]
+    unsigned char* xt0 = wl2 + p.w_bytes;                         // 2 x [RB_XH][RB_XW][ps*16]
+    unsigned char* tt = xt0 + 2 * p.x_bytes;                      // [RB_IH][RB_IW][ps*16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int q = lane >> 4;
     const int lr = lane & 15;
-    const int tx0 = blockIdx.x * RB_TW;
-    const int ty0 = blockIdx.y * RB_TH;
     const int psb = p.ps * 16;
 
     for (int g = tid; g < p.S * 4; g += 512) {
@@ -69,146 +75,178 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tab1[g] = o1;
         tab2[g] = o2;
     }
-    {   // x tile, zero padded at the frame border
-        const int row_chunks = RB_XW * p.ncg;
-        const float inv_rc = 1.0f / (float)row_chunks;
-        const int total = RB_XH * row_chunks;
-        for (int idx = tid; idx < total; idx += 512) {
-            const int r = (int)(((float)idx + 0.5f) * inv_rc);
-            const int i = idx - r * row_chunks;
-            const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
-            const int cg = i - c * p.ncg;
-            const int iy = ty0 - 2 + r, ix = tx0 - 2 + c;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-                v = *reinterpret_cast<const uint4*>(p.src + ((size_t)iy * p.w + ix) * p.c + cg * 8);
-            *reinterpret_cast<uint4*>(xt + (size_t)(r * RB_XW + c) * psb + cg * 16) = v;
-        }
+    {
         const int n16 = p.S * MT * 2 * 64;
         for (int i = tid; i < n16; i += 512) {
             reinterpret_cast<uint4*>(wl1)[i] = p.w1[i];
             reinterpret_cast<uint4*>(wl2)[i] = p.w2[i];
         }
     }
+    // x-tile chunk bookkeeping: chunk idx -> (pixel, channel group); identical for every tile
+    const int row_chunks = RB_XW * p.ncg;
+    const int total = RB_XH * row_chunks;
+    const float inv_rc = 1.0f / (float)row_chunks;
+    int xr[RB_XCH_MAX], xc[RB_XCH_MAX], xoff[RB_XCH_MAX], xcg[RB_XCH_MAX];
+#pragma unroll
+    for (int k = 0; k < RB_XCH_MAX; ++k) {
+        const int idx = min(tid + k * 512, total - 1);
+        const int r = (int)(((float)idx + 0.5f) * inv_rc);
+        const int i = idx - r * row_chunks;
+        const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+        xr[k] = r; xc[k] = c; xcg[k] = i - c * p.ncg;
+        xoff[k] = (r * RB_XW + c) * psb + xcg[k] * 16;
+    }
+    uint4 xv[RB_XCH_MAX];
+    auto x_fetch = [&](int tile) {                 // global -> registers (zero padded at the frame border)
+        const int ty0 = (tile / p.tiles_x) * RB_TH, tx0 = (tile % p.tiles_x) * RB_TW;
+#pragma unroll
+        for (int k = 0; k < RB_XCH_MAX; ++k) {
+            const int iy = ty0 - 2 + xr[k], ix = tx0 - 2 + xc[k];
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+                v = *reinterpret_cast<const uint4*>(p.src + ((size_t)iy * p.w + ix) * p.c + xcg[k] * 8);
+            xv[k] = v;
+        }
+    };
+    auto x_park = [&](unsigned char* xt) {         // registers -> LDS
+#pragma unroll
+        for (int k = 0; k < RB_XCH_MAX; ++k)
+            if (tid + k * 512 < total) *reinterpret_cast<uint4*>(xt + xoff[k]) = xv[k];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) { x_fetch(tile); x_park(xt0); }
     __syncthreads();
 
-    // ---------------- phase 1: t = act(conv1(x) + b1) on the halo region -------------------------
-    {
-        int pb[RB_T1W], pp[RB_T1W];
+    int cur = 0;
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        const int ty0 = (tile / p.tiles_x) * RB_TH, tx0 = (tile % p.tiles_x) * RB_TW;
+        const unsigned char* xt = xt0 + (size_t)cur * p.x_bytes;
+        const bool has_next = (tile + (int)gridDim.x < p.n_tiles);
+        if (has_next) x_fetch(tile + gridDim.x);    // in flight during both phases
+        asm volatile("" ::: "memory");
+
+        // ---------------- phase 1: t = act(conv1(x) + b1) on the halo region -------------------------
+        {
+            int pb[RB_T1W];
 #pragma unroll
-        for (int t = 0; t < RB_T1W; ++t) {
-            int pix = (wave * RB_T1W + t) * 16 + lr;
-            pix = min(pix, RB_NI - 1);
-            const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RB_IW));
-            const int c = pix - r * RB_IW;
-            pp[t] = pix;
-            pb[t] = (r * RB_XW + c) * psb;
-        }
-        f32x4 acc[MT][RB_T1W];
+            for (int t = 0; t < RB_T1W; ++t) {
+                int pix = (wave * RB_T1W + t) * 16 + lr;
+                pix = min(pix, RB_NI - 1);
+                const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RB_IW));
+                const int c = pix - r * RB_IW;
+                pb[t] = (r * RB_XW + c) * psb;
+            }
+            f32x4 acc[MT][RB_T1W];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < RB_T1W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.S; ++s) {
-            const int toff = tab1[s * 4 + q];
-            f16x8 ah[MT], al[MT];
+                for (int t = 0; t < RB_T1W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.S; ++s) {
+                const int toff = tab1[s * 4 + q];
+                f16x8 ah[MT], al[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
-                al[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
+                    al[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < RB_T1W; ++t) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(xt + pb[t] + toff);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < RB_T1W; ++t) {
-                const f16x8 b = *reinterpret_cast<const f16x8*>(xt + pb[t] + toff);
+                const int tl = wave * RB_T1W + t;
+                const int pix = tl * 16 + lr;
+                if (tl >= RB_T1 || pix >= RB_NI) continue;
+                const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RB_IW));
+                const int c = pix - r * RB_IW;
+                const int iy = ty0 - 1 + r, ix = tx0 - 1 + c;
+                const bool inside = (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                    const int co0 = m * 16 + q * 4;
+                    if (co0 >= p.c) continue;
+                    const float4 bv = *reinterpret_cast<const float4*>(p.b1 + co0);
+                    f16x4 o;
+                    o[0] = (f16)(inside ? rv_lrelu(acc[m][t][0] + bv.x, p.act_slope) : 0.f);
+                    o[1] = (f16)(inside ? rv_lrelu(acc[m][t][1] + bv.y, p.act_slope) : 0.f);
+                    o[2] = (f16)(inside ? rv_lrelu(acc[m][t][2] + bv.z, p.act_slope) : 0.f);
+                    o[3] = (f16)(inside ? rv_lrelu(acc[m][t][3] + bv.w, p.act_slope) : 0.f);
+                    *reinterpret_cast<f16x4*>(tt + (size_t)pix * psb + co0 * 2) = o;
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < RB_T1W; ++t) {
-            const int tile = wave * RB_T1W + t;
-            const int pix = tile * 16 + lr;
-            if (tile >= RB_T1 || pix >= RB_NI) continue;
-            const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RB_IW));
-            const int c = pix - r * RB_IW;
-            const int iy = ty0 - 1 + r, ix = tx0 - 1 + c;
-            const bool inside = (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co0 = m * 16 + q * 4;
-                if (co0 >= p.c) continue;
-                const float4 bv = *reinterpret_cast<const float4*>(p.b1 + co0);
-                f16x4 o;
-                o[0] = (f16)(inside ? rv_lrelu(acc[m][t][0] + bv.x, p.act_slope) : 0.f);
-                o[1] = (f16)(inside ? rv_lrelu(acc[m][t][1] + bv.y, p.act_slope) : 0.f);
-                o[2] = (f16)(inside ? rv_lrelu(acc[m][t][2] + bv.z, p.act_slope) : 0.f);
-                o[3] = (f16)(inside ? rv_lrelu(acc[m][t][3] + bv.w, p.act_slope) : 0.f);
-                *reinterpret_cast<f16x4*>(tt + (size_t)pix * psb + co0 * 2) = o;
-            }
-        }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---------------- phase 2: out = x + conv2(t) + b2 ------------------------------------------------
-    {
-        int pb[RB_T2W];
+        // ---------------- phase 2: out = x + conv2(t) + b2 ------------------------------------------------
+        {
+            int pb[RB_T2W];
 #pragma unroll
-        for (int t = 0; t < RB_T2W; ++t) {
-            const int ti = wave * RB_T2W + t;
-            const int row = ti >> 1;
-            const int col = (ti & 1) * 16 + lr;
-            pb[t] = (row * RB_IW + col) * psb;
-        }
-        f32x4 acc[MT][RB_T2W];
+            for (int t = 0; t < RB_T2W; ++t) {
+                const int ti = wave * RB_T2W + t;
+                const int row = ti >> 1;
+                const int col = (ti & 1) * 16 + lr;
+                pb[t] = (row * RB_IW + col) * psb;
+            }
+            f32x4 acc[MT][RB_T2W];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < RB_T2W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.S; ++s) {
-            const int toff = tab2[s * 4 + q];
-            f16x8 ah[MT], al[MT];
+                for (int t = 0; t < RB_T2W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.S; ++s) {
+                const int toff = tab2[s * 4 + q];
+                f16x8 ah[MT], al[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
-                al[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
+                    al[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < RB_T2W; ++t) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(tt + pb[t] + toff);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < RB_T2W; ++t) {
-                const f16x8 b = *reinterpret_cast<const f16x8*>(tt + pb[t] + toff);
+                const int ti = wave * RB_T2W + t;
+                const int row = ti >> 1;
+                const int col = (ti & 1) * 16 + lr;
+                const int oy = ty0 + row, ox = tx0 + col;
+                if (oy >= p.h || ox >= p.w) continue;
+                const unsigned char* xr_ = xt + (size_t)((row + 2) * RB_XW + (col + 2)) * psb;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
+                    const int co0 = m * 16 + q * 4;
+                    if (co0 >= p.c) continue;
+                    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + co0);
+                    const f16x4 xv4 = *reinterpret_cast<const f16x4*>(xr_ + co0 * 2);
+                    float y[4] = {acc[m][t][0] + bv.x + (float)xv4[0], acc[m][t][1] + bv.y + (float)xv4[1],
+                                  acc[m][t][2] + bv.z + (float)xv4[2], acc[m][t][3] + bv.w + (float)xv4[3]};
+                    if (p.post_slope != 1.0f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.post_slope);
+                    }
+                    f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                    *reinterpret_cast<f16x4*>(p.out + ((size_t)oy * p.w + ox) * p.c + co0) = o;
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < RB_T2W; ++t) {
-            const int ti = wave * RB_T2W + t;
-            const int row = ti >> 1;
-            const int col = (ti & 1) * 16 + lr;
-            const int oy = ty0 + row, ox = tx0 + col;
-            if (oy >= p.h || ox >= p.w) continue;
-            const unsigned char* xr = xt + (size_t)((row + 2) * RB_XW + (col + 2)) * psb;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co0 = m * 16 + q * 4;
-                if (co0 >= p.c) continue;
-                const float4 bv = *reinterpret_cast<const float4*>(p.b2 + co0);
-                const f16x4 xv = *reinterpret_cast<const f16x4*>(xr + co0 * 2);
-                float y[4] = {acc[m][t][0] + bv.x + (float)xv[0], acc[m][t][1] + bv.y + (float)xv[1],
-                              acc[m][t][2] + bv.z + (float)xv[2], acc[m][t][3] + bv.w + (float)xv[3]};
-                if (p.post_slope != 1.0f) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], p.post_slope);
-                }
-                f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-                *reinterpret_cast<f16x4*>(p.out + ((size_t)oy * p.w + ox) * p.c + co0) = o;
-            }
-        }
+        asm volatile("" ::: "memory");
+        if (has_next) x_park(xt0 + (size_t)(cur ^ 1) * p.x_bytes);
+        __syncthreads();                   // next x tile visible; t tile free for the next phase 1
+        cur ^= 1;
     }
 }
 
@@ -231,8 +269,9 @@ extern "C" int refvsr_resblock_fits(int c) {
     const int S = (9 * ncg + 3) / 4;
     const int MT = (c + 15) / 16;
     if (MT > 2) return 0;
+    if (RB_XH * RB_XW * ncg > RB_XCH_MAX * 512) return 0;        // x-tile prefetch registers
     const size_t lds = (size_t)((S * 4 * 2 * 4 + 15) / 16 * 16) + 2 * (size_t)S * MT * 2 * 1024 +
-                       (size_t)RB_XH * RB_XW * ps * 16 + (size_t)RB_IH * RB_IW * ps * 16;
+                       2 * (size_t)RB_XH * RB_XW * ps * 16 + (size_t)RB_IH * RB_IW * ps * 16;
     return lds <= 160 * 1024 ? 1 : 0;
 }
 
@@ -256,8 +295,19 @@ extern "C" int refvsr_resblock_mfma(const void* src, int c, int h, int w, const 
     a.tab_bytes = (a.S * 4 * 2 * 4 + 15) / 16 * 16;
     a.w_bytes = a.S * MT * 2 * 1024;
     a.x_bytes = RB_XH * RB_XW * a.ps * 16;
-    const size_t lds = (size_t)a.tab_bytes + 2 * (size_t)a.w_bytes + a.x_bytes + (size_t)RB_IH * RB_IW * a.ps * 16;
-    dim3 grid(rv_cdiv(w, RB_TW), rv_cdiv(h, RB_TH));
+    const size_t lds = (size_t)a.tab_bytes + 2 * (size_t)a.w_bytes + 2 * (size_t)a.x_bytes +
+                       (size_t)RB_IH * RB_IW * a.ps * 16;
+    a.tiles_x = rv_cdiv(w, RB_TW);
+    a.n_tiles = a.tiles_x * rv_cdiv(h, RB_TH);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        RV_HIP(hipGetDevice(&dev));
+        RV_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    dim3 grid(a.n_tiles < n_cu ? a.n_tiles : n_cu);             // persistent: one workgroup per CU
     if (MT == 1) return launch_resblock<1>(a, grid, lds, (hipStream_t)stream);
     return launch_resblock<2>(a, grid, lds, (hipStream_t)stream);
 }
