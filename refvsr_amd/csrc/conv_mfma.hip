@@ -52,15 +52,16 @@ struct ConvArgs {
     const float* res_planar; float add_const, clamp_lo, clamp_hi;
     int tab_bytes, wl_bytes;         // LDS carve sizes
     int gather;                      // 1: no LDS input tile, B fragments gathered from global memory
+    int wbufs;                       // weight-chunk LDS buffers: 2 (one barrier per chunk) or 1 when LDS is tight
 };
 
 template <int MT, int TILES, bool F32, bool GATHER>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tab = reinterpret_cast<int*>(smem);
     unsigned char* wl = smem + p.tab_bytes;
-    unsigned char* tile = wl + p.wl_bytes;
+    unsigned char* tile = wl + p.wbufs * p.wl_bytes;      // [weight-chunk buffer(s)][input tile]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,24 +148,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Weight chunks: two LDS buffers; chunk c+1 is fetched into registers while chunk c feeds the MFMAs and is
+    // parked in the other buffer afterwards -> one barrier per chunk and no exposed global-load latency.
+    constexpr int WPT = (CONV_CH * MT * WFR * 64) / 256;         // uint4 per thread per chunk (4 * MT * WFR)
     const uint4* wsrc = p.wpack + (size_t)zg * p.S * MT * WFR * 64;
-    auto load_weights = [&](int s0) {
-        const int n16 = min(CONV_CH, p.S - s0) * MT * WFR * 64;
-        const uint4* g = wsrc + (size_t)s0 * MT * WFR * 64;
+    const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
+    // named registers, not an array: hipcc keeps a prefetch *array* in scratch memory here (scratch_store right
+    // behind every load), which serialises the whole prefetch
+    static_assert(WPT <= 12, "prefetch register set");
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
+#define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
+#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * 256, n16n - 1)];
+#define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * 256 < n16n) d[tid + k * 256] = w##k; }
+    {
+        const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
         uint4* d = reinterpret_cast<uint4*>(wl);
-        for (int i = tid; i < n16; i += 256) d[i] = g[i];
-    };
-    load_weights(0);                           // issued together with the tile staging: one latency, one barrier
+        for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];     // chunk 0, issued together with the tile staging
+    }
     __syncthreads();
-    for (int s0 = 0; s0 < p.S; s0 += CONV_CH) {
-        const int ns = min(CONV_CH, p.S - s0);
+    auto compute_chunk = [&](const int c, const int s0, const int ns) {
+        const unsigned char* wcur = wl + (size_t)(p.wbufs == 2 ? (c & 1) : 0) * p.wl_bytes;
         for (int sl = 0; sl < ns; ++sl) {
             const int toff = tab[(s0 + sl) * 4 + q];
             if constexpr (F32) {
                 f32x4 a[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const f32x4*>(wl + ((size_t)(sl * MT + m) * 64 + lane) * 16);
+                    a[m] = *reinterpret_cast<const f32x4*>(wcur + ((size_t)(sl * MT + m) * 64 + lane) * 16);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     const uint4 braw = load_b(pbase[t], toff);
@@ -180,8 +190,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 f16x8 ah[MT], al[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    ah[m] = *reinterpret_cast<const f16x8*>(wl + ((size_t)((sl * MT + m) * 2 + 0) * 64 + lane) * 16);
-                    al[m] = *reinterpret_cast<const f16x8*>(wl + ((size_t)((sl * MT + m) * 2 + 1) * 64 + lane) * 16);
+                    ah[m] = *reinterpret_cast<const f16x8*>(wcur + ((size_t)((sl * MT + m) * 2 + 0) * 64 + lane) * 16);
+                    al[m] = *reinterpret_cast<const f16x8*>(wcur + ((size_t)((sl * MT + m) * 2 + 1) * 64 + lane) * 16);
                 }
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
@@ -195,10 +205,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 }
             }
         }
-        if (s0 + CONV_CH < p.S) {
-            __syncthreads();                   // chunk fully consumed
-            load_weights(s0 + CONV_CH);
-            __syncthreads();
+    };
+    if (n_chunks == 1) {
+        compute_chunk(0, 0, p.S);
+    } else {
+        for (int c = 0; c < n_chunks; ++c) {
+            const int s0 = c * CONV_CH;
+            const int ns = min(CONV_CH, p.S - s0);
+            const bool has_next = (c + 1 < n_chunks);
+            // the prefetch is unconditional (the last iteration re-reads its own chunk and drops it) so that the
+            // prefetch registers have one definition per iteration: a conditional definition makes hipcc copy them
+            // right behind the loads, i.e. wait for every load before the MFMA loop
+            const int sn = has_next ? s0 + CONV_CH : s0;
+            const int n16n = min(CONV_CH, p.S - sn) * MT * WFR * 64;
+            {
+                const uint4* g = wsrc + (size_t)sn * MT * WFR * 64;
+                RV_W_ALL(RV_W_LOAD)
+            }
+            compute_chunk(c, s0, ns);
+            if (has_next) {
+                if (p.wbufs != 2) __syncthreads();                 // single buffer: everyone must be done reading it
+                uint4* d = reinterpret_cast<uint4*>(wl + (size_t)(p.wbufs == 2 ? ((c + 1) & 1) : 0) * p.wl_bytes);
+                RV_W_ALL(RV_W_STORE)
+                __syncthreads();
+            }
         }
     }
 
@@ -342,31 +372,35 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     const int n_mt = (d->cout + 15) / 16;
     const int nz = (n_mt + MT - 1) / MT;
     a.tab_bytes = ((a.S * 4 * 4 + 15) / 16) * 16;
-    a.wl_bytes = CONV_CH * MT * (f32 ? 1 : 2) * 1024;
+    // weight-chunk buffers: single-chunk convs (S <= CONV_CH) need one exactly-sized buffer; chunked convs get two
+    // (one barrier per chunk) unless the input tile then no longer fits LDS.
+    a.wl_bytes = (a.S <= CONV_CH ? a.S : CONV_CH) * MT * (f32 ? 1 : 2) * 1024;
+    a.wbufs = 1;
 
-    // pick the pixel-tile height: 8 rows x 32 cols if the staged input fits, else 4 rows
+    // pick the pixel-tile height: 8 rows x 32 cols if the staged input fits, else 4 rows; else drop the 2nd weight buffer
     int tiles = 4;
     size_t lds = 0;
-    for (;;) {
-        const int TH = tiles * 2;
+    auto lds_for = [&](int tl, int wb) {
+        const int TH = tl * 2;
         a.LH = (TH - 1) * a.stride + a.ks;
         a.LW = (CONV_TW - 1) * a.stride + a.ks;
-        lds = (size_t)a.tab_bytes + a.wl_bytes + (size_t)a.LH * a.LW * a.ps * 16;
-        if (lds <= 160 * 1024 || tiles == 2) break;
-        tiles = 2;
-    }
+        return (size_t)a.tab_bytes + (size_t)wb * a.wl_bytes + (size_t)a.LH * a.LW * a.ps * 16;
+    };
+    lds = lds_for(4, a.wbufs);
+    if (lds > 160 * 1024) { tiles = 2; lds = lds_for(2, a.wbufs); }
+    if (lds > 160 * 1024 && a.wbufs == 2) { a.wbufs = 1; tiles = 4; lds = lds_for(4, 1); if (lds > 160 * 1024) { tiles = 2; lds = lds_for(2, 1); } }
     if (lds > 160 * 1024) {                        // strided predictor convs: gather B fragments from global memory
         a.gather = 1;
+        a.wbufs = 1;
         tiles = 4;
         a.LH = a.LW = 0;
-        lds = (size_t)a.tab_bytes + a.wl_bytes;
+        lds = (size_t)a.tab_bytes + (size_t)a.wbufs * a.wl_bytes;
         RV_CHECK(d->h_in < 60000 && d->w_in < 60000, "conv: frame too large for gather-mode coordinates");
     }
     // prefer 2 blocks/CU for mid-size tiles
     if (!a.gather && tiles == 4 && lds > 80 * 1024 && d->h_out * d->w_out > 64 * 1024) {
-        const int LH2 = 3 * a.stride + a.ks;
-        const size_t lds2 = (size_t)a.tab_bytes + a.wl_bytes + (size_t)LH2 * a.LW * a.ps * 16;
-        if (lds2 <= 80 * 1024) { tiles = 2; a.LH = LH2; lds = lds2; }
+        const size_t lds2 = lds_for(2, a.wbufs);
+        if (lds2 <= 80 * 1024) { tiles = 2; lds = lds2; } else { lds = lds_for(4, a.wbufs); }
     }
     dim3 grid(rv_cdiv(d->w_out, CONV_TW), rv_cdiv(d->h_out, tiles * 2), nz);
     hipStream_t st = (hipStream_t)stream;

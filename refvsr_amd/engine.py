@@ -387,6 +387,9 @@ class Engine(object):
             self.flow_cache = {}
             return [FrameCtx(lrs[i].contiguous(), refs[i].contiguous()) for i in range(t)]
         prev = self.prev_window
+        if prev and prev[0].lr.shape != lrs.shape[1:]:          # new clip geometry: nothing to reuse
+            prev = []
+            self.flow_cache = {}
         if prev:
             # candidates in order of likelihood: the window slid by one (i+1), did not move (i), slid back (i-1);
             # all candidate pairs are compared by ONE kernel launch + one D2H sync
@@ -463,6 +466,9 @@ class Engine(object):
         if not is_first_frame and self.fw_feat is None:
             raise RuntimeError('is_first_frame=False but no forward state is held (first call of a stream '
                                'must pass is_first_frame=True, cf. RefVSR.py:257-258)')
+        if not is_first_frame and tuple(self.fw_feat.shape[:2]) != (h, w):
+            raise RuntimeError('frame size changed from %s to %s without is_first_frame=True'
+                               % (tuple(self.fw_feat.shape[:2]), (h, w)))
         gradio = bool(self.cfg.EVAL.is_gradio)
         zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if gradio else None
         fr = self._frames(lrs, refs)

@@ -131,6 +131,12 @@ def test_batch_and_api_contract(dev):
     fresh, _, _ = make_net('config_RefVSR_small_L1', 3, dev)
     with pytest.raises(RuntimeError, match='is_first_frame'):
         fresh(x[:1], r[:1], False)            # no forward state yet (reference crashes here too)
+    # a new clip with another geometry on the same module: caches are dropped, state must be restarted
+    lr2, rf2, _ = make_clip(2, 48, 32, seed=2)
+    w2 = window_indices(0, 2, 3)
+    with pytest.raises(RuntimeError, match='frame size changed'):
+        single(lr2[w2][None].to(dev), rf2[w2][None].to(dev), False)
+    assert single(lr2[w2][None].to(dev), rf2[w2][None].to(dev), True)['result'].shape == (1, 3, 192, 128)
     # updating the weights re-packs them
     sd2 = {k: v * 0.5 for k, v in sd.items()}
     single.load_state_dict(sd2)
