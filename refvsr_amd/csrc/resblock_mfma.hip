@@ -75,13 +75,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tab1[g] = o1;
         tab2[g] = o2;
     }
-    {
-        const int n16 = p.S * MT * 2 * 64;
-        for (int i = tid; i < n16; i += 512) {
-            reinterpret_cast<uint4*>(wl1)[i] = p.w1[i];
-            reinterpret_cast<uint4*>(wl2)[i] = p.w2[i];
-        }
-    }
+    const int n16w = p.S * MT * 2 * 64;            // uint4 per weight set (<= 4 * 512 for the supported shapes)
+    for (int i = tid; i < n16w; i += 512) reinterpret_cast<uint4*>(wl1)[i] = p.w1[i];
     // x-tile chunk bookkeeping: chunk idx -> (pixel, channel group); identical for every tile
     const int row_chunks = RB_XW * p.ncg;
     const int total = RB_XH * row_chunks;
@@ -116,6 +111,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int tile = blockIdx.x;
     if (tile < p.n_tiles) { x_fetch(tile); x_park(xt0); }
+    // conv2's weights are not needed before phase 2 of the first tile: fetch them into (named) registers now and park
+    // them in LDS behind phase 1, so only x + w1 sit on the start-up critical path
+    uint4 v0, v1, v2, v3;
+    {
+        const int last = n16w - 1;
+        v0 = p.w2[min(tid, last)];
+        v1 = p.w2[min(tid + 512, last)];
+        v2 = p.w2[min(tid + 1024, last)];
+        v3 = p.w2[min(tid + 1536, last)];
+    }
+    bool w2_parked = false;
     __syncthreads();
 
     int cur = 0;
@@ -182,6 +188,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     *reinterpret_cast<f16x4*>(tt + (size_t)pix * psb + co0 * 2) = o;
                 }
             }
+        }
+        if (!w2_parked) {
+            uint4* d = reinterpret_cast<uint4*>(wl2);
+            if (tid < n16w) d[tid] = v0;
+            if (tid + 512 < n16w) d[tid + 512] = v1;
+            if (tid + 1024 < n16w) d[tid + 1024] = v2;
+            if (tid + 1536 < n16w) d[tid + 1536] = v3;
+            w2_parked = true;
         }
         __syncthreads();
 
@@ -270,6 +284,7 @@ extern "C" int refvsr_resblock_fits(int c) {
     const int MT = (c + 15) / 16;
     if (MT > 2) return 0;
     if (RB_XH * RB_XW * ncg > RB_XCH_MAX * 512) return 0;        // x-tile prefetch registers
+    if (S * MT * 2 * 64 > 4 * 512) return 0;                     // conv2 weight prefetch registers
     const size_t lds = (size_t)((S * 4 * 2 * 4 + 15) / 16 * 16) + 2 * (size_t)S * MT * 2 * 1024 +
                        2 * (size_t)RB_XH * RB_XW * ps * 16 + (size_t)RB_IH * RB_IW * ps * 16;
     return lds <= 160 * 1024 ? 1 : 0;
