@@ -41,6 +41,7 @@ class FrameCtx(object):
         self.idx = None         # int32 [Hf*Wf]
         self.aligned = None     # aa1 output nhwc16 [h,w,C]
         self.aligned_up = None  # aa2 output nhwc16 [2h,2w,C]
+        self.ready = None       # pipelined mode: HIP event recorded on the preparation stream once all of the above exist
 
 
 class Weights(object):
@@ -150,6 +151,11 @@ class Engine(object):
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
         self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
         self._side = None
+        # pipelined mode (opt-in, see forward()): internal streams M (backward branch + upsampler), F (forward branch),
+        # P (per-frame preparation + flows); the caller's stream only receives the result
+        self.pipelined = bool(getattr(config, 'pipelined', False))
+        self._pipe = None
+        self._inflight = collections.deque()
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.reset_state()
 
@@ -163,6 +169,14 @@ class Engine(object):
         self.max_frame_itr_num = self.cfg.reset_branch
         self.prev_window = []
         self.flow_cache = {}
+        self.id_cache = {}
+
+    def set_pipelined(self, on=True):
+        """Opt in to cross-call pipelining.  Contract: forward() is then given `frame_ids` (one hashable id per window
+        frame; equal ids <=> equal (lr, ref) content within a stream) and the input tensors are already materialised
+        when forward() is called (e.g. a pre-loaded clip) -- the engine's internal streams do not wait for work that
+        is still pending on the caller's stream.  Results are bit-identical to the default mode."""
+        self.pipelined = bool(on)
 
     def export_state(self):
         """Forward-branch state as planar fp32 tensors (what RefVSR.py:279-283 keeps)."""
@@ -218,11 +232,20 @@ class Engine(object):
             fr.pyr = lv[::-1]
         return fr.pyr
 
-    def flow(self, fr_ref, fr_supp):
-        """FlowNet(ref, supp) (SPyNet.py:49-139), cached per ordered frame pair."""
+    def flow(self, fr_ref, fr_supp, share=None):
+        """FlowNet(ref, supp) (SPyNet.py:49-139), cached per ordered frame pair.  `share`: streams that will consume
+        the result besides the current one (pipelined mode): the tensor is recorded on them and carries an event."""
         key = (fr_ref.uid, fr_supp.uid)
-        if key in self.flow_cache:
-            return self.flow_cache[key]
+        hit = self.flow_cache.get(key)
+        if hit is not None:
+            out, ev = hit
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                out.record_stream(torch.cuda.current_stream())
+            return out
+        for f in (fr_ref, fr_supp):
+            if f.ready is not None:
+                torch.cuda.current_stream().wait_event(f.ready)
         pr, ps = self.pyramid(fr_ref), self.pyramid(fr_supp)
         h, w = fr_ref.lr.shape[1:]
         flow = None
@@ -234,7 +257,13 @@ class Engine(object):
             flow = ops.conv(self.cw(p + '4.conv'), x, planar_out=True, res_planar=fup)
         h_up, w_up = flow.shape[1:]
         out = ops.resize(flow, (h, w), ops.RS_BILINEAR, chan_mul=[float(w) / float(w_up), float(h) / float(h_up)])
-        self.flow_cache[key] = out
+        ev = None
+        if share:
+            ev = torch.cuda.Event()
+            ev.record()
+            for st in share:
+                out.record_stream(st)
+        self.flow_cache[key] = (out, ev)
         return out
 
     def feature_match(self, fr):
@@ -378,11 +407,27 @@ class Engine(object):
         return ops.conv(self.cw('conv_last'), out, planar_out=True, res_planar=base, clamp=(0.0, 1.0))
 
     # ------------------------------------------------------------------ window bookkeeping
-    def _frames(self, lrs, refs):
+    def _frames(self, lrs, refs, frame_ids=None):
         """Wrap the t frames of this window, reusing per-frame contexts of the previous window (or of
-        earlier positions in this window) whose content is identical."""
+        earlier positions in this window) whose content is identical -- or, when the caller supplies frame ids,
+        whose id matches (no device work, no synchronisation)."""
         t = lrs.shape[0]
         frames = [None] * t
+        if frame_ids is not None and self.cache:
+            assert len(frame_ids) == t
+            if self.id_cache and next(iter(self.id_cache.values())).lr.shape != lrs.shape[1:]:
+                self.id_cache, self.flow_cache = {}, {}
+            for i, fid in enumerate(frame_ids):
+                fr = self.id_cache.get(fid)
+                if fr is None:
+                    fr = self.id_cache[fid] = FrameCtx(lrs[i].contiguous(), refs[i].contiguous())
+                frames[i] = fr
+            keep = set(frame_ids)
+            self.id_cache = {k: v for k, v in self.id_cache.items() if k in keep}
+            live = set(f.uid for f in frames)
+            self.flow_cache = {k2: v for k2, v in self.flow_cache.items() if k2[0] in live and k2[1] in live}
+            self.prev_window = frames
+            return frames
         if not self.cache:
             self.flow_cache = {}
             return [FrameCtx(lrs[i].contiguous(), refs[i].contiguous()) for i in range(t)]
@@ -416,6 +461,111 @@ class Engine(object):
         self.flow_cache = {k2: v for k2, v in self.flow_cache.items() if k2[0] in live and k2[1] in live}
         self.prev_window = frames
         return frames
+
+    # ------------------------------------------------------------------ pipelined forward (opt-in)
+    def _pipe_streams(self, dev):
+        if self._pipe is None or self._pipe[0].device != dev:
+            self._pipe = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        return self._pipe
+
+    @torch.no_grad()
+    def _forward_pipelined(self, lrs, refs, is_first_frame, want_vis, frame_ids):
+        """Same computation as _forward_seq, spread over three internal streams so that consecutive calls overlap:
+        P prepares the window's new frame and its flows while M is still walking the previous call's backward branch
+        and F its forward-branch step.  Dependencies are carried by HIP events (per-frame `ready`, per-flow, per-call
+        forward-branch result); every tensor that crosses streams is recorded on its consumers so the caching
+        allocator cannot recycle it early; the host may run at most two calls ahead of the GPU."""
+        t, _, h, w = lrs.shape
+        ctr, C, dev = t // 2, self.C, lrs.device
+        caller = torch.cuda.current_stream()
+        M, F_, P = self._pipe_streams(dev)
+        while len(self._inflight) >= 2:
+            self._inflight.popleft().synchronize()
+        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
+            is_first_frame = True
+        for st in (M, F_, P):
+            lrs.record_stream(st)
+            refs.record_stream(st)
+        if is_first_frame or self.fw_feat is None or bool(self.cfg.EVAL.is_gradio):
+            # restart of the forward branch: run the reference order on M, after everything in flight
+            M.wait_stream(P)
+            M.wait_stream(F_)
+            with torch.cuda.stream(M):
+                out, vis = self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
+            for st in (F_, P):
+                st.wait_stream(M)
+        else:
+            assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
+            fr = self._frames(lrs, refs, frame_ids)
+            share = (M, F_, P)
+            # ---- P: everything that is a function of single frames / frame pairs
+            with torch.cuda.stream(P):
+                for i in range(ctr, t):
+                    f = fr[i]
+                    if f.conf is None:
+                        self.pyramid(f)
+                        self.prepare_frame(f)
+                        for x in [f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                            for st in share:
+                                x.record_stream(st)
+                        f.ready = torch.cuda.Event()
+                        f.ready.record()
+                    else:
+                        if f.pyr is None:
+                            self.pyramid(f)
+                        if f.ready is None:      # prepared on M by a first-frame call: make it safe on F and P too
+                            for x in [f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                                for st in share:
+                                    x.record_stream(st)
+                bw_flows = {i: self.flow(fr[i], fr[i + 1], share) for i in range(ctr, t - 1)}
+            # ---- F: forward-branch step (state of the previous call, cached frames)
+            with torch.cuda.stream(F_):
+                for f in (fr[ctr], fr[ctr + 1]):
+                    if f.ready is not None:
+                        F_.wait_event(f.ready)
+                for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
+                    x.record_stream(F_)
+                flow_f = lambda a, b: self.flow(fr[a], fr[b], share)
+                fw = self._forward_branch(fr, flow_f, t, h, w, False)
+                for x in fw:
+                    x.record_stream(M)
+                ev_fw = torch.cuda.Event()
+                ev_fw.record()
+            # ---- M: backward branch + upsampler
+            with torch.cuda.stream(M):
+                feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
+                feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
+                conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+                for i in range(t - 1, ctr - 1, -1):
+                    if fr[i].ready is not None:
+                        M.wait_event(fr[i].ready)
+                    if i < t - 1:
+                        fl = self.flow(fr[i], fr[i + 1], share)          # cached by P above: waits on its event
+                        feat = ops.warp_nhwc16(feat, fl)
+                        conf = ops.warp_planar(conf, fl)
+                        feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
+                    feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
+                    feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+                M.wait_event(ev_fw)
+                out = self.compute_up(feat_up, fw[1], conf, fw[2], fr[ctr].lr)
+                vis = None
+                if want_vis:
+                    vis = collections.OrderedDict()
+                    vis['conf_map'] = fr[ctr].conf
+                    vis['conf_map_prop'] = ops.max2(conf, fw[2])
+                    vis['conf_map_prop_backward'] = conf
+                    vis['conf_map_prop_forward'] = fw[2]
+            del bw_flows
+            self.frame_itr_num += 1
+        done = torch.cuda.Event()
+        done.record(M)
+        caller.wait_event(done)
+        out.record_stream(caller)
+        if vis:
+            for v in vis.values():
+                v.record_stream(caller)
+        self._inflight.append(done)
+        return out, vis
 
     def _side_stream(self, dev, k=0):
         if self._side is None or self._side[0].device != dev:
@@ -452,8 +602,15 @@ class Engine(object):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, lrs, refs, is_first_frame, want_vis=False):
-        """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None)."""
+    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
+        """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None).
+        frame_ids (optional): one hashable id per window frame -> the window cache is keyed by id instead of by
+        content comparison; together with set_pipelined(True) it enables cross-call stream pipelining."""
+        if self.pipelined and frame_ids is not None and self.cache and self.overlap:
+            return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids)
+        return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
+
+    def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
         assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
         t, _, h, w = lrs.shape
         assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
@@ -471,7 +628,7 @@ class Engine(object):
                                % (tuple(self.fw_feat.shape[:2]), (h, w)))
         gradio = bool(self.cfg.EVAL.is_gradio)
         zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if gradio else None
-        fr = self._frames(lrs, refs)
+        fr = self._frames(lrs, refs, frame_ids)
         flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b]))   # :183-191
         range_start = 0 if is_first_frame else ctr                                  # :173-176
         # Two-stream overlap (steady state): the forward-branch step depends only on cached per-frame data and

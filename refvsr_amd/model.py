@@ -92,13 +92,19 @@ class Network(nn.Module):
     def engine(self, n=0):
         return self._engines[n]
 
+    def set_pipelined(self, on=True):
+        """Cross-call stream pipelining (see Engine.set_pipelined for the contract)."""
+        self.config.pipelined = bool(on)
+        for e in self._engines:
+            e.set_pipelined(on)
+
     def ensure_engines(self, n, device):
         W = self._weights(device)
         while len(self._engines) < n:
             self._engines.append(Engine(self.config, W))
         return self._engines
 
-    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False):
+    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, frame_ids=None):
         """Same contract as RefVSR.py:151: lrs, refs [n,t,3,h,w] in [0,1]; returns OrderedDict with
         'result' [n,3,4h,4w] (+ 'eval_vis' when is_log and config.save_sample)."""
         if is_train:
@@ -114,7 +120,8 @@ class Network(nn.Module):
         want_vis = bool(is_log and self.config.save_sample)
         results, vis_all = [], []
         for b in range(n):
-            out, vis = self._engines[b].forward(lrs[b], refs[b], bool(is_first_frame), want_vis)
+            out, vis = self._engines[b].forward(lrs[b], refs[b], bool(is_first_frame), want_vis,
+                                                None if frame_ids is None else [(b, f) for f in frame_ids])
             results.append(out)
             vis_all.append(vis)
         outs = collections.OrderedDict()
@@ -154,5 +161,6 @@ class SRNet(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         return super().load_state_dict(strip_module_prefix(state_dict), strict=strict)
 
-    def forward(self, x, ref, is_first_frame=True, is_log=False, is_train=False):
-        return self.Network.forward(x, ref, is_first_frame, is_log=is_log, is_train=is_train)
+    def forward(self, x, ref, is_first_frame=True, is_log=False, is_train=False, frame_ids=None):
+        """frame_ids (optional extension, not in the reference): one id per window frame, see Engine.forward."""
+        return self.Network.forward(x, ref, is_first_frame, is_log=is_log, is_train=is_train, frame_ids=frame_ids)

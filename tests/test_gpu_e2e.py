@@ -116,6 +116,32 @@ def test_hd_midsize_against_live_oracle(dev):
         assert a.shape == (1, 3, 512, 768) and maxdiff(a, want) < 2e-2 and psnr(a, want) > 55.0 and d_psnr < 1e-3
 
 
+def test_pipelined_mode_is_bit_identical(dev):
+    """frame_ids + set_pipelined(True): three internal streams, host running ahead, no content compare -- the output
+    stream must equal the default sequential mode bit for bit (incl. a reset_branch rollover and repeated runs)."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 9, 5
+    lr, rf, _ = make_clip(nfr, 96, 128, seed=11)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    wl = [lr[w][None].contiguous() for w in wins]
+    wr = [rf[w][None].contiguous() for w in wins]
+    torch.cuda.synchronize()
+    ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    want = [ref_net(wl[f], wr[f], f == 0)['result'].clone() for f in range(nfr)]
+    for rep in range(3):
+        net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+        net.Network.set_pipelined(True)
+        outs = [net(wl[f], wr[f], f == 0, frame_ids=wins[f])['result'] for f in range(nfr)]     # no sync in between
+        torch.cuda.synchronize()
+        for f in range(nfr):
+            assert torch.equal(outs[f], want[f]), 'pipelined frame %d differs (repeat %d)' % (f, rep)
+    # ids without pipelining (cache keyed by id, default stream order)
+    net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    for f in range(nfr):
+        assert torch.equal(net(wl[f], wr[f], f == 0, frame_ids=wins[f])['result'], want[f])
+
+
 def test_batch_and_api_contract(dev):
     from refvsr_amd.synth import make_clip, window_indices
     lr, rf, _ = make_clip(2, 32, 48, seed=1)
