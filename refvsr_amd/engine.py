@@ -465,7 +465,8 @@ class Engine(object):
     # ------------------------------------------------------------------ pipelined forward (opt-in)
     def _pipe_streams(self, dev):
         if self._pipe is None or self._pipe[0].device != dev:
-            self._pipe = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            self._pipe = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            self._pipe_calls = 0
         return self._pipe
 
     @torch.no_grad()
@@ -478,26 +479,30 @@ class Engine(object):
         t, _, h, w = lrs.shape
         ctr, C, dev = t // 2, self.C, lrs.device
         caller = torch.cuda.current_stream()
-        M, F_, P = self._pipe_streams(dev)
+        M0, M1, F_, P = self._pipe_streams(dev)
+        # the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch
+        # carries state), so calls alternate between two M streams and overlap
+        M, Mo = (M0, M1) if (self._pipe_calls & 1) == 0 else (M1, M0)
+        self._pipe_calls += 1
         while len(self._inflight) >= 2:
             self._inflight.popleft().synchronize()
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
             is_first_frame = True
-        for st in (M, F_, P):
+        for st in (M0, M1, F_, P):
             lrs.record_stream(st)
             refs.record_stream(st)
         if is_first_frame or self.fw_feat is None or bool(self.cfg.EVAL.is_gradio):
             # restart of the forward branch: run the reference order on M, after everything in flight
-            M.wait_stream(P)
-            M.wait_stream(F_)
+            for st in (P, F_, Mo):
+                M.wait_stream(st)
             with torch.cuda.stream(M):
                 out, vis = self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
-            for st in (F_, P):
+            for st in (F_, P, Mo):
                 st.wait_stream(M)
         else:
             assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
             fr = self._frames(lrs, refs, frame_ids)
-            share = (M, F_, P)
+            share = (M0, M1, F_, P)
             # ---- P: everything that is a function of single frames / frame pairs
             with torch.cuda.stream(P):
                 for i in range(ctr, t):
@@ -528,7 +533,8 @@ class Engine(object):
                 flow_f = lambda a, b: self.flow(fr[a], fr[b], share)
                 fw = self._forward_branch(fr, flow_f, t, h, w, False)
                 for x in fw:
-                    x.record_stream(M)
+                    x.record_stream(M0)
+                    x.record_stream(M1)
                 ev_fw = torch.cuda.Event()
                 ev_fw.record()
             # ---- M: backward branch + upsampler
