@@ -348,7 +348,7 @@ class Engine(object):
         if par:
             side = self._side_stream(fr.lr.device, 1)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):
                 ref_feat, ref_feat_down = self._ref_encoders(fr)
         fr.conf, fr.idx, (gh, gw) = self.feature_match(fr)
         if par:
@@ -495,7 +495,7 @@ class Engine(object):
             # restart of the forward branch: run the reference order on M, after everything in flight
             for st in (P, F_, Mo):
                 M.wait_stream(st)
-            with torch.cuda.stream(M):
+            with ops.on_stream(M):
                 out, vis = self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
             for st in (F_, P, Mo):
                 st.wait_stream(M)
@@ -504,7 +504,7 @@ class Engine(object):
             fr = self._frames(lrs, refs, frame_ids)
             share = (M0, M1, F_, P)
             # ---- P: everything that is a function of single frames / frame pairs
-            with torch.cuda.stream(P):
+            with ops.on_stream(P):
                 for i in range(ctr, t):
                     f = fr[i]
                     if f.conf is None:
@@ -524,7 +524,7 @@ class Engine(object):
                                     x.record_stream(st)
                 bw_flows = {i: self.flow(fr[i], fr[i + 1], share) for i in range(ctr, t - 1)}
             # ---- F: forward-branch step (state of the previous call, cached frames)
-            with torch.cuda.stream(F_):
+            with ops.on_stream(F_):
                 for f in (fr[ctr], fr[ctr + 1]):
                     if f.ready is not None:
                         F_.wait_event(f.ready)
@@ -538,7 +538,7 @@ class Engine(object):
                 ev_fw = torch.cuda.Event()
                 ev_fw.record()
             # ---- M: backward branch + upsampler
-            with torch.cuda.stream(M):
+            with ops.on_stream(M):
                 feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
                 feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
                 conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
@@ -614,7 +614,8 @@ class Engine(object):
         content comparison; together with set_pipelined(True) it enables cross-call stream pipelining."""
         if self.pipelined and frame_ids is not None and self.cache and self.overlap:
             return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids)
-        return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
+        with ops.on_stream(torch.cuda.current_stream()):
+            return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
 
     def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
         assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
@@ -647,7 +648,7 @@ class Engine(object):
                 self.pyramid(fr[i])                        # shared by both streams: build on main before the fork
             side = self._side_stream(dev)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):
                 for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
                     x.record_stream(side)
                 fw = self._forward_branch(fr, flow, t, h, w, False)

@@ -61,13 +61,23 @@ class Network(nn.Module):
             assert name.startswith('Network.')
             p = nn.Parameter(torch.zeros(shape), requires_grad=False)
             _register(self, name[len('Network.'):], p)
+        self._plist = None
         self._packed = None
         self._packed_key = None
         self._engines = []
 
     # -- weights ------------------------------------------------------------------------------
     def _weights_key(self):
-        return tuple((p.device, p._version, p.data_ptr()) for p in self.parameters())
+        # cheap change detector (a full walk over named_parameters() costs > 1 ms per call): cached parameter list,
+        # summed in-place version counters, storage address and device of the first / last tensor
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        pl = self._plist
+        return (len(pl), sum(p._version for p in pl), pl[0].data_ptr(), pl[-1].data_ptr(), pl[0].device, pl[0].dtype)
+
+    def _apply(self, fn, *a, **k):               # .to() / .cuda() / .half() replace parameter storage
+        self._plist = None
+        return super()._apply(fn, *a, **k)
 
     def _weights(self, device):
         key = (self._weights_key(), str(device))

@@ -13,8 +13,34 @@ from .hip import (OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32, RS_BICUBIC, RS_
                   RS_BILINEAR_AC, RS_NEAREST)
 
 
+_STREAM = None        # cached hipStream_t of the stream selected with on_stream(); None -> ask torch every time
+
+
 def _stream():
+    if _STREAM is not None:
+        return _STREAM
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class on_stream(object):
+    """`with ops.on_stream(s):` == `with torch.cuda.stream(s):` + caches the raw stream handle for the kernel
+    launches inside (torch.cuda.current_stream() costs ~8 us of host time per call, x ~350 launches per frame)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        global _STREAM
+        self.prev = _STREAM
+        self.ctx.__enter__()
+        _STREAM = C.c_void_p(self.stream.cuda_stream)
+        return self.stream
+
+    def __exit__(self, *exc):
+        global _STREAM
+        _STREAM = self.prev
+        return self.ctx.__exit__(*exc)
 
 
 def _ptr(t):
@@ -47,13 +73,18 @@ def _farr(vals):
 
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'desc', 'odtype')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
         self.bias = pk['bias'].to(device).contiguous()
         self.cout, self.ksteps, self.mt, self.ksize = pk['cout'], pk['ksteps'], pk['mt'], pk['ksize']
         self.cpads, self.shuffle, self.f32 = pk['cpads'], pk['shuffle'], bool(pk.get('f32', False))
+        # launch descriptor with the per-weight fields filled once (the C side copies it at every call)
+        d = self.desc = hip.RefvsrConv()
+        d.wpack, d.bias = self.wpack.data_ptr(), self.bias.data_ptr()
+        d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
+        self.odtype = torch.float32 if self.f32 else torch.float16
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
@@ -75,22 +106,24 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         pad = k // 2
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1
-    d = hip.RefvsrConv()
+    d = cw.desc
     d.src0, d.c0, d.src1, d.c1 = src0.data_ptr(), c0, (src1.data_ptr() if src1 is not None else None), c1
     d.h_in, d.w_in, d.h_out, d.w_out = h, w, ho, wo
-    d.ksize, d.stride, d.pad = k, stride, pad
-    d.wpack, d.bias = cw.wpack.data_ptr(), cw.bias.data_ptr()
-    d.cout, d.mt_per_block, d.ksteps = cw.cout, cw.mt, cw.ksteps
+    d.stride, d.pad = stride, pad
     d.act_slope, d.post_slope = act, post
-    d.f32 = int(f32)
     if mul is not None:
         _nhwc(mul, f32)
         assert tuple(mul.shape[:2]) == (ho, wo)
         d.mul, d.mul_c = mul.data_ptr(), mul.shape[2]
+    else:
+        d.mul, d.mul_c = None, 0
     if res is not None:
         _nhwc(res, f32)
         assert tuple(res.shape[:2]) == (ho, wo)
         d.res, d.res_c = res.data_ptr(), res.shape[2]
+    else:
+        d.res, d.res_c = None, 0
+    d.res_planar, d.add_const, d.clamp_lo, d.clamp_hi = None, 0.0, 0.0, 0.0
     if planar_out:
         out = torch.empty((cw.cout, ho, wo), dtype=torch.float32, device=src0.device)
         d.out_mode, d.out_c = OUT_PLANAR32, 0
@@ -106,7 +139,7 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         out = torch.empty((2 * ho, 2 * wo, co), dtype=torch.float16, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16_SHUFFLE2, co
     else:
-        out = torch.empty((ho, wo, cw.cout), dtype=torch.float32 if f32 else torch.float16, device=src0.device)
+        out = torch.empty((ho, wo, cw.cout), dtype=cw.odtype, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16, cw.cout
     d.out = out.data_ptr()
     hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
