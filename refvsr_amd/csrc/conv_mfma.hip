@@ -30,6 +30,7 @@
 //
 // Replaces nn.Conv2d call sites listed in include/refvsr_hip.h.
 #include "common.h"
+#include <stdlib.h>
 
 #define CONV_CH 8          // K-steps of weights staged per LDS chunk
 #define CONV_TW 32         // output tile width in pixels
@@ -53,9 +54,10 @@ struct ConvArgs {
     int tab_bytes, wl_bytes;         // LDS carve sizes
     int gather;                      // 1: no LDS input tile, B fragments gathered from global memory
     int wbufs;                       // weight-chunk LDS buffers: 2 (one barrier per chunk) or 1 when LDS is tight
+    int tiles_x, n_xy;               // pixel tiles per row / per frame; workgroups walk tiles (persistent when gridDim.x < n_xy)
 };
 
-template <int MT, int TILES, bool F32, bool GATHER>
+template <int MT, int TILES, bool F32, bool GATHER, bool SINGLE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -68,62 +70,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const int wave = tid >> 6;
     const int q = lane >> 4;
     const int lr = lane & 15;
+    const int lp = (p.stride == 1) ? rv_pix16(lr) : lr;      // pixel of the 16-pixel tile this lane's MFMA column holds
     constexpr int TH = TILES * 2;
-    const int tx0 = blockIdx.x * CONV_TW;
-    const int ty0 = blockIdx.y * TH;
     const int zg = blockIdx.z;
 
-    // ---- K-block -> LDS byte offset table -------------------------------------------------
+    // ---- K-slot -> LDS byte offset table (K order: common.h:rv_kslot) ---------------------------
     for (int g = tid; g < p.S * 4; g += 256) {
-        int off = GATHER ? -1 : 0;
+        int off, slot;
         if (g < p.G) {
             const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
             const int cg = g - tap * p.ncg;
             const int ty = tap / p.ks;
             const int tx = tap - ty * p.ks;
             off = GATHER ? (ty | (tx << 8) | (cg << 16)) : ((ty * p.LW + tx) * p.ps + cg) * 16;
+            slot = rv_kslot(ty, tx, cg, p.ks, p.ncg);
+        } else {                                   // zero-weight blocks: any readable offset of the partner's parity
+            const int j = g - p.G;
+            slot = rv_kpad_slot(j, p.ks, p.ncg);
+            off = GATHER ? -1 : (slot < p.G ? 0 : (p.ncg > 1 ? 16 : (p.ks > 1 ? p.ps * 16 : 0)));
         }
-        tab[g] = off;
+        tab[slot] = off;
     }
 
-    // ---- stage the input tile (zero padded) -----------------------------------------------
-    if constexpr (!GATHER) {
-        const int iy0 = ty0 * p.stride - p.pad;
-        const int ix0 = tx0 * p.stride - p.pad;
-        const int row_chunks = p.LW * p.ncg;
-        const float inv_rc = 1.0f / (float)row_chunks;
-        const int total = p.LH * row_chunks;
-        for (int idx = tid; idx < total; idx += 256) {
-            const int r = (int)(((float)idx + 0.5f) * inv_rc);
-            const int i = idx - r * row_chunks;
-            const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
-            const int cg = i - c * p.ncg;
-            const int iy = iy0 + r;
-            const int ix = ix0 + c;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
-                const size_t pix = (size_t)iy * p.w_in + ix;
-                if (cg < p.ncg0)
-                    v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16);
-                else
-                    v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
-            }
-            *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
-        }
-    }
-
-    // ---- per-lane base offsets of this wave's pixel tiles -----------------------------------
+    // ---- per-lane base offsets of this wave's pixel tiles (tile mode: independent of the tile origin) -------------
     int pbase[TILES];        // tile mode: LDS byte offset of the pixel's window origin; gather mode: packed (iy0, ix0)
+    if constexpr (!GATHER) {
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        const int ti = wave * TILES + t;
-        const int row = ti >> 1;
-        const int col = (ti & 1) * 16 + lr;
-        if constexpr (GATHER) {
-            const int iy = (ty0 + row) * p.stride - p.pad + 4096, ix = (tx0 + col) * p.stride - p.pad + 4096;
-            pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
-        } else {
-            pbase[t] = ((row * p.stride) * p.LW + col * p.stride) * p.ps * 16;
+        for (int t = 0; t < TILES; ++t) {
+            const int ti = wave * TILES + t;
+            pbase[t] = (((ti >> 1) * p.stride) * p.LW + ((ti & 1) * 16 + lp) * p.stride) * p.ps * 16;
         }
     }
     auto load_b = [&](int pb, int toff) -> uint4 {
@@ -142,14 +117,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         return v;
     };
 
-    f32x4 acc[MT][TILES];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // Weight chunks: two LDS buffers; chunk c+1 is fetched into registers while chunk c feeds the MFMAs and is
-    // parked in the other buffer afterwards -> one barrier per chunk and no exposed global-load latency.
+    // Weight chunks: chunk c+1 is fetched into registers while chunk c feeds the MFMAs and parked afterwards.
+    // Single-chunk convs (all 3x3 convs up to 32 input channels) load their weights ONCE per workgroup: the per-CU
+    // vector-memory path, not HBM or the matrix pipe, bounds the large maps, and re-fetching 29 KB of weights for
+    // every 8x32-pixel tile was half of that traffic.
     constexpr int WPT = (CONV_CH * MT * WFR * 64) / 256;         // uint4 per thread per chunk (4 * MT * WFR)
     const uint4* wsrc = p.wpack + (size_t)zg * p.S * MT * WFR * 64;
     const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
@@ -158,55 +129,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     static_assert(WPT <= 12, "prefetch register set");
     uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
 #define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
-#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * 256, n16n - 1)];
-#define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * 256 < n16n) d[tid + k * 256] = w##k; }
-    {
+#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tidv + k * 256, n16n - 1)];
+#define RV_W_STORE(k) if constexpr (WPT > k) { if (tidv + k * 256 < n16n) d[tidv + k * 256] = w##k; }
+    auto load_chunk0 = [&](const int t0) {
         const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
         uint4* d = reinterpret_cast<uint4*>(wl);
-        for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];     // chunk 0, issued together with the tile staging
+        for (int i = t0; i < n16; i += 256) d[i] = wsrc[i];
+    };
+    if constexpr (SINGLE) load_chunk0(tid);       // SINGLE (template flag): all K-steps fit one chunk, S <= CONV_CH
+
+    // bias of this lane's output channels: fetched once, ahead of the K loop
+    float4 bias_r[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co0 = (zg * MT + m) * 16 + q * 4;
+        bias_r[m] = *reinterpret_cast<const float4*>(p.bias + co0);   // the bias array is padded to nz*MT*16 floats
     }
-    __syncthreads();
-    auto compute_chunk = [&](const int c, const int s0, const int ns) {
-        const unsigned char* wcur = wl + (size_t)(p.wbufs == 2 ? (c & 1) : 0) * p.wl_bytes;
-        for (int sl = 0; sl < ns; ++sl) {
-            const int toff = tab[(s0 + sl) * 4 + q];
-            if constexpr (F32) {
-                f32x4 a[MT];
+
+    // K loop, software pipelined: the fragments of step s+1 are read (LDS, or global memory in gather mode) while
+    // the MFMAs of step s are in the matrix pipe.
+    constexpr int NA = MT * WFR;                                 // 16-byte A fragments per K-step
+    f32x4 acc[MT][TILES];
+    auto load_frag = [&](const unsigned char* wcur, const int sl, const int toff, uint4 (&a)[NA], uint4 (&b)[TILES]) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const f32x4*>(wcur + ((size_t)(sl * MT + m) * 64 + lane) * 16);
+        for (int i = 0; i < NA; ++i)
+            a[i] = *reinterpret_cast<const uint4*>(wcur + ((size_t)(sl * NA + i) * 64 + lane) * 16);
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    const uint4 braw = load_b(pbase[t], toff);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(&braw);
+        for (int t = 0; t < TILES; ++t) b[t] = load_b(pbase[t], toff);
+    };
+    auto mfma_step = [&](const uint4 (&a)[NA], const uint4 (&b)[TILES]) {
+        if constexpr (F32) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], b[j], acc[m][t], 0, 0, 0);
-                    }
-                }
-            } else {
-                f16x8 ah[MT], al[MT];
+            for (int t = 0; t < TILES; ++t) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&b[t]);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    ah[m] = *reinterpret_cast<const f16x8*>(wcur + ((size_t)((sl * MT + m) * 2 + 0) * 64 + lane) * 16);
-                    al[m] = *reinterpret_cast<const f16x8*>(wcur + ((size_t)((sl * MT + m) * 2 + 1) * 64 + lane) * 16);
-                }
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&a[m]);
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    const uint4 braw = load_b(pbase[t], toff);
-                    const f16x8 b = *reinterpret_cast<const f16x8*>(&braw);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[m][t], 0, 0, 0);
                 }
             }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)                            // all hi products, then all lo: no back-to-back
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {                  // MFMAs on one accumulator
+                    const f16x8 bv = *reinterpret_cast<const f16x8*>(&b[t]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const f16x8 av = *reinterpret_cast<const f16x8*>(&a[m * 2 + h]);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][t], 0, 0, 0);
+                    }
+                }
         }
     };
-    if (n_chunks == 1) {
+    auto compute_chunk = [&](const int c, const int s0, const int ns) {
+        const unsigned char* wcur = wl + (size_t)(p.wbufs == 2 ? (c & 1) : 0) * p.wl_bytes;
+        const int* tq = tab + s0 * 4 + q;
+        const int last = ns - 1;
+        // two fragment sets, the loop unrolled by two: set 1 is read while set 0 is in the matrix pipe and vice versa;
+        // the table entry of a step is fetched half an iteration before its fragments.  Steps past the end re-read the
+        // last one (dropped), so every register has one unconditional definition per iteration.
+        uint4 a0[NA], b0[TILES], a1[NA], b1[TILES];
+        load_frag(wcur, 0, tq[0], a0, b0);
+        int t1 = tq[min(1, last) * 4];
+        for (int sl = 0; sl < ns; sl += 2) {
+            const int s1 = min(sl + 1, last), s2 = min(sl + 2, last), s3 = min(sl + 3, last);
+            const int t2 = tq[s2 * 4];
+            load_frag(wcur, s1, t1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);                     // reads stay above the MFMAs they overlap with
+            mfma_step(a0, b0);
+            const int t3 = tq[s3 * 4];
+            load_frag(wcur, s2, t2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sl + 1 < ns) mfma_step(a1, b1);
+            t1 = t3;
+        }
+    };
+
+    // ---- tile walk: workgroup b of XCD x = b % 8 takes every (workgroups-in-XCD)-th tile of the x-th eighth of the
+    // frame, so that the tiles in flight on one XCD are neighbours and share their halo rows in that XCD's L2 ----------
+    int k_lo = blockIdx.x, k_hi = p.n_xy, k_step = gridDim.x;
+    if (SINGLE && gridDim.x >= 8) {                // (chunked convs: one workgroup per tile, identity mapping)
+        const int xcd = blockIdx.x & 7;
+        const int band = (p.n_xy + 7) >> 3;
+        k_step = ((int)gridDim.x - xcd + 7) >> 3;
+        k_lo = xcd * band + (blockIdx.x >> 3);
+        k_hi = min(xcd * band + band, p.n_xy);
+    }
+    for (int tl = k_lo; tl < k_hi; tl += (SINGLE ? k_step : (1 << 30))) {      // chunked convs: one tile per workgroup
+    const int tyi = tl / p.tiles_x;
+    const int tx0 = (tl - tyi * p.tiles_x) * CONV_TW;
+    const int ty0 = tyi * TH;
+    if (tl != k_lo) __syncthreads();               // the previous tile's LDS reads are done
+    int tidv = tid;                                // opaque per tile: keeps the staging index math out of the registers
+    asm volatile("" : "+v"(tidv));                 // that live across the K loop (hipcc hoists it out of the tile loop)
+
+    // ---- stage the input tile (zero padded) -----------------------------------------------
+    if constexpr (!GATHER) {
+        const int iy0 = ty0 * p.stride - p.pad;
+        const int ix0 = tx0 * p.stride - p.pad;
+        const int row_chunks = p.LW * p.ncg;
+        const float inv_rc = 1.0f / (float)row_chunks;
+        const int total = p.LH * row_chunks;
+        for (int idx = tidv; idx < total; idx += 256) {
+            const int r = (int)(((float)idx + 0.5f) * inv_rc);
+            const int i = idx - r * row_chunks;
+            const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+            const int cg = i - c * p.ncg;
+            const int iy = iy0 + r;
+            const int ix = ix0 + c;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
+                const size_t pix = (size_t)iy * p.w_in + ix;
+                if (cg < p.ncg0)
+                    v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16);
+                else
+                    v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
+            }
+            *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int ti = wave * TILES + t;
+            const int iy = (ty0 + (ti >> 1)) * p.stride - p.pad + 4096, ix = (tx0 + (ti & 1) * 16 + lp) * p.stride - p.pad + 4096;
+            pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
+        }
+    }
+    if constexpr (!SINGLE) load_chunk0(tidv);             // chunked weights share one buffer: chunk 0 comes back for every tile
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if constexpr (SINGLE) {
         compute_chunk(0, 0, p.S);
     } else {
         for (int c = 0; c < n_chunks; ++c) {
@@ -233,19 +292,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 
     // ---- epilogue -------------------------------------------------------------------------
+    // (lane-derived values re-derived from the per-tile opaque id: otherwise hipcc hoists the whole epilogue address
+    // math -- dozens of 64-bit products -- out of the tile loop and keeps it in registers across the K loop)
+    const int lane_e = tidv & 63, wave_e = tidv >> 6, q_e = lane_e >> 4;
+    const int lp_e = (p.stride == 1) ? rv_pix16(lane_e & 15) : (lane_e & 15);
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-        const int ti = wave * TILES + t;
+        const int ti = wave_e * TILES + t;
         const int oy = ty0 + (ti >> 1);
-        const int ox = tx0 + (ti & 1) * 16 + lr;
+        const int ox = tx0 + (ti & 1) * 16 + lp_e;
         if (oy >= p.h_out || ox >= p.w_out) continue;
         const size_t opix = (size_t)oy * p.w_out + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int co0 = (zg * MT + m) * 16 + q * 4;
+            const int co0 = (zg * MT + m) * 16 + q_e * 4;
             if (co0 >= p.cout) continue;
             float y[4];
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0);
+            const float4 bv = bias_r[m];
             y[0] = acc[m][t][0] + bv.x; y[1] = acc[m][t][1] + bv.y;
             y[2] = acc[m][t][2] + bv.z; y[3] = acc[m][t][3] + bv.w;
 #pragma unroll
@@ -310,19 +373,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
         }
     }
+    }   // tile walk
 }
 
-typedef void (*conv_kernel_t)(ConvArgs);
+static int rv_num_cus() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
 
-template <int MT, int TILES, bool F32, bool GATHER>
-static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+// `persistent`: single-chunk convs launch only as many workgroups as the chip holds at once (occupancy x CUs, a
+// multiple of 8 for the XCD banding) and walk the tiles; everything else launches one workgroup per tile.
+template <int MT, int TILES, bool F32, bool GATHER, bool SINGLE>
+static int launch_conv(ConvArgs& a, int nz, size_t lds, bool persistent, hipStream_t st) {
     static bool attr_done = false;
+    const void* fn = reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>);
     if (!attr_done) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER>), grid, dim3(256), lds, st, a);
+    int gx = a.n_xy;
+    if (persistent) {
+        static size_t occ_lds[4] = {0, 0, 0, 0};
+        static int occ_val[4] = {0, 0, 0, 0};
+        int occ = 0;
+        for (int i = 0; i < 4; ++i)
+            if (occ_lds[i] == lds && occ_val[i] > 0) occ = occ_val[i];
+        if (occ == 0) {
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>, 256, lds));
+            if (occ < 1) occ = 1;
+            static int slot = 0;
+            occ_lds[slot & 3] = lds; occ_val[slot & 3] = occ; ++slot;
+        }
+        int cap = (rv_num_cus() * occ / nz) & ~7;
+        if (cap < 8) cap = 8;
+        if (const char* e = getenv("REFVSR_CONV_WG_CAP")) {       // test hook: force many tiles per workgroup
+            const int v = atoi(e);
+            if (v >= 1) cap = v;
+        }
+        if (gx > cap) gx = cap;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>), dim3(gx, 1, nz), dim3(256), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -357,7 +453,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     a.h_in = d->h_in; a.w_in = d->w_in; a.h_out = d->h_out; a.w_out = d->w_out;
     a.ks = d->ksize; a.stride = d->stride; a.pad = d->pad;
     a.G = d->ksize * d->ksize * a.ncg;
-    a.S = (a.G + 3) / 4;
+    a.S = rv_ksteps(d->ksize, a.ncg);
     RV_CHECK(a.S == d->ksteps, "conv: ksteps mismatch (descriptor %d, geometry %d)", d->ksteps, a.S);
     a.inv_ncg = 1.0f / (float)a.ncg;
     a.wpack = (const uint4*)d->wpack; a.bias = d->bias; a.cout = d->cout;
@@ -402,17 +498,25 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         const size_t lds2 = lds_for(2, a.wbufs);
         if (lds2 <= 80 * 1024) { tiles = 2; lds = lds2; } else { lds = lds_for(4, a.wbufs); }
     }
-    dim3 grid(rv_cdiv(d->w_out, CONV_TW), rv_cdiv(d->h_out, tiles * 2), nz);
+    a.tiles_x = rv_cdiv(d->w_out, CONV_TW);
+    a.n_xy = a.tiles_x * rv_cdiv(d->h_out, tiles * 2);
+    const bool single = a.S <= CONV_CH;              // all weights in one LDS chunk: persistent workgroups, weights fetched once
+    const bool persistent = single && !a.gather && getenv("REFVSR_CONV_NO_PERSIST") == nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (a.gather) {                                // only the fp16 strided predictors need it
+    if (a.gather) {                                // only the fp16 strided predictors need it (5x5 x 64 channels: chunked)
         RV_CHECK(!f32, "conv: gather mode is built for the fp16 path only");
-        if (MT == 1) return launch_conv<1, 4, false, true>(a, grid, lds, st);
-        if (MT == 2) return launch_conv<2, 4, false, true>(a, grid, lds, st);
-        return launch_conv<3, 4, false, true>(a, grid, lds, st);
+        RV_CHECK(!single, "conv: gather mode expects a chunked weight stream");
+        if (MT == 1) return launch_conv<1, 4, false, true, false>(a, nz, lds, false, st);
+        if (MT == 2) return launch_conv<2, 4, false, true, false>(a, nz, lds, false, st);
+        return launch_conv<3, 4, false, true, false>(a, nz, lds, false, st);
     }
-#define RV_CONV_CASE(M, T)                                                        \
-    if (MT == M && tiles == T)                                                    \
-        return f32 ? launch_conv<M, T, true, false>(a, grid, lds, st) : launch_conv<M, T, false, false>(a, grid, lds, st);
+#define RV_CONV_CASE(M, T)                                                                                  \
+    if (MT == M && tiles == T) {                                                                            \
+        if (f32) return single ? launch_conv<M, T, true, false, true>(a, nz, lds, persistent, st)           \
+                               : launch_conv<M, T, true, false, false>(a, nz, lds, false, st);              \
+        return single ? launch_conv<M, T, false, false, true>(a, nz, lds, persistent, st)                   \
+                      : launch_conv<M, T, false, false, false>(a, nz, lds, false, st);                      \
+    }
     RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
     RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)
     RV_CONV_CASE(3, 2) RV_CONV_CASE(3, 4)

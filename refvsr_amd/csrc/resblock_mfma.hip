@@ -43,6 +43,48 @@ struct ResBlockArgs {
     int tiles_x, n_tiles;
 };
 
+// Software-pipelined K loop shared by both phases: two fragment sets, unrolled by two (see conv_mfma.hip).
+template <int MT, int T>
+__device__ __forceinline__ void rb_kloop(f32x4 (&acc)[MT][T], const unsigned char* wl, const int* tq,
+                                         const unsigned char* src, const int (&pb)[T], const int S, const int lane) {
+    constexpr int NA = MT * 2;
+    auto load_frag = [&](const int s, const int toff, uint4 (&a)[NA], uint4 (&b)[T]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = *reinterpret_cast<const uint4*>(wl + ((size_t)(s * NA + i) * 64 + lane) * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) b[t] = *reinterpret_cast<const uint4*>(src + pb[t] + toff);
+    };
+    auto mfma_step = [&](const uint4 (&a)[NA], const uint4 (&b)[T]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(&b[t]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f16x8 av = *reinterpret_cast<const f16x8*>(&a[m * 2 + h]);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][t], 0, 0, 0);
+                }
+            }
+    };
+    const int last = S - 1;
+    uint4 a0[NA], b0[T], a1[NA], b1[T];
+    load_frag(0, tq[0], a0, b0);
+    int t1 = tq[min(1, last) * 4];
+    for (int s = 0; s < S; s += 2) {
+        const int s1 = min(s + 1, last), s2 = min(s + 2, last), s3 = min(s + 3, last);
+        const int t2 = tq[s2 * 4];
+        load_frag(s1, t1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(a0, b0);
+        const int t3 = tq[s3 * 4];
+        load_frag(s2, t2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S) mfma_step(a1, b1);
+        t1 = t3;
+    }
+}
+
 #define RB_XCH_MAX 5                      // uint4 prefetch registers per thread for one x tile (20*36*ncg / 512, ncg <= 3)
 
 template <int MT>
@@ -59,11 +101,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int q = lane >> 4;
-    const int lr = lane & 15;
+    const int lr = rv_pix16(lane & 15);      // pixel (of a 16-pixel MFMA tile) held by this lane's column
     const int psb = p.ps * 16;
 
-    for (int g = tid; g < p.S * 4; g += 512) {
-        int o1 = 0, o2 = 0;
+    for (int g = tid; g < p.S * 4; g += 512) {                    // K-slot -> offset (K order: common.h:rv_kslot)
+        int o1, o2, slot;
         if (g < p.G) {
             const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
             const int cg = g - tap * p.ncg;
@@ -71,9 +113,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int tx = tap - ty * 3;
             o1 = ((ty * RB_XW + tx) * p.ps + cg) * 16;
             o2 = ((ty * RB_IW + tx) * p.ps + cg) * 16;
+            slot = rv_kslot(ty, tx, cg, 3, p.ncg);
+        } else {                                                  // zero-weight blocks: offset of the partner's parity
+            slot = rv_kpad_slot(g - p.G, 3, p.ncg);
+            o1 = o2 = (slot < p.G) ? 0 : (p.ncg > 1 ? 16 : p.ps * 16);
         }
-        tab1[g] = o1;
-        tab2[g] = o2;
+        tab1[slot] = o1;
+        tab2[slot] = o2;
     }
     const int n16w = p.S * MT * 2 * 64;            // uint4 per weight set (<= 4 * 512 for the supported shapes)
     for (int i = tid; i < n16w; i += 512) reinterpret_cast<uint4*>(wl1)[i] = p.w1[i];
@@ -122,6 +168,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         v3 = p.w2[min(tid + 1536, last)];
     }
     bool w2_parked = false;
+    float4 b1r[MT], b2r[MT];                        // biases of this lane's output channels: fetched once
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co0 = min(m * 16 + q * 4, p.c - 4);
+        b1r[m] = *reinterpret_cast<const float4*>(p.b1 + co0);
+        b2r[m] = *reinterpret_cast<const float4*>(p.b2 + co0);
+    }
     __syncthreads();
 
     int cur = 0;
@@ -148,24 +201,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < RB_T1W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < p.S; ++s) {
-                const int toff = tab1[s * 4 + q];
-                f16x8 ah[MT], al[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ah[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
-                    al[m] = *reinterpret_cast<const f16x8*>(wl1 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
-                }
-#pragma unroll
-                for (int t = 0; t < RB_T1W; ++t) {
-                    const f16x8 b = *reinterpret_cast<const f16x8*>(xt + pb[t] + toff);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
-                    }
-                }
-            }
+            rb_kloop<MT, RB_T1W>(acc, wl1, tab1 + q, xt, pb, p.S, lane);
 #pragma unroll
             for (int t = 0; t < RB_T1W; ++t) {
                 const int tl = wave * RB_T1W + t;
@@ -179,7 +215,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int m = 0; m < MT; ++m) {
                     const int co0 = m * 16 + q * 4;
                     if (co0 >= p.c) continue;
-                    const float4 bv = *reinterpret_cast<const float4*>(p.b1 + co0);
+                    const float4 bv = b1r[m];
                     f16x4 o;
                     o[0] = (f16)(inside ? rv_lrelu(acc[m][t][0] + bv.x, p.act_slope) : 0.f);
                     o[1] = (f16)(inside ? rv_lrelu(acc[m][t][1] + bv.y, p.act_slope) : 0.f);
@@ -197,6 +233,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (tid + 1536 < n16w) d[tid + 1536] = v3;
             w2_parked = true;
         }
+        // the next x tile (loads issued before phase 1) goes to the other LDS buffer here, not after the output stores:
+        // waiting for it there also waited for every store of this tile (vmcnt is in order)
+        if (has_next) x_park(xt0 + (size_t)(cur ^ 1) * p.x_bytes);
         __syncthreads();
 
         // ---------------- phase 2: out = x + conv2(t) + b2 ------------------------------------------------
@@ -214,24 +253,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < RB_T2W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < p.S; ++s) {
-                const int toff = tab2[s * 4 + q];
-                f16x8 ah[MT], al[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ah[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 0) * 64 + lane) * 16);
-                    al[m] = *reinterpret_cast<const f16x8*>(wl2 + ((size_t)((s * MT + m) * 2 + 1) * 64 + lane) * 16);
-                }
-#pragma unroll
-                for (int t = 0; t < RB_T2W; ++t) {
-                    const f16x8 b = *reinterpret_cast<const f16x8*>(tt + pb[t] + toff);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], b, acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], b, acc[m][t], 0, 0, 0);
-                    }
-                }
-            }
+            rb_kloop<MT, RB_T2W>(acc, wl2, tab2 + q, tt, pb, p.S, lane);
 #pragma unroll
             for (int t = 0; t < RB_T2W; ++t) {
                 const int ti = wave * RB_T2W + t;
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int m = 0; m < MT; ++m) {
                     const int co0 = m * 16 + q * 4;
                     if (co0 >= p.c) continue;
-                    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + co0);
+                    const float4 bv = b2r[m];
                     const f16x4 xv4 = *reinterpret_cast<const f16x4*>(xr_ + co0 * 2);
                     float y[4] = {acc[m][t][0] + bv.x + (float)xv4[0], acc[m][t][1] + bv.y + (float)xv4[1],
                                   acc[m][t][2] + bv.z + (float)xv4[2], acc[m][t][3] + bv.w + (float)xv4[3]};
@@ -257,9 +279,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        asm volatile("" ::: "memory");
-        if (has_next) x_park(xt0 + (size_t)(cur ^ 1) * p.x_bytes);
-        __syncthreads();                   // next x tile visible; t tile free for the next phase 1
+        __syncthreads();                   // t tile free for the next phase 1
         cur ^= 1;
     }
 }
@@ -280,7 +300,7 @@ static int launch_resblock(const ResBlockArgs& a, dim3 grid, size_t lds, hipStre
 extern "C" int refvsr_resblock_fits(int c) {
     if (c <= 0 || c % 8 != 0) return 0;
     const int ncg = c / 8, ps = ncg | 1;
-    const int S = (9 * ncg + 3) / 4;
+    const int S = rv_ksteps(3, ncg);
     const int MT = (c + 15) / 16;
     if (MT > 2) return 0;
     if (RB_XH * RB_XW * ncg > RB_XCH_MAX * 512) return 0;        // x-tile prefetch registers
@@ -301,7 +321,7 @@ extern "C" int refvsr_resblock_mfma(const void* src, int c, int h, int w, const 
     memset(&a, 0, sizeof(a));
     a.src = (const f16*)src; a.out = (f16*)out;
     a.c = c; a.ncg = c / 8; a.ps = a.ncg | 1; a.h = h; a.w = w;
-    a.G = 9 * a.ncg; a.S = (a.G + 3) / 4;
+    a.G = 9 * a.ncg; a.S = rv_ksteps(3, a.ncg);
     RV_CHECK(a.S == ksteps, "resblock: ksteps mismatch (%d vs %d)", ksteps, a.S);
     a.inv_ncg = 1.0f / (float)a.ncg;
     a.w1 = (const uint4*)w1; a.b1 = b1; a.w2 = (const uint4*)w2; a.b2 = b2;

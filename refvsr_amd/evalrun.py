@@ -96,6 +96,7 @@ class ClipSet(object):
             'HR_UW': self._frame(self.hr_uw[v][f]),
             'is_first': f == 0, 'video_name': name, 'video_idx': v, 'video_len': len(self.lr_uw),
             'frame_idx': f, 'frame_len': n, 'frame_name': os.path.basename(self.lr_uw[v][f]),
+            'frame_ids': [(v, int(i)) for i in win],     # names the window's frames for the cross-window cache
         }
 
 
@@ -157,7 +158,8 @@ def evaluate(config, net=None, log=print):
                 net.Network.reset()
             t0 = time.time()
             lr, rf = it['LR_UW'][None].to(dev), it['LR_REF_W'][None].to(dev)
-            out = net(lr, rf, it['is_first'], is_log=False, is_train=False)['result']
+            kw = {'frame_ids': it['frame_ids']} if getattr(E, 'use_frame_ids', True) and 'frame_ids' in it else {}
+            out = net(lr, rf, it['is_first'], is_log=False, is_train=False, **kw)['result']
             torch.cuda.synchronize()
             dt = time.time() - t0
             out_cpu = out[0].float().cpu()

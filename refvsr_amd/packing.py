@@ -2,9 +2,11 @@
 refvsr_conv_mfma (refvsr_amd/csrc/conv_mfma.hip).
 
 GEMM view: D[row][pixel] = sum_k Wk[row][k] * X[k][pixel].
-  k-block g = tap*ncg + cg (tap = ky*ks + kx, cg = 16-byte channel group of the concatenated, padded
-  input: 8 halfs, or 4 floats in f32 mode); K-step s covers blocks 4s..4s+3; lane l of a wave
-  supplies block 4s + (l>>4) for row (l&15) of a 16-row tile.
+  k-block = (tap, cg) (tap = ky*ks + kx, cg = 16-byte channel group of the concatenated, padded
+  input: 8 halfs, or 4 floats in f32 mode), placed at slot kslot(ky, kx, cg) -- even-parity blocks
+  ((kx + cg) & 1 == 0) first, then the odd ones, so that the two K-blocks one ds_read_b128 lane group
+  mixes never collide on LDS banks (csrc/common.h:rv_kslot); K-step s covers slots 4s..4s+3; lane l of a
+  wave supplies slot 4s + (l>>4) for row (l&15) of a 16-row tile.
   fp16 : packed[z][s][m][hi|lo][lane][8] = split(Wk[(z*MT+m)*16 + (lane&15)][(4s + (lane>>4))*8 : +8])
          with hi = fp16(w), lo = fp16(w - hi)  (two MFMAs per fragment, ~22-bit weights)
   f32  : packed[z][s][m][lane][4]        = Wk[...][(4s + (lane>>4))*4 : +4]
@@ -33,6 +35,29 @@ def choose_mt(cout):
     if n_mt % 2 == 0:
         return 2
     return 3
+
+
+def keven(ks, ncg):
+    """Number of even-parity K-blocks (csrc/common.h:rv_keven)."""
+    ce, co = (ncg + 1) >> 1, ncg >> 1
+    return ks * (((ks + 1) >> 1) * ce + (ks >> 1) * co)
+
+
+def ksteps(ks, ncg):
+    return (ks * ks * ncg + (keven(ks, ncg) & 1) + 3) // 4
+
+
+def kslot(ty, tx, cg, ks, ncg):
+    """Slot of K-block (ty, tx, cg) in the packed K order (csrc/common.h:rv_kslot, same closed form)."""
+    ce, co = (ncg + 1) >> 1, ncg >> 1
+    p = (tx + cg) & 1
+    c0, c1 = (co, ce) if p else (ce, co)
+    row = ((ks + 1) >> 1) * c0 + (ks >> 1) * c1
+    rank = ty * row + ((tx + 1) >> 1) * c0 + (tx >> 1) * c1 + (cg >> 1)
+    if not p:
+        return rank
+    E = keven(ks, ncg)
+    return E + (E & 1) + rank
 
 
 def kmatrix(w, src_channels, shuffle=False, grp=8):
@@ -74,14 +99,16 @@ def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False):
     grp = 4 if f32 else 8
     assert not (f32 and shuffle)
     Wk, rows, ncg = kmatrix(w, src_channels, shuffle, grp)
-    G = ks * ks * ncg
-    S = (G + 3) // 4
+    S = ksteps(ks, ncg)
     MT = mt or choose_mt(cout)
     n_mt = (cout + 15) // 16
     nz = (n_mt + MT - 1) // MT
     R = nz * MT * 16
     full = np.zeros((R, S * 4 * grp), np.float32)
-    full[:cout, :G * grp] = Wk
+    for tap in range(ks * ks):
+        for cg in range(ncg):
+            g, j = tap * ncg + cg, kslot(tap // ks, tap % ks, cg, ks, ncg)
+            full[:cout, j * grp:(j + 1) * grp] = Wk[:, g * grp:(g + 1) * grp]
     # [nz, MT, lr, S, q, grp] -> [nz, S, MT, q, lr, grp]
     frag = full.reshape(nz, MT, 16, S, 4, grp).transpose(0, 3, 1, 4, 2, 5).reshape(nz, S, MT, 64, grp)
     frag = torch.from_numpy(np.ascontiguousarray(frag))

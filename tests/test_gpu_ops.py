@@ -107,6 +107,42 @@ def test_conv_mfma_vs_conv2d(dev, co, cins, ks, stride, h, w, shuffle):
     assert err < 1e-3          # fp16 output rounding (2^-11 relative) + fp32 accumulation order
 
 
+@pytest.mark.parametrize('cap', ['8', '24'])
+def test_conv_mfma_persistent_tile_walk(dev, monkeypatch, cap):
+    """Single-chunk convs run on persistent workgroups that walk the pixel tiles (XCD-banded order).  Forcing a tiny
+    workgroup count makes every workgroup take many tiles; the result must not depend on the walk."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(77)
+    for (co, cins, ks, h, w, shuffle, f32) in [(24, [24], 3, 37, 70, False, False), (24, [3, 24], 3, 64, 100, False, False),
+                                               (96, [24], 3, 41, 33, True, False), (3, [24], 3, 50, 90, False, False),
+                                               (16, [64], 1, 45, 77, False, True), (64, [3], 3, 33, 65, False, True)]:
+        cin = sum(cins)
+        wt = torch.randn(co, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        x = torch.randn(cin, h, w, generator=g)
+        cw = ops.ConvWeights(pack_conv(wt, b, cins, shuffle, f32=f32), dev)
+        srcs, o = [], 0
+        for c in cins:
+            srcs.append(ops.pack_nhwc32(x[o:o + c].to(dev)) if f32 else nhwc(x[o:o + c], dev))
+            o += c
+        kw = dict(planar_out=True) if co == 3 else {}
+        monkeypatch.delenv('REFVSR_CONV_WG_CAP', raising=False)
+        free = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, act=0.2, **kw).clone()
+        monkeypatch.setenv('REFVSR_CONV_WG_CAP', cap)
+        walked = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, act=0.2, **kw)
+        monkeypatch.delenv('REFVSR_CONV_WG_CAP', raising=False)
+        assert torch.equal(free, walked), (co, cins, ks, h, w)
+        xin = x if f32 else x.half().float()
+        want = F.leaky_relu(F.conv2d(xin[None], wt, b, padding=ks // 2), 0.2)[0]
+        if shuffle:
+            want = F.pixel_shuffle(want[None], 2)[0]
+        got = walked.cpu() if co == 3 else (walked.permute(2, 0, 1).cpu() if f32 else planar(walked))
+        err = rel(got, want)
+        report('conv_mfma tile walk cap=%s co%d cin%s k%d' % (cap, co, cins, ks), rel=err)
+        assert err < 1e-3
+
+
 def test_conv_mfma_gather_mode_strided(dev):
     """5x5 stride-4 / stride-8 offset predictors of the HD configs (alignment.py:20): the staged tile cannot fit
     LDS, the kernel switches to gathering B fragments from global memory."""

@@ -54,6 +54,33 @@ def test_state_dict_generator_is_deterministic(small_cfg):
     assert torch.allclose(w[:, :, 0, 0], torch.diag(1.0 / torch.tensor(weights.VGG_STD)))
 
 
+def _slot_enumeration(ks, ncg):
+    """The K order by construction (independent of the closed form in packing.kslot / common.h:rv_kslot): even-parity
+    blocks in natural order, one zero block if their count is odd, the odd-parity blocks, zero blocks up to 4*S."""
+    nat = [(ty, tx, cg) for ty in range(ks) for tx in range(ks) for cg in range(ncg)]
+    ev = [b for b in nat if (b[1] + b[2]) % 2 == 0]
+    od = [b for b in nat if (b[1] + b[2]) % 2 == 1]
+    order = ev + ([None] if len(ev) % 2 else []) + od
+    return order + [None] * (-len(order) % 4)
+
+
+@pytest.mark.parametrize('ks', [1, 3, 5, 7])
+def test_kblock_order_closed_form(ks):
+    from refvsr_amd.packing import keven, kslot, ksteps
+    for ncg in range(1, 20):
+        order = _slot_enumeration(ks, ncg)
+        assert ksteps(ks, ncg) * 4 == len(order)
+        assert keven(ks, ncg) == sum(1 for b in order if b is not None and (b[1] + b[2]) % 2 == 0)
+        for j, b in enumerate(order):
+            if b is not None:
+                assert kslot(b[0], b[1], b[2], ks, ncg) == j
+        # every ds_read_b128 lane group mixes slots (4s, 4s+1) or (4s+2, 4s+3): same parity, or one of them is a zero block
+        for j in range(0, len(order), 2):
+            a, b = order[j], order[j + 1]
+            if a is not None and b is not None:
+                assert (a[1] + a[2]) % 2 == (b[1] + b[2]) % 2
+
+
 def _emulate(srcs, pk, ks, stride, pad, ho, wo):
     """numpy model of conv_mfma.hip's K walk: K-block g -> (tap, channel group) -> strided gather."""
     X = np.concatenate(srcs, -1)
@@ -67,16 +94,16 @@ def _emulate(srcs, pk, ks, stride, pad, ho, wo):
     nz, S, MT = wp.shape[:3]
     grp = 4 if pk['f32'] else 8
     out = np.zeros((nz * MT * 16, ho, wo), np.float32)
+    order = _slot_enumeration(ks, ncg)
+    assert len(order) == 4 * S
     for z in range(nz):
         for m in range(MT):
             for s in range(S):
                 for q in range(4):
-                    g = 4 * s + q
-                    if g >= ks * ks * ncg:
+                    if order[4 * s + q] is None:
                         assert not wp[z, s, m, q * 16:(q + 1) * 16].any()     # padded K-blocks carry zero weights
                         continue
-                    tap, cg = divmod(g, ncg)
-                    ty, tx = divmod(tap, ks)
+                    ty, tx, cg = order[4 * s + q]
                     A = wp[z, s, m, q * 16:(q + 1) * 16]
                     B = Xp[ty:ty + ho * stride:stride, tx:tx + wo * stride:stride, cg * grp:cg * grp + grp]
                     out[(z * MT + m) * 16:(z * MT + m + 1) * 16] += np.einsum('rk,yxk->ryx', A, B)
