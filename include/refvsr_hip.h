@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 1
+#define REFVSR_ABI_VERSION 2   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -67,6 +67,9 @@ typedef struct RefvsrConv {
 } RefvsrConv;
 
 int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
+/* Tuning / test knob (no reference counterpart): upper bound on the workgroups one single-chunk conv launches; each
+ * workgroup walks the remaining pixel tiles.  0 = automatic (occupancy x CUs).  Results do not depend on it. */
+int refvsr_set_conv_workgroup_cap(int cap);
 
 /* Fused residual block  out = post( x + conv2( act( conv1(x) ) ) ),  3x3, C -> C, stride 1 (one launch; the
  * intermediate map lives in LDS): ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97) and ResBlock

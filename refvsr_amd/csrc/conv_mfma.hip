@@ -376,6 +376,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }   // tile walk
 }
 
+static int g_wg_cap = 0;
+extern "C" int refvsr_set_conv_workgroup_cap(int cap) {
+    g_wg_cap = cap > 0 ? cap : 0;
+    return 0;
+}
+
 static int rv_num_cus() {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -412,10 +418,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, bool persistent, hipStre
         }
         int cap = (rv_num_cus() * occ / nz) & ~7;
         if (cap < 8) cap = 8;
-        if (const char* e = getenv("REFVSR_CONV_WG_CAP")) {       // test hook: force many tiles per workgroup
-            const int v = atoi(e);
-            if (v >= 1) cap = v;
-        }
+        if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>), dim3(gx, 1, nz), dim3(256), lds, st, a);
@@ -501,7 +504,8 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     a.tiles_x = rv_cdiv(d->w_out, CONV_TW);
     a.n_xy = a.tiles_x * rv_cdiv(d->h_out, tiles * 2);
     const bool single = a.S <= CONV_CH;              // all weights in one LDS chunk: persistent workgroups, weights fetched once
-    const bool persistent = single && !a.gather && getenv("REFVSR_CONV_NO_PERSIST") == nullptr;
+    static const bool no_persist = getenv("REFVSR_CONV_NO_PERSIST") != nullptr;   // A/B knob, read once
+    const bool persistent = single && !a.gather && !no_persist;
     hipStream_t st = (hipStream_t)stream;
     if (a.gather) {                                // only the fp16 strided predictors need it (5x5 x 64 channels: chunked)
         RV_CHECK(!f32, "conv: gather mode is built for the fp16 path only");

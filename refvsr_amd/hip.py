@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RefvsrConv(C.Structure):
@@ -43,6 +43,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     'refvsr_init': [],
     'refvsr_conv_mfma': [C.POINTER(RefvsrConv), _P],
+    'refvsr_set_conv_workgroup_cap': [_I],
     'refvsr_resblock_fits': [_I],
     'refvsr_resblock_mfma': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],

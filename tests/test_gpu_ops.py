@@ -107,11 +107,11 @@ def test_conv_mfma_vs_conv2d(dev, co, cins, ks, stride, h, w, shuffle):
     assert err < 1e-3          # fp16 output rounding (2^-11 relative) + fp32 accumulation order
 
 
-@pytest.mark.parametrize('cap', ['8', '24'])
-def test_conv_mfma_persistent_tile_walk(dev, monkeypatch, cap):
+@pytest.mark.parametrize('cap', [8, 24])
+def test_conv_mfma_persistent_tile_walk(dev, cap):
     """Single-chunk convs run on persistent workgroups that walk the pixel tiles (XCD-banded order).  Forcing a tiny
     workgroup count makes every workgroup take many tiles; the result must not depend on the walk."""
-    from refvsr_amd import ops
+    from refvsr_amd import hip, ops
     from refvsr_amd.packing import pack_conv
     g = torch.Generator().manual_seed(77)
     for (co, cins, ks, h, w, shuffle, f32) in [(24, [24], 3, 37, 70, False, False), (24, [3, 24], 3, 64, 100, False, False),
@@ -127,11 +127,12 @@ def test_conv_mfma_persistent_tile_walk(dev, monkeypatch, cap):
             srcs.append(ops.pack_nhwc32(x[o:o + c].to(dev)) if f32 else nhwc(x[o:o + c], dev))
             o += c
         kw = dict(planar_out=True) if co == 3 else {}
-        monkeypatch.delenv('REFVSR_CONV_WG_CAP', raising=False)
         free = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, act=0.2, **kw).clone()
-        monkeypatch.setenv('REFVSR_CONV_WG_CAP', cap)
-        walked = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, act=0.2, **kw)
-        monkeypatch.delenv('REFVSR_CONV_WG_CAP', raising=False)
+        hip.lib().refvsr_set_conv_workgroup_cap(cap)
+        try:
+            walked = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, act=0.2, **kw)
+        finally:
+            hip.lib().refvsr_set_conv_workgroup_cap(0)
         assert torch.equal(free, walked), (co, cins, ks, h, w)
         xin = x if f32 else x.half().float()
         want = F.leaky_relu(F.conv2d(xin[None], wt, b, padding=ks // 2), 0.2)[0]
@@ -139,14 +140,14 @@ def test_conv_mfma_persistent_tile_walk(dev, monkeypatch, cap):
             want = F.pixel_shuffle(want[None], 2)[0]
         got = walked.cpu() if co == 3 else (walked.permute(2, 0, 1).cpu() if f32 else planar(walked))
         err = rel(got, want)
-        report('conv_mfma tile walk cap=%s co%d cin%s k%d' % (cap, co, cins, ks), rel=err)
+        report('conv_mfma tile walk cap=%d co%d cin%s k%d' % (cap, co, cins, ks), rel=err)
         assert err < 1e-3
 
 
 def test_conv_mfma_gather_mode_strided(dev):
     """5x5 stride-4 / stride-8 offset predictors of the HD configs (alignment.py:20): the staged tile cannot fit
     LDS, the kernel switches to gathering B fragments from global memory."""
-    from refvsr_amd import ops
+    from refvsr_amd import hip, ops
     from refvsr_amd.packing import pack_conv
     g = torch.Generator().manual_seed(77)
     for stride, h, w in ((4, 64, 96), (8, 128, 192), (8, 72, 200)):
