@@ -2,37 +2,45 @@
 //
 //   D[cout][pixel] = sum_k  W[cout][k] * X[k][pixel],   k = (tap, channel)   (fp32 accumulate)
 //
-// * A operand = packed weights (rows = 16 output channels), B operand = 16 consecutive output
-//   pixels of one image row.  With this orientation a lane ends up holding 4 consecutive output
-//   channels of ONE pixel, so the epilogue stores 8-byte channel vectors straight into the HWC map.
-// * One workgroup = 4 waves = an (2*TILES) x 32 output-pixel tile.  The input tile (+halo, zero
-//   padded at the frame border, two concatenated sources) is staged ONCE through LDS with coalesced
-//   16-byte loads of HWC rows; every tap of every output pixel is then an LDS read.
-//   LDS pixel stride is forced odd (in 16-byte slots) so 16 consecutive pixels hit 16 distinct slots.
-// * K is walked in 32-deep steps; per step lane l consumes K-block g = 4*step + (l>>4), an
-//   8-channel group of one tap.  g -> LDS byte offset comes from a small table built per block, so
-//   kernel size, stride and channel count are runtime values (one kernel serves 1x1..7x7).
-// * Weights are pre-packed on the host in exact fragment order and streamed through LDS in chunks of
-//   CH K-steps shared by the 4 waves.  fp16 mode: every weight is carried as hi + lo halves
-//   ([kstep][mtile][hi|lo][lane][8 halfs], two MFMAs per B fragment): a plain fp16 weight rounding is a
-//   *systematic* perturbation of the network and was measured to dominate the PSNR-parity error
-//   (tools/precision_sim.py); hi+lo gives ~22-bit weights for one extra MFMA.
-// * F32 mode (template flag): the same walk on v_mfma_f32_16x16x4_f32 with fp32 HWC activations and fp32
-//   weights ([kstep][mtile][lane][4 floats]; a K-block is 4 channels, 4 MFMAs per 16-byte fragment) --
-//   bitwise an fp32 FMA chain.  Used for the VGG feature extractor of the matching, whose arg-max is
-//   discontinuous in the features.
-// * Epilogue fuses bias, (leaky)ReLU, alpha-multiply, residual, post-activation, pixel-shuffle or a
-//   planar fp32 store with residual / constant / clamp.
-// * Gather mode (runtime flag, chosen when the staged tile would not fit LDS, i.e. the stride-4/8 5x5
-//   offset predictors of the HD configs, alignment.py:20 with stride = ks): windows of neighbouring output
-//   pixels do not overlap there, so B fragments are read straight from global memory (16 bytes per lane,
-//   zero for out-of-frame taps) and only the weights go through LDS.
+// * A operand = packed weights (rows = 16 output channels), B operand = 16 output pixels of one image row.  With
+//   this orientation a lane ends up holding 4 consecutive output channels of ONE pixel, so the epilogue stores
+//   8-byte channel vectors straight into the HWC map.
+// * One workgroup = 4 waves = an (2*TILES) x 32 output-pixel tile.  The input tile (+halo, zero padded at the frame
+//   border, two concatenated sources) is staged through LDS with coalesced 16-byte loads of HWC rows; every tap of
+//   every output pixel is then an LDS read.  LDS pixel stride is odd (in 16-byte slots); together with the K-block
+//   order and the pixel permutation of common.h (rv_kslot, rv_pix16) the ds_read_b128 of a B fragment is bank
+//   conflict free.
+// * K is walked in 32-deep steps; per step lane l consumes K-slot 4*step + (l>>4), an 8-channel group of one tap.
+//   slot -> LDS byte offset comes from a small table built per workgroup, so kernel size, stride and channel count
+//   are runtime values (one kernel serves 1x1..7x7).  The K loop is software pipelined (two fragment sets).
+// * Weights are pre-packed on the host in exact fragment order.  fp16 mode: every weight is carried as hi + lo halves
+//   ([kstep][mtile][hi|lo][lane][8 halfs], two MFMAs per B fragment): a plain fp16 weight rounding is a *systematic*
+//   perturbation of the network and was measured to dominate the PSNR-parity error (tools/precision_sim.py); hi+lo
+//   gives ~22-bit weights for one extra MFMA.
+// * RESIDENT mode (template flag; up to CONV_RES_MAX K-steps, i.e. every 3x3 conv with <= 56 input channels, the 5x5
+//   3->32 and the first SPyNet 7x7): the whole weight set stays in LDS and the workgroup is persistent -- it walks
+//   pixel tiles (XCD-banded order) and fetches the NEXT tile into registers while the matrix pipe works on the current
+//   one.  On the 2x / HR maps the per-CU vector-memory path bounds these convs: re-fetching 29-57 KB of weights per
+//   8x32-pixel tile was more than half of its traffic, and a fresh workgroup per tile exposed the staging latency.
+//   Otherwise (SPyNet 7x7 32/64-channel layers, 5x5 64-channel predictors, VGG 64->64) weights stream through LDS in
+//   chunks of CONV_CH K-steps, register-prefetched, one workgroup per tile.
+// * F32 mode (template flag): the same walk on v_mfma_f32_16x16x4_f32 with fp32 HWC activations and fp32 weights
+//   ([kstep][mtile][lane][4 floats]; a K-block is 4 channels, 4 MFMAs per 16-byte fragment) -- bitwise an fp32 FMA
+//   chain.  Used for the VGG feature extractor of the matching, whose arg-max is discontinuous in the features.
+// * Epilogue fuses bias, (leaky)ReLU, alpha-multiply, residual, post-activation, pixel-shuffle or a planar fp32
+//   store with residual / constant / clamp.
+// * Gather mode (template flag, chosen when the staged tile would not fit LDS, i.e. the stride-4/8 5x5 offset
+//   predictors of the HD configs, alignment.py:20 with stride = ks): windows of neighbouring output pixels do not
+//   overlap there, so B fragments are read straight from global memory (16 bytes per lane, zero for out-of-frame
+//   taps) and only the weights go through LDS.
 //
 // Replaces nn.Conv2d call sites listed in include/refvsr_hip.h.
 #include "common.h"
 #include <stdlib.h>
 
-#define CONV_CH 8          // K-steps of weights staged per LDS chunk
+#define CONV_CH 8          // K-steps of weights per streamed LDS chunk (chunked convs)
+#define CONV_RES_MAX 16    // K-steps a resident weight set may have (persistent convs)
+#define CONV_XPF 8         // uint4 prefetch registers per thread for the next input tile (persistent convs)
 #define CONV_TW 32         // output tile width in pixels
 
 struct ConvArgs {
@@ -53,17 +61,18 @@ struct ConvArgs {
     const float* res_planar; float add_const, clamp_lo, clamp_hi;
     int tab_bytes, wl_bytes;         // LDS carve sizes
     int gather;                      // 1: no LDS input tile, B fragments gathered from global memory
-    int wbufs;                       // weight-chunk LDS buffers: 2 (one barrier per chunk) or 1 when LDS is tight
-    int tiles_x, n_xy;               // pixel tiles per row / per frame; workgroups walk tiles (persistent when gridDim.x < n_xy)
+    int tiles_x, n_xy;               // pixel tiles per row / per frame
+    int prefetch;                    // resident kernels: 1 = next tile prefetched into registers during the K loop
 };
 
-template <int MT, int TILES, bool F32, bool GATHER, bool SINGLE>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
+    static_assert(!(GATHER && RESIDENT), "gather mode streams its weights");
     constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tab = reinterpret_cast<int*>(smem);
     unsigned char* wl = smem + p.tab_bytes;
-    unsigned char* tile = wl + p.wbufs * p.wl_bytes;      // [weight-chunk buffer(s)][input tile]
+    unsigned char* tile = wl + p.wl_bytes;           // [table][weights: resident set | one chunk][input tile]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -117,26 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         return v;
     };
 
-    // Weight chunks: chunk c+1 is fetched into registers while chunk c feeds the MFMAs and parked afterwards.
-    // Single-chunk convs (all 3x3 convs up to 32 input channels) load their weights ONCE per workgroup: the per-CU
-    // vector-memory path, not HBM or the matrix pipe, bounds the large maps, and re-fetching 29 KB of weights for
-    // every 8x32-pixel tile was half of that traffic.
-    constexpr int WPT = (CONV_CH * MT * WFR * 64) / 256;         // uint4 per thread per chunk (4 * MT * WFR)
     const uint4* wsrc = p.wpack + (size_t)zg * p.S * MT * WFR * 64;
-    const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
-    // named registers, not an array: hipcc keeps a prefetch *array* in scratch memory here (scratch_store right
-    // behind every load), which serialises the whole prefetch
-    static_assert(WPT <= 12, "prefetch register set");
-    uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
-#define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
-#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tidv + k * 256, n16n - 1)];
-#define RV_W_STORE(k) if constexpr (WPT > k) { if (tidv + k * 256 < n16n) d[tidv + k * 256] = w##k; }
-    auto load_chunk0 = [&](const int t0) {
-        const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
-        uint4* d = reinterpret_cast<uint4*>(wl);
-        for (int i = t0; i < n16; i += 256) d[i] = wsrc[i];
-    };
-    if constexpr (SINGLE) load_chunk0(tid);       // SINGLE (template flag): all K-steps fit one chunk, S <= CONV_CH
 
     // bias of this lane's output channels: fetched once, ahead of the K loop
     float4 bias_r[MT];
@@ -146,10 +136,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         bias_r[m] = *reinterpret_cast<const float4*>(p.bias + co0);   // the bias array is padded to nz*MT*16 floats
     }
 
-    // K loop, software pipelined: the fragments of step s+1 are read (LDS, or global memory in gather mode) while
-    // the MFMAs of step s are in the matrix pipe.
+    // ---- K loop, software pipelined: the fragments of step s+1 are read (LDS, or global memory in gather mode)
+    // while the MFMAs of step s are in the matrix pipe --------------------------------------------------------------
     constexpr int NA = MT * WFR;                                 // 16-byte A fragments per K-step
     f32x4 acc[MT][TILES];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     auto load_frag = [&](const unsigned char* wcur, const int sl, const int toff, uint4 (&a)[NA], uint4 (&b)[TILES]) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -184,8 +180,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 }
         }
     };
-    auto compute_chunk = [&](const int c, const int s0, const int ns) {
-        const unsigned char* wcur = wl + (size_t)(p.wbufs == 2 ? (c & 1) : 0) * p.wl_bytes;
+    // K-steps s0 .. s0+ns-1 with their weight fragments at wcur (fragment index relative to s0)
+    auto compute_steps = [&](const unsigned char* wcur, const int s0, const int ns) {
         const int* tq = tab + s0 * 4 + q;
         const int last = ns - 1;
         // two fragment sets, the loop unrolled by two: set 1 is read while set 0 is in the matrix pipe and vice versa;
@@ -208,93 +204,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         }
     };
 
-    // ---- tile walk: workgroup b of XCD x = b % 8 takes every (workgroups-in-XCD)-th tile of the x-th eighth of the
-    // frame, so that the tiles in flight on one XCD are neighbours and share their halo rows in that XCD's L2 ----------
-    int k_lo = blockIdx.x, k_hi = p.n_xy, k_step = gridDim.x;
-    if (SINGLE && gridDim.x >= 8) {                // (chunked convs: one workgroup per tile, identity mapping)
-        const int xcd = blockIdx.x & 7;
-        const int band = (p.n_xy + 7) >> 3;
-        k_step = ((int)gridDim.x - xcd + 7) >> 3;
-        k_lo = xcd * band + (blockIdx.x >> 3);
-        k_hi = min(xcd * band + band, p.n_xy);
-    }
-    for (int tl = k_lo; tl < k_hi; tl += (SINGLE ? k_step : (1 << 30))) {      // chunked convs: one tile per workgroup
-    const int tyi = tl / p.tiles_x;
-    const int tx0 = (tl - tyi * p.tiles_x) * CONV_TW;
-    const int ty0 = tyi * TH;
-    if (tl != k_lo) __syncthreads();               // the previous tile's LDS reads are done
-    int tidv = tid;                                // opaque per tile: keeps the staging index math out of the registers
-    asm volatile("" : "+v"(tidv));                 // that live across the K loop (hipcc hoists it out of the tile loop)
-
-    // ---- stage the input tile (zero padded) -----------------------------------------------
-    if constexpr (!GATHER) {
-        const int iy0 = ty0 * p.stride - p.pad;
-        const int ix0 = tx0 * p.stride - p.pad;
-        const int row_chunks = p.LW * p.ncg;
-        const float inv_rc = 1.0f / (float)row_chunks;
-        const int total = p.LH * row_chunks;
-        for (int idx = tidv; idx < total; idx += 256) {
-            const int r = (int)(((float)idx + 0.5f) * inv_rc);
-            const int i = idx - r * row_chunks;
-            const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
-            const int cg = i - c * p.ncg;
-            const int iy = iy0 + r;
-            const int ix = ix0 + c;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
-                const size_t pix = (size_t)iy * p.w_in + ix;
-                if (cg < p.ncg0)
-                    v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16);
-                else
-                    v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
-            }
-            *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const int ti = wave * TILES + t;
-            const int iy = (ty0 + (ti >> 1)) * p.stride - p.pad + 4096, ix = (tx0 + (ti & 1) * 16 + lp) * p.stride - p.pad + 4096;
-            pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
-        }
-    }
-    if constexpr (!SINGLE) load_chunk0(tidv);             // chunked weights share one buffer: chunk 0 comes back for every tile
-
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    if constexpr (SINGLE) {
-        compute_chunk(0, 0, p.S);
-    } else {
-        for (int c = 0; c < n_chunks; ++c) {
-            const int s0 = c * CONV_CH;
-            const int ns = min(CONV_CH, p.S - s0);
-            const bool has_next = (c + 1 < n_chunks);
-            // the prefetch is unconditional (the last iteration re-reads its own chunk and drops it) so that the
-            // prefetch registers have one definition per iteration: a conditional definition makes hipcc copy them
-            // right behind the loads, i.e. wait for every load before the MFMA loop
-            const int sn = has_next ? s0 + CONV_CH : s0;
-            const int n16n = min(CONV_CH, p.S - sn) * MT * WFR * 64;
-            {
-                const uint4* g = wsrc + (size_t)sn * MT * WFR * 64;
-                RV_W_ALL(RV_W_LOAD)
-            }
-            compute_chunk(c, s0, ns);
-            if (has_next) {
-                if (p.wbufs != 2) __syncthreads();                 // single buffer: everyone must be done reading it
-                uint4* d = reinterpret_cast<uint4*>(wl + (size_t)(p.wbufs == 2 ? ((c + 1) & 1) : 0) * p.wl_bytes);
-                RV_W_ALL(RV_W_STORE)
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- epilogue -------------------------------------------------------------------------
-    // (lane-derived values re-derived from the per-tile opaque id: otherwise hipcc hoists the whole epilogue address
-    // math -- dozens of 64-bit products -- out of the tile loop and keeps it in registers across the K loop)
-    const int lane_e = tidv & 63, wave_e = tidv >> 6, q_e = lane_e >> 4;
+    // ---- epilogue of one tile; `tide` = thread id, opaque per tile in the persistent walk (otherwise hipcc hoists the
+    // whole epilogue address math -- dozens of 64-bit products -- out of the tile loop and keeps it in registers) -----
+    auto epilogue = [&](const int ty0, const int tx0, const int tide) {
+    const int lane_e = tide & 63, wave_e = tide >> 6, q_e = lane_e >> 4;
     const int lp_e = (p.stride == 1) ? rv_pix16(lane_e & 15) : (lane_e & 15);
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -373,7 +286,169 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
         }
     }
-    }   // tile walk
+    };
+
+    if constexpr (RESIDENT) {
+        // ================= persistent workgroup: resident weights, register-prefetched tiles =====================
+        {
+            const int n16 = p.S * MT * WFR * 64;
+            uint4* d = reinterpret_cast<uint4*>(wl);
+            for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];
+        }
+        // tile walk: workgroup b of XCD x = b % 8 takes every (workgroups-in-XCD)-th tile of the x-th eighth of the
+        // frame, so that the tiles in flight on one XCD are neighbours and share their halo rows in that XCD's L2
+        int tl = blockIdx.x, k_hi = p.n_xy, k_step = gridDim.x;
+        if (gridDim.x >= 8) {
+            const int xcd = blockIdx.x & 7;
+            const int band = (p.n_xy + 7) >> 3;
+            k_step = ((int)gridDim.x - xcd + 7) >> 3;
+            tl = xcd * band + (blockIdx.x >> 3);
+            k_hi = min(xcd * band + band, p.n_xy);
+        }
+        // input-tile chunk k of this thread: 16 bytes = (row r, column c, channel group cg) of the LH x LW tile
+        const int row_chunks = p.LW * p.ncg;
+        const int total = p.LH * row_chunks;                       // <= CONV_XPF * 256 (host)
+        int xq[CONV_XPF];                                          // r << 16 | c << 8 | cg, or -1 past the tile
+        {
+            const float inv_rc = 1.0f / (float)row_chunks;
+#pragma unroll
+            for (int k = 0; k < CONV_XPF; ++k) {
+                const int idx = tid + k * 256;
+                const int r = (int)(((float)idx + 0.5f) * inv_rc);
+                const int i = idx - r * row_chunks;
+                const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+                xq[k] = idx < total ? ((r << 16) | (c << 8) | (i - c * p.ncg)) : -1;
+            }
+        }
+        uint4 xv[CONV_XPF];
+        auto x_fetch = [&](const int t) {                          // global -> registers (zero padded at the frame border)
+            const int tyi = t / p.tiles_x;
+            const int iy0 = tyi * TH * p.stride - p.pad;
+            const int ix0 = (t - tyi * p.tiles_x) * CONV_TW * p.stride - p.pad;
+#pragma unroll
+            for (int k = 0; k < CONV_XPF; ++k) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                int e = xq[k];
+                asm volatile("" : "+v"(e));                        // decode per tile: keeps (r, c, cg, addresses) x 8 out of
+                const int iy = iy0 + (e >> 16), ix = ix0 + ((e >> 8) & 0xff), cg = e & 0xff;   // the registers live across the K loop
+                if (e >= 0 && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
+                    const size_t pix = (size_t)iy * p.w_in + ix;
+                    v = (cg < p.ncg0) ? *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16)
+                                      : *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
+                }
+                xv[k] = v;
+            }
+        };
+        auto x_park = [&]() {                                      // registers -> LDS tile
+#pragma unroll
+            for (int k = 0; k < CONV_XPF; ++k) {
+                int e = xq[k];
+                asm volatile("" : "+v"(e));
+                if (e >= 0)
+                    *reinterpret_cast<uint4*>(tile + ((size_t)((e >> 16) * p.LW + ((e >> 8) & 0xff)) * p.ps + (e & 0xff)) * 16) = xv[k];
+            }
+        };
+        // Schedule per tile i:  fetch tile i+1 into registers | K loop(i) | barrier | park tile i+1 | epilogue(i) | barrier.
+        // The park sits BEFORE the output stores: vmcnt retires in order, so waiting for the prefetch behind them would
+        // also wait for every store of the tile.  (p.prefetch == 0, an A/B knob: the next tile is fetched and parked in
+        // one go after the K loop, i.e. with its latency exposed.)
+        if (tl < k_hi) { x_fetch(tl); x_park(); }
+        __syncthreads();                                           // table, weights, first tile
+        for (; tl < k_hi; tl += k_step) {
+            const bool has_next = tl + k_step < k_hi;
+            if (has_next && p.prefetch) x_fetch(tl + k_step);      // in flight during the K loop
+            asm volatile("" ::: "memory");
+            zero_acc();
+            compute_steps(wl, 0, p.S);
+            __syncthreads();                                       // every wave is done reading the LDS tile
+            if (has_next) {
+                if (!p.prefetch) x_fetch(tl + k_step);
+                x_park();
+            }
+            asm volatile("" ::: "memory");
+            int tide = tid;
+            asm volatile("" : "+v"(tide));
+            const int tyi = tl / p.tiles_x;
+            epilogue(tyi * TH, (tl - tyi * p.tiles_x) * CONV_TW, tide);
+            __syncthreads();                                       // next tile visible
+        }
+    } else {
+        // ================= one tile per workgroup, weights streamed in chunks =======================================
+        const int tl = blockIdx.x;
+        const int tyi = tl / p.tiles_x;
+        const int tx0 = (tl - tyi * p.tiles_x) * CONV_TW;
+        const int ty0 = tyi * TH;
+        if constexpr (!GATHER) {                                   // stage the input tile (zero padded)
+            const int iy0 = ty0 * p.stride - p.pad;
+            const int ix0 = tx0 * p.stride - p.pad;
+            const int row_chunks = p.LW * p.ncg;
+            const float inv_rc = 1.0f / (float)row_chunks;
+            const int total = p.LH * row_chunks;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int r = (int)(((float)idx + 0.5f) * inv_rc);
+                const int i = idx - r * row_chunks;
+                const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+                const int cg = i - c * p.ncg;
+                const int iy = iy0 + r;
+                const int ix = ix0 + c;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
+                    const size_t pix = (size_t)iy * p.w_in + ix;
+                    if (cg < p.ncg0)
+                        v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16);
+                    else
+                        v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
+                }
+                *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const int ti = wave * TILES + t;
+                const int iy = (ty0 + (ti >> 1)) * p.stride - p.pad + 4096, ix = (tx0 + (ti & 1) * 16 + lp) * p.stride - p.pad + 4096;
+                pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
+            }
+        }
+        // Weight chunks: chunk c+1 is fetched into registers while chunk c feeds the MFMAs and parked afterwards.
+        constexpr int WPT = (CONV_CH * MT * WFR * 64) / 256;         // uint4 per thread per chunk (4 * MT * WFR)
+        const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
+        // named registers, not an array: hipcc keeps a prefetch *array* in scratch memory here (scratch_store right
+        // behind every load), which serialises the whole prefetch
+        static_assert(WPT <= 12, "prefetch register set");
+        uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
+#define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
+#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * 256, n16n - 1)];
+#define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * 256 < n16n) d[tid + k * 256] = w##k; }
+        {
+            const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
+            uint4* d = reinterpret_cast<uint4*>(wl);
+            for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];     // chunk 0, issued together with the tile staging
+        }
+        zero_acc();
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+            const int s0 = c * CONV_CH;
+            const int ns = min(CONV_CH, p.S - s0);
+            const bool has_next = (c + 1 < n_chunks);
+            // the prefetch is unconditional (the last iteration re-reads its own chunk and drops it) so that the
+            // prefetch registers have one definition per iteration: a conditional definition makes hipcc copy them
+            // right behind the loads, i.e. wait for every load before the MFMA loop
+            const int sn = has_next ? s0 + CONV_CH : s0;
+            const int n16n = min(CONV_CH, p.S - sn) * MT * WFR * 64;
+            {
+                const uint4* g = wsrc + (size_t)sn * MT * WFR * 64;
+                RV_W_ALL(RV_W_LOAD)
+            }
+            compute_steps(wl, s0, ns);
+            if (has_next) {
+                __syncthreads();                                   // everyone is done reading the chunk buffer
+                uint4* d = reinterpret_cast<uint4*>(wl);
+                RV_W_ALL(RV_W_STORE)
+                __syncthreads();
+            }
+        }
+        epilogue(ty0, tx0, tid);
+    }
 }
 
 static int g_wg_cap = 0;
@@ -393,27 +468,27 @@ static int rv_num_cus() {
     return n_cu;
 }
 
-// `persistent`: single-chunk convs launch only as many workgroups as the chip holds at once (occupancy x CUs, a
-// multiple of 8 for the XCD banding) and walk the tiles; everything else launches one workgroup per tile.
-template <int MT, int TILES, bool F32, bool GATHER, bool SINGLE>
-static int launch_conv(ConvArgs& a, int nz, size_t lds, bool persistent, hipStream_t st) {
+// RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
+// the XCD banding) and walk the tiles; the others launch one workgroup per tile.
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT>
+static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
     static bool attr_done = false;
-    const void* fn = reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>);
     if (!attr_done) {
-        RV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     int gx = a.n_xy;
-    if (persistent) {
+    if (RESIDENT) {
         static size_t occ_lds[4] = {0, 0, 0, 0};
         static int occ_val[4] = {0, 0, 0, 0};
+        static int slot = 0;
         int occ = 0;
         for (int i = 0; i < 4; ++i)
             if (occ_lds[i] == lds && occ_val[i] > 0) occ = occ_val[i];
         if (occ == 0) {
-            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>, 256, lds));
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>, 256, lds));
             if (occ < 1) occ = 1;
-            static int slot = 0;
             occ_lds[slot & 3] = lds; occ_val[slot & 3] = occ; ++slot;
         }
         int cap = (rv_num_cus() * occ / nz) & ~7;
@@ -421,7 +496,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, bool persistent, hipStre
         if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, SINGLE>), dim3(gx, 1, nz), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>), dim3(gx, 1, nz), dim3(256), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -471,55 +546,71 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     const int n_mt = (d->cout + 15) / 16;
     const int nz = (n_mt + MT - 1) / MT;
     a.tab_bytes = ((a.S * 4 * 4 + 15) / 16) * 16;
-    // weight-chunk buffers: single-chunk convs (S <= CONV_CH) need one exactly-sized buffer; chunked convs get two
-    // (one barrier per chunk) unless the input tile then no longer fits LDS.
-    a.wl_bytes = (a.S <= CONV_CH ? a.S : CONV_CH) * MT * (f32 ? 1 : 2) * 1024;
-    a.wbufs = 1;
+    const int wfr_kb = MT * (f32 ? 1 : 2) * 1024;      // bytes of weight fragments per K-step
+    static const bool no_resident = getenv("REFVSR_CONV_NO_PERSIST") != nullptr;   // A/B knob, read once
+    const size_t LDS_MAX = 160 * 1024;
 
-    // pick the pixel-tile height: 8 rows x 32 cols if the staged input fits, else 4 rows; else drop the 2nd weight buffer
     int tiles = 4;
     size_t lds = 0;
-    auto lds_for = [&](int tl, int wb) {
-        const int TH = tl * 2;
-        a.LH = (TH - 1) * a.stride + a.ks;
+    auto tile_bytes = [&](int tl) {
+        a.LH = (tl * 2 - 1) * a.stride + a.ks;
         a.LW = (CONV_TW - 1) * a.stride + a.ks;
-        return (size_t)a.tab_bytes + (size_t)wb * a.wl_bytes + (size_t)a.LH * a.LW * a.ps * 16;
+        return (size_t)a.LH * a.LW * a.ps * 16;
     };
-    lds = lds_for(4, a.wbufs);
-    if (lds > 160 * 1024) { tiles = 2; lds = lds_for(2, a.wbufs); }
-    if (lds > 160 * 1024 && a.wbufs == 2) { a.wbufs = 1; tiles = 4; lds = lds_for(4, 1); if (lds > 160 * 1024) { tiles = 2; lds = lds_for(2, 1); } }
-    if (lds > 160 * 1024) {                        // strided predictor convs: gather B fragments from global memory
-        a.gather = 1;
-        a.wbufs = 1;
+    // RESIDENT: whole weight set in LDS, persistent workgroups with a register-prefetched input tile.  Needs few enough
+    // K-steps, a tile that fits the prefetch registers, and LDS for >= 2 workgroups per CU (8 x 32 pixels preferred,
+    // 4 x 32 when that buys a second / third workgroup).
+    bool resident = false;
+    static const int res_max = getenv("REFVSR_CONV_RES_MAX") ? atoi(getenv("REFVSR_CONV_RES_MAX")) : CONV_RES_MAX;   // A/B knob
+    if (!no_resident && a.S <= res_max && a.S <= CONV_RES_MAX) {
+        int best_wg = 0;
+        for (int tl = 4; tl >= 2; tl -= 2) {
+            const size_t tb = tile_bytes(tl);
+            const size_t need = (size_t)a.tab_bytes + (size_t)a.S * wfr_kb + tb;
+            const int chunks = a.LH * a.LW * a.ncg;
+            const int wg = need <= LDS_MAX ? (int)(LDS_MAX / need) : 0;
+            if (chunks > CONV_XPF * 256 || wg == 0) continue;
+            if (best_wg == 0 || (best_wg < 2 && wg > best_wg)) { best_wg = wg; tiles = tl; lds = need; resident = true; }
+        }
+        if (resident) { a.wl_bytes = a.S * wfr_kb; tile_bytes(tiles); }
+    }
+    if (!resident) {
+        // chunked weights (one CONV_CH-step buffer): 8 x 32 pixels if the staged input fits, else 4 x 32, else gather mode
+        a.wl_bytes = (a.S <= CONV_CH ? a.S : CONV_CH) * wfr_kb;
+        auto lds_for = [&](int tl) { return (size_t)a.tab_bytes + (size_t)a.wl_bytes + tile_bytes(tl); };
         tiles = 4;
-        a.LH = a.LW = 0;
-        lds = (size_t)a.tab_bytes + (size_t)a.wbufs * a.wl_bytes;
-        RV_CHECK(d->h_in < 60000 && d->w_in < 60000, "conv: frame too large for gather-mode coordinates");
+        lds = lds_for(4);
+        if (lds > LDS_MAX) { tiles = 2; lds = lds_for(2); }
+        if (lds > LDS_MAX) {                           // strided predictor convs: gather B fragments from global memory
+            a.gather = 1;
+            tiles = 4;
+            a.LH = a.LW = 0;
+            lds = (size_t)a.tab_bytes + (size_t)a.wl_bytes;
+            RV_CHECK(d->h_in < 60000 && d->w_in < 60000, "conv: frame too large for gather-mode coordinates");
+        }
+        // prefer 2 blocks/CU for mid-size tiles
+        if (!a.gather && tiles == 4 && lds > LDS_MAX / 2 && d->h_out * d->w_out > 64 * 1024) {
+            const size_t lds2 = lds_for(2);
+            if (lds2 <= LDS_MAX / 2) { tiles = 2; lds = lds2; } else { lds = lds_for(4); }
+        }
     }
-    // prefer 2 blocks/CU for mid-size tiles
-    if (!a.gather && tiles == 4 && lds > 80 * 1024 && d->h_out * d->w_out > 64 * 1024) {
-        const size_t lds2 = lds_for(2, a.wbufs);
-        if (lds2 <= 80 * 1024) { tiles = 2; lds = lds2; } else { lds = lds_for(4, a.wbufs); }
-    }
+    static const bool no_prefetch = getenv("REFVSR_CONV_NO_PREFETCH") != nullptr;   // A/B knob, read once
+    a.prefetch = no_prefetch ? 0 : 1;
     a.tiles_x = rv_cdiv(d->w_out, CONV_TW);
     a.n_xy = a.tiles_x * rv_cdiv(d->h_out, tiles * 2);
-    const bool single = a.S <= CONV_CH;              // all weights in one LDS chunk: persistent workgroups, weights fetched once
-    static const bool no_persist = getenv("REFVSR_CONV_NO_PERSIST") != nullptr;   // A/B knob, read once
-    const bool persistent = single && !a.gather && !no_persist;
     hipStream_t st = (hipStream_t)stream;
-    if (a.gather) {                                // only the fp16 strided predictors need it (5x5 x 64 channels: chunked)
+    if (a.gather) {                                // only the fp16 strided predictors need it
         RV_CHECK(!f32, "conv: gather mode is built for the fp16 path only");
-        RV_CHECK(!single, "conv: gather mode expects a chunked weight stream");
-        if (MT == 1) return launch_conv<1, 4, false, true, false>(a, nz, lds, false, st);
-        if (MT == 2) return launch_conv<2, 4, false, true, false>(a, nz, lds, false, st);
-        return launch_conv<3, 4, false, true, false>(a, nz, lds, false, st);
+        if (MT == 1) return launch_conv<1, 4, false, true, false>(a, nz, lds, st);
+        if (MT == 2) return launch_conv<2, 4, false, true, false>(a, nz, lds, st);
+        return launch_conv<3, 4, false, true, false>(a, nz, lds, st);
     }
-#define RV_CONV_CASE(M, T)                                                                                  \
-    if (MT == M && tiles == T) {                                                                            \
-        if (f32) return single ? launch_conv<M, T, true, false, true>(a, nz, lds, persistent, st)           \
-                               : launch_conv<M, T, true, false, false>(a, nz, lds, false, st);              \
-        return single ? launch_conv<M, T, false, false, true>(a, nz, lds, persistent, st)                   \
-                      : launch_conv<M, T, false, false, false>(a, nz, lds, false, st);                      \
+#define RV_CONV_CASE(M, T)                                                                                \
+    if (MT == M && tiles == T) {                                                                          \
+        if (f32) return resident ? launch_conv<M, T, true, false, true>(a, nz, lds, st)                   \
+                                 : launch_conv<M, T, true, false, false>(a, nz, lds, st);                 \
+        return resident ? launch_conv<M, T, false, false, true>(a, nz, lds, st)                           \
+                        : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
     }
     RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
     RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/gpu_ops_report.txt
 echo "== pytest gpu ==" | tee gpurun_out/final.log
-timeout 1200 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider -n 2 > gpurun_out/pytest_gpu_full.log 2>&1
+timeout 1200 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider -n 4 > gpurun_out/pytest_gpu_full.log 2>&1
 grep -E "^(FAILED|ERROR|SKIPPED)|passed|failed" gpurun_out/pytest_gpu_full.log | tail -30 | tee -a gpurun_out/final.log
 grep -E "^E  " gpurun_out/pytest_gpu_full.log | head -40 | tee -a gpurun_out/final.log
 echo "== smoke ==" | tee -a gpurun_out/final.log

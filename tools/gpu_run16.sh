@@ -1,0 +1,18 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+L=gpurun_out/run16.log
+echo "== pytest (without the live-oracle and two-process tests) ==" | tee $L
+timeout 600 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -n 4 -k "not live_oracle and not two_process" > gpurun_out/pytest_gpu_part.log 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/pytest_gpu_part.log | tail -20 | tee -a $L
+grep -E "^E  " gpurun_out/pytest_gpu_part.log | head -30 | cut -c1-300 | tee -a $L
+fmt='import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],2),"fps", round(d["ms_per_step"],3),"ms; match", round(d["roofline"]["mean_launch_ms"],3),"ms", round(d["roofline"]["frac"],3))'
+echo "== bench OLD (ab_old) ==" | tee -a $L
+(cd ab_old && timeout 600 python bench.py --steps 40 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "$fmt") | tee -a $L
+echo "== bench NEW ==" | tee -a $L
+timeout 600 python bench.py --steps 40 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "$fmt" | tee -a $L
+echo "== bench NEW, REFVSR_CONV_NO_PERSIST=1 ==" | tee -a $L
+REFVSR_CONV_NO_PERSIST=1 timeout 600 python bench.py --steps 40 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "$fmt" | tee -a $L
+echo "== microbench NEW ==" | tee -a $L
+timeout 300 python tools/bench_kernels.py 2>&1 | grep -E "^conv|^resblock" | tee -a $L
