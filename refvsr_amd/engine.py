@@ -465,7 +465,10 @@ class Engine(object):
     # ------------------------------------------------------------------ pipelined forward (opt-in)
     def _pipe_streams(self, dev):
         if self._pipe is None or self._pipe[0].device != dev:
-            self._pipe = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            # P (per-frame preparation: SPyNet pyramid, matching, reference encoders) may run at high priority so that the
+            # 254-workgroup matching kernel is not queued behind the persistent conv workgroups of the other streams
+            hi = -1 if os.environ.get('REFVSR_STREAM_PRIORITY', '0') == '1' else 0
+            self._pipe = [torch.cuda.Stream(device=dev) for _ in range(3)] + [torch.cuda.Stream(device=dev, priority=hi)]
             self._pipe_calls = 0
         return self._pipe
 
