@@ -1,20 +1,35 @@
 #!/usr/bin/env python3
-"""A few launches of the throughput-bound conv shapes for rocprofv3 --pmc (LDS / MFMA counters)."""
+"""A few launches of the throughput-bound conv shapes for rocprofv3 --pmc (LDS / MFMA / wait / HBM counters)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from refvsr_amd import ops
+from refvsr_amd import hip, ops
 from refvsr_amd.packing import pack_conv
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 C = 24
 w1 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+w2 = torch.randn(C, 2 * C, 3, 3, generator=g) / (2 * C * 9) ** 0.5
 c1 = ops.ConvWeights(pack_conv(w1, torch.zeros(C), [C]), dev)
 c2 = ops.ConvWeights(pack_conv(w1.flip(0), torch.zeros(C), [C]), dev)
+c3 = ops.ConvWeights(pack_conv(w2, torch.zeros(C), [C, C]), dev)
 x = ops.pack_nhwc16(torch.randn(C, 540, 960, generator=g).to(dev))
+y = ops.pack_nhwc16(torch.randn(C, 540, 960, generator=g).to(dev))
+xh = ops.pack_nhwc16(torch.randn(C, 1080, 1920, generator=g).to(dev))
 for _ in range(3):
-    ops.conv(c1, x, act=0.2)
+    ops.conv(c1, x, act=0.2)            # 2x map, resident weights
 for _ in range(3):
-    ops.resblock(c1, c2, x, act=0.0)
+    ops.conv(c3, x, y, act=0.2, res=x)  # 2x map, 48 -> 24 with residual
+hip.lib().refvsr_set_conv_workgroup_cap(760)     # same kernel as the 2x launch: a different grid tells them apart
+for _ in range(3):
+    ops.conv(c1, xh, act=0.2)           # HR map
+hip.lib().refvsr_set_conv_workgroup_cap(0)
+xl = ops.pack_nhwc16(torch.randn(C, 270, 480, generator=g).to(dev))
+for _ in range(3):
+    ops.conv(c1, xl, act=0.2)           # LR map (one tile per workgroup)
+for _ in range(3):
+    ops.resblock(c1, c2, xl, act=0.0)   # LR map, fused pair
+for _ in range(3):
+    ops.resblock(c1, c2, x, act=0.0)    # 2x map, fused pair
 torch.cuda.synchronize()
 print('done')
