@@ -548,16 +548,12 @@ class OracleNetwork(object):
         return conv(out, W, 'Network.conv_last') + base
 
     # -- forward -----------------------------------------------------------------------------
-    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, trace=None):
-        """Network.forward (RefVSR.py:151-325), inference semantics (is_train=False)."""
-        assert not is_train, 'oracle covers the inference path only'
+    def phase_a(self, lrs, refs, first_hint=False):
+        """State-independent part of Network.forward: flows, matching and the backward branch (RefVSR.py:182-238)."""
         W = self.W
         n, t, c, h, w = lrs.shape
         C = self.C
         ctr = t // 2
-        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
-            is_first_frame = True                                            # :168-170
-        range_start = 0 if is_first_frame else ctr                           # :173-176
         gradio = bool(self.cfg.EVAL.is_gradio)
         ff, bf = [], []
         for j in range(t - 1):                                               # :182-186
@@ -565,7 +561,7 @@ class OracleNetwork(object):
         for j in range(1, t):                                                # :187-191
             bf.append(torch.zeros(n, 2, h, w) if gradio else spynet(lrs[:, j - 1], lrs[:, j], W))
         conf_maps, index_maps = [None] * t, [None] * t
-        for i in range(range_start, t):                                      # :196-204
+        for i in range(0 if first_hint else ctr, t):                         # :196-204
             conf_maps[i], index_maps[i] = self._feature_match(lrs[:, i], refs[:, i])
         # backward branch :211-238
         feat = torch.zeros(n, C, h, w)
@@ -582,13 +578,28 @@ class OracleNetwork(object):
             rf, rfd = self._ref_feats(refs[:, i])
             feat, feat_up, conf = self._rap(lrs[:, i], refs[:, i], conf_maps[i], conf,
                                             index_maps[i], feat, feat_up, rfd, rf)
-        bw_up, conf_bw = feat_up, conf
+        return dict(lrs=lrs, refs=refs, ff=ff, bf=bf, conf_maps=conf_maps, index_maps=index_maps,
+                    bw_up=feat_up, conf_bw=conf)
+
+    def phase_b(self, pa, is_first_frame, is_log=False, trace=None):
+        """State-dependent rest: forward branch (:240-283), BW/FW fusion + upsampler (:288-297)."""
+        W = self.W
+        lrs, refs, ff, conf_maps, index_maps = pa['lrs'], pa['refs'], pa['ff'], pa['conf_maps'], pa['index_maps']
+        bw_up, conf_bw = pa['bw_up'], pa['conf_bw']
+        n, t, c, h, w = lrs.shape
+        C = self.C
+        ctr = t // 2
+        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
+            is_first_frame = True                                            # :168-170
         # forward branch :240-283
         if is_first_frame:
             feat = torch.zeros(n, C, h, w)
             feat_up = torch.zeros(n, C, 2 * h, 2 * w)
             conf = torch.zeros(n, 1, h, w)
-            range_start = 0
+            range_start = 0                                                  # :173-176
+            for i in range(0, ctr):                                          # matching of the frames before the centre
+                if conf_maps[i] is None:                                     # (:196-204 with range_start = 0)
+                    conf_maps[i], index_maps[i] = self._feature_match(lrs[:, i], refs[:, i])
         else:
             range_start = ctr
         for i in range(range_start, ctr + 1):
@@ -621,7 +632,7 @@ class OracleNetwork(object):
         outs = collections.OrderedDict()
         outs['result'] = out
         if trace is not None:
-            trace.update(forward_flows=torch.stack(ff, 1), backward_flows=torch.stack(bf, 1),
+            trace.update(forward_flows=torch.stack(ff, 1), backward_flows=torch.stack(pa['bf'], 1),
                          conf_maps=conf_maps, index_maps=index_maps, backward_feat_UP=bw_up,
                          conf_map_prop_backward=conf_bw, conf_map_prop_forward=conf,
                          forward_feat_UP=feat_up, is_first_frame=is_first_frame)
@@ -633,6 +644,13 @@ class OracleNetwork(object):
             ev['conf_map_prop_forward'] = conf
             outs['eval_vis'] = ev
         return outs
+
+    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, trace=None):
+        """Network.forward (RefVSR.py:151-325), inference semantics (is_train=False); = phase_a + phase_b (the split
+        exists for the multi-GPU wavefront test: phase A is state-free, phase B carries the forward-branch state)."""
+        assert not is_train, 'oracle covers the inference path only'
+        first = bool(is_first_frame) or (self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num)
+        return self.phase_b(self.phase_a(lrs, refs, first_hint=first), is_first_frame, is_log=is_log, trace=trace)
 
     __call__ = forward
 

@@ -581,6 +581,22 @@ class Engine(object):
             self._side = [torch.cuda.Stream(device=dev) for _ in range(2)]
         return self._side[k]
 
+    def _backward_branch(self, fr, flow, t, h, w):
+        """Backward propagation branch (RefVSR.py:211-238): restarts from zeros in every window."""
+        C, ctr, dev = self.C, t // 2, fr[0].lr.device
+        feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
+        feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
+        conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+        for i in range(t - 1, ctr - 1, -1):
+            if i < t - 1:
+                fl = flow(i, i + 1)                       # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
+                feat = ops.warp_nhwc16(feat, fl)
+                conf = ops.warp_planar(conf, fl)
+                feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
+            feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
+            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+        return feat_up, conf
+
     def _forward_branch(self, fr, flow, t, h, w, is_first_frame):
         """Forward propagation branch (RefVSR.py:240-283); updates the carried state.  Runs on the current stream."""
         C, ctr, dev = self.C, t // 2, fr[0].lr.device
@@ -620,12 +636,78 @@ class Engine(object):
         with ops.on_stream(torch.cuda.current_stream()):
             return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
 
-    def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
+    # ------------------------------------------------------------------ two-phase forward (multi-GPU wavefront)
+    def _check_window(self, lrs, refs):
         assert lrs.is_cuda and lrs.dtype == torch.float32 and lrs.dim() == 4 and lrs.shape == refs.shape
         t, _, h, w = lrs.shape
         assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
         assert not self.hd or (h % 8 == 0 and w % 8 == 0), 'flag_HD_in needs h, w divisible by 8'
-        C = self.C
+        return t, h, w
+
+    @torch.no_grad()
+    def phase_a(self, lrs, refs, frame_ids=None, first_hint=False):
+        """Everything of one forward() that does NOT depend on the carried forward-branch state: frame preparation
+        (flows, matching, reference encoders, alignment -- cached across windows as usual) and the whole backward
+        branch (RefVSR.py:182-238), i.e. 85-90 % of the work.  Returns a handle for phase_b.  Used by
+        shard.run_wavefront: every rank runs phase A of all its frames concurrently, then the ranks run phase B one
+        after the other along the state hand-off chain.  first_hint: the call is expected to be a first frame / reset
+        frame, prepare frames 0..ctr-1 now instead of lazily in phase B."""
+        t, h, w = self._check_window(lrs, refs)
+        ctr, dev = t // 2, lrs.device
+        with ops.on_stream(torch.cuda.current_stream()):
+            zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if bool(self.cfg.EVAL.is_gradio) else None
+            fr = self._frames(lrs, refs, frame_ids)
+            flow = (lambda a, b: zero_flow) if zero_flow is not None else (lambda a, b: self.flow(fr[a], fr[b]))
+            for i in range(0 if first_hint else ctr, t):
+                self.prepare_frame(fr[i])
+            bw_up, conf_bw = self._backward_branch(fr, flow, t, h, w)
+            # the flows the forward branch will ask for, computed here (parallel phase) and pinned in the handle: the
+            # flow cache only keeps pairs of the current window
+            flows = {(ctr + 1, ctr): flow(ctr + 1, ctr)}
+            if first_hint:
+                for i in range(1, ctr + 1):
+                    flows[(i, i - 1)] = flow(i, i - 1)
+        return dict(fr=fr, flows=flows, zero_flow=zero_flow, bw_up=bw_up, conf_bw=conf_bw, t=t, h=h, w=w)
+
+    @torch.no_grad()
+    def phase_b(self, pa, is_first_frame, want_vis=False):
+        """The state-dependent rest of forward(): forward-branch step (RefVSR.py:240-283) + BW/FW fusion and upsampler
+        (:288-297).  Must be called in frame order; (phase_a, phase_b) of a frame == forward() of that frame."""
+        fr, t, h, w = pa['fr'], pa['t'], pa['h'], pa['w']
+        ctr = t // 2
+        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
+            is_first_frame = True                                                   # :168-170
+        if not is_first_frame and self.fw_feat is None:
+            raise RuntimeError('is_first_frame=False but no forward state is held (first call of a stream '
+                               'must pass is_first_frame=True, cf. RefVSR.py:257-258)')
+        if not is_first_frame and tuple(self.fw_feat.shape[:2]) != (h, w):
+            raise RuntimeError('frame size changed from %s to %s without is_first_frame=True'
+                               % (tuple(self.fw_feat.shape[:2]), (h, w)))
+        with ops.on_stream(torch.cuda.current_stream()):
+            def flow(a, b):
+                if pa['zero_flow'] is not None:
+                    return pa['zero_flow']
+                hit = pa['flows'].get((a, b))
+                return hit if hit is not None else self.flow(fr[a], fr[b])
+            if is_first_frame:
+                for i in range(0, ctr):
+                    self.prepare_frame(fr[i])                  # no-op when phase A had the hint
+            feat, feat_up, conf = self._forward_branch(fr, flow, t, h, w, is_first_frame)
+            out = self.compute_up(pa['bw_up'], feat_up, pa['conf_bw'], conf, fr[ctr].lr)
+            if is_first_frame:                                                      # :292-295
+                self.frame_itr_num = 0
+            self.frame_itr_num += 1
+            vis = None
+            if want_vis:
+                vis = collections.OrderedDict()
+                vis['conf_map'] = fr[ctr].conf
+                vis['conf_map_prop'] = ops.max2(pa['conf_bw'], conf)
+                vis['conf_map_prop_backward'] = pa['conf_bw']
+                vis['conf_map_prop_forward'] = conf
+        return out, vis
+
+    def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
+        t, h, w = self._check_window(lrs, refs)
         ctr = t // 2
         dev = lrs.device
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
@@ -658,19 +740,7 @@ class Engine(object):
         for i in range(range_start, t):                                             # :196-204 (+ per-frame RAP parts)
             self.prepare_frame(fr[i])
 
-        # ---- backward branch (:211-238)
-        feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
-        feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
-        conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
-        for i in range(t - 1, ctr - 1, -1):
-            if i < t - 1:
-                fl = flow(i, i + 1)                       # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
-                feat = ops.warp_nhwc16(feat, fl)
-                conf = ops.warp_planar(conf, fl)
-                feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
-            feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
-            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
-        bw_up, conf_bw = feat_up, conf
+        bw_up, conf_bw = self._backward_branch(fr, flow, t, h, w)
 
         # ---- forward branch (:240-283)
         if overlap:

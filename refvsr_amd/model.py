@@ -145,6 +145,32 @@ class Network(nn.Module):
             outs['eval_vis'] = ev
         return outs
 
+    # ---- two-phase forward for the multi-GPU wavefront (refvsr_amd/shard.py:run_wavefront; not in the reference) ----
+    def phase_a(self, lrs, refs, frame_ids=None, first_hint=False):
+        """State-independent part of forward() (preparation + backward branch) for lrs, refs [n,t,3,h,w]."""
+        hip.lib()
+        if not lrs.is_cuda:
+            raise RuntimeError('refvsr_amd.Network runs on the GPU only (got a %s tensor); there is no CPU path' % lrs.device)
+        lrs, refs = lrs.float().contiguous(), refs.float().contiguous()
+        self.ensure_engines(lrs.shape[0], lrs.device)
+        return [self._engines[b].phase_a(lrs[b], refs[b], None if frame_ids is None else [(b, f) for f in frame_ids],
+                                         first_hint) for b in range(lrs.shape[0])]
+
+    def phase_b(self, handles, is_first_frame, is_log=False):
+        """State-dependent rest (forward-branch step + upsampler); same return value as forward()."""
+        want_vis = bool(is_log and self.config.save_sample)
+        res = [self._engines[b].phase_b(h, bool(is_first_frame), want_vis) for b, h in enumerate(handles)]
+        outs = collections.OrderedDict()
+        if is_log:
+            outs['vis'] = collections.OrderedDict()
+        outs['result'] = torch.stack([r[0] for r in res], 0)
+        if want_vis:
+            ev = collections.OrderedDict()
+            for k in res[0][1]:
+                ev[k] = torch.stack([r[1][k] for r in res], 0)
+            outs['eval_vis'] = ev
+        return outs
+
 
 class SRNet(nn.Module):
     """models/SRNet.py:SRNet surface."""

@@ -11,8 +11,16 @@ frame_itr_num -- RefVSR.py:96-101,279-283).  The backward branch restarts from z
     (RCCL send/recv over a single xGMI link; 63.8 MB fp32 for RefVSR_small at 270p).  There is no
     all-reduce anywhere on the inference path.
 
-`run_sharded` is executor-agnostic (anything with forward/export_state/import_state), so the
-protocol is tested on CPU with the gloo backend and the oracle as executor.
+  * the hand-off chain serialises the ranks if each waits for the previous one to finish its whole
+    shard (`run_sharded`).  `run_wavefront` splits every frame into phase A -- flows, matching,
+    reference encoders, alignment and the whole backward branch, 85-90 % of the work, independent of
+    the carried state -- and phase B -- one forward-branch step + the upsampler.  All ranks run phase A
+    of all their frames concurrently; phase B then runs as a wavefront rank 0 -> 1 -> ... behind the
+    hand-off, so the serial part of an N-rank run is ~(10-15 %) x nframes instead of 100 %.
+
+`run_sharded` / `run_wavefront` are executor-agnostic (anything with forward or phase_a/phase_b and
+export_state/import_state), so the protocols are tested on CPU with the gloo backend and the oracle as
+executor, and on one GPU with two processes and the real engine.
 """
 import torch
 import torch.distributed as dist
@@ -91,6 +99,38 @@ def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels
         if on_result is not None:
             on_result(f, out)
     nxt = partition(nframes, world, reset_branch, aligned)[rank + 1] if rank + 1 < world else None
+    if nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch):
+        send_state(executor.export_state(), rank + 1, device)
+    return results
+
+
+def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None):
+    """Two-phase run of this rank's share (balanced contiguous ranges, any boundary).
+
+    executor.phase_a(lrs, refs, frame_index, first_hint) -> handle   (state-free; all ranks concurrently)
+    executor.phase_b(handle, is_first_frame) -> result               (carries the forward-branch state; in frame order)
+    Results are identical to the sequential run.  Returns {frame: result} for the local frames."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    parts = partition(nframes, world)
+    start, end = parts[rank]
+    handles = {}
+    for f in range(start, end):                                   # ---- phase A: no communication, no state
+        lrs, refs = get_window(f)
+        hint = f == 0 or bool(reset_branch and f % reset_branch == 0) or (f == start and not needs_handoff(start, reset_branch))
+        handles[f] = executor.phase_a(lrs, refs, f, hint)
+    results = {}
+    if end > start and needs_handoff(start, reset_branch):        # ---- phase B: wavefront behind the hand-off
+        executor.import_state(recv_state(rank - 1, channels, device))
+        first = False
+    else:
+        first = True
+    for f in range(start, end):
+        out = executor.phase_b(handles.pop(f), first)
+        first = False
+        results[f] = out
+        if on_result is not None:
+            on_result(f, out)
+    nxt = parts[rank + 1] if rank + 1 < world else None
     if nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch):
         send_state(executor.export_state(), rank + 1, device)
     return results

@@ -142,6 +142,28 @@ def test_pipelined_mode_is_bit_identical(dev):
         assert torch.equal(net(wl[f], wr[f], f == 0, frame_ids=wins[f])['result'], want[f])
 
 
+def test_two_phase_forward_is_bit_identical(dev):
+    """phase_a (state-free: preparation + backward branch) of ALL frames first, then phase_b (forward-branch step +
+    upsampler) in frame order -- the multi-GPU wavefront schedule -- must equal forward() bit for bit, including
+    the first frame, a reset_branch rollover (hinted and un-hinted) and the HD configuration."""
+    from refvsr_amd.synth import make_clip, window_indices
+    for name, t, size, reset in [('config_RefVSR_small_L1', 5, (64, 96), 4), ('config_RefVSR_small_MFID_8K', 3, (32, 48), None)]:
+        nfr = 7
+        lr, rf, _ = make_clip(nfr, size[0], size[1], seed=13)
+        lr, rf = lr.to(dev), rf.to(dev)
+        wins = [window_indices(f, nfr, t) for f in range(nfr)]
+        ref_net, _, _ = make_net(name, t, dev, reset=reset, save_sample=False)
+        want = [ref_net(lr[w][None], rf[w][None], f == 0)['result'].clone() for f, w in enumerate(wins)]
+        for hinted in (True, False):
+            net, _, _ = make_net(name, t, dev, reset=reset, save_sample=False)
+            hs = [net.Network.phase_a(lr[w][None], rf[w][None], frame_ids=w,
+                                      first_hint=hinted and (f == 0 or bool(reset and f % reset == 0)))
+                  for f, w in enumerate(wins)]
+            for f in range(nfr):
+                got = net.Network.phase_b(hs[f], f == 0)['result']
+                assert torch.equal(got, want[f]), '%s: two-phase frame %d differs (hinted=%s)' % (name, f, hinted)
+
+
 def test_batch_and_api_contract(dev):
     from refvsr_amd.synth import make_clip, window_indices
     lr, rf, _ = make_clip(2, 32, 48, seed=1)
@@ -240,6 +262,12 @@ class _HipExec(object):
     def __call__(self, lrs, refs, first):
         return self.net(lrs[None].cuda(), refs[None].cuda(), first)['result'][0].cpu()
 
+    def phase_a(self, lrs, refs, f, hint):
+        return self.net.Network.phase_a(lrs[None].cuda(), refs[None].cuda(), first_hint=hint)
+
+    def phase_b(self, handles, first):
+        return self.net.Network.phase_b(handles, first)['result'][0].cpu()
+
     def export_state(self):
         st = self.eng.export_state()
         return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
@@ -248,7 +276,7 @@ class _HipExec(object):
         self.eng.import_state({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in st.items()})
 
 
-def _shard_worker(rank, world, port, reset, aligned, q):
+def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -258,16 +286,21 @@ def _shard_worker(rank, world, port, reset, aligned, q):
     lr, rf, _ = make_clip(6, 32, 48, seed=3)
     get = lambda f: (lr[window_indices(f, 6, 3)], rf[window_indices(f, 6, 3)])
     ex = _HipExec(reset)
-    res = shard.run_sharded(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu', aligned=aligned)
+    if wavefront:
+        res = shard.run_wavefront(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu')
+    else:
+        res = shard.run_sharded(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu', aligned=aligned)
     q.put((rank, {f: v.clone().numpy() for f, v in res.items()}))     # by value: no fd passing after exit
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('reset,aligned', [(None, False), (3, True)])
-def test_two_process_sharding_matches_sequential(dev, reset, aligned):
-    """Frame sharding across two ranks (state hand-off, and the exchange-free reset-aligned partition) must
-    reproduce the single-process stream bit-for-bit on the HIP engine."""
+@pytest.mark.parametrize('reset,aligned,wavefront', [(None, False, False), (3, True, False), (None, False, True),
+                                                     (4, False, True)])
+def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront):
+    """Frame sharding across two ranks (state hand-off, the exchange-free reset-aligned partition, and the
+    phase-A / phase-B wavefront -- also with a reset inside a shard) must reproduce the single-process stream
+    bit-for-bit on the HIP engine."""
     import socket
     import torch.multiprocessing as mp
     from refvsr_amd.synth import make_clip, window_indices
@@ -277,7 +310,7 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned):
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, reset, aligned, q)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, reset, aligned, q, wavefront)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}

@@ -20,6 +20,12 @@ class _Exec(object):
     def __call__(self, lrs, refs, first):
         return self.o.forward(lrs[None], refs[None], first)['result'][0]
 
+    def phase_a(self, lrs, refs, f, hint):
+        return self.o.phase_a(lrs[None], refs[None], first_hint=hint)
+
+    def phase_b(self, handle, first):
+        return self.o.phase_b(handle, first)['result'][0]
+
     def export_state(self):
         return self.o.export_state()
 
@@ -39,7 +45,7 @@ def _setup(reset):
     return cfg, sd, get
 
 
-def _worker(rank, world, port, reset, aligned, q):
+def _worker(rank, world, port, reset, aligned, q, wavefront=False):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -47,7 +53,10 @@ def _worker(rank, world, port, reset, aligned, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from refvsr_amd import shard
     cfg, sd, get = _setup(reset)
-    res = shard.run_sharded(_Exec(cfg, sd), get, 6, 3, reset, cfg.mid_channels, 'cpu', aligned=aligned)
+    if wavefront:
+        res = shard.run_wavefront(_Exec(cfg, sd), get, 6, 3, reset, cfg.mid_channels, 'cpu')
+    else:
+        res = shard.run_sharded(_Exec(cfg, sd), get, 6, 3, reset, cfg.mid_channels, 'cpu', aligned=aligned)
     q.put((rank, {f: v.clone().numpy() for f, v in res.items()}))     # by value: no fd passing after exit
     dist.barrier()
     dist.destroy_process_group()
@@ -61,11 +70,11 @@ def _free_port():
     return p
 
 
-def _run(reset, aligned):
+def _run(reset, aligned, wavefront=False):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, reset, aligned, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, reset, aligned, q, wavefront)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -94,3 +103,13 @@ def test_handoff_partition_matches_sequential():
 
 def test_reset_aligned_partition_is_exchange_free():
     _run(reset=3, aligned=True)              # boundary at a multiple of reset_branch: no communication
+
+
+def test_wavefront_matches_sequential():
+    """phase A of all frames first, phase B behind the hand-off: boundary at frame 3 (no reset), bit-identical."""
+    _run(reset=None, aligned=False, wavefront=True)
+
+
+def test_wavefront_with_reset_inside_a_shard():
+    """reset_branch=4: frame 4 (inside rank 1's shard, which starts behind a hand-off) restarts the forward branch."""
+    _run(reset=4, aligned=False, wavefront=True)
