@@ -721,13 +721,17 @@ class Engine(object):
         gradio = bool(self.cfg.EVAL.is_gradio)
         zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if gradio else None
         fr = self._frames(lrs, refs, frame_ids)
-        flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b]))   # :183-191
         range_start = 0 if is_first_frame else ctr                                  # :173-176
         # Two-stream overlap (steady state): the forward-branch step depends only on cached per-frame data and
         # the carried state, not on this window's new frame, so it runs on a side stream while the main stream
         # prepares the new frame (matching, encoders, alignment) and walks the backward branch.
         main = torch.cuda.current_stream()
         overlap = (self.overlap and not is_first_frame and fr[ctr].conf is not None)
+        # with two streams every flow carries an event and is recorded on both: at a clip end the window repeats its
+        # last frame, the two branches then ask for the SAME pair (fr[ctr], fr[ctr+1]) and the second one takes the
+        # first one's tensor out of the cache -- from the other stream
+        share = (main, self._side_stream(dev)) if overlap else None
+        flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b], share))   # :183-191
         if overlap:
             for i in range(ctr, t):
                 self.pyramid(fr[i])                        # shared by both streams: build on main before the fork
