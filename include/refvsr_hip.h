@@ -70,6 +70,11 @@ int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
 /* Tuning / test knob (no reference counterpart): upper bound on the workgroups one single-chunk conv launches; each
  * workgroup walks the remaining pixel tiles.  0 = automatic (occupancy x CUs).  Results do not depend on it. */
 int refvsr_set_conv_workgroup_cap(int cap);
+/* Packing contract of `wpack` (host-side helpers, no GPU needed): K-slot of K-block (ty, tx, cg) of a ks x ks conv over
+ * ncg 16-byte channel groups, and the number of 4-slot K-steps; refvsr_amd/packing.py:kslot/ksteps are the same closed
+ * forms and tests/test_capi.py pins the two against each other.  Return the value (>= 0), not a status. */
+int refvsr_kslot(int ty, int tx, int cg, int ksize, int ncg);
+int refvsr_ksteps(int ksize, int ncg);
 
 /* Fused residual block  out = post( x + conv2( act( conv1(x) ) ) ),  3x3, C -> C, stride 1 (one launch; the
  * intermediate map lives in LDS): ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97) and ResBlock

@@ -457,6 +457,9 @@ extern "C" int refvsr_set_conv_workgroup_cap(int cap) {
     return 0;
 }
 
+extern "C" int refvsr_kslot(int ty, int tx, int cg, int ksize, int ncg) { return rv_kslot(ty, tx, cg, ksize, ncg); }
+extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg); }
+
 static int rv_num_cus() {
     static int n_cu = 0;
     if (n_cu == 0) {

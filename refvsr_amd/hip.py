@@ -44,6 +44,8 @@ SIGNATURES = {
     'refvsr_init': [],
     'refvsr_conv_mfma': [C.POINTER(RefvsrConv), _P],
     'refvsr_set_conv_workgroup_cap': [_I],
+    'refvsr_kslot': [_I, _I, _I, _I, _I],        # returns the slot, not a status
+    'refvsr_ksteps': [_I, _I],                   # returns the K-step count
     'refvsr_resblock_fits': [_I],
     'refvsr_resblock_mfma': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],

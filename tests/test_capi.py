@@ -59,3 +59,22 @@ def test_conv_descriptor_layout_matches_header():
         for part in decl.split(','):
             names.append(part.replace('*', ' ').split()[-1])
     assert names == [f[0] for f in hip.RefvsrConv._fields_]
+
+
+def test_packing_contract_matches_the_library(libpath):
+    """The K-block order is computed twice -- packing.py on the host side of the boundary, rv_kslot inside the kernels.
+    The library exports its closed form as host functions so that the two are pinned against each other without a GPU."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import kslot, ksteps
+    h = hip.lib()
+    for ks in (1, 3, 5, 7):
+        for ncg in range(1, 18):
+            assert h.refvsr_ksteps(ks, ncg) == ksteps(ks, ncg)
+            slots = set()
+            for ty in range(ks):
+                for tx in range(ks):
+                    for cg in range(ncg):
+                        j = h.refvsr_kslot(ty, tx, cg, ks, ncg)
+                        assert j == kslot(ty, tx, cg, ks, ncg)
+                        slots.add(j)
+            assert len(slots) == ks * ks * ncg and max(slots) < 4 * ksteps(ks, ncg)

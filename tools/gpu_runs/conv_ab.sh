@@ -2,7 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-L=gpurun_out/run17.log
+L=gpurun_out/conv_ab.log
 echo "== pytest ops + fixtures ==" | tee $L
 timeout 600 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -n 4 -k "not live_oracle and not two_process and not full_size" > gpurun_out/pytest_gpu_part.log 2>&1
 grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/pytest_gpu_part.log | tail -20 | tee -a $L

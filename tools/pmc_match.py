@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the dominant kernel (match_top2) a few times at the BASELINE size so that rocprofv3 --pmc can
-attribute HBM traffic counters to it (one counter set per run, see tools/gpu_run3.sh)."""
+attribute HBM traffic counters to it (one counter set per run, see tools/gpu_runs/final.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
