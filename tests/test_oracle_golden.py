@@ -97,7 +97,7 @@ def test_compute_up(small_cfg, small_sd):
 
 E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_small_L1'),
        ('S_24x32_t5_reset3', 'config_RefVSR_small_L1'), ('F_16x24_t3', 'config_RefVSR_MFID'),
-       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K')]
+       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1')]
 
 
 @pytest.mark.parametrize('tag,name', E2E)

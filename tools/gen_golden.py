@@ -287,12 +287,22 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    E2E = [('S_16x16_t3', 'config_RefVSR_small_L1', 3, 16, 16, 4, 'keep'),
+           ('S_18x26_t5', 'config_RefVSR_small_L1', 5, 18, 26, 4, 'keep'),
+           ('S_24x32_t5_reset3', 'config_RefVSR_small_L1', 5, 24, 32, 5, 3),
+           ('F_16x24_t3', 'config_RefVSR_MFID', 3, 16, 24, 3, 'keep'),
+           ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K', 3, 32, 48, 3, 'keep'),
+           # 7-frame windows on a 5-frame clip: every window replicates frames at a clip edge (datasets.py:233-234)
+           ('S_16x24_t7', 'config_RefVSR_small_L1', 7, 16, 24, 5, 'keep')]
+    if '--only' in sys.argv:                     # regenerate one end-to-end fixture: --only S_16x24_t7
+        tag = sys.argv[sys.argv.index('--only') + 1]
+        for e in E2E:
+            if e[0] == tag:
+                gen_e2e(*e[:6], reset_override=e[6])
+        return
     gen_ops()
-    gen_e2e('S_16x16_t3', 'config_RefVSR_small_L1', 3, 16, 16, 4)
-    gen_e2e('S_18x26_t5', 'config_RefVSR_small_L1', 5, 18, 26, 4)
-    gen_e2e('S_24x32_t5_reset3', 'config_RefVSR_small_L1', 5, 24, 32, 5, reset_override=3)
-    gen_e2e('F_16x24_t3', 'config_RefVSR_MFID', 3, 16, 24, 3)
-    gen_e2e('HD_32x48_t3', 'config_RefVSR_small_MFID_8K', 3, 32, 48, 3)
+    for e in E2E:
+        gen_e2e(*e[:6], reset_override=e[6])
     # state-dict contract checksums for all six configs
     sums = {}
     for name in ('config_RefVSR_small_L1', 'config_RefVSR_small_MFID', 'config_RefVSR_L1', 'config_RefVSR_MFID',
