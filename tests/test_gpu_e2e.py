@@ -164,6 +164,27 @@ def test_two_phase_forward_is_bit_identical(dev):
                 assert torch.equal(got, want[f]), '%s: two-phase frame %d differs (hinted=%s)' % (name, f, hinted)
 
 
+def test_streams_are_deterministic(dev):
+    """Race detector: the same stream run ten times (default two-stream mode, clip edges with replicated frames,
+    reset rollover; S and HD configurations) must give the same bits every time -- an unsynchronised cross-stream
+    hand-over shows up as run-to-run differences long before it shows up as a visible error."""
+    from refvsr_amd.synth import make_clip, window_indices
+    for name, t, size, reset in [('config_RefVSR_small_L1', 5, (32, 48), 3), ('config_RefVSR_small_MFID_8K', 3, (32, 48), None)]:
+        nfr = 5
+        lr, rf, _ = make_clip(nfr, size[0], size[1], seed=21)
+        lr, rf = lr.to(dev), rf.to(dev)
+        wins = [window_indices(f, nfr, t) for f in range(nfr)]
+        first = None
+        for rep in range(10):
+            net, _, _ = make_net(name, t, dev, reset=reset, save_sample=False)
+            outs = [net(lr[w][None], rf[w][None], f == 0)['result'].clone() for f, w in enumerate(wins)]
+            torch.cuda.synchronize()
+            if first is None:
+                first = outs
+            for f in range(nfr):
+                assert torch.equal(outs[f], first[f]), '%s: frame %d differs between run 0 and run %d' % (name, f, rep)
+
+
 def test_batch_and_api_contract(dev):
     from refvsr_amd.synth import make_clip, window_indices
     lr, rf, _ = make_clip(2, 32, 48, seed=1)
