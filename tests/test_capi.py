@@ -78,3 +78,43 @@ def test_packing_contract_matches_the_library(libpath):
                         assert j == kslot(ty, tx, cg, ks, ncg)
                         slots.add(j)
             assert len(slots) == ks * ks * ncg and max(slots) < 4 * ksteps(ks, ncg)
+
+
+def test_argument_validation_precedes_device_work(libpath):
+    """Error behaviour of the boundary: every entry point validates its arguments before touching the device and
+    reports through refvsr_last_error() -- so the checks run (and are pinned) in the GPU-less container too."""
+    from refvsr_amd import hip
+    h = hip.lib()
+    P = ctypes.c_void_p
+    buf = (ctypes.c_char * 4096)()                    # host memory standing in for device pointers: never dereferenced
+    p = ctypes.cast(buf, P)
+
+    def expect(rc, text):
+        assert rc != 0 and text in h.refvsr_last_error().decode(), h.refvsr_last_error()
+
+    d = hip.RefvsrConv()
+    d.src0, d.c0, d.h_in, d.w_in, d.h_out, d.w_out = p, 12, 8, 8, 8, 8       # 12 channels: not a 16-byte multiple
+    expect(h.refvsr_conv_mfma(ctypes.byref(d), None), 'src0/c0 invalid (c0=12)')
+    d.c0, d.ksize, d.stride, d.pad = 24, 9, 1, 4
+    expect(h.refvsr_conv_mfma(ctypes.byref(d), None), 'bad geometry')
+    d.ksize, d.pad, d.wpack, d.bias, d.out, d.mt_per_block, d.cout, d.out_c = 3, 1, p, p, p, 4, 24, 24
+    expect(h.refvsr_conv_mfma(ctypes.byref(d), None), 'mt_per_block must be 1..3')
+    d.mt_per_block, d.cout = 2, 22
+    expect(h.refvsr_conv_mfma(ctypes.byref(d), None), 'nhwc16 output needs cout % 4 == 0')
+    d.cout, d.out_mode, d.res = 24, 1, p                                      # pixel shuffle with a residual
+    expect(h.refvsr_conv_mfma(ctypes.byref(d), None), 'pixel-shuffle output constraints')
+
+    assert h.refvsr_resblock_fits(24) == 1 and h.refvsr_resblock_fits(16) == 1
+    assert h.refvsr_resblock_fits(48) == 0 and h.refvsr_resblock_fits(20) == 0
+    expect(h.refvsr_resblock_mfma(p, 24, 8, 8, p, p, p, p, 7, 0.0, 1.0, p, None), 'in-place operation is not supported')
+    q = ctypes.cast(ctypes.addressof(buf) + 2048, P)
+    expect(h.refvsr_resblock_mfma(p, 48, 8, 8, p, p, p, p, 14, 0.0, 1.0, q, None), 'channel count 48 not supported')
+
+    expect(h.refvsr_pack_nhwc16(p, 3, 8, 8, q, 12, None), 'pack_nhwc16: bad args')
+    expect(h.refvsr_resize(p, 3, 8, 8, q, 16, 16, 7, 0.0, 1.0, None, None, None, 0, 0, 0, None), 'resize: bad mode 7')
+    expect(h.refvsr_warp_nhwc16(p, 1, 8, 24, q, 8, 8, q, None), 'warp_nhwc16: bad args')
+    expect(h.refvsr_match_top2(p, 1, q, 512, 1, q, q, None), 'match_top2')
+    expect(h.refvsr_aligned_sample(p, 1, 1, 1, 24, q, q, None), 'map too small for reflection padding')
+    expect(h.refvsr_block_gather_nhwc16(p, 8, 8, 20, q, 4, 4, 2, q, None), 'block_gather')
+    flags = (ctypes.c_void_p * 1)(p)
+    expect(h.refvsr_buffers_equal(flags, flags, 1, 24, q, None), 'multiple of 16 bytes')
