@@ -147,6 +147,9 @@ class Engine(object):
         self.match_row_splits = 1
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
+        # two residual blocks per launch on the LR maps: bit-identical to two launches (verified on the GPU at the op level),
+        # speed and end-to-end behaviour not yet measured -> opt-in until they are
+        self.chain_resblocks = os.environ.get('REFVSR_RESBLOCK_CHAIN', '0') == '1'
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
         self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
@@ -196,29 +199,39 @@ class Engine(object):
     def cw(self, name):
         return self.W.conv[name]
 
+    def _block_chain(self, x, pairs, act):
+        """A run of residual blocks x <- x + conv2(act(conv1 x)); pairs = [(conv1, conv2), ...] packed weights.
+        One launch per block (fused kernel), two launches per block (fuse_resblocks off), or -- experimental, opt-in
+        with REFVSR_RESBLOCK_CHAIN=1 -- one launch per TWO blocks on maps of about one 16x32 tile per CU."""
+        i, n = 0, len(pairs)
+        chain = (self.chain_resblocks and self.fuse_resblocks and ops.resblock2_fits(x.shape[2])
+                 and ((x.shape[0] + 15) // 16) * ((x.shape[1] + 31) // 32) <= 320)
+        while i < n:
+            if chain and i + 1 < n:
+                x = ops.resblock2([pairs[i][0], pairs[i][1], pairs[i + 1][0], pairs[i + 1][1]], x, act=act)
+                i += 2
+                continue
+            c1, c2 = pairs[i]
+            if self.fuse_resblocks:
+                x = ops.resblock(c1, c2, x, act=act)
+            else:
+                t = ops.conv(c1, x, act=act)
+                x = ops.conv(c2, t, res=x)
+            i += 1
+        return x
+
     def res_list(self, x, name, n):
         """ResList (RefVSR_/common.py:64-82) with ResBlocks (:25-39)."""
-        x0 = x
-        for i in range(n):
-            c1, c2 = self.cw('%s.RBs.%d.conv1' % (name, i)), self.cw('%s.RBs.%d.conv2' % (name, i))
-            if self.fuse_resblocks:
-                x = ops.resblock(c1, c2, x, act=0.2)
-            else:
-                t = ops.conv(c1, x, act=0.2)
-                x = ops.conv(c2, t, res=x)
-        return ops.conv(self.cw(name + '.conv_tail'), x, res=x0)
+        pairs = [(self.cw('%s.RBs.%d.conv1' % (name, i)), self.cw('%s.RBs.%d.conv2' % (name, i))) for i in range(n)]
+        y = self._block_chain(x, pairs, 0.2)
+        return ops.conv(self.cw(name + '.conv_tail'), y, res=x)
 
     def resblocks(self, lr8, feat, name):
         """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources."""
         x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1)
-        for i in range(self.nb):
-            c1, c2 = self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i))
-            if self.fuse_resblocks:
-                x = ops.resblock(c1, c2, x, act=0.0)
-            else:
-                t = ops.conv(c1, x, act=0.0)
-                x = ops.conv(c2, t, res=x)
-        return x
+        pairs = [(self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i)))
+                 for i in range(self.nb)]
+        return self._block_chain(x, pairs, 0.0)
 
     def pyramid(self, fr):
         """SPyNet.forward resize-to-/32 + normalise + 5x avg_pool2d (SPyNet.py:62-81,117-126)."""

@@ -162,6 +162,26 @@ def resblock(cw1, cw2, x, act, post=1.0):
     return out
 
 
+def resblock2_fits(c):
+    return bool(hip.lib().refvsr_resblock2_fits(int(c)))
+
+
+def resblock2(cws, x, act, post1=1.0, post2=1.0):
+    """refvsr_resblock2_mfma: two chained residual blocks (cws = packed conv1..conv4) in one launch."""
+    import ctypes
+    _nhwc(x)
+    h, w, c = x.shape
+    assert len(cws) == 4
+    for cw in cws:
+        assert cw.cpads == [c] and cw.cout == c and cw.ksize == 3 and not cw.f32 and not cw.shuffle and cw.wpack.shape[0] == 1
+    out = torch.empty_like(x)
+    wq = (ctypes.c_void_p * 4)(*[_ptr(cw.wpack) for cw in cws])
+    bq = (ctypes.c_void_p * 4)(*[_ptr(cw.bias) for cw in cws])
+    hip.check(hip.lib().refvsr_resblock2_mfma(_ptr(x), c, h, w, wq, bq, cws[0].ksteps, act, post1, post2, _ptr(out),
+                                              _stream()), 'resblock2_mfma')
+    return out
+
+
 def conv_direct(x, w, b, stride=1, pad=None, act=1.0, nhwc16_out=False):
     """refvsr_conv_direct_f32 on a planar fp32 map; w fp32 [cout,cin,k,k] on the device."""
     _planar(x)

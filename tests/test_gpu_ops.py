@@ -144,6 +144,26 @@ def test_conv_mfma_persistent_tile_walk(dev, cap):
         assert err < 1e-3
 
 
+def test_resblock2_chain_matches_two_launches(dev):
+    """Two chained residual blocks in one launch (4-pixel halo recomputation) == two fused-block launches, bit for bit:
+    same K order, same fp16 rounding points, zero padding of the intermediate block output at the frame border."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(31)
+    for C, h, w, act, p1, p2 in [(24, 37, 70, 0.0, 1.0, 1.0), (24, 270, 480, 0.0, 1.0, 1.0), (16, 16, 32, 0.2, 1.0, 0.2),
+                                 (24, 5, 9, 0.2, 0.2, 1.0), (8, 48, 33, 0.0, 1.0, 1.0)]:
+        assert ops.resblock2_fits(C)
+        cws = []
+        for _ in range(4):
+            wt = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+            cws.append(ops.ConvWeights(pack_conv(wt, torch.randn(C, generator=g) * 0.1, [C]), dev))
+        x = nhwc(torch.randn(C, h, w, generator=g), dev)
+        two = ops.resblock(cws[2], cws[3], ops.resblock(cws[0], cws[1], x, act=act, post=p1), act=act, post=p2)
+        one = ops.resblock2(cws, x, act=act, post1=p1, post2=p2)
+        report('resblock2 chain C%d %dx%d' % (C, h, w), abs=maxdiff(one.float().cpu(), two.float().cpu()))
+        assert torch.equal(one, two), (C, h, w)
+
+
 def test_conv_mfma_gather_mode_strided(dev):
     """5x5 stride-4 / stride-8 offset predictors of the HD configs (alignment.py:20): the staged tile cannot fit
     LDS, the kernel switches to gathering B fragments from global memory."""
