@@ -149,7 +149,7 @@ class Engine(object):
                                and not os.environ.get('REFVSR_NO_FUSE'))
         # two residual blocks per launch on the LR maps: bit-identical to two launches (verified on the GPU at the op level),
         # speed and end-to-end behaviour not yet measured -> opt-in until they are
-        self.chain_resblocks = os.environ.get('REFVSR_RESBLOCK_CHAIN', '0') == '1'
+        self.chain_resblocks = int(os.environ.get('REFVSR_RESBLOCK_CHAIN', '0') or 0)      # 1: LR maps only, 2: every map
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
         self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
@@ -202,10 +202,10 @@ class Engine(object):
     def _block_chain(self, x, pairs, act):
         """A run of residual blocks x <- x + conv2(act(conv1 x)); pairs = [(conv1, conv2), ...] packed weights.
         One launch per block (fused kernel), two launches per block (fuse_resblocks off), or -- experimental, opt-in
-        with REFVSR_RESBLOCK_CHAIN=1 -- one launch per TWO blocks on maps of about one 16x32 tile per CU."""
+        with REFVSR_RESBLOCK_CHAIN=1 -- one launch per TWO blocks on maps of about one 16x32 tile per CU (=2: on every map)."""
         i, n = 0, len(pairs)
         chain = (self.chain_resblocks and self.fuse_resblocks and ops.resblock2_fits(x.shape[2])
-                 and ((x.shape[0] + 15) // 16) * ((x.shape[1] + 31) // 32) <= 320)
+                 and (self.chain_resblocks >= 2 or ((x.shape[0] + 15) // 16) * ((x.shape[1] + 31) // 32) <= 320))
         while i < n:
             if chain and i + 1 < n:
                 x = ops.resblock2([pairs[i][0], pairs[i][1], pairs[i + 1][0], pairs[i + 1][1]], x, act=act)

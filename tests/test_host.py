@@ -227,7 +227,7 @@ def test_block_chain_pairs_blocks_in_order(monkeypatch):
 
     class E(object):
         _block_chain = engine.Engine._block_chain
-        fuse_resblocks, chain_resblocks = True, True
+        fuse_resblocks, chain_resblocks = True, 1
     e = E()
     for n in (1, 2, 5, 24):
         pairs = [('a%d' % i, 'b%d' % i) for i in range(n)]
@@ -235,5 +235,7 @@ def test_block_chain_pairs_blocks_in_order(monkeypatch):
         assert e._block_chain(X((270, 480, 24)), pairs, 0.2).hist == want          # LR map: chained
         assert e._block_chain(X((540, 960, 24)), pairs, 0.2).hist == want          # 2x map: one block per launch
         assert e._block_chain(X((270, 480, 48)), pairs, 0.2).hist == want          # C = 48: chain kernel does not fit
-    e.chain_resblocks = False
+    e.chain_resblocks = 2
+    assert e._block_chain(X((540, 960, 24)), pairs, 0.2).hist == want              # mode 2: chained on every map
+    e.chain_resblocks = 0
     assert e._block_chain(X((270, 480, 24)), pairs, 0.0).hist == tuple((a, b, 0.0) for a, b in pairs)

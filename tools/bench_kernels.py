@@ -62,6 +62,9 @@ def bench_match():
     emit('match_patches(lr): %.1f us' % us)
 
 
+# NOTE: timeit() launches back to back from Python; anything below ~12 us per call is bounded by the host launch rate,
+# not by the kernel.  For the short kernels run this script under rocprofv3 (tools/gpu_runs/microbench_rocprof.sh) and
+# read the per-kernel device durations.
 def bench_conv():
     g = torch.Generator().manual_seed(1)
     cases = [  # name, cout, cins, ks, stride, h, w, shuffle, f32
@@ -109,6 +112,11 @@ def bench_conv():
         us_t = timeit(lambda: ops.conv(c2, ops.conv(c1, x, act=0.0), res=x))
         fl = 2 * 2.0 * h * w * C * C * 9
         emit('resblock %-5s fused %7.1f us (%6.1f TFLOP/s useful)   two launches %7.1f us' % (name, us_f, fl / us_f / 1e6, us_t))
+        # two chained blocks in one launch vs two fused-block launches (same result bit for bit)
+        cws = [c1, c2, c2, c1]
+        us_c = timeit(lambda: ops.resblock2(cws, x, act=0.0))
+        us_2 = timeit(lambda: ops.resblock(c2, c1, ops.resblock(c1, c2, x, act=0.0), act=0.0))
+        emit('resblock %-5s chain-of-2 %7.1f us   two fused launches %7.1f us' % (name, us_c, us_2))
     # launch floor: smallest possible conv
     wt = torch.randn(24, 24, 3, 3) * 0.1
     cw = ops.ConvWeights(pack_conv(wt, torch.zeros(24), [24]), dev)
