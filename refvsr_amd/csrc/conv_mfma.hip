@@ -567,7 +567,9 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     static const int res_max = getenv("REFVSR_CONV_RES_MAX") ? atoi(getenv("REFVSR_CONV_RES_MAX")) : CONV_RES_MAX;   // A/B knob
     if (!no_resident && a.S <= res_max && a.S <= CONV_RES_MAX) {
         int best_wg = 0;
+        static const int force_tiles = getenv("REFVSR_CONV_TILES") ? atoi(getenv("REFVSR_CONV_TILES")) : 0;   // A/B knob: 2 | 4
         for (int tl = 4; tl >= 2; tl -= 2) {
+            if (force_tiles && tl != force_tiles) continue;
             const size_t tb = tile_bytes(tl);
             const size_t need = (size_t)a.tab_bytes + (size_t)a.S * wfr_kb + tb;
             const int chunks = a.LH * a.LW * a.ncg;
