@@ -10,6 +10,12 @@ for mode in 0 1 2 0 1 2; do
   echo "== bench REFVSR_RESBLOCK_CHAIN=$mode ==" | tee -a $L
   REFVSR_RESBLOCK_CHAIN=$mode timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "$fmt" | tee -a $L
 done
+# HIP maps the engine's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues: in the round-1 trace the preparation
+# stream (P, with the matching kernel) and the forward-branch stream (F) shared one queue and therefore ran in order
+for q in 4 8; do
+  echo "== bench GPU_MAX_HW_QUEUES=$q ==" | tee -a $L
+  GPU_MAX_HW_QUEUES=$q timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "$fmt" | tee -a $L
+done
 for mode in 1 2; do
   echo "== tests with REFVSR_RESBLOCK_CHAIN=$mode ==" | tee -a $L
   REFVSR_RESBLOCK_CHAIN=$mode timeout 600 python -m pytest tests/test_gpu_e2e.py -m gpu -q --no-header -p no:cacheprovider -n 3 \
