@@ -84,14 +84,17 @@ int refvsr_resblock_fits(int c);
 int refvsr_resblock_mfma(const void* src, int c, int h, int w, const void* w1, const float* b1,
                          const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
                          void* out, void* stream);
-/* TWO chained residual blocks in one launch (same reference code, applied twice): y = post1(x + conv2(act(conv1 x))),
- * out = post2(y + conv4(act(conv3 y))); wq[4] / bq[4]: packed weights / biases of conv1..conv4.  For maps of about one
- * 16x32 tile per CU (the LR maps), where a single block is launch / latency bound.  Bit-identical to two
- * refvsr_resblock_mfma launches (tests/test_gpu_ops.py::test_resblock2_chain_matches_two_launches).  Round 1: verified
- * on the GPU at the op level, its speed not yet measured -- the engine uses it only with REFVSR_RESBLOCK_CHAIN=1. */
-int refvsr_resblock2_fits(int c);
-int refvsr_resblock2_mfma(const void* src, int c, int h, int w, const void* const* wq, const float* const* bq,
-                          int ksteps, float act_slope, float post1, float post2, void* out, void* stream);
+/* The same fused block on a smaller footprint (4 waves, 8 x 32 tile, both weight sets + one activation tile in LDS,
+ * the intermediate map overwrites the input tile): two workgroups per CU, so one's epilogue runs under the other's
+ * MFMAs.  Bit-identical to refvsr_resblock_mfma.  Slopes must lie in [0, 1]. */
+int refvsr_resblock_lean_fits(int c);
+int refvsr_resblock_lean(const void* src, int c, int h, int w, const void* w1, const float* b1,
+                         const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
+                         void* out, void* stream);
+/* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
+ * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its
+ * iter-th tile at buf[12 * workgroup + i] (uint64; [8], [9] = 100 MHz s_memrealtime at entry / exit, [10] = s_memtime at exit) -- tools/probe_resblock.py.  NULL switches it off (default). */
+int refvsr_set_probe(void* buf, int iter);
 
 /* fp32 direct convolution on planar maps (VGG feature extractor + MeanShift of FeatureMatching,
  * attention.py:28-50,62-70, and the 2->16 confidence convs RefVSR.py:47-52).  Kept in fp32 because

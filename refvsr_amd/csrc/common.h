@@ -37,6 +37,41 @@ void refvsr_set_error(const char* fmt, ...);
 
 static inline int rv_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Per-device caches (function attributes, occupancy, CU count): one process may drive several GPUs.
+#define RV_MAX_DEVICES 16
+static inline int rv_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= RV_MAX_DEVICES) d = 0;
+    return d;
+}
+static inline int rv_num_cus() {
+    static int n_cu[RV_MAX_DEVICES] = {};
+    const int d = rv_device();
+    if (n_cu[d] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess) n_cu[d] = prop.multiProcessorCount;
+        if (n_cu[d] <= 0) n_cu[d] = 256;
+    }
+    return n_cu[d];
+}
+
+// Persistent tile walk, XCD-aware and balanced.  Workgroup b runs on XCD b % 8 (observed placement, used for speed only):
+// the workgroups of one XCD get consecutive ranks, rank r walks the CONTIGUOUS tile range [r*n/g, (r+1)*n/g), so every
+// workgroup has floor or ceil(n/g) tiles (a strided walk inside fixed eighths of the frame left single workgroups with
+// twice the tiles of the others whenever g ~ n) and the tiles in flight on one XCD are neighbours sharing halo rows in
+// that XCD's L2.
+__device__ __forceinline__ void rv_tile_range(const int n_tiles, int& t_begin, int& t_end) {
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    int rank = b;
+    if (g >= 8) {
+        const int xcd = b & 7;
+        rank = b >> 3;
+        for (int y = 0; y < xcd; ++y) rank += (g - y + 7) >> 3;
+    }
+    t_begin = (int)(((long long)rank * n_tiles) / g);
+    t_end = (int)(((long long)(rank + 1) * n_tiles) / g);
+}
+
 // ReflectionPad2d index (no edge repeat): -1 -> 1, n -> n-2.  Valid for -n < i < 2n-1.
 __device__ __forceinline__ int rv_reflect(int i, int n) {
     i = i < 0 ? -i : i;

@@ -295,16 +295,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             uint4* d = reinterpret_cast<uint4*>(wl);
             for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];
         }
-        // tile walk: workgroup b of XCD x = b % 8 takes every (workgroups-in-XCD)-th tile of the x-th eighth of the
-        // frame, so that the tiles in flight on one XCD are neighbours and share their halo rows in that XCD's L2
-        int tl = blockIdx.x, k_hi = p.n_xy, k_step = gridDim.x;
-        if (gridDim.x >= 8) {
-            const int xcd = blockIdx.x & 7;
-            const int band = (p.n_xy + 7) >> 3;
-            k_step = ((int)gridDim.x - xcd + 7) >> 3;
-            tl = xcd * band + (blockIdx.x >> 3);
-            k_hi = min(xcd * band + band, p.n_xy);
-        }
+        int tl, k_hi;                                              // this workgroup's tiles (common.h:rv_tile_range)
+        rv_tile_range(p.n_xy, tl, k_hi);
+        constexpr int k_step = 1;
         // input-tile chunk k of this thread: 16 bytes = (row r, column c, channel group cg) of the LH x LW tile
         const int row_chunks = p.LW * p.ncg;
         const int total = p.LH * row_chunks;                       // <= CONV_XPF * 256 (host)
@@ -460,39 +453,30 @@ extern "C" int refvsr_set_conv_workgroup_cap(int cap) {
 extern "C" int refvsr_kslot(int ty, int tx, int cg, int ksize, int ncg) { return rv_kslot(ty, tx, cg, ksize, ncg); }
 extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg); }
 
-static int rv_num_cus() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    return n_cu;
-}
-
 // RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
 // the XCD banding) and walk the tiles; the others launch one workgroup per tile.
 template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT>
 static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    // per device: the dynamic-LDS attribute and the occupancy table (a process may drive several GPUs)
+    static bool attr_done[RV_MAX_DEVICES] = {};
+    const int dev = rv_device();
+    if (!attr_done[dev]) {
         RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     int gx = a.n_xy;
     if (RESIDENT) {
-        static size_t occ_lds[4] = {0, 0, 0, 0};
-        static int occ_val[4] = {0, 0, 0, 0};
-        static int slot = 0;
+        static size_t occ_lds[RV_MAX_DEVICES][4] = {};
+        static int occ_val[RV_MAX_DEVICES][4] = {};
+        static int slot[RV_MAX_DEVICES] = {};
         int occ = 0;
         for (int i = 0; i < 4; ++i)
-            if (occ_lds[i] == lds && occ_val[i] > 0) occ = occ_val[i];
+            if (occ_lds[dev][i] == lds && occ_val[dev][i] > 0) occ = occ_val[dev][i];
         if (occ == 0) {
             RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>, 256, lds));
             if (occ < 1) occ = 1;
-            occ_lds[slot & 3] = lds; occ_val[slot & 3] = occ; ++slot;
+            occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
         int cap = (rv_num_cus() * occ / nz) & ~7;
         if (cap < 8) cap = 8;

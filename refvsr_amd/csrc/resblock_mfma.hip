@@ -41,6 +41,8 @@ struct ResBlockArgs {
     float act_slope, post_slope;
     int tab_bytes, w_bytes, x_bytes;     // LDS carve
     int tiles_x, n_tiles;
+    unsigned long long* probe;           // debug: per-workgroup s_memtime stamps (refvsr_set_probe), normally null
+    int probe_iter;                      // which tile iteration of the workgroup is stamped
 };
 
 // Software-pipelined K loop shared by both phases: two fragment sets, unrolled by two (see conv_mfma.hip).
@@ -103,6 +105,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int q = lane >> 4;
     const int lr = rv_pix16(lane & 15);      // pixel (of a 16-pixel MFMA tile) held by this lane's column
     const int psb = p.ps * 16;
+#define RB_STAMP(i) do { if (p.probe && tid == 0) p.probe[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    RB_STAMP(0);
+    if (p.probe && tid == 0) p.probe[blockIdx.x * 12 + 8] = __builtin_amdgcn_s_memrealtime();
 
     for (int g = tid; g < p.S * 4; g += 512) {                    // K-slot -> offset (K order: common.h:rv_kslot)
         int o1, o2, slot;
@@ -175,10 +180,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         b1r[m] = *reinterpret_cast<const float4*>(p.b1 + co0);
         b2r[m] = *reinterpret_cast<const float4*>(p.b2 + co0);
     }
+    RB_STAMP(1);
     __syncthreads();
+    RB_STAMP(2);
 
-    int cur = 0;
-    for (; tile < p.n_tiles; tile += gridDim.x) {
+    int cur = 0, iter = 0;
+    for (; tile < p.n_tiles; tile += gridDim.x, ++iter) {
         const int ty0 = (tile / p.tiles_x) * RB_TH, tx0 = (tile % p.tiles_x) * RB_TW;
         const unsigned char* xt = xt0 + (size_t)cur * p.x_bytes;
         const bool has_next = (tile + (int)gridDim.x < p.n_tiles);
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int t = 0; t < RB_T1W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             rb_kloop<MT, RB_T1W>(acc, wl1, tab1 + q, xt, pb, p.S, lane);
+            if (iter == p.probe_iter) RB_STAMP(3);
 #pragma unroll
             for (int t = 0; t < RB_T1W; ++t) {
                 const int tl = wave * RB_T1W + t;
@@ -236,7 +244,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the next x tile (loads issued before phase 1) goes to the other LDS buffer here, not after the output stores:
         // waiting for it there also waited for every store of this tile (vmcnt is in order)
         if (has_next) x_park(xt0 + (size_t)(cur ^ 1) * p.x_bytes);
+        if (iter == p.probe_iter) RB_STAMP(4);
         __syncthreads();
+        if (iter == p.probe_iter) RB_STAMP(5);
 
         // ---------------- phase 2: out = x + conv2(t) + b2 ------------------------------------------------
         {
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int t = 0; t < RB_T2W; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             rb_kloop<MT, RB_T2W>(acc, wl2, tab2 + q, tt, pb, p.S, lane);
+            if (iter == p.probe_iter) RB_STAMP(6);
 #pragma unroll
             for (int t = 0; t < RB_T2W; ++t) {
                 const int ti = wave * RB_T2W + t;
@@ -279,284 +290,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        if (iter == p.probe_iter) RB_STAMP(7);
         __syncthreads();                   // t tile free for the next phase 1
         cur ^= 1;
     }
+    if (p.probe && tid == 0) {
+        p.probe[blockIdx.x * 12 + 9] = __builtin_amdgcn_s_memrealtime();
+        p.probe[blockIdx.x * 12 + 10] = __builtin_amdgcn_s_memtime();
+    }
+#undef RB_STAMP
+}
+
+static unsigned long long* g_rb_probe = nullptr;
+static int g_rb_probe_iter = 0;
+extern "C" int refvsr_set_probe(void* buf, int iter) {
+    g_rb_probe = (unsigned long long*)buf;
+    g_rb_probe_iter = iter;
+    return 0;
 }
 
 template <int MT>
 static int launch_resblock(const ResBlockArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[RV_MAX_DEVICES] = {};
+    const int dev = rv_device();
+    if (!attr_done[dev]) {
         RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_mfma_kernel<MT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL((resblock_mfma_kernel<MT>), grid, dim3(512), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
-}
-
-// =====================================================================================================================
-// Two chained residual blocks in ONE launch:  y = x + conv2(act(conv1(x)));  out = y + conv4(act(conv3(y))).
-// On the LR maps a fused block is one 16x32 tile per CU and ~13 us of which ~3.5 us are MFMA time: launch, weight / tile
-// fetch and the store tail dominate, and 96-128 such launches per frame sit on the serial chain of the propagation
-// branches.  Chaining two blocks pays 1.19x the MFMAs (4-pixel halo recomputation) for half the launches and half the
-// HBM round trips.  One workgroup = one 16x32 output tile (not persistent: meant for maps with <= ~1 tile per CU):
-//
-//   X [24][40]   x tile (halo 4, zero padded)                     -> later y (halo 2) IN PLACE at offset (2, 2)
-//   T [22][38]   t1 = act(conv1 x) on 22x38  (phase 1)            -> later t2 = act(conv3 y) on 18x34  (phase 3)
-//   phase 2: y  = post1(x + conv2 t1) on 20x36, 0 outside the frame (= conv3's zero padding)
-//   phase 4: out = post2(y + conv4 t2) on 16x32 -> global
-//   weights ping-pong through two LDS buffers (w1 -> w3, w2 -> w4), the next set is fetched into named registers
-//   during the current phase.
-// Bit-identical to two refvsr_resblock_mfma launches (same K order, same fp16 rounding points).
-#define RC_XH 24
-#define RC_XW 40
-#define RC_TH 22
-#define RC_TW 38
-#define RC_XCH 6                          // uint4 per thread for the x tile (24*40*ncg / 512, ncg <= 3)
-
-struct ResChainArgs {
-    const f16* src; f16* out;
-    int c, ncg, ps, h, w;
-    int G, S;
-    float inv_ncg;
-    const uint4* wq[4]; const float* bq[4];
-    float act_slope, post1, post2;
-    int tab_bytes, w_bytes, x_bytes;
-    int tiles_x;
-};
-
-// one conv phase over a flattened RH x RW pixel region: region pixel (r, c) reads its 3x3 window at source pixel
-// (r + oy, c + ox) of an LDS map with `pitch` pixels per row; T 16-pixel MFMA tiles per wave
-template <int MT, int T, typename Epi>
-__device__ __forceinline__ void rc_phase(const unsigned char* src, const int pitch, const int oy, const int ox,
-                                         const int RH, const int RW, const unsigned char* wl, const int* tq, const int S,
-                                         const int psb, const int wave, const int lane, const int lp, Epi epi) {
-    const int NP = RH * RW;
-    const float inv_rw = 1.0f / (float)RW;
-    int pb[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int pix = min((wave * T + t) * 16 + lp, NP - 1);
-        const int r = (int)(((float)pix + 0.5f) * inv_rw);
-        const int c = pix - r * RW;
-        pb[t] = ((r + oy) * pitch + (c + ox)) * psb;
-    }
-    f32x4 acc[MT][T];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    rb_kloop<MT, T>(acc, wl, tq, src, pb, S, lane);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int pix = (wave * T + t) * 16 + lp;
-        if (pix >= NP) continue;
-        const int r = (int)(((float)pix + 0.5f) * inv_rw);
-        const int c = pix - r * RW;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) epi(r, c, m, acc[m][t]);
-    }
-}
-
-template <int MT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_chain2_kernel(ResChainArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* tabx = reinterpret_cast<int*>(smem);                     // K-slot -> offset in a pitch-RC_XW map
-    int* tabt = tabx + p.S * 4;                                    // K-slot -> offset in a pitch-RC_TW map
-    unsigned char* wa = smem + p.tab_bytes;                        // weights of phases 1, 3
-    unsigned char* wb = wa + p.w_bytes;                            // weights of phases 2, 4
-    unsigned char* X = wb + p.w_bytes;                             // [RC_XH][RC_XW][ps*16]
-    unsigned char* Tm = X + p.x_bytes;                             // [RC_TH][RC_TW][ps*16]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int q = lane >> 4;
-    const int lp = rv_pix16(lane & 15);
-    const int psb = p.ps * 16;
-    const int ty0 = (blockIdx.x / p.tiles_x) * RB_TH, tx0 = (blockIdx.x % p.tiles_x) * RB_TW;
-
-    for (int g = tid; g < p.S * 4; g += 512) {                    // K order: common.h:rv_kslot
-        int o1, o2, slot;
-        if (g < p.G) {
-            const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
-            const int cg = g - tap * p.ncg;
-            const int ty = tap / 3;
-            const int tx = tap - ty * 3;
-            o1 = ((ty * RC_XW + tx) * p.ps + cg) * 16;
-            o2 = ((ty * RC_TW + tx) * p.ps + cg) * 16;
-            slot = rv_kslot(ty, tx, cg, 3, p.ncg);
-        } else {
-            slot = rv_kpad_slot(g - p.G, 3, p.ncg);
-            o1 = o2 = (slot < p.G) ? 0 : (p.ncg > 1 ? 16 : p.ps * 16);
-        }
-        tabx[slot] = o1;
-        tabt[slot] = o2;
-    }
-    const int n16w = p.S * MT * 2 * 64;                           // uint4 per weight set (<= 4 * 512)
-    for (int i = tid; i < n16w; i += 512) reinterpret_cast<uint4*>(wa)[i] = p.wq[0][i];
-    {                                                             // x tile, halo 4, zero padded at the frame border
-        const int row_chunks = RC_XW * p.ncg;
-        const int total = RC_XH * row_chunks;
-        const float inv_rc = 1.0f / (float)row_chunks;
-#pragma unroll
-        for (int k = 0; k < RC_XCH; ++k) {
-            const int idx = tid + k * 512;
-            if (idx < total) {
-                const int r = (int)(((float)idx + 0.5f) * inv_rc);
-                const int i = idx - r * row_chunks;
-                const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
-                const int cg = i - c * p.ncg;
-                const int iy = ty0 - 4 + r, ix = tx0 - 4 + c;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-                    v = *reinterpret_cast<const uint4*>(p.src + ((size_t)iy * p.w + ix) * p.c + cg * 8);
-                *reinterpret_cast<uint4*>(X + (size_t)(r * RC_XW + c) * psb + cg * 16) = v;
-            }
-        }
-    }
-    // the next weight set travels through four named registers while the current phase computes
-    uint4 v0, v1, v2, v3;
-    const int last = n16w - 1;
-#define RC_W_FETCH(W) { v0 = (W)[min(tid, last)]; v1 = (W)[min(tid + 512, last)]; v2 = (W)[min(tid + 1024, last)]; v3 = (W)[min(tid + 1536, last)]; }
-#define RC_W_PARK(D) { uint4* d_ = reinterpret_cast<uint4*>(D); if (tid < n16w) d_[tid] = v0; if (tid + 512 < n16w) d_[tid + 512] = v1; \
-                       if (tid + 1024 < n16w) d_[tid + 1024] = v2; if (tid + 1536 < n16w) d_[tid + 1536] = v3; }
-    RC_W_FETCH(p.wq[1])
-    float4 br[4][MT];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) br[j][m] = *reinterpret_cast<const float4*>(p.bq[j] + min(m * 16 + q * 4, p.c - 4));
-    __syncthreads();
-
-    auto act4 = [&](const f32x4 a, const float4 b, const float slope, const bool keep) -> f16x4 {
-        f16x4 o;
-        o[0] = (f16)(keep ? rv_lrelu(a[0] + b.x, slope) : 0.f);
-        o[1] = (f16)(keep ? rv_lrelu(a[1] + b.y, slope) : 0.f);
-        o[2] = (f16)(keep ? rv_lrelu(a[2] + b.z, slope) : 0.f);
-        o[3] = (f16)(keep ? rv_lrelu(a[3] + b.w, slope) : 0.f);
-        return o;
-    };
-    auto res4 = [&](const f32x4 a, const float4 b, const f16x4 x, const float post, const bool keep) -> f16x4 {
-        float y[4] = {a[0] + b.x + (float)x[0], a[1] + b.y + (float)x[1], a[2] + b.z + (float)x[2], a[3] + b.w + (float)x[3]};
-        if (post != 1.0f) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = rv_lrelu(y[i], post);
-        }
-        f16x4 o = {(f16)(keep ? y[0] : 0.f), (f16)(keep ? y[1] : 0.f), (f16)(keep ? y[2] : 0.f), (f16)(keep ? y[3] : 0.f)};
-        return o;
-    };
-
-    // ---- phase 1: t1 = act(conv1(x) + b1) on 22 x 38, origin (ty0 - 3, tx0 - 3) ---------------------------------------
-    rc_phase<MT, 7>(X, RC_XW, 0, 0, RC_TH, RC_TW, wa, tabx + q, p.S, psb, wave, lane, lp,
-                    [&](const int r, const int c, const int m, const f32x4 a) {
-                        const int co0 = m * 16 + q * 4;
-                        if (co0 >= p.c) return;
-                        const int iy = ty0 - 3 + r, ix = tx0 - 3 + c;
-                        const bool inside = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-                        *reinterpret_cast<f16x4*>(Tm + (size_t)(r * RC_TW + c) * psb + co0 * 2) = act4(a, br[0][m], p.act_slope, inside);
-                    });
-    RC_W_PARK(wb)                                                 // w2 (wb was never used before)
-    RC_W_FETCH(p.wq[2])
-    __syncthreads();
-    // ---- phase 2: y = post1(x + conv2(t1) + b2) on 20 x 36, origin (ty0 - 2, tx0 - 2); in place over x at (+2, +2) -------
-    rc_phase<MT, 6>(Tm, RC_TW, 0, 0, 20, 36, wb, tabt + q, p.S, psb, wave, lane, lp,
-                    [&](const int r, const int c, const int m, const f32x4 a) {
-                        const int co0 = m * 16 + q * 4;
-                        if (co0 >= p.c) return;
-                        const int iy = ty0 - 2 + r, ix = tx0 - 2 + c;
-                        const bool inside = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-                        unsigned char* xp = X + (size_t)((r + 2) * RC_XW + (c + 2)) * psb + co0 * 2;
-                        const f16x4 xv = *reinterpret_cast<const f16x4*>(xp);
-                        *reinterpret_cast<f16x4*>(xp) = res4(a, br[1][m], xv, p.post1, inside);
-                    });
-    RC_W_PARK(wa)                                                 // w3 (every wave left phase 1, the last reader of wa,
-    RC_W_FETCH(p.wq[3])                                           //     at the barrier above)
-    __syncthreads();                                              // y complete, w3 visible
-    // ---- phase 3: t2 = act(conv3(y) + b3) on 18 x 34, origin (ty0 - 1, tx0 - 1); window origin X(r + 2, c + 2) ---------
-    rc_phase<MT, 5>(X, RC_XW, 2, 2, 18, 34, wa, tabx + q, p.S, psb, wave, lane, lp,
-                    [&](const int r, const int c, const int m, const f32x4 a) {
-                        const int co0 = m * 16 + q * 4;
-                        if (co0 >= p.c) return;
-                        const int iy = ty0 - 1 + r, ix = tx0 - 1 + c;
-                        const bool inside = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-                        *reinterpret_cast<f16x4*>(Tm + (size_t)(r * RC_TW + c) * psb + co0 * 2) = act4(a, br[2][m], p.act_slope, inside);
-                    });
-    RC_W_PARK(wb)                                                 // w4 (every wave left phase 2 at the barrier above)
-    __syncthreads();                                              // t2 complete, w4 visible
-    // ---- phase 4: out = post2(y + conv4(t2) + b4) on 16 x 32 -> global ------------------------------------------------
-    rc_phase<MT, 4>(Tm, RC_TW, 0, 0, RB_TH, RB_TW, wb, tabt + q, p.S, psb, wave, lane, lp,
-                    [&](const int r, const int c, const int m, const f32x4 a) {
-                        const int co0 = m * 16 + q * 4;
-                        const int oy = ty0 + r, ox = tx0 + c;
-                        if (co0 >= p.c || oy >= p.h || ox >= p.w) return;
-                        const f16x4 yv = *reinterpret_cast<const f16x4*>(X + (size_t)((r + 4) * RC_XW + (c + 4)) * psb + co0 * 2);
-                        *reinterpret_cast<f16x4*>(p.out + ((size_t)oy * p.w + ox) * p.c + co0) = res4(a, br[3][m], yv, p.post2, true);
-                    });
-#undef RC_W_FETCH
-#undef RC_W_PARK
-}
-
-static size_t rc_lds_bytes(int c) {
-    const int ncg = c / 8, ps = ncg | 1;
-    const int S = rv_ksteps(3, ncg);
-    const int MT = (c + 15) / 16;
-    return (size_t)((S * 4 * 2 * 4 + 15) / 16 * 16) + 2 * (size_t)S * MT * 2 * 1024 +
-           (size_t)RC_XH * RC_XW * ps * 16 + (size_t)RC_TH * RC_TW * ps * 16;
-}
-
-extern "C" int refvsr_resblock2_fits(int c) {
-    if (c <= 0 || c % 8 != 0) return 0;
-    const int ncg = c / 8;
-    const int S = rv_ksteps(3, ncg);
-    const int MT = (c + 15) / 16;
-    if (MT > 2) return 0;
-    if (RC_XH * RC_XW * ncg > RC_XCH * 512) return 0;             // x-tile staging slots
-    if (S * MT * 2 * 64 > 4 * 512) return 0;                      // weight prefetch registers
-    return rc_lds_bytes(c) <= 160 * 1024 ? 1 : 0;
-}
-
-template <int MT>
-static int launch_chain2(const ResChainArgs& a, int n_tiles, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain2_kernel<MT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((resblock_chain2_kernel<MT>), dim3(n_tiles), dim3(512), lds, st, a);
-    RV_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int refvsr_resblock2_mfma(const void* src, int c, int h, int w, const void* const* wq, const float* const* bq,
-                                     int ksteps, float act_slope, float post1, float post2, void* out, void* stream) {
-    RV_CHECK(src && out && wq && bq && h > 0 && w > 0, "resblock2: bad args");
-    for (int j = 0; j < 4; ++j) RV_CHECK(wq[j] && bq[j], "resblock2: null weights / bias %d", j);
-    RV_CHECK(src != out, "resblock2: in-place operation is not supported (neighbouring tiles read the input halo)");
-    RV_CHECK(refvsr_resblock2_fits(c), "resblock2: channel count %d not supported by the chained kernel", c);
-    RV_CHECK(refvsr_init() == 0, "init failed");
-    ResChainArgs a;
-    memset(&a, 0, sizeof(a));
-    a.src = (const f16*)src; a.out = (f16*)out;
-    a.c = c; a.ncg = c / 8; a.ps = a.ncg | 1; a.h = h; a.w = w;
-    a.G = 9 * a.ncg; a.S = rv_ksteps(3, a.ncg);
-    RV_CHECK(a.S == ksteps, "resblock2: ksteps mismatch (%d vs %d)", ksteps, a.S);
-    a.inv_ncg = 1.0f / (float)a.ncg;
-    for (int j = 0; j < 4; ++j) { a.wq[j] = (const uint4*)wq[j]; a.bq[j] = bq[j]; }
-    a.act_slope = act_slope; a.post1 = post1; a.post2 = post2;
-    const int MT = (c + 15) / 16;
-    a.tab_bytes = (a.S * 4 * 2 * 4 + 15) / 16 * 16;
-    a.w_bytes = a.S * MT * 2 * 1024;
-    a.x_bytes = RC_XH * RC_XW * a.ps * 16;
-    a.tiles_x = rv_cdiv(w, RB_TW);
-    const int n_tiles = a.tiles_x * rv_cdiv(h, RB_TH);
-    const size_t lds = rc_lds_bytes(c);
-    if (MT == 1) return launch_chain2<1>(a, n_tiles, lds, (hipStream_t)stream);
-    return launch_chain2<2>(a, n_tiles, lds, (hipStream_t)stream);
 }
 
 extern "C" int refvsr_resblock_fits(int c) {
@@ -596,14 +360,9 @@ extern "C" int refvsr_resblock_mfma(const void* src, int c, int h, int w, const 
                        (size_t)RB_IH * RB_IW * a.ps * 16;
     a.tiles_x = rv_cdiv(w, RB_TW);
     a.n_tiles = a.tiles_x * rv_cdiv(h, RB_TH);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        RV_HIP(hipGetDevice(&dev));
-        RV_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    a.probe = g_rb_probe;
+    a.probe_iter = g_rb_probe_iter;
+    const int n_cu = rv_num_cus();
     dim3 grid(a.n_tiles < n_cu ? a.n_tiles : n_cu);             // persistent: one workgroup per CU
     if (MT == 1) return launch_resblock<1>(a, grid, lds, (hipStream_t)stream);
     return launch_resblock<2>(a, grid, lds, (hipStream_t)stream);

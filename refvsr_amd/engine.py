@@ -33,8 +33,10 @@ class FrameCtx(object):
 
     def __init__(self, lr, ref):
         self.uid = next(_uid)
-        self.lr = lr            # planar fp32 [3,h,w]
-        self.ref = ref
+        # the context OWNS its frames (clones): it outlives the call in the window cache, and a caller that refills one
+        # static input buffer in place must neither change cached data nor make the content compare see "equal" frames
+        self.lr = lr.clone()    # planar fp32 [3,h,w]
+        self.ref = ref.clone()
         self.lr8 = None         # nhwc16 [h,w,8]
         self.pyr = None         # SPyNet pyramid of lr, coarse -> fine
         self.conf = None        # planar [1,h,w]
@@ -147,9 +149,6 @@ class Engine(object):
         self.match_row_splits = 1
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
-        # two residual blocks per launch on the LR maps: bit-identical to two launches (verified on the GPU at the op level),
-        # speed and end-to-end behaviour not yet measured -> opt-in until they are
-        self.chain_resblocks = int(os.environ.get('REFVSR_RESBLOCK_CHAIN', '0') or 0)      # 1: LR maps only, 2: every map
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
         self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
@@ -201,23 +200,15 @@ class Engine(object):
 
     def _block_chain(self, x, pairs, act):
         """A run of residual blocks x <- x + conv2(act(conv1 x)); pairs = [(conv1, conv2), ...] packed weights.
-        One launch per block (fused kernel), two launches per block (fuse_resblocks off), or -- experimental, opt-in
-        with REFVSR_RESBLOCK_CHAIN=1 -- one launch per TWO blocks on maps of about one 16x32 tile per CU (=2: on every map)."""
-        i, n = 0, len(pairs)
-        chain = (self.chain_resblocks and self.fuse_resblocks and ops.resblock2_fits(x.shape[2])
-                 and (self.chain_resblocks >= 2 or ((x.shape[0] + 15) // 16) * ((x.shape[1] + 31) // 32) <= 320))
-        while i < n:
-            if chain and i + 1 < n:
-                x = ops.resblock2([pairs[i][0], pairs[i][1], pairs[i + 1][0], pairs[i + 1][1]], x, act=act)
-                i += 2
-                continue
-            c1, c2 = pairs[i]
+        One launch per block (fused kernel) or two launches per block (fuse_resblocks off / unsupported channel count).
+        (A kernel chaining TWO blocks per launch with halo recomputation was built in round 1 and measured in round 2:
+        29.3 us vs 2 x 14.7 us on the LR maps, slower on the 2x maps and 4 % slower end to end -- removed.)"""
+        for c1, c2 in pairs:
             if self.fuse_resblocks:
                 x = ops.resblock(c1, c2, x, act=act)
             else:
                 t = ops.conv(c1, x, act=act)
                 x = ops.conv(c2, t, res=x)
-            i += 1
         return x
 
     def res_list(self, x, name, n):
@@ -433,7 +424,7 @@ class Engine(object):
             for i, fid in enumerate(frame_ids):
                 fr = self.id_cache.get(fid)
                 if fr is None:
-                    fr = self.id_cache[fid] = FrameCtx(lrs[i].contiguous(), refs[i].contiguous())
+                    fr = self.id_cache[fid] = FrameCtx(lrs[i], refs[i])
                 frames[i] = fr
             keep = set(frame_ids)
             self.id_cache = {k: v for k, v in self.id_cache.items() if k in keep}
@@ -443,7 +434,7 @@ class Engine(object):
             return frames
         if not self.cache:
             self.flow_cache = {}
-            return [FrameCtx(lrs[i].contiguous(), refs[i].contiguous()) for i in range(t)]
+            return [FrameCtx(lrs[i], refs[i]) for i in range(t)]
         prev = self.prev_window
         if prev and prev[0].lr.shape != lrs.shape[1:]:          # new clip geometry: nothing to reuse
             prev = []
@@ -464,12 +455,12 @@ class Engine(object):
             for n_, (a, b) in enumerate(pp):
                 if eq[2 * n_] and eq[2 * n_ + 1]:
                     if frames[a] is None:
-                        frames[a] = FrameCtx(lrs[a].contiguous(), refs[a].contiguous())
+                        frames[a] = FrameCtx(lrs[a], refs[a])
                     if frames[b] is None:
                         frames[b] = frames[a]
         for i in range(t):
             if frames[i] is None:
-                frames[i] = FrameCtx(lrs[i].contiguous(), refs[i].contiguous())
+                frames[i] = FrameCtx(lrs[i], refs[i])
         live = set(f.uid for f in frames)
         self.flow_cache = {k2: v for k2, v in self.flow_cache.items() if k2[0] in live and k2[1] in live}
         self.prev_window = frames
@@ -516,17 +507,24 @@ class Engine(object):
             for st in (F_, P, Mo):
                 st.wait_stream(M)
         else:
+            self._check_window(lrs, refs)
             assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
-            fr = self._frames(lrs, refs, frame_ids)
             share = (M0, M1, F_, P)
             # ---- P: everything that is a function of single frames / frame pairs
             with ops.on_stream(P):
+                n_ctx = next(_uid)
+                fr = self._frames(lrs, refs, frame_ids)            # new frames are cloned here, on P
+                for f in fr:
+                    if f.uid > n_ctx:
+                        for st in share:
+                            f.lr.record_stream(st)
+                            f.ref.record_stream(st)
                 for i in range(ctr, t):
                     f = fr[i]
                     if f.conf is None:
                         self.pyramid(f)
                         self.prepare_frame(f)
-                        for x in [f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                        for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
                             for st in share:
                                 x.record_stream(st)
                         f.ready = torch.cuda.Event()
@@ -535,7 +533,7 @@ class Engine(object):
                         if f.pyr is None:
                             self.pyramid(f)
                         if f.ready is None:      # prepared on M by a first-frame call: make it safe on F and P too
-                            for x in [f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                            for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
                                 for st in share:
                                     x.record_stream(st)
                 bw_flows = {i: self.flow(fr[i], fr[i + 1], share) for i in range(ctr, t - 1)}
@@ -644,10 +642,15 @@ class Engine(object):
         """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None).
         frame_ids (optional): one hashable id per window frame -> the window cache is keyed by id instead of by
         content comparison; together with set_pipelined(True) it enables cross-call stream pipelining."""
-        if self.pipelined and frame_ids is not None and self.cache and self.overlap:
-            return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids)
-        with ops.on_stream(torch.cuda.current_stream()):
-            return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
+        if is_first_frame and frame_ids is not None:
+            # the caller starts a new clip: ids of the previous clip must not match (the internal reset_branch restart
+            # of a running clip keeps the cache -- same clip, same ids)
+            self.id_cache, self.flow_cache = {}, {}
+        with torch.cuda.device(lrs.device):          # launches go to the tensors' device, whatever the current device is
+            if self.pipelined and frame_ids is not None and self.cache and self.overlap:
+                return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids)
+            with ops.on_stream(torch.cuda.current_stream()):
+                return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
 
     # ------------------------------------------------------------------ two-phase forward (multi-GPU wavefront)
     def _check_window(self, lrs, refs):

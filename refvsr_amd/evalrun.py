@@ -52,7 +52,9 @@ def read_frame(path):
 def write_frame(path, img, quality=None):
     from PIL import Image
     a = (img.detach().float().cpu().clamp(0, 1).numpy().transpose(1, 2, 0) * 255.0)
-    im = Image.fromarray(a.astype(np.uint8))         # cv2.imwrite truncates float*255 the same way
+    # cv2.imwrite converts a float image with convertTo(CV_8U) = saturate_cast<uchar>: round to nearest, saturate
+    # (eval_qual_quan.py:117-119 hands it output*255 as float)
+    im = Image.fromarray(np.rint(a).clip(0, 255).astype(np.uint8))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     im.save(path, **({'quality': quality} if quality else {}))
 

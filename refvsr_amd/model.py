@@ -86,7 +86,10 @@ class Network(nn.Module):
             self._packed = Weights(self.config, sd, device)
             self._packed_key = key
             for e in self._engines:
+                # everything an engine caches (per-frame matching / encodings / flows, the forward-branch state) was
+                # computed with the old weights
                 e.W = self._packed
+                e.reset_state()
         return self._packed
 
     def reset(self):

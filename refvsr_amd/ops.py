@@ -5,6 +5,7 @@ Layouts: `planar` = float32 [C,H,W];  `nhwc16` = float16 [H,W,Cs] (Cs % 8 == 0).
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -146,39 +147,31 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     return out
 
 
+# Two kernels implement the fused block with identical results: 'lean' (4 waves, 8x32 tile, 77 KB LDS at C = 24, two
+# workgroups per CU -- resblock_lean.hip) and 'wide' (8 waves, 16x32 tile, one 154 KB workgroup per CU -- resblock_mfma.hip).
+RESBLOCK_KERNEL = os.environ.get('REFVSR_RESBLOCK', 'lean')
+
+
 def resblock_fits(c):
+    if RESBLOCK_KERNEL == 'lean' and hip.lib().refvsr_resblock_lean_fits(int(c)):
+        return True
     return bool(hip.lib().refvsr_resblock_fits(int(c)))
 
 
-def resblock(cw1, cw2, x, act, post=1.0):
-    """refvsr_resblock_mfma: post(x + conv2(act(conv1(x)))) in one launch (3x3, C->C)."""
+def resblock(cw1, cw2, x, act, post=1.0, kernel=None):
+    """refvsr_resblock_lean / refvsr_resblock_mfma: post(x + conv2(act(conv1(x)))) in one launch (3x3, C->C)."""
     _nhwc(x)
     h, w, c = x.shape
     assert cw1.cpads == [c] and cw2.cpads == [c] and cw1.cout == c and cw2.cout == c and cw1.ksize == 3
     assert not cw1.f32 and not cw1.shuffle and cw1.wpack.shape[0] == 1
     out = torch.empty_like(x)
-    hip.check(hip.lib().refvsr_resblock_mfma(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
-                                             _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_mfma')
-    return out
-
-
-def resblock2_fits(c):
-    return bool(hip.lib().refvsr_resblock2_fits(int(c)))
-
-
-def resblock2(cws, x, act, post1=1.0, post2=1.0):
-    """refvsr_resblock2_mfma: two chained residual blocks (cws = packed conv1..conv4) in one launch."""
-    import ctypes
-    _nhwc(x)
-    h, w, c = x.shape
-    assert len(cws) == 4
-    for cw in cws:
-        assert cw.cpads == [c] and cw.cout == c and cw.ksize == 3 and not cw.f32 and not cw.shuffle and cw.wpack.shape[0] == 1
-    out = torch.empty_like(x)
-    wq = (ctypes.c_void_p * 4)(*[_ptr(cw.wpack) for cw in cws])
-    bq = (ctypes.c_void_p * 4)(*[_ptr(cw.bias) for cw in cws])
-    hip.check(hip.lib().refvsr_resblock2_mfma(_ptr(x), c, h, w, wq, bq, cws[0].ksteps, act, post1, post2, _ptr(out),
-                                              _stream()), 'resblock2_mfma')
+    kernel = kernel or RESBLOCK_KERNEL
+    if kernel == 'lean' and hip.lib().refvsr_resblock_lean_fits(c):
+        hip.check(hip.lib().refvsr_resblock_lean(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
+                                                 _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_lean')
+    else:
+        hip.check(hip.lib().refvsr_resblock_mfma(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
+                                                 _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_mfma')
     return out
 
 

@@ -213,6 +213,52 @@ def test_batch_and_api_contract(dev):
     assert not torch.equal(single(x[:1], r[:1], True)['result'], outs['result'][:1])
 
 
+def test_static_input_buffer_refilled_in_place(dev):
+    """A caller that keeps ONE pair of input buffers and refills them in place for every window (a common serving
+    pattern) must get the same stream as a caller that passes fresh tensors: the window cache owns its frames, it must
+    neither see the refill as 'equal content' nor serve stale per-frame data (with and without frame ids)."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 6, 5
+    lr, rf, _ = make_clip(nfr, 32, 48, seed=17)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    want = [ref_net(lr[w][None].clone(), rf[w][None].clone(), f == 0)['result'].clone() for f, w in enumerate(wins)]
+    for use_ids in (False, True):
+        net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+        buf_l, buf_r = torch.empty((1, t, 3, 32, 48), device=dev), torch.empty((1, t, 3, 32, 48), device=dev)
+        for f, w in enumerate(wins):
+            buf_l.copy_(lr[w][None])
+            buf_r.copy_(rf[w][None])
+            got = net(buf_l, buf_r, f == 0, frame_ids=wins[f] if use_ids else None)['result']
+            assert torch.equal(got, want[f]), 'frame %d differs with a refilled input buffer (ids=%s)' % (f, use_ids)
+
+
+def test_weight_reload_drops_cached_state(dev):
+    """load_state_dict on a module that already ran: the next call on the SAME window must equal a fresh module with
+    the new weights -- no manual reset(), no stale per-frame data computed with the old weights."""
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, _ = make_clip(3, 32, 48, seed=19)
+    lr, rf = lr.to(dev), rf.to(dev)
+    net, cfg, sd = make_net('config_RefVSR_small_L1', 3, dev, save_sample=False)
+    w = window_indices(1, 3, 3)
+    ids = list(w)
+    net(lr[w][None], rf[w][None], True, frame_ids=ids)
+    net(lr[w][None], rf[w][None], False, frame_ids=ids)
+    sd2 = {k: (v * 0.75 if 'sub_mean' not in k else v) for k, v in sd.items()}
+    net.load_state_dict(sd2)
+    fresh, _, _ = make_net('config_RefVSR_small_L1', 3, dev, save_sample=False)
+    fresh.load_state_dict(sd2)
+    want = fresh(lr[w][None], rf[w][None], True, frame_ids=ids)['result']
+    got = net(lr[w][None], rf[w][None], True, frame_ids=ids)['result']
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError, match='is_first_frame'):      # the forward state of the old weights is gone too
+        net2, _, _ = make_net('config_RefVSR_small_L1', 3, dev, save_sample=False)
+        net2(lr[w][None], rf[w][None], True)
+        net2.load_state_dict(sd2)
+        net2(lr[w][None], rf[w][None], False)
+
+
 def test_full_size_properties(dev):
     """BASELINE config[1] geometry (270x480 -> 1080x1920, t=5): determinism, reset-aligned sharding and
     the state hand-off reproduce the sequential stream bit-for-bit."""

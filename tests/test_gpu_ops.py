@@ -144,26 +144,6 @@ def test_conv_mfma_persistent_tile_walk(dev, cap):
         assert err < 1e-3
 
 
-def test_resblock2_chain_matches_two_launches(dev):
-    """Two chained residual blocks in one launch (4-pixel halo recomputation) == two fused-block launches, bit for bit:
-    same K order, same fp16 rounding points, zero padding of the intermediate block output at the frame border."""
-    from refvsr_amd import ops
-    from refvsr_amd.packing import pack_conv
-    g = torch.Generator().manual_seed(31)
-    for C, h, w, act, p1, p2 in [(24, 37, 70, 0.0, 1.0, 1.0), (24, 270, 480, 0.0, 1.0, 1.0), (16, 16, 32, 0.2, 1.0, 0.2),
-                                 (24, 5, 9, 0.2, 0.2, 1.0), (8, 48, 33, 0.0, 1.0, 1.0)]:
-        assert ops.resblock2_fits(C)
-        cws = []
-        for _ in range(4):
-            wt = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
-            cws.append(ops.ConvWeights(pack_conv(wt, torch.randn(C, generator=g) * 0.1, [C]), dev))
-        x = nhwc(torch.randn(C, h, w, generator=g), dev)
-        two = ops.resblock(cws[2], cws[3], ops.resblock(cws[0], cws[1], x, act=act, post=p1), act=act, post=p2)
-        one = ops.resblock2(cws, x, act=act, post1=p1, post2=p2)
-        report('resblock2 chain C%d %dx%d' % (C, h, w), abs=maxdiff(one.float().cpu(), two.float().cpu()))
-        assert torch.equal(one, two), (C, h, w)
-
-
 def test_conv_mfma_gather_mode_strided(dev):
     """5x5 stride-4 / stride-8 offset predictors of the HD configs (alignment.py:20): the staged tile cannot fit
     LDS, the kernel switches to gathering B fragments from global memory."""
@@ -219,7 +199,8 @@ def test_conv_mfma_epilogues(dev):
     assert maxdiff(got, want) < 1e-4
 
 
-@pytest.mark.parametrize('C,h,w,act', [(24, 16, 32, 0.0), (24, 45, 83, 0.2), (24, 270, 480, 0.0), (16, 19, 33, 0.2)])
+@pytest.mark.parametrize('C,h,w,act', [(24, 16, 32, 0.0), (24, 45, 83, 0.2), (24, 270, 480, 0.0), (16, 19, 33, 0.2), (8, 7, 5, 0.1),
+                                     (32, 50, 70, 0.2), (24, 540, 960, 0.2)])
 def test_resblock_fused(dev, C, h, w, act):
     """Fused conv-act-conv+residual launch vs the same block as two conv launches and vs torch."""
     from refvsr_amd import ops
@@ -245,6 +226,11 @@ def test_resblock_fused(dev, C, h, w, act):
     assert same < 4e-3            # both round the intermediate and the output to fp16; summation order differs
     fused_p = ops.resblock(c1, c2, xin, act=act, post=0.2)
     assert rel(planar(fused_p), F.leaky_relu(want, 0.2)) < 1e-3
+    # the two fused kernels (4-wave 8x32-tile 'lean', 8-wave 16x32-tile 'wide') agree bit for bit
+    if ops.hip.lib().refvsr_resblock_fits(C) and ops.hip.lib().refvsr_resblock_lean_fits(C):
+        for post in (1.0, 0.2):
+            assert torch.equal(ops.resblock(c1, c2, xin, act=act, post=post, kernel='lean'),
+                               ops.resblock(c1, c2, xin, act=act, post=post, kernel='wide')), 'lean != wide'
 
 
 def test_conv_mfma_f32_mode(dev):

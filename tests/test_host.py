@@ -209,9 +209,8 @@ def test_partition():
     assert not shard.needs_handoff(18, 9) and shard.needs_handoff(20, 9)
 
 
-def test_block_chain_pairs_blocks_in_order(monkeypatch):
-    """Engine._block_chain: with the chained kernel enabled, blocks are consumed two at a time in order (an odd tail as a
-    single block), only on small maps; the sequence of weights applied must equal the plain one-block-per-launch walk."""
+def test_block_chain_applies_blocks_in_order(monkeypatch):
+    """Engine._block_chain: one fused launch per block (or two conv launches when fusing is off), in order."""
     from refvsr_amd import engine, ops
 
     class X(object):                               # stands in for an nhwc16 map: records what was applied to it
@@ -219,23 +218,16 @@ def test_block_chain_pairs_blocks_in_order(monkeypatch):
             self.shape, self.hist = shape, tuple(hist)
 
     monkeypatch.setattr(ops, 'resblock', lambda c1, c2, x, act, post=1.0: X(x.shape, x.hist + ((c1, c2, act),)))
-    monkeypatch.setattr(ops, 'resblock2', lambda cws, x, act, post1=1.0, post2=1.0:
-                        X(x.shape, x.hist + ((cws[0], cws[1], act), (cws[2], cws[3], act))))
-    monkeypatch.setattr(ops, 'resblock2_fits', lambda c: c in (8, 16, 24))
-    calls = []
-    monkeypatch.setattr(ops, 'conv', lambda cw, x, act=1.0, res=None: calls.append(cw) or X(x.shape, x.hist + ((cw, act),)))
+    monkeypatch.setattr(ops, 'conv', lambda cw, x, act=1.0, res=None: X(x.shape, x.hist + ((cw, act, res is not None),)))
 
     class E(object):
         _block_chain = engine.Engine._block_chain
-        fuse_resblocks, chain_resblocks = True, 1
+        fuse_resblocks = True
     e = E()
     for n in (1, 2, 5, 24):
         pairs = [('a%d' % i, 'b%d' % i) for i in range(n)]
-        want = tuple((a, b, 0.2) for a, b in pairs)
-        assert e._block_chain(X((270, 480, 24)), pairs, 0.2).hist == want          # LR map: chained
-        assert e._block_chain(X((540, 960, 24)), pairs, 0.2).hist == want          # 2x map: one block per launch
-        assert e._block_chain(X((270, 480, 48)), pairs, 0.2).hist == want          # C = 48: chain kernel does not fit
-    e.chain_resblocks = 2
-    assert e._block_chain(X((540, 960, 24)), pairs, 0.2).hist == want              # mode 2: chained on every map
-    e.chain_resblocks = 0
-    assert e._block_chain(X((270, 480, 24)), pairs, 0.0).hist == tuple((a, b, 0.0) for a, b in pairs)
+        assert e._block_chain(X((270, 480, 24)), pairs, 0.2).hist == tuple((a, b, 0.2) for a, b in pairs)
+    e.fuse_resblocks = False
+    want = tuple(x for a, b in pairs for x in ((a, 0.0, False), (b, 1.0, True)))
+    assert e._block_chain(X((270, 480, 24)), pairs, 0.0).hist == want
+

@@ -256,25 +256,44 @@ def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep'):
 
 
 def gen_full(nframes=2, stride=8):
-    """Full BASELINE size (270x480 -> 1080x1920, t=5): PSNR scalars + a strided sub-sample of the result
-    (the full frame is 24.9 MB).  ~3 min + 1.5 min per frame on 8 cores, 18 GB RSS."""
+    """Full BASELINE size (270x480 -> 1080x1920, t=5), random AND 'plausible' weights: PSNR scalars, a strided
+    sub-sample of the result, two full-resolution 128x128 crops per frame (the full frame is 24.9 MB) and -- the
+    matching is where fp16 near-ties would show -- the index map and confidence map of every window's centre frame
+    (they depend on the frame and the VGG head only, so they are stored once).  ~3 min + 1.5 min per frame and
+    variant on 8 cores, 18 GB RSS."""
     from refvsr_amd.synth import make_clip, window_indices
-    print('== full-size S 270x480 t=5, %d frames ==' % nframes)
-    net, cfg, mine, sd = ref_net('config_RefVSR_small_L1', 5, save_sample=False)
-    lr, rf, gt = make_clip(nframes, 270, 480, seed=0)
-    arrs = dict(nframes=np.int64(nframes), stride=np.int64(stride),
-                lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
     import time
-    with torch.no_grad():
-        for f in range(nframes):
-            w = window_indices(f, nframes, 5)
-            t0 = time.time()
-            res = net(lr[w][None], rf[w][None], f == 0, is_log=False, is_train=False)['result']
-            mse = torch.mean((res - gt[f][None]) ** 2)
-            p = float(10 * torch.log10(1 / mse))
-            print('  frame %d: %.1f s, PSNR vs GT %.6f dB' % (f, time.time() - t0, p))
-            arrs['psnr_%d' % f] = np.float64(p)
-            arrs['sub_%d' % f] = res[0, :, ::stride, ::stride].clone()
+    lr, rf, gt = make_clip(nframes, 270, 480, seed=0)
+    crops = [(300, 500), (700, 1400)]                 # top-left corners of the 128x128 full-resolution crops
+    arrs = dict(nframes=np.int64(nframes), stride=np.int64(stride), crops=np.asarray(crops, np.int64),
+                lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
+    for variant in (None, 'plausible'):
+        tag = '' if variant is None else 'p_'
+        print('== full-size S 270x480 t=5, %d frames, weights: %s ==' % (nframes, variant or 'random'))
+        net, cfg, mine, sd = ref_net('config_RefVSR_small_L1', 5, save_sample=False)
+        if variant:
+            net.load_state_dict(wts.make_state_dict(mine, SEED_W, variant=variant), strict=True)
+        matches = []
+        hook = net.Network.feature_match.register_forward_hook(lambda m, i, o: matches.append((o[0].clone(), o[1].clone())))
+        with torch.no_grad():
+            for f in range(nframes):
+                w = window_indices(f, nframes, 5)
+                del matches[:]
+                t0 = time.time()
+                res = net(lr[w][None], rf[w][None], f == 0, is_log=False, is_train=False)['result']
+                mse = torch.mean((res - gt[f][None]) ** 2)
+                p = float(10 * torch.log10(1 / mse))
+                print('  frame %d: %.1f s, PSNR vs GT %.6f dB' % (f, time.time() - t0, p))
+                arrs[tag + 'psnr_%d' % f] = np.float64(p)
+                for ci, (y0, x0) in enumerate(crops):
+                    arrs[tag + 'crop%d_%d' % (ci, f)] = res[0, :, y0:y0 + 128, x0:x0 + 128].clone()
+                if variant is None:
+                    arrs['sub_%d' % f] = res[0, :, ::stride, ::stride].clone()
+                    # feature_match is called for window positions range_start..t-1: the centre frame is call ctr - range_start
+                    conf, idx = matches[2 if f == 0 else 0]
+                    arrs['conf_%d' % f] = conf[0, 0].clone()
+                    arrs['idx_%d' % f] = idx[0].to(torch.int32).clone()
+        hook.remove()
     save('e2e_full_S_270x480_t5', **arrs)
 
 
