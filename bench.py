@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: 4x SR output frames/s of RefVSR_small (270x480 -> 1080x1920, frame_num=5),
-steady-state sliding-window inference through the drop-in SRNet surface on the HIP path.
+"""Headline benchmark: 4x SR output frames/s (BASELINE.json `metric`), steady-state sliding-window inference through
+the drop-in SRNet surface on the HIP path.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one forward call = one 1080p output frame.  Inputs (the synthetic LR / Ref clip) are
-resident in HBM before the timed region.  With N > 1 every rank runs K steps on its own
-reset-aligned shard of one long clip (exchange-free partition, refvsr_amd/shard.py), so per-GPU
-work is fixed ("weak") and there is no data-path collective; the timed region is bracketed by
-barrier + synchronize and the MAX over ranks is reported.
+One "step" = one forward call = one output frame.  Inputs (the synthetic LR / Ref clip, every sliding window) are
+resident in HBM before the timed region.  Workload (default): BASELINE configs[1] -- RefVSR_small_L1, 270x480 ->
+1080x1920, frame_num = 5; `--config config_RefVSR_MFID` is configs[2], `--config config_RefVSR_MFID_8K --size 1080x1920`
+configs[4] on one GPU.  With N > 1 every rank runs K steps on its own reset-aligned shard of one long clip
+(exchange-free partition, refvsr_amd/shard.py): per-GPU work fixed ("weak"), no data-path collective; the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is reported.
 
-Extra objects on the JSON line:
-  roofline     -- the dominant kernel (fused matching GEMM + arg-max, MFMA-bound): algorithmic
-                  FLOPs per launch / mean launch duration measured with HIP events on the launch
-                  stream during the timed steps, against the 2.5 PFLOP/s dense fp16 MFMA peak.
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference itself cannot
-                  travel) timed on this host on a bounded sample of the same workload.
+What the JSON line carries beside the contract fields:
+  value              -- the build's fastest supported call mode: windows named by frame ids (`frame_ids=`) and calls
+                        pipelined over the engine's internal streams (`set_pipelined`) -- two documented EXTENSIONS of
+                        the reference's call surface (what the build's own eval harness, refvsr_amd/evalrun.py, uses)
+  dropin_surface     -- the same K steps through the UNMODIFIED reference call surface (`net(x, ref, is_first_frame)`,
+                        frames recognised by content, no pipelining): what run.py / eval.py get with the 3-line plug-in
+  roofline           -- the dominant kernel (fused matching GEMM + arg-max, MFMA-bound): algorithmic FLOPs per launch /
+                        mean launch duration from HIP events recorded around every launch inside the timed region
+  kernels            -- device time per launch (HIP events around back-to-back launches queued behind a long kernel, so
+                        the host launch rate does not enter) of the time-dominant conv kernels (MFMA and HBM fractions)
+                        and of the HBM-bound warp / gather / sampler / resize kernels (GB/s of algorithmic bytes against
+                        8 TB/s; `traffic` = PMC FETCH_SIZE x2 + WRITE_SIZE per launch from profiles/pmc_kernels.json)
+  whole_path         -- algorithmic TFLOP per output frame (refvsr_amd/flops.py, config-aware) x frames/s against the
+                        dense fp16 MFMA peak
+  wavefront (N > 1)  -- BASELINE configs[3]: a 64-frame clip of config_RefVSR_small_MFID (reset_branch = 9) sharded over
+                        the N ranks by frame index with the forward-state hand-off over RCCL send/recv
+                        (shard.run_wavefront); per-frame checksums are compared with a single-rank run
+  cpu_baseline       -- the CPU oracle (a port of the reference's algorithm; the reference itself cannot travel) timed on
+                        this host: ONE full steady-state forward as the reference executes it, nothing sampled
 """
 import argparse
 import json
@@ -32,9 +46,11 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-H, W_, T = 270, 480, 5
 PEAK_F16_TFLOPS = 2500.0          # dense MFMA f16/bf16 peak, MI355X_MICROARCH.md
-ALG_TFLOP_PER_FRAME = 2.490       # de-duplicated algorithmic work per output frame
+PEAK_HBM_GBS = 8000.0             # HBM3E spec peak (6.3 TB/s achievable by a float4 copy), MI355X_MICROARCH.md
+SURVEY_DEDUP_TFLOP = {'config_RefVSR_small_L1': 2.490, 'config_RefVSR_small_MFID': 2.490}   # SURVEY.md 8(d), 270x480 t=5
+BASELINE_CONFIG = {'config_RefVSR_small_L1': 'configs[1]', 'config_RefVSR_MFID': 'configs[2]',
+                   'config_RefVSR_small_MFID': 'configs[3]', 'config_RefVSR_MFID_8K': 'configs[4]'}
 
 
 def usable_cores():
@@ -50,52 +66,182 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline_child():
+def cpu_baseline_child(config, h, w, t):
     """Runs in a child process (so a slow host can be cut off without losing the GPU number)."""
     from refvsr_amd import get_config, make_state_dict
     from refvsr_amd.synth import make_clip
+    from oracle import refvsr_oracle as orc
     ncores = min(usable_cores(), 64)
     torch.set_num_threads(ncores)
-    cfg = get_config('bench', 'bench', 'config_RefVSR_small_L1')
-    cfg.frame_num = T
+    cfg = get_config('bench', 'bench', config)
+    cfg.frame_num = t
     sd = make_state_dict(cfg, 1234)
-    lr, rf, _ = make_clip(T, H, W_, seed=0)
-    out = cpu_baseline(cfg, sd, lr, rf)
-    out['host_cpu_count'] = os.cpu_count()
-    out['usable_cores'] = usable_cores()
-    print('CPU_BASELINE ' + json.dumps(out), flush=True)
-
-
-def cpu_baseline(cfg, sd, lr, rf):
-    """One steady-state forward of the oracle exactly as the reference executes it (8 SPyNet calls,
-    3 matchings, 3 backward + 1 forward RAP steps, upsampler) at the full 270x480 size.  The
-    matching GEMM (86% of the reference's CPU time) is evaluated on 1/16 of the LR columns and its
-    time scaled back by 16; everything else runs in full."""
-    from oracle import refvsr_oracle as orc
-    nthreads = torch.get_num_threads()
-    sample = 16
-    o = orc.OracleNetwork(cfg, sd, match_chunk=8192, match_sample=sample)
-    # forward state of a previous call (values do not influence the timing)
-    C = cfg.mid_channels
-    o.forward_feat_prop_prev = torch.zeros(1, C, H, W_)
-    o.forward_flow_prev = torch.zeros(1, 2, H, W_)
-    o.forward_feat_prop_UP_prev = torch.zeros(1, C, 2 * H, 2 * W_)
-    o.forward_conf_map_prop_prev = torch.zeros(1, 1, H, W_)
+    lr, rf, _ = make_clip(t, h, w, seed=0)
+    o = orc.OracleNetwork(cfg, sd, match_chunk=8192)
+    C = cfg.mid_channels                      # forward state of a previous call (values do not influence the timing)
+    o.forward_feat_prop_prev = torch.zeros(1, C, h, w)
+    o.forward_flow_prev = torch.zeros(1, 2, h, w)
+    o.forward_feat_prop_UP_prev = torch.zeros(1, C, 2 * h, 2 * w)
+    o.forward_conf_map_prop_prev = torch.zeros(1, 1, h, w)
     o.frame_itr_num = 1
-    x, r = lr[:T][None].cpu(), rf[:T][None].cpu()
+    x, r = lr[:t][None], rf[:t][None]
     with torch.no_grad():
         t0 = time.perf_counter()
         o.forward(x, r, False)
         total = time.perf_counter() - t0
-    scaled = (total - o.match_seconds) + o.match_seconds * sample
-    return {
-        'value': 1.0 / scaled, 'unit': 'frames/s', 'cores': nthreads, 'kind': 'port',
-        'sample': ('1 steady-state forward as the reference executes it (8 SPyNet, 3 matchings, 3+1 RAP steps, '
-                   'upsampler) at 270x480 t=5 fp32, torch CPU; matching GEMM on 1/%d of the LR columns, '
-                   'its time (%.2f s) scaled x%d; measured %.2f s -> %.2f s/frame' %
-                   (sample, o.match_seconds, sample, total, scaled)),
-        'seconds_per_frame': scaled,
-    }
+    out = {'value': 1.0 / total, 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
+           'sample': ('1 full steady-state forward as the reference executes it (%d SPyNet calls, %d matchings, %d+1 '
+                      'propagation steps, upsampler) at %dx%d t=%d fp32, torch CPU, nothing sampled or scaled: %.2f s'
+                      % (2 * (t - 1), t // 2 + 1, t - t // 2, h, w, t, total)),
+           'seconds_per_frame': total, 'host_cpu_count': os.cpu_count(), 'usable_cores': usable_cores()}
+    print('CPU_BASELINE ' + json.dumps(out), flush=True)
+
+
+def queued_launch_us(fn, iters, blocker):
+    """Device time per launch of fn(): `iters` launches are queued behind a long-running kernel (`blocker`), so the GPU
+    executes them back to back and the host launch rate does not enter; HIP events on the launch stream."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    blocker()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def kernel_rooflines(cfg, eng, h, w, dev):
+    """Per-kernel achieved rates on this GPU, in isolation (after the timed region; never part of `value`)."""
+    from refvsr_amd import ops
+    C = cfg.mid_channels
+    g = torch.Generator().manual_seed(3)
+    rnd16 = lambda hh, ww, c: ops.pack_nhwc16(torch.randn(c, hh, ww, generator=g).to(dev))
+    x_lr, x_2x = rnd16(h, w, C), rnd16(2 * h, 2 * w, C)
+    flow = (torch.randn(2, h, w, generator=g) * 2).to(dev)
+    flow2 = ops.flow_up2(flow)
+    idx = torch.randint(0, (h // 2) * (w // 2), (h * w,), generator=g, dtype=torch.int32).to(dev)
+    aff = (torch.rand(3, h, w, generator=g) * 0.4 + 0.8).to(dev)
+    lr = torch.rand(3, h, w, generator=g).to(dev)
+    big_a, big_b = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
+    blocker = lambda: torch.mm(big_a, big_b)          # ~1 ms of GPU time to queue the measured launches behind
+    traffic = {}
+    pj = os.path.join(ROOT, 'profiles', 'pmc_kernels.json')
+    if os.path.exists(pj):
+        try:
+            traffic = json.load(open(pj)).get('traffic_bytes_per_launch', {})
+        except Exception:  # noqa: BLE001
+            traffic = {}
+    out = []
+
+    def add(name, fn, flops, nbytes, bound, tkey=None, iters=40):
+        us = queued_launch_us(fn, iters, blocker)
+        tf, gbs = flops / us / 1e6, nbytes / us / 1e3
+        ent = {'kernel': name, 'bound': bound, 'us_per_launch': round(us, 2), 'algorithmic_flops': flops, 'algorithmic_bytes': nbytes,
+               'tflops': round(tf, 1), 'frac_mfma': round(tf / PEAK_F16_TFLOPS, 4), 'gbs': round(gbs, 1),
+               'frac_hbm': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic.get(tkey or name)}
+        ent['achieved'], ent['peak'], ent['unit'] = (gbs, PEAK_HBM_GBS, 'GB/s') if bound == 'hbm' else (tf, PEAK_F16_TFLOPS, 'TFLOP/s')
+        ent['frac'] = ent['achieved'] / ent['peak']
+        out.append(ent)
+
+    nb = cfg.num_blocks
+    pair = lambda name: (eng.cw(name + '.conv1'), eng.cw(name + '.conv2'))
+    c1, c2 = pair('backward_resblocks.main.2.%d' % (nb // 2))
+    d1, d2 = pair('feat_decoder2.RBs.1')
+    rb_flops = lambda px: 2 * 2.0 * 9 * C * C * px
+    rb_bytes = lambda px: 2.0 * px * C * 2 + 2 * (c1.wpack.numel() * 2)
+    if eng.fuse_resblocks:
+        add('resblock_fused LR (backward_resblocks)', lambda: ops.resblock(c1, c2, x_lr, act=0.0), rb_flops(h * w), rb_bytes(h * w), 'mfma',
+            'resblock LR')
+        add('resblock_fused 2x (feat_decoder2)', lambda: ops.resblock(d1, d2, x_2x, act=0.2), rb_flops(4 * h * w), rb_bytes(4 * h * w), 'mfma',
+            'resblock 2x')
+    cw = eng.cw('conv_hr')
+    x_hr = rnd16(4 * h, 4 * w, C)
+    add('conv_mfma HR %d->%d 3x3 (conv_hr)' % (C, C), lambda: ops.conv(cw, x_hr, act=0.1), 2.0 * 9 * C * C * 16 * h * w,
+        2.0 * 16 * h * w * C * 2, 'mfma', 'conv HR')
+    cwu = eng.cw('upsample2.upsample_conv')
+    add('conv_mfma 2x %d->%d 3x3 + pixel shuffle (upsample2)' % (C, 4 * C), lambda: ops.conv(cwu, x_2x, act=0.1), 2.0 * 9 * C * 4 * C * 4 * h * w,
+        (4 * h * w * C + 16 * h * w * C) * 2.0, 'mfma', 'conv shuffle 2x')
+    wb = lambda px: (2.0 * C * 2 + 8) * px
+    add('warp_nhwc16 LR', lambda: ops.warp_nhwc16(x_lr, flow), 0.0, wb(h * w), 'hbm', 'warp LR')
+    add('warp_nhwc16 2x', lambda: ops.warp_nhwc16(x_2x, flow2), 0.0, wb(4 * h * w), 'hbm', 'warp 2x')
+    # algorithmic bytes of the gathers: every input byte once + every output byte once (re-reads are cache hits)
+    add('block_gather_nhwc16 2x (aa2)', lambda: ops.block_gather_nhwc16(x_lr, idx, h, w, 2), 0.0, C * 2.0 * (4 * h * w + h * w) + 4.0 * h * w,
+        'hbm', 'gather 2x')
+    add('aligned_sample 2x (AlignedConv2d sampler)', lambda: ops.aligned_sample(x_2x, aff, 2), 0.0, 2.0 * C * 2 * 4 * h * w + 12.0 * h * w, 'hbm',
+        'aligned_sample 2x')
+    add('resize bicubic x4 (base)', lambda: ops.bicubic_scale(lr, 4, clamp01=True), 0.0, 3 * 4.0 * (h * w + 16 * h * w), 'hbm', 'bicubic x4')
+    return out
+
+
+def run_wavefront_leg(args, rank, world, dev, backend, h, w):
+    """BASELINE configs[3]: an args.clip-frame clip of config_RefVSR_small_MFID (reset_branch = 9), sharded by frame index
+    over the ranks with the forward-state hand-off (RCCL send/recv of one packed fp16 buffer per shard boundary)."""
+    from refvsr_amd import SRNet, get_config, make_state_dict, shard
+    from refvsr_amd.synth import make_clip, window_indices
+    name = 'config_RefVSR_small_MFID'
+    cfg = get_config('bench', 'bench', name)
+    cfg.frame_num = t = 5
+    nfr = args.clip
+    net = SRNet(cfg).to(dev).eval()
+    net.load_state_dict(make_state_dict(cfg, 1234))
+    start, end = shard.partition(nfr, world)[rank]
+    lo, hi = max(start - t // 2, 0), min(end + t // 2, nfr)
+    lr, rf, _ = make_clip(hi - lo, h, w, seed=0, start=lo)          # this rank's frames (+ input halo), resident in HBM
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = {f: torch.tensor([i - lo for i in window_indices(f, nfr, t)], device=dev) for f in range(start, end)}
+    win = {f: (lr[wins[f]].contiguous(), rf[wins[f]].contiguous()) for f in range(start, end)}
+    ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
+    comm_dev = dev if backend == 'nccl' else torch.device('cpu')
+    # warm-up: kernels, allocator and the point-to-point communicators (their first use costs seconds)
+    if end > start:
+        ex.phase_b(ex.phase_a(win[start][0], win[start][1], start, True), True)
+    net.Network.reset()
+    tok = torch.zeros(1, device=comm_dev)
+    if rank + 1 < world:
+        dist.send(tok, rank + 1)
+    if rank > 0:
+        dist.recv(tok, rank - 1)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev)
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # per-frame checksums of every rank -> rank 0, compared with rank 0's own sequential run of the whole clip
+    sums = torch.zeros(nfr, 2, dtype=torch.float64, device=comm_dev)
+    for f, r in res.items():
+        rd = r.double()
+        sums[f, 0], sums[f, 1] = rd.sum().to(comm_dev), (rd * rd).sum().to(comm_dev)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    out = None
+    if rank == 0:
+        ncheck = min(nfr, args.clip_check)
+        net.Network.reset()
+        lr0, rf0, _ = make_clip(min(ncheck + t // 2, nfr), h, w, seed=0)
+        lr0, rf0 = lr0.to(dev), rf0.to(dev)
+        ok = True
+        for f in range(ncheck):
+            # windows of the FULL clip (indices beyond the generated prefix only occur at f >= ncheck)
+            wi = torch.tensor(window_indices(f, nfr, t), device=dev)
+            r = net(lr0[wi][None], rf0[wi][None], f == 0)['result'][0].double()
+            ok = ok and float(r.sum()) == float(sums[f, 0]) and float((r * r).sum()) == float(sums[f, 1])
+        C = cfg.mid_channels
+        out = {'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
+                           '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
+               'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
+               'schedule': 'phase A (flows, matching, encoders, alignment, backward branch) of all frames concurrently on all ranks; '
+                           'phase B (forward-branch step + upsampler) rank 0 -> 1 -> ... behind the hand-off',
+               'handoff': {'backend': backend, 'messages': sum(1 for r in range(1, world) if shard.needs_handoff(shard.partition(nfr, world)[r][0], cfg.reset_branch)),
+                           'bytes_per_message': 16 + h * w * (10 * C + 12), 'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
+                           'overlap': 'isend issued when the last frame\'s state is final, under its upsampler'},
+               'frames_checked_against_single_rank_run': ncheck, 'frames_equal': bool(ok)}
+    dist.barrier()
+    return out
 
 
 def main():
@@ -104,15 +250,25 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='config_RefVSR_small_L1')
+    ap.add_argument('--size', default='270x480', help='LR frame size HxW (1080x1920 for the 8K configs)')
+    ap.add_argument('--frames', type=int, default=5, help='sliding-window length (frame_num)')
     ap.add_argument('--no-cache', action='store_true', help='execute exactly the work the reference executes')
-    ap.add_argument('--no-frame-ids', action='store_true', help='let the engine recognise frames by content comparison')
+    ap.add_argument('--no-frame-ids', action='store_true', help='headline through the plain call surface (content compare)')
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap consecutive calls on internal streams')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the second timed pass through the unmodified call surface')
+    ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline measurements')
+    ap.add_argument('--no-wavefront', action='store_true', help='N > 1: skip the sharded-clip leg with the state hand-off')
+    ap.add_argument('--clip', type=int, default=64, help='N > 1: frames of the sharded clip (BASELINE configs[3]: 64)')
+    ap.add_argument('--clip-check', type=int, default=12, help='frames of the sharded clip re-run on one rank and compared')
+    ap.add_argument('--wavefront-timeout', type=float, default=180.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-baseline-timeout', type=float, default=240.0)
+    ap.add_argument('--cpu-baseline-timeout', type=float, default=300.0)
     args = ap.parse_args()
+    H, W_ = [int(v) for v in args.size.lower().split('x')]
+    T = args.frames
     if args.cpu_baseline_only:
-        cpu_baseline_child()
+        cpu_baseline_child(args.config, H, W_, T)
         return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -133,6 +289,7 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     from refvsr_amd import SRNet, get_config, make_state_dict
+    from refvsr_amd.flops import tflop_per_frame
     from refvsr_amd.synth import make_clip, window_indices
     cfg = get_config('bench', 'bench', args.config)
     cfg.frame_num = T
@@ -146,41 +303,58 @@ def main():
     start = rank * int(math.ceil(nfr / float(R))) * R          # reset-aligned shard start (exchange-free)
     lr, rf, _ = make_clip(nfr, H, W_, seed=0, start=start)
     lr, rf = lr.to(dev), rf.to(dev)                             # inputs resident in HBM
-    # the sliding windows are materialised before the timed region (inputs resident in HBM); frame ids let the engine
-    # key its window cache without comparing frame contents and pipeline consecutive calls over its internal streams
+    # the sliding windows are materialised before the timed region (inputs resident in HBM)
     wins = [window_indices(f, nfr, T) for f in range(nfr)]
     win_lr = [lr[torch.tensor(w, device=dev)][None].contiguous() for w in wins]
     win_rf = [rf[torch.tensor(w, device=dev)][None].contiguous() for w in wins]
-    use_ids = not args.no_frame_ids
-    if use_ids and not args.no_pipeline:
-        net.Network.set_pipelined(True)
     torch.cuda.synchronize()
-
-    def step(f):
-        ids = [start + i for i in wins[f]] if use_ids else None
-        return net(win_lr[f], win_rf[f], f == 0, frame_ids=ids)['result']
-
     eng = net.Network.ensure_engines(1, dev)[0]
-    for f in range(args.warmup):
-        out = step(f)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    eng.kernel_events = []                                       # HIP events around the dominant kernel
-    t0 = time.perf_counter()
-    for f in range(args.warmup, nfr):
-        out = step(f)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert bool(torch.isfinite(out).all())
+
+    def timed_pass(use_ids, pipelined, collect_events):
+        """W untimed + K timed steps of a new clip; returns (seconds for the K steps, last output)."""
+        net.Network.reset()
+        net.Network.set_pipelined(bool(use_ids and pipelined))
+
+        def step(f):
+            ids = [start + i for i in wins[f]] if use_ids else None
+            if ids is None:
+                return net(win_lr[f], win_rf[f], f == 0)['result']                  # the reference's call, verbatim
+            return net(win_lr[f], win_rf[f], f == 0, frame_ids=ids)['result']
+        out = None
+        for f in range(args.warmup):
+            out = step(f)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.kernel_events = [] if collect_events else None                           # HIP events around the dominant kernel
+        t0 = time.perf_counter()
+        for f in range(args.warmup, nfr):
+            out = step(f)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert bool(torch.isfinite(out).all())
+        ev = eng.kernel_events
+        eng.kernel_events = None
+        net.Network.set_pipelined(False)
+        return elapsed, ev
+
+    use_ids = not args.no_frame_ids
+    pipelined = use_ids and not args.no_pipeline and cfg.cache_windows
+    elapsed, ev = timed_pass(use_ids, pipelined, True)
+    dropin = None
+    if not args.no_dropin and (use_ids or pipelined):
+        el2, _ = timed_pass(False, False, False)
+        dropin = {'value': world * args.steps / el2, 'unit': 'frames/s', 'ms_per_step': 1e3 * el2 / args.steps,
+                  'call': "net(x, ref, is_first_frame)['result'] -- the reference's positional call, frames recognised by content "
+                          '(one device->host flag read per call), default stream order'}
 
     # first-frame latency (SURVEY 8(d) asks for it beside the steady-state rate): a new clip on a cold window cache,
     # measured AFTER the timed region, host clock around one synchronised call; never part of `value`
@@ -196,30 +370,37 @@ def main():
         except Exception:  # noqa: BLE001  (an extra figure must never take the headline number down)
             first_ms = None
 
+    line = None
     if rank == 0:
         fps = world * args.steps / elapsed
+        alg, parts = tflop_per_frame(cfg, H, W_, T, dedup=True)
+        alg_exec, _ = tflop_per_frame(cfg, H, W_, T, dedup=False)
+        tag = BASELINE_CONFIG.get(args.config)
         line = {
-            'metric': '4x SR frames/sec (270p->1080p, RefVSR_small)', 'value': fps, 'unit': 'frames/s',
+            'metric': '4x SR frames/sec (%dp->%dp, %s)' % (H, 4 * H, args.config.replace('config_', '')), 'value': fps, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': '%s 4x SR, 270x480 -> 1080x1920, frame_num=5, steady-state sliding window, n=1 '
-                                   '(BASELINE configs[1]); synthetic clip seed 0, seeded random weights 1234' % args.config,
+            'config': {'workload': '%s 4x SR, %dx%d -> %dx%d, frame_num=%d, steady-state sliding window, n=1%s; synthetic clip seed 0, '
+                                   'seeded random weights 1234' % (args.config, H, W_, 4 * H, 4 * W_, T, ' (BASELINE %s)' % tag if tag else ''),
                        'frames_per_rank': args.steps, 'parallelism': 'frame-shard x%d (reset-aligned, no collective)' % world,
-                       'window_cache': bool(cfg.cache_windows), 'frame_ids': use_ids,
-                       'pipelined_calls': bool(use_ids and not args.no_pipeline and cfg.cache_windows),
-                       'precision': 'fp16 HWC feature maps + fp16 MFMA operands, fp32 accumulate; fp32 matching features / flows / output'},
+                       'window_cache': bool(cfg.cache_windows), 'frame_ids': bool(use_ids), 'pipelined_calls': bool(pipelined),
+                       'call_surface': ('extended: frame_ids= + set_pipelined(True)' if pipelined else
+                                        'extended: frame_ids=' if use_ids else 'reference call surface'),
+                       'precision': 'fp16 HWC feature maps + fp16 hi+lo MFMA weights, fp32 accumulate; fp32 matching features / flows / '
+                                    'output; exact fp32 arg-max'},
+            'dropin_surface': dropin,
         }
         # ---- roofline of the dominant kernel (match_top2) from the events recorded in the timed region
-        ev = getattr(eng, 'kernel_events', None) or []
-        if ev:
-            ms = [a.elapsed_time(b) for a, b in ev]
+        ms = [a.elapsed_time(b) for a, b in (ev or [])]
+        if ms:
             mean_ms = sum(ms) / len(ms)
-            n_lr, n_ref = H * W_, (H // 2) * (W_ // 2)
+            hm, wm = (H // (cfg.scale // 2), W_ // (cfg.scale // 2)) if cfg.flag_HD_in else (H, W_)
+            n_lr, n_ref = ((hm // 2) * (wm // 2), (hm // 4) * (wm // 4)) if cfg.flag_HD_in else (hm * wm, (hm // 2) * (wm // 2))
             flops = 2.0 * n_lr * n_ref * 144
             ach = flops / (mean_ms * 1e-3) / 1e12
             traffic, tsrc = None, None
             pj = os.path.join(ROOT, 'profiles', 'pmc_match_top2.json')
-            if os.path.exists(pj):           # HBM bytes per launch from the PMC passes (tools/pmc_to_json.py); not live
+            if os.path.exists(pj) and (n_lr, n_ref) == (129600, 32400):   # HBM bytes per launch from the PMC passes; not live
                 try:
                     traffic = json.load(open(pj))['traffic_bytes_per_launch']
                     tsrc = 'profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
@@ -232,19 +413,57 @@ def main():
         else:
             line['roofline'] = None
         line['first_frame_ms'] = first_ms
-        line['whole_path'] = {'algorithmic_tflop_per_frame_dedup': ALG_TFLOP_PER_FRAME,
-                              'achieved_tflops_per_gpu': ALG_TFLOP_PER_FRAME * fps / world,
-                              'frac_of_f16_mfma_peak': ALG_TFLOP_PER_FRAME * fps / world / PEAK_F16_TFLOPS}
+        sv = SURVEY_DEDUP_TFLOP.get(args.config) if (H, W_, T) == (270, 480, 5) else None
+        line['whole_path'] = {
+            'algorithmic_tflop_per_frame': alg, 'breakdown': {k: round(v, 4) for k, v in parts.items()},
+            'counting': 'refvsr_amd/flops.py: every conv / GEMM of the layer list once per output frame (2 SPyNet, 1 matching, 1 encoder + '
+                        'alignment pass, %d+1 propagation steps, 1 upsampler); as the reference executes a call: %.3f' % (T - T // 2, alg_exec),
+            'achieved_tflops_per_gpu': alg * fps / world, 'frac_of_f16_mfma_peak': alg * fps / world / PEAK_F16_TFLOPS,
+            'survey_8d_tflop_per_frame': sv,
+            'frac_of_f16_mfma_peak_on_survey_figure': (sv * fps / world / PEAK_F16_TFLOPS) if sv else None}
+        if not args.no_kernels:
+            try:
+                line['kernels'] = kernel_rooflines(cfg, eng, H, W_, dev)
+            except Exception as e:  # noqa: BLE001
+                line['kernels'] = {'error': repr(e)[:300]}
+    if world > 1 and not args.no_wavefront:
+        # The extra leg must never take the headline number down: if it has not returned within the deadline (a hung
+        # send / recv, a rank that died) every rank leaves through a watchdog, rank 0 after printing the line.
+        import threading
+
+        def bail():
+            if rank == 0:
+                line['wavefront'] = {'error': 'not finished within %.0f s' % args.wavefront_timeout}
+                line['cpu_baseline'] = None
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.wavefront_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            wf = run_wavefront_leg(args, rank, world, dev, backend, H, W_)
+        except Exception as e:  # noqa: BLE001
+            wf = {'error': repr(e)[:400]}
+            if rank == 0:
+                line['wavefront'] = wf
+                line['cpu_baseline'] = None
+                print(json.dumps(line), flush=True)
+            os._exit(0)                       # the other ranks may be blocked in a collective: do not wait for them
+        dog.cancel()
+        if rank == 0:
+            line['wavefront'] = wf
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             import subprocess
             try:                     # child process + timeout: the baseline leg must never take the GPU number down
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'],
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--config', args.config,
+                                    '--size', args.size, '--frames', str(T)],
                                    capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
-                tag = [ln for ln in r.stdout.splitlines() if ln.startswith('CPU_BASELINE ')]
-                if not tag:
+                tagl = [ln for ln in r.stdout.splitlines() if ln.startswith('CPU_BASELINE ')]
+                if not tagl:
                     raise RuntimeError('no result (rc=%d): %s' % (r.returncode, r.stderr[-300:]))
-                line['cpu_baseline'] = json.loads(tag[-1][len('CPU_BASELINE '):])
-                line['cpu_baseline']['gpu_over_cpu'] = fps / line['cpu_baseline']['value']
+                line['cpu_baseline'] = json.loads(tagl[-1][len('CPU_BASELINE '):])
+                line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']
             except Exception as e:  # noqa: BLE001
                 line['cpu_baseline'] = {'error': repr(e)[:300]}
         else:

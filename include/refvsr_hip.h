@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 2   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot) */
+#define REFVSR_ABI_VERSION 3   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+                                  3: exact matching (match_patches rows32, match_refine flagging, match_exact), lean ResBlock */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -159,18 +160,27 @@ int refvsr_spynet_level_input(const float* ref, const float* supp, const float* 
 #define REFVSR_MATCH_ROWCHUNK 256 /* reference rows are padded to a multiple of this               */
 #define REFVSR_MATCH_COLBLOCK 512 /* LR columns are padded to a multiple of this                    */
 /* feat: planar fp32 [16][h][w].  Writes rows [h*w][KP] fp16 of L2-normalised reflect-padded 3x3
- * patches (channel order c*9+ky*3+kx, RefVSR_/utils.py:29-57) and inv_norm[h*w] = 1/max(|p|,1e-12). */
-int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, void* stream);
+ * patches (channel order c*9+ky*3+kx, RefVSR_/utils.py:29-57), inv_norm[h*w] = 1/max(|p|,1e-12) and, when rows32 != NULL,
+ * the un-normalised fp32 patches [h*w][144] (operand of refvsr_match_exact). */
+int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, float* rows32, void* stream);
 /* Fused cosine GEMM + column top-2 (never materialises the [n_ref x n_lr] matrix).
  * ref_rows: [n_ref_pad][KP], lr_rows: [n_lr_pad][KP] (pads zero).  row_splits >= 1 partitions the
- * reference rows over blockIdx.y.  cand_idx: int32 [n_lr][2*row_splits] (first-max-wins order). */
+ * reference rows over blockIdx.y.  cand_idx / cand_val: [n_lr][2*row_splits] (first-max-wins order). */
 int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr_rows, int n_lr, int row_splits,
                       int32_t* cand_idx, float* cand_val, void* stream);
 /* Exact fp32 re-rank of the candidates: conf[p] = max_c <lr_patch p, ref_patch c> (normalised),
- * idx[p] = that candidate (smallest index on ties, like torch.max). */
+ * idx[p] = that candidate (smallest index on ties, like torch.max).  When flagged != NULL (int32 [1 + h*w], [0] = 0 on
+ * entry): columns whose re-ranked maximum does not clear the runner-up's fp16 score (cand_val) by `margin` -- i.e. where
+ * a row outside the candidate list could still be the true arg-max -- are appended to flagged[1..], flagged[0] counts. */
 int refvsr_match_refine(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
-                        const float* inv_lr, const float* inv_ref, const int32_t* cand_idx, int ncand,
-                        float* conf, int32_t* idx, void* stream);
+                        const float* inv_lr, const float* inv_ref, const int32_t* cand_idx, const float* cand_val,
+                        int ncand, float margin, int32_t* flagged, float* conf, int32_t* idx, void* stream);
+/* Exhaustive exact-fp32 arg-max (v_mfma_f32_16x16x4_f32 = an fp32 FMA chain) for the flagged columns; overwrites their
+ * conf / idx.  ref_rows32: fp32 [n_ref][144] from refvsr_match_patches; keys: uint64 [h*w] zeroed scratch.  The flagged
+ * count is read on the device (no host synchronisation); with no flagged column the launch is a no-op. */
+int refvsr_match_exact(const float* lr_feat, int h, int w, const float* ref_rows32, int n_ref,
+                       const float* inv_lr, const float* inv_ref, const int32_t* flagged, void* keys,
+                       float* conf, int32_t* idx, void* stream);
 /* Unfused fp32 reference kernel of the same op (test / debugging aid, O(n_ref*n_lr*144) VALU). */
 int refvsr_match_naive(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
                        float* conf, int32_t* idx, void* stream);

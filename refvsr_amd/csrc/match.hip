@@ -21,17 +21,14 @@
 
 #define KP REFVSR_MATCH_KP            // halfs per row (152)
 #define ROWB (KP * 2)                 // bytes per row (304)
-#define CHUNK 128                     // reference rows per LDS stage (variants 0-3); variant 4 stages REFVSR_MATCH_ROWCHUNK
 #define COLB REFVSR_MATCH_COLBLOCK    // LR columns per workgroup
 #define KSTEPS 9
-#define CHUNK_U4 (CHUNK * ROWB / 16)  // 2432 uint4 per stage
-#define PF ((CHUNK_U4 + 511) / 512)   // uint4 prefetch registers per thread (5)
 
 // ---------------------------------------------------------------------------------------------
 // patch rows: reflect-pad 3x3 unfold + L2 normalise -> fp16 [L][KP], plus 1/norm
 // ---------------------------------------------------------------------------------------------
 __global__ void match_patches_kernel(const float* __restrict__ feat, int h, int w, f16* __restrict__ rows,
-                                     float* __restrict__ inv_norm) {
+                                     float* __restrict__ inv_norm, float* __restrict__ rows32) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= h * w) return;
     const int y = p / w, x = p - y * w;
@@ -53,6 +50,7 @@ __global__ void match_patches_kernel(const float* __restrict__ feat, int h, int 
     // 144 = 18 groups of 8 halfs; element e = c*9 + ky*3 + kx
     for (int g = 0; g < 19; ++g) {
         f16x8 o;
+        float raw[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = g * 8 + k;
@@ -60,18 +58,25 @@ __global__ void match_patches_kernel(const float* __restrict__ feat, int h, int 
             if (e < 144) {
                 const int c = e / 9, t = e - c * 9;
                 const int ky = t / 3, kx = t - ky * 3;
-                v = feat[c * plane + (size_t)yy[ky] * w + xx[kx]] * inv;
+                v = feat[c * plane + (size_t)yy[ky] * w + xx[kx]];
             }
-            o[k] = (f16)v;
+            raw[k] = v;
+            o[k] = (f16)(v * inv);
         }
         *reinterpret_cast<f16x8*>(row + g * 8) = o;
+        if (rows32 && g < 18) {                                // un-normalised fp32 patch (the exact search's operand)
+            float4* d = reinterpret_cast<float4*>(rows32 + (size_t)p * 144 + g * 8);
+            d[0] = make_float4(raw[0], raw[1], raw[2], raw[3]);
+            d[1] = make_float4(raw[4], raw[5], raw[6], raw[7]);
+        }
     }
 }
 
-extern "C" int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, void* stream) {
+extern "C" int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, float* rows32,
+                                    void* stream) {
     RV_CHECK(feat && rows && inv_norm && h >= 2 && w >= 2, "match_patches: bad args");
     hipLaunchKernelGGL(match_patches_kernel, dim3(rv_cdiv(h * w, 128)), dim3(128), 0, (hipStream_t)stream,
-                       feat, h, w, (f16*)rows, inv_norm);
+                       feat, h, w, (f16*)rows, inv_norm, rows32);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -85,31 +90,6 @@ __device__ __forceinline__ bool rv_better(float va, int ia, float vb, int ib) {
     return va > vb || (va == vb && ia < ib);
 }
 
-__device__ __forceinline__ void top2_scan(Top2& s, const f32x16& acc, int rowbase, int n_ref) {
-    // fast reject: nothing in this 16-row slice beats the running second best
-    float tm = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
-    tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])), fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]))));
-    if (tm > s.m2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                  // increasing r == increasing row index
-            const int row = rowbase + (r & 3) + 8 * (r >> 2);
-            const float v = acc[r];
-            if (row < n_ref) {
-                if (v > s.m1) { s.m2 = s.m1; s.i2 = s.i1; s.m1 = v; s.i1 = row; }
-                else if (v > s.m2) { s.m2 = v; s.i2 = row; }
-            }
-        }
-    }
-}
-
-// V = 0: first version (kept for A/B: the compiler hoists the LDS write of the prefetched chunk above
-//        the compute loop, exposing the global-load latency once per chunk).
-// V = 1: prefetch pinned -- global loads issued before, LDS writes after the MFMA loop.
-// V = 2: V1 + row-tile loop fully unrolled with the next tile's A fragments read during the current
-//        tile's MFMAs (explicit register double buffering).
-// V = 3: V2 + accumulator double buffering: the 18 MFMAs of row tile rt+1 are issued BEFORE the column
-//        reduction of tile rt, so the VALU max-trees run under the matrix pipe; the two per-column-tile
-//        slow paths share one (rare) branch.
 __device__ __forceinline__ float acc_max(const f32x16& a) {
     float t0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), t1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
     float t2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), t3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
@@ -130,178 +110,10 @@ __device__ __forceinline__ void top2_insert(Top2& s, const f32x16& acc, int rowb
     }
 }
 
-template <int V>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void match_top2_kernel(
-    const f16* __restrict__ ref_rows, int n_ref, const f16* __restrict__ lr_rows, int n_lr,
-    int chunks_per_split, int n_chunks, int row_splits, int32_t* __restrict__ cand_idx, float* __restrict__ cand_val) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][CHUNK * ROWB];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int l31 = lane & 31;
-    const int hi = lane >> 5;
-    const int col0 = blockIdx.x * COLB + wave * 64;
-    const int c_begin = blockIdx.y * chunks_per_split;
-    const int c_end = min(c_begin + chunks_per_split, n_chunks);
-
-    // stationary operand: this wave's 2 x 32 LR columns, 9 K-steps each (72 VGPRs)
-    f16x8 bfrag[2][KSTEPS];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const f16* src = lr_rows + (size_t)(col0 + ct * 32 + l31) * KP + hi * 8;
-#pragma unroll
-        for (int k = 0; k < KSTEPS; ++k) bfrag[ct][k] = *reinterpret_cast<const f16x8*>(src + k * 16);
-    }
-    Top2 st[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) { st[ct].m1 = st[ct].m2 = -INFINITY; st[ct].i1 = st[ct].i2 = 0; }
-
-    const uint4* gsrc = reinterpret_cast<const uint4*>(ref_rows);
-    uint4 pf[PF];
-    // per-thread staging slots: slot k covers uint4 index tid + 512*k; the last one is clamped (branch-free load)
-    int pfi[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) pfi[k] = min(tid + k * 512, CHUNK_U4 - 1);
-    const bool last_ok = (tid + (PF - 1) * 512) < CHUNK_U4;
-
-    if (c_begin < c_end) {                     // prologue: first chunk straight to LDS buffer 0
-#pragma unroll
-        for (int k = 0; k < PF; ++k) pf[k] = gsrc[(size_t)c_begin * CHUNK_U4 + pfi[k]];
-#pragma unroll
-        for (int k = 0; k < PF; ++k)
-            if (k < PF - 1 || last_ok) reinterpret_cast<uint4*>(lds[0])[pfi[k]] = pf[k];
-    }
-    __syncthreads();
-
-    int buf = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-        const bool has_next = (c + 1 < c_end);
-        if (has_next) {
-#pragma unroll
-            for (int k = 0; k < PF; ++k) pf[k] = gsrc[(size_t)(c + 1) * CHUNK_U4 + pfi[k]];
-        }
-        if (V >= 1) asm volatile("" ::: "memory");        // keep the loads above, in flight during the MFMAs
-        const unsigned char* L = lds[buf];
-        if (V == 3) {
-            constexpr int NRT = CHUNK / 32;
-            f16x8 afA[KSTEPS], afB[KSTEPS];
-            const unsigned char* ap = L + (size_t)l31 * ROWB + hi * 16;
-#pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) afA[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
-            f32x16 accA0, accA1, accB0, accB1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accA0[r] = 0.0f; accA1[r] = 0.0f; }
-#pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) {
-                accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[0][k], accA0, 0, 0, 0);
-                accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[1][k], accA1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-                f32x16& c0 = (rt & 1) ? accB0 : accA0;           // finished tile
-                f32x16& c1 = (rt & 1) ? accB1 : accA1;
-                f32x16& n0 = (rt & 1) ? accA0 : accB0;           // tile in flight
-                f32x16& n1 = (rt & 1) ? accA1 : accB1;
-                f16x8* nf = (rt & 1) ? afA : afB;
-                if (rt + 1 < NRT) {
-                    const unsigned char* an = ap + (size_t)(rt + 1) * 32 * ROWB;
-#pragma unroll
-                    for (int k = 0; k < KSTEPS; ++k) nf[k] = *reinterpret_cast<const f16x8*>(an + k * 32);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { n0[r] = 0.0f; n1[r] = 0.0f; }
-#pragma unroll
-                    for (int k = 0; k < KSTEPS; ++k) {
-                        n0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(nf[k], bfrag[0][k], n0, 0, 0, 0);
-                        n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(nf[k], bfrag[1][k], n1, 0, 0, 0);
-                    }
-                }
-                const float t0 = acc_max(c0), t1 = acc_max(c1);
-                if (t0 > st[0].m2 || t1 > st[1].m2) {
-                    const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
-                    if (t0 > st[0].m2) top2_insert(st[0], c0, rowbase, n_ref);
-                    if (t1 > st[1].m2) top2_insert(st[1], c1, rowbase, n_ref);
-                }
-            }
-        } else if (V <= 1) {
-#pragma unroll 1
-            for (int rt = 0; rt < CHUNK / 32; ++rt) {
-                f16x8 afrag[KSTEPS];
-                const unsigned char* ap = L + (size_t)(rt * 32 + l31) * ROWB + hi * 16;
-#pragma unroll
-                for (int k = 0; k < KSTEPS; ++k) afrag[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
-                f32x16 acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-#pragma unroll
-                for (int k = 0; k < KSTEPS; ++k) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[k], bfrag[0][k], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[k], bfrag[1][k], acc1, 0, 0, 0);
-                }
-                const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
-                top2_scan(st[0], acc0, rowbase, n_ref);
-                top2_scan(st[1], acc1, rowbase, n_ref);
-            }
-        } else {
-            f16x8 afA[KSTEPS], afB[KSTEPS];
-            const unsigned char* ap = L + (size_t)l31 * ROWB + hi * 16;
-#pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) afA[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
-#pragma unroll
-            for (int rt = 0; rt < CHUNK / 32; ++rt) {
-                f16x8* cur = (rt & 1) ? afB : afA;
-                f16x8* nxt = (rt & 1) ? afA : afB;
-                if (rt + 1 < CHUNK / 32) {
-                    const unsigned char* an = ap + (size_t)(rt + 1) * 32 * ROWB;
-#pragma unroll
-                    for (int k = 0; k < KSTEPS; ++k) nxt[k] = *reinterpret_cast<const f16x8*>(an + k * 32);
-                }
-                f32x16 acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-#pragma unroll
-                for (int k = 0; k < KSTEPS; ++k) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[k], bfrag[0][k], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[k], bfrag[1][k], acc1, 0, 0, 0);
-                }
-                const int rowbase = c * CHUNK + rt * 32 + 4 * hi;
-                top2_scan(st[0], acc0, rowbase, n_ref);
-                top2_scan(st[1], acc1, rowbase, n_ref);
-            }
-        }
-        if (V >= 1) asm volatile("" ::: "memory");        // ... and the LDS writes below
-        if (has_next) {
-#pragma unroll
-            for (int k = 0; k < PF; ++k)
-                if (k < PF - 1 || last_ok) reinterpret_cast<uint4*>(lds[buf ^ 1])[pfi[k]] = pf[k];
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    // merge the two half-waves (same column, disjoint row subsets), then lanes 0..31 publish
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        Top2 a = st[ct], b;
-        b.m1 = __shfl_xor(a.m1, 32); b.m2 = __shfl_xor(a.m2, 32);
-        b.i1 = __shfl_xor(a.i1, 32); b.i2 = __shfl_xor(a.i2, 32);
-        Top2 o;
-        if (rv_better(a.m1, a.i1, b.m1, b.i1)) {
-            o.m1 = a.m1; o.i1 = a.i1;
-            if (rv_better(a.m2, a.i2, b.m1, b.i1)) { o.m2 = a.m2; o.i2 = a.i2; } else { o.m2 = b.m1; o.i2 = b.i1; }
-        } else {
-            o.m1 = b.m1; o.i1 = b.i1;
-            if (rv_better(b.m2, b.i2, a.m1, a.i1)) { o.m2 = b.m2; o.i2 = b.i2; } else { o.m2 = a.m1; o.i2 = a.i1; }
-        }
-        const int col = col0 + ct * 32 + l31;
-        if (hi == 0 && col < n_lr) {
-            const size_t o2 = ((size_t)col * row_splits + blockIdx.y) * 2;
-            cand_idx[o2] = o.i1; cand_idx[o2 + 1] = o.i2;
-            cand_val[o2] = o.m1; cand_val[o2 + 1] = o.m2;
-        }
-    }
-}
-
-// Variant 4: variant 3's schedule (accumulator double buffering) on 256-row stages: one barrier per 288
+// Schedule history (round 1, identical outputs, MI355X): plain loop 2.0 ms -> prefetch pinned around the MFMA loop 1.95 ->
+// A-fragment double buffering 1.69 -> accumulator double buffering + branch-free top-2 (the VALU max-trees run under the
+// matrix pipe) 1.26 -> 256-row stages (below) 1.17 ms.  The earlier variants were removed from the library in round 2.
+// Accumulator double buffering on 256-row stages: one barrier per 288
 // MFMAs/wave, LDS 2 x 76 KiB, the next stage fetched in two halves so only 20 VGPRs are pinned.
 // (Keeping a second A-fragment set in flight as well needs > 256 VGPRs at 2 waves/SIMD and spills.)
 #define CHUNK4 REFVSR_MATCH_ROWCHUNK
@@ -460,27 +272,13 @@ extern "C" int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr
                                  int32_t* cand_idx, float* cand_val, void* stream) {
     RV_CHECK(ref_rows && lr_rows && cand_idx && cand_val && n_ref >= 2 && n_lr >= 1 && row_splits >= 1,
              "match_top2: bad args");
-    static int variant = -1;                 // tuning knob (A/B of schedules inside one process): REFVSR_MATCH_VARIANT
-    const char* ev = getenv("REFVSR_MATCH_VARIANT");
-    const int want = ev ? atoi(ev) : 4;
-    if (want != variant) variant = (want >= 0 && want <= 4) ? want : 4;
-    const int chunk_rows = (variant == 4) ? CHUNK4 : CHUNK;
-    const int n_chunks = rv_cdiv(n_ref, chunk_rows);
+    const int n_chunks = rv_cdiv(n_ref, CHUNK4);
     RV_CHECK(row_splits <= n_chunks, "match_top2: row_splits (%d) > row chunks (%d)", row_splits, n_chunks);
     const int cps = rv_cdiv(n_chunks, row_splits);
     RV_CHECK((row_splits - 1) * cps < n_chunks, "match_top2: empty row split (use fewer splits)");
     dim3 grid(rv_cdiv(n_lr, COLB), row_splits);
-#define RV_MATCH_LAUNCH(V)                                                                                   \
-    hipLaunchKernelGGL(match_top2_kernel<V>, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, \
-                       n_ref, (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val)
-    if (variant == 0) RV_MATCH_LAUNCH(0);
-    else if (variant == 1) RV_MATCH_LAUNCH(1);
-    else if (variant == 2) RV_MATCH_LAUNCH(2);
-    else if (variant == 3) RV_MATCH_LAUNCH(3);
-    else
-        hipLaunchKernelGGL(match_top2_kernel_v4, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, n_ref,
-                           (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val);
-#undef RV_MATCH_LAUNCH
+    hipLaunchKernelGGL(match_top2_kernel_v4, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, n_ref,
+                       (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -507,7 +305,8 @@ __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, 
 
 __global__ void match_refine_kernel(const float* __restrict__ lf, int h, int w, const float* __restrict__ rf, int hr,
                                     int wr, const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
-                                    const int32_t* __restrict__ cand, int ncand, float* __restrict__ conf,
+                                    const int32_t* __restrict__ cand, const float* __restrict__ cand_val, int ncand,
+                                    float margin, int32_t* __restrict__ flagged, float* __restrict__ conf,
                                     int32_t* __restrict__ idx) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= h * w) return;
@@ -528,15 +327,149 @@ __global__ void match_refine_kernel(const float* __restrict__ lf, int h, int w, 
     }
     conf[p] = best;
     idx[p] = bi;
+    // Can a row OUTSIDE the candidate list beat `best`?  Its fp16-GEMM score is <= the runner-up's (the second entry of
+    // every row split), its exact value at most `margin` above that: if best clears that bound the answer is final,
+    // otherwise the column goes to the exhaustive fp32 search (refvsr_match_exact).
+    if (flagged) {
+        float m2 = -INFINITY;
+        for (int k = 1; k < ncand; k += 2) m2 = fmaxf(m2, cand_val[(size_t)p * ncand + k]);
+        if (!(best - m2 >= margin)) flagged[1 + atomicAdd(flagged, 1)] = p;
+    }
 }
 
 extern "C" int refvsr_match_refine(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
-                                   const float* inv_lr, const float* inv_ref, const int32_t* cand_idx, int ncand,
-                                   float* conf, int32_t* idx, void* stream) {
+                                   const float* inv_lr, const float* inv_ref, const int32_t* cand_idx,
+                                   const float* cand_val, int ncand, float margin, int32_t* flagged, float* conf,
+                                   int32_t* idx, void* stream) {
     RV_CHECK(lr_feat && ref_feat && inv_lr && inv_ref && cand_idx && conf && idx, "match_refine: null pointer");
     RV_CHECK(h >= 2 && w >= 2 && hr >= 2 && wr >= 2 && ncand >= 1, "match_refine: bad sizes");
+    RV_CHECK(flagged == nullptr || (cand_val != nullptr && ncand % 2 == 0), "match_refine: flagging needs the top-2 values");
     hipLaunchKernelGGL(match_refine_kernel, dim3(rv_cdiv(h * w, 128)), dim3(128), 0, (hipStream_t)stream,
-                       lr_feat, h, w, ref_feat, hr, wr, inv_lr, inv_ref, cand_idx, ncand, conf, idx);
+                       lr_feat, h, w, ref_feat, hr, wr, inv_lr, inv_ref, cand_idx, cand_val, ncand, margin, flagged, conf, idx);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exhaustive exact-fp32 search for the columns the fp16 GEMM cannot decide
+// ---------------------------------------------------------------------------------------------
+// The fp16 operands of match_top2 perturb a correlation by ~3e-5 (up to ~1e-4 for peaky patches).  Where the best two
+// candidates are further apart than that, the top-2 + fp32 re-rank is provably the exact arg-max; where they are not
+// (flat or repetitive image regions: many reference patches nearly equally similar) a THIRD row may be the true maximum.
+// Those columns -- flagged by match_refine -- are searched exhaustively here on v_mfma_f32_16x16x4_f32 (bitwise an fp32
+// FMA chain over k = 0..143 in order, i.e. the same value patch_dot computes): 64 flagged columns per workgroup pass,
+// the reference rows (fp32 [n_ref][144], written by match_patches) split over the 4 waves x gridDim.y; per column
+// (value, first index) maxima are merged through a 64-bit atomicMax key.  The list is read on the device: no host sync.
+#define EX_COLS 64
+__device__ __forceinline__ unsigned long long ex_key(float v, int row) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                // order-preserving float -> uint
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)row);   // ties: smaller row wins
+}
+
+__global__ __launch_bounds__(256) void match_exact_kernel(const float* __restrict__ lf, int h, int w,
+                                                          const float* __restrict__ ref32, int n_ref,
+                                                          const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
+                                                          const int32_t* __restrict__ flagged,
+                                                          unsigned long long* __restrict__ keys) {
+    const int count = flagged[0];
+    const int ngroups = (count + EX_COLS - 1) / EX_COLS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int n_tiles = (n_ref + 15) >> 4;
+    // work item = (column group, row part): with few flagged columns the reference rows are split further so that the
+    // whole chip works on them (the count is only known here, on the device)
+    const int nsplit = max(1, min(64, (2 * (int)gridDim.x) / max(ngroups, 1)));
+    const int nparts = nsplit * 4;
+    const size_t plane = (size_t)h * w;
+    for (int item = blockIdx.x; item < ngroups * nsplit; item += gridDim.x) {
+        const int g = item / nsplit;
+        const int part = (item - g * nsplit) * 4 + wave;
+        // B operand: 4 tiles of 16 flagged columns, K-step s supplies k = 4s + kq
+        float b[4][36];
+        float il[4];
+        int colv[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int fi = g * EX_COLS + ct * 16 + n16;
+            const int col = fi < count ? flagged[1 + fi] : -1;
+            colv[ct] = col;
+            const int cc = max(col, 0);
+            const int y = cc / w, x = cc - y * w;
+            il[ct] = col >= 0 ? inv_lr[cc] : 0.0f;
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                const int e = 4 * s + kq;
+                const int c = e / 9, t = e - c * 9;
+                const int ky = t / 3, kx = t - ky * 3;
+                b[ct][s] = lf[c * plane + (size_t)rv_reflect(y + ky - 1, h) * w + rv_reflect(x + kx - 1, w)];
+            }
+        }
+        float best[4];
+        int besti[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { best[ct] = -INFINITY; besti[ct] = 0x7fffffff; }
+        for (int tile = part; tile < n_tiles; tile += nparts) {
+            const float* arow = ref32 + (size_t)min(tile * 16 + n16, n_ref - 1) * 144 + kq;
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                const float a = arow[4 * s];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[ct][s], acc[ct], 0, 0, 0);
+            }
+            // lane holds rows 4*kq + j (j = 0..3) of column n16: increasing j == increasing row, strict > keeps the first
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = tile * 16 + 4 * kq + j;
+                if (row < n_ref) {
+                    const float ir = inv_ref[row];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const float v = acc[ct][j] * il[ct] * ir;
+                        if (v > best[ct]) { best[ct] = v; besti[ct] = row; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            unsigned long long k = besti[ct] == 0x7fffffff ? 0ull : ex_key(best[ct], besti[ct]);
+            const unsigned long long k1 = __shfl_xor(k, 16);
+            k = k1 > k ? k1 : k;
+            const unsigned long long k2 = __shfl_xor(k, 32);
+            k = k2 > k ? k2 : k;
+            if (kq == 0 && colv[ct] >= 0 && k != 0ull) atomicMax(&keys[g * EX_COLS + ct * 16 + n16], k);
+        }
+    }
+}
+
+__global__ void match_exact_finish_kernel(const int32_t* __restrict__ flagged, const unsigned long long* __restrict__ keys,
+                                          float* __restrict__ conf, int32_t* __restrict__ idx) {
+    const int count = flagged[0];
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < count; f += gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[f];
+        unsigned u = (unsigned)(k >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        const int col = flagged[1 + f];
+        conf[col] = __uint_as_float(u);
+        idx[col] = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+    }
+}
+
+extern "C" int refvsr_match_exact(const float* lr_feat, int h, int w, const float* ref_rows32, int n_ref,
+                                  const float* inv_lr, const float* inv_ref, const int32_t* flagged, void* keys,
+                                  float* conf, int32_t* idx, void* stream) {
+    RV_CHECK(lr_feat && ref_rows32 && inv_lr && inv_ref && flagged && keys && conf && idx, "match_exact: null pointer");
+    RV_CHECK(h >= 2 && w >= 2 && n_ref >= 2, "match_exact: bad sizes");
+    // fixed grid, one workgroup per CU (the flagged count lives on the device; the kernel sizes its work items from it)
+    hipLaunchKernelGGL(match_exact_kernel, dim3(rv_num_cus()), dim3(256), 0, (hipStream_t)stream, lr_feat, h, w, ref_rows32, n_ref,
+                       inv_lr, inv_ref, flagged, (unsigned long long*)keys);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(match_exact_finish_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, flagged,
+                       (const unsigned long long*)keys, conf, idx);
     RV_LAUNCH_CHECK();
     return 0;
 }

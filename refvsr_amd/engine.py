@@ -147,6 +147,7 @@ class Engine(object):
         self.hd = bool(config.flag_HD_in)
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
+        self.match_margin = float(getattr(config, 'match_exact_margin', ops.MATCH_EXACT_MARGIN))
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
@@ -193,6 +194,48 @@ class Engine(object):
         self.fw_feat_up = ops.pack_nhwc16(st['feat_up'].contiguous())
         self.fw_conf = st['conf'].contiguous()
         self.frame_itr_num = int(st['frame_itr_num'])
+
+    # ---- the same state as ONE contiguous device buffer in the engine's native layouts (the multi-GPU hand-off message):
+    #      [16-byte header: frame_itr_num, h, w, C as int32][feat fp16 HWC][feat_up fp16 HWC][flow fp32 planar][conf fp32 planar]
+    #      = (5C*2 + 12) * h*w + 16 bytes -- half the bytes of the planar fp32 export, no unpack / pack kernels, one message
+    def state_nbytes(self, h, w):
+        return 16 + h * w * (2 * self.C + 8 * self.C + 8 + 4)
+
+    def export_state_packed(self):
+        if self.fw_feat is None:
+            return None
+        h, w = self.fw_feat.shape[:2]
+        buf = torch.empty(self.state_nbytes(h, w), dtype=torch.uint8, device=self.fw_feat.device)
+        buf[:16].view(torch.int32).copy_(torch.tensor([self.frame_itr_num, h, w, self.C], dtype=torch.int32), non_blocking=False)
+        o = 16
+        for t in (self.fw_feat, self.fw_feat_up, self.fw_flow, self.fw_conf):
+            n = t.numel() * t.element_size()
+            buf[o:o + n].view(t.dtype).copy_(t.reshape(-1))
+            o += n
+        return buf
+
+    def import_state_packed(self, buf):
+        hdr = buf[:16].view(torch.int32).cpu().tolist()
+        itr, h, w, C = hdr
+        assert C == self.C and buf.numel() == self.state_nbytes(h, w), 'state buffer does not match this model'
+        dev = buf.device
+        o = 16
+
+        def take(shape, dtype):
+            nonlocal o
+            n = 1
+            for d in shape:
+                n *= d
+            n *= torch.empty((), dtype=dtype).element_size()
+            t = buf[o:o + n].view(dtype).view(shape).clone()
+            o += n
+            return t
+        self.fw_feat = take((h, w, C), torch.float16)
+        self.fw_feat_up = take((2 * h, 2 * w, C), torch.float16)
+        self.fw_flow = take((2, h, w), torch.float32)
+        self.fw_conf = take((1, h, w), torch.float32)
+        self.frame_itr_num = int(itr)
+        assert dev == self.fw_feat.device
 
     # ------------------------------------------------------------------ building blocks
     def cw(self, name):
@@ -297,17 +340,18 @@ class Engine(object):
         lr_f = extract(lr_n)
         ref_f = extract(ops.avgpool2(ref_n))
         lr_rows, inv_lr = ops.match_patches(lr_f, ops.hip.MATCH_COLBLOCK)
-        ref_rows, inv_ref = ops.match_patches(ref_f, ops.hip.MATCH_ROWCHUNK)
+        ref_rows, inv_ref, ref_rows32 = ops.match_patches(ref_f, ops.hip.MATCH_ROWCHUNK, want_rows32=True)
         n_lr = lr_f.shape[1] * lr_f.shape[2]
         n_ref = ref_f.shape[1] * ref_f.shape[2]
         if self.kernel_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        cand, _ = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, self.match_row_splits)
+        cand, cand_val = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, self.match_row_splits)
         if self.kernel_events is not None:
             e1.record()
             self.kernel_events.append((e0, e1))
-        conf, idx = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand)
+        # exact fp32 re-rank of the top-2 + exhaustive fp32 search of the columns the fp16 GEMM cannot decide
+        conf, idx, _ = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand, cand_val, self.match_margin, ref_rows32)
         conf = conf.view(1, lr_f.shape[1], lr_f.shape[2])
         grid = (lr_f.shape[1], lr_f.shape[2])
         if grid[0] != h:                                                           # attention.py:96-98 (HD)
@@ -670,7 +714,7 @@ class Engine(object):
         frame, prepare frames 0..ctr-1 now instead of lazily in phase B."""
         t, h, w = self._check_window(lrs, refs)
         ctr, dev = t // 2, lrs.device
-        with ops.on_stream(torch.cuda.current_stream()):
+        with torch.cuda.device(dev), ops.on_stream(torch.cuda.current_stream(dev)):
             zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if bool(self.cfg.EVAL.is_gradio) else None
             fr = self._frames(lrs, refs, frame_ids)
             flow = (lambda a, b: zero_flow) if zero_flow is not None else (lambda a, b: self.flow(fr[a], fr[b]))
@@ -686,9 +730,11 @@ class Engine(object):
         return dict(fr=fr, flows=flows, zero_flow=zero_flow, bw_up=bw_up, conf_bw=conf_bw, t=t, h=h, w=w)
 
     @torch.no_grad()
-    def phase_b(self, pa, is_first_frame, want_vis=False):
+    def phase_b(self, pa, is_first_frame, want_vis=False, after_state=None):
         """The state-dependent rest of forward(): forward-branch step (RefVSR.py:240-283) + BW/FW fusion and upsampler
-        (:288-297).  Must be called in frame order; (phase_a, phase_b) of a frame == forward() of that frame."""
+        (:288-297).  Must be called in frame order; (phase_a, phase_b) of a frame == forward() of that frame.
+        after_state: callable invoked once the carried state of this frame is final (before the upsampler is enqueued) --
+        the multi-GPU wavefront starts its hand-off send there, under the upsampler."""
         fr, t, h, w = pa['fr'], pa['t'], pa['h'], pa['w']
         ctr = t // 2
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
@@ -709,10 +755,12 @@ class Engine(object):
                 for i in range(0, ctr):
                     self.prepare_frame(fr[i])                  # no-op when phase A had the hint
             feat, feat_up, conf = self._forward_branch(fr, flow, t, h, w, is_first_frame)
-            out = self.compute_up(pa['bw_up'], feat_up, pa['conf_bw'], conf, fr[ctr].lr)
             if is_first_frame:                                                      # :292-295
                 self.frame_itr_num = 0
             self.frame_itr_num += 1
+            if after_state is not None:
+                after_state()
+            out = self.compute_up(pa['bw_up'], feat_up, pa['conf_bw'], conf, fr[ctr].lr)
             vis = None
             if want_vis:
                 vis = collections.OrderedDict()

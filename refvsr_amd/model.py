@@ -159,10 +159,12 @@ class Network(nn.Module):
         return [self._engines[b].phase_a(lrs[b], refs[b], None if frame_ids is None else [(b, f) for f in frame_ids],
                                          first_hint) for b in range(lrs.shape[0])]
 
-    def phase_b(self, handles, is_first_frame, is_log=False):
-        """State-dependent rest (forward-branch step + upsampler); same return value as forward()."""
+    def phase_b(self, handles, is_first_frame, is_log=False, after_state=None):
+        """State-dependent rest (forward-branch step + upsampler); same return value as forward().
+        after_state: see Engine.phase_b (called for sample 0)."""
         want_vis = bool(is_log and self.config.save_sample)
-        res = [self._engines[b].phase_b(h, bool(is_first_frame), want_vis) for b, h in enumerate(handles)]
+        res = [self._engines[b].phase_b(h, bool(is_first_frame), want_vis, after_state if b == 0 else None)
+               for b, h in enumerate(handles)]
         outs = collections.OrderedDict()
         if is_log:
             outs['vis'] = collections.OrderedDict()

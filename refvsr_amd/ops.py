@@ -334,15 +334,16 @@ def _round_up(a, b):
     return (a + b - 1) // b * b
 
 
-def match_patches(feat, row_pad):
-    """feat planar [16,h,w] -> (rows fp16 [pad(h*w), KP] zero padded, inv_norm fp32 [h*w])."""
+def match_patches(feat, row_pad, want_rows32=False):
+    """feat planar [16,h,w] -> (rows fp16 [pad(h*w), KP] zero padded, inv_norm fp32 [h*w][, rows32 fp32 [h*w,144]])."""
     _planar(feat, 16)
     h, w = feat.shape[1:]
     n = h * w
     rows = torch.zeros((_round_up(n, row_pad), hip.MATCH_KP), dtype=torch.float16, device=feat.device)
     inv = torch.empty((n,), dtype=torch.float32, device=feat.device)
-    hip.check(hip.lib().refvsr_match_patches(_ptr(feat), h, w, _ptr(rows), _ptr(inv), _stream()), 'match_patches')
-    return rows, inv
+    rows32 = torch.empty((n, 144), dtype=torch.float32, device=feat.device) if want_rows32 else None
+    hip.check(hip.lib().refvsr_match_patches(_ptr(feat), h, w, _ptr(rows), _ptr(inv), _ptr(rows32), _stream()), 'match_patches')
+    return (rows, inv, rows32) if want_rows32 else (rows, inv)
 
 
 def match_top2(ref_rows, n_ref, lr_rows, n_lr, row_splits=1):
@@ -355,7 +356,16 @@ def match_top2(ref_rows, n_ref, lr_rows, n_lr, row_splits=1):
     return ci, cv
 
 
-def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand):
+# fp16-GEMM scores of rows outside the candidate list are trusted to this margin; columns whose exact maximum does not
+# clear the runner-up's fp16 score by it are searched exhaustively in fp32 (refvsr_match_exact).  The fp16 operand
+# rounding perturbs a correlation by ~3e-5 (measured), bounded by 2^-10 = 9.8e-4 in the worst case.
+MATCH_EXACT_MARGIN = 2.5e-4
+
+
+def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cand_val=None, margin=None, ref_rows32=None):
+    """Exact re-rank of the candidates; with cand_val / margin / ref_rows32 also the exhaustive exact search of the
+    columns the fp16 GEMM cannot decide.  margin = inf searches EVERY column exhaustively (test aid).
+    Returns (conf, idx) or (conf, idx, flagged int32 [1 + n], [0] = count) when flagging is on."""
     _planar(lr_feat, 16)
     _planar(ref_feat, 16)
     h, w = lr_feat.shape[1:]
@@ -363,9 +373,24 @@ def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand):
     assert cand.dtype == torch.int32 and cand.shape[0] == h * w and cand.is_contiguous()
     conf = torch.empty((h * w,), dtype=torch.float32, device=lr_feat.device)
     idx = torch.empty((h * w,), dtype=torch.int32, device=lr_feat.device)
+    if margin is None:
+        hip.check(hip.lib().refvsr_match_refine(_ptr(lr_feat), h, w, _ptr(ref_feat), hr, wr, _ptr(inv_lr), _ptr(inv_ref),
+                                                _ptr(cand), None, cand.shape[1], 0.0, None, _ptr(conf), _ptr(idx), _stream()),
+                  'match_refine')
+        return conf, idx
+    assert cand_val is not None and ref_rows32 is not None and cand_val.shape == cand.shape and cand_val.is_contiguous()
+    assert ref_rows32.dtype == torch.float32 and tuple(ref_rows32.shape) == (hr * wr, 144) and ref_rows32.is_contiguous()
+    # one zeroed scratch allocation: [flag count + list (int32 1 + n, padded to 8 bytes)] [merge keys uint64 n]
+    n = h * w
+    fl_words = (n + 2) // 2 * 2
+    scratch = torch.zeros(fl_words + 2 * n, dtype=torch.int32, device=lr_feat.device)
+    flagged, keys = scratch[:n + 1], scratch[fl_words:]
     hip.check(hip.lib().refvsr_match_refine(_ptr(lr_feat), h, w, _ptr(ref_feat), hr, wr, _ptr(inv_lr), _ptr(inv_ref),
-                                            _ptr(cand), cand.shape[1], _ptr(conf), _ptr(idx), _stream()), 'match_refine')
-    return conf, idx
+                                            _ptr(cand), _ptr(cand_val), cand.shape[1], float(margin), _ptr(flagged), _ptr(conf),
+                                            _ptr(idx), _stream()), 'match_refine')
+    hip.check(hip.lib().refvsr_match_exact(_ptr(lr_feat), h, w, _ptr(ref_rows32), hr * wr, _ptr(inv_lr), _ptr(inv_ref),
+                                           _ptr(flagged), _ptr(keys), _ptr(conf), _ptr(idx), _stream()), 'match_exact')
+    return conf, idx, flagged
 
 
 def match_naive(lr_feat, ref_feat):

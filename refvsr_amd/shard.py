@@ -54,16 +54,34 @@ def needs_handoff(start, reset_branch):
     return start != 0 and not (reset_branch and start % reset_branch == 0)
 
 
-def send_state(state, dst, device):
-    """state: dict of planar fp32 tensors + frame_itr_num (Engine.export_state())."""
+def send_state(state, dst, device, async_op=False):
+    """Hand the forward-branch state to rank `dst`.
+
+    * `state` a tensor: the packed device buffer of Engine.export_state_packed() (fp16 HWC maps + fp32 flow / conf in
+      ONE message, 32.7 MB for RefVSR_small at 270p) -- the RCCL path: one send, no unpack kernels; `async_op=True`
+      returns the work handle of an isend so that the sender's remaining kernels (the upsampler of its last frame) run
+      under the transfer.
+    * `state` a dict of planar fp32 tensors + frame_itr_num (executor-agnostic form, e.g. the oracle on gloo)."""
+    if torch.is_tensor(state):
+        buf = state if str(state.device).startswith(str(device)) else state.to(device)
+        if async_op:
+            return dist.isend(buf, dst)
+        dist.send(buf, dst)
+        return None
     meta = torch.tensor([float(state['frame_itr_num'])] + [float(d) for k in STATE_KEYS for d in state[k].shape[-2:]],
                         dtype=torch.float32, device=device)
     dist.send(meta, dst)
     for k in STATE_KEYS:
         dist.send(state[k].contiguous().to(device), dst)
+    return None
 
 
-def recv_state(src, channels, device):
+def recv_state(src, channels, device, nbytes=None):
+    """Counterpart of send_state; nbytes: size of the packed buffer (Engine.state_nbytes) -> returns that buffer."""
+    if nbytes is not None:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        dist.recv(buf, src)
+        return buf
     meta = torch.empty(1 + 2 * len(STATE_KEYS), dtype=torch.float32, device=device)
     dist.recv(meta, src)
     meta = meta.cpu().tolist()
@@ -77,6 +95,20 @@ def recv_state(src, channels, device):
     return st
 
 
+def _import(executor, src, channels, device):
+    """Receive the state from rank src into the executor (packed single-message form when the executor offers it)."""
+    nb = executor.state_nbytes() if hasattr(executor, 'state_nbytes') else None
+    st = recv_state(src, channels, device, nb)
+    if nb is not None:
+        executor.import_state_packed(st)
+    else:
+        executor.import_state(st)
+
+
+def _export(executor):
+    return executor.export_state_packed() if hasattr(executor, 'export_state_packed') else executor.export_state()
+
+
 def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels, device, aligned=False,
                 on_result=None):
     """Run this rank's share of an nframes clip.
@@ -87,7 +119,7 @@ def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels
     start, end = partition(nframes, world, reset_branch, aligned)[rank]
     results = {}
     if end > start and needs_handoff(start, reset_branch):
-        executor.import_state(recv_state(rank - 1, channels, device))
+        _import(executor, rank - 1, channels, device)
         first = False
     else:
         first = True
@@ -100,7 +132,7 @@ def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels
             on_result(f, out)
     nxt = partition(nframes, world, reset_branch, aligned)[rank + 1] if rank + 1 < world else None
     if nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch):
-        send_state(executor.export_state(), rank + 1, device)
+        send_state(_export(executor), rank + 1, device)
     return results
 
 
@@ -120,17 +152,65 @@ def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channe
         handles[f] = executor.phase_a(lrs, refs, f, hint)
     results = {}
     if end > start and needs_handoff(start, reset_branch):        # ---- phase B: wavefront behind the hand-off
-        executor.import_state(recv_state(rank - 1, channels, device))
+        _import(executor, rank - 1, channels, device)
         first = False
     else:
         first = True
+    nxt = parts[rank + 1] if rank + 1 < world else None
+    handoff = nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch)
+    pending = []
+
+    def start_send():        # called by phase_b of the LAST local frame as soon as its carried state is final:
+        pending.append(send_state(_export(executor), rank + 1, device, async_op=True))   # the upsampler runs under the send
+    early = handoff and getattr(executor, 'supports_after_state', False)
     for f in range(start, end):
-        out = executor.phase_b(handles.pop(f), first)
+        if early and f == end - 1:
+            out = executor.phase_b(handles.pop(f), first, after_state=start_send)
+        else:
+            out = executor.phase_b(handles.pop(f), first)
         first = False
         results[f] = out
         if on_result is not None:
             on_result(f, out)
-    nxt = parts[rank + 1] if rank + 1 < world else None
-    if nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch):
-        send_state(executor.export_state(), rank + 1, device)
+    if handoff and not pending:
+        send_state(_export(executor), rank + 1, device)
+    for wk in pending:
+        if wk is not None:
+            wk.wait()
     return results
+
+
+class EngineExecutor(object):
+    """Adapter of the HIP `SRNet` (refvsr_amd/model.py) to run_sharded / run_wavefront: windows are named by their frame
+    indices (id-keyed window cache, no content compare), the hand-off uses the packed single-message state."""
+    supports_after_state = True
+
+    def __init__(self, net, device, h, w, nframes, frame_num, keep_on_device=True):
+        self.net, self.dev, self.h, self.w, self.nframes, self.t = net, device, h, w, nframes, frame_num
+        self.keep = keep_on_device
+        self.eng = net.Network.ensure_engines(1, device)[0]
+
+    def _ids(self, f):
+        return [min(max(f - self.t // 2 + k, 0), self.nframes - 1) for k in range(self.t)]
+
+    def _out(self, r):
+        return r if self.keep else r.cpu()
+
+    def __call__(self, lrs, refs, first, f=None):
+        ids = None if f is None else self._ids(f)
+        return self._out(self.net(lrs[None].to(self.dev), refs[None].to(self.dev), first, frame_ids=ids)['result'][0])
+
+    def phase_a(self, lrs, refs, f, hint):
+        return self.net.Network.phase_a(lrs[None].to(self.dev), refs[None].to(self.dev), frame_ids=self._ids(f), first_hint=hint)
+
+    def phase_b(self, handles, first, after_state=None):
+        return self._out(self.net.Network.phase_b(handles, first, after_state=after_state)['result'][0])
+
+    def state_nbytes(self):
+        return self.eng.state_nbytes(self.h, self.w)
+
+    def export_state_packed(self):
+        return self.eng.export_state_packed()
+
+    def import_state_packed(self, buf):
+        self.eng.import_state_packed(buf.to(self.dev))

@@ -129,15 +129,21 @@ def _gain(name):
 
 
 PLAUSIBLE_HEAD_GAIN = 0.1
+PLAUSIBLE_STATE_GAIN = 0.5
 
 
 def make_state_dict(config, seed=1234, dtype=torch.float32, variant=None):
     """Deterministic synthetic weights (fan-in scaled uniform), keyed exactly like the reference.
 
-    variant='plausible': the same draw with the output head (`conv_last`) damped by PLAUSIBLE_HEAD_GAIN, so that the
-    result is the bicubic base plus a residual of about the size of the bicubic error (PSNR vs GT ~27 dB on the
-    synthetic clips instead of ~12 dB) -- the operating point at which a PSNR difference is as sensitive to the
-    build's error as it is for a trained model.  Every layer in front of the head is unchanged."""
+    variant='plausible': the same draw, made to behave like a trained network in the two respects that matter for a
+    parity measurement.  (1) The output head (`conv_last`) is damped by PLAUSIBLE_HEAD_GAIN: the result is the bicubic
+    base plus a residual of about the size of the bicubic error (PSNR vs GT ~27-28 dB on the synthetic clips instead
+    of ~12 dB), the operating point at which a PSNR difference is as sensitive to the build's error as for a trained
+    model.  (2) The convs through which the carried state re-enters the propagation branches
+    (`{backward,forward}_resblocks.main.0`) are damped by PLAUSIBLE_STATE_GAIN, which makes the recurrence contractive:
+    with the plain random draw the REFERENCE itself amplifies any perturbation by ~1.4x per frame (a 1e-5 change of the
+    first input frame grows to 5e-5 within 13 frames in the fp32 oracle, the output saturates, PSNR vs GT sinks to
+    6 dB), so deviations at depth measure the network's conditioning, not the build."""
     assert variant in (None, 'plausible')
     sd = collections.OrderedDict()
     for name, shape in state_spec(config).items():
@@ -156,6 +162,8 @@ def make_state_dict(config, seed=1234, dtype=torch.float32, variant=None):
             a = rs.uniform(-bound, bound, size=shape).astype(np.float32)
         if variant == 'plausible' and name.startswith('Network.conv_last.'):
             a = a * np.float32(PLAUSIBLE_HEAD_GAIN)
+        if variant == 'plausible' and name.endswith('_resblocks.main.0.weight'):
+            a = a * np.float32(PLAUSIBLE_STATE_GAIN)
         sd[name] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
     return sd
 

@@ -26,6 +26,11 @@ def dev():
     return torch.device('cuda:0')
 
 
+def get_config_reset(name):
+    from refvsr_amd import get_config
+    return get_config('p', 'm', name).reset_branch
+
+
 def make_net(name, t, dev, reset='keep', cache=True, save_sample=True):
     from refvsr_amd import SRNet, get_config, make_state_dict
     cfg = get_config('p', 'm', name)
@@ -69,9 +74,11 @@ def test_stream_against_reference_fixture(dev, tag, name):
                conf=e_conf, flow=e_flow)
         assert net.Network.frame_itr_num == int(g['itr_%d' % f])
         assert res.shape == want.shape and float(res.min()) >= 0.0 and float(res.max()) <= 1.0
-        # tolerances: fp16 HWC feature maps through ~100 layers and a recurrent state
-        assert e_res < 2e-2 and psnr(res, want) > 55.0
-        assert e_feat < 3e-2 and e_up < 3e-2 and e_conf < 1e-3 and e_flow < 5e-2
+        # tolerances = 2x the worst value measured on MI355X over the six streams (profiles/r01_final3_gpu_parity_report.txt:
+        # result 5.6e-3 / 63.1 dB, feat 1.2e-2, feat_up 1.0e-2, conf 1.2e-4, flow 2.3e-4): fp16 HWC feature maps through
+        # ~100 layers and a recurrent state
+        assert e_res < 1.2e-2 and psnr(res, want) > 60.0
+        assert e_feat < 2.5e-2 and e_up < 2.1e-2 and e_conf < 2.5e-4 and e_flow < 5e-4
         for k, v in outs['eval_vis'].items():
             assert maxdiff(v.cpu(), g['ev_%s_%d' % (k, f)]) < 1e-3, k
         worst = max(worst, e_res)
@@ -97,6 +104,51 @@ def test_midsize_against_live_oracle_and_cache_equivalence(dev):
         report('e2e 64x96 f%d' % f, res=maxdiff(a, want), psnr_vs_oracle=float(psnr(a, want)), dPSNR_vs_gt=float(d_psnr))
         assert maxdiff(a, want) < 2e-2 and psnr(a, want) > 55.0
         assert d_psnr < 1e-3          # north-star parity bar: |PSNR(build,GT) - PSNR(oracle,GT)| <= 1e-3 dB
+
+
+def test_long_recurrence_against_live_oracle(dev):
+    """27 frames at 64x96 with reset_branch = 26 (the value of config_RefVSR_small_L1, RefVSR.py:168-170): the forward
+    branch's state is carried through 26 calls and restarted by the 27th.  PSNR(build, oracle) is reported per depth.
+
+    * 'plausible' weights (contractive recurrence, like a trained network; refvsr_amd/weights.py): the error must stay
+      bounded at every depth -- result within 2x of the shallow-stream figures -- and |dPSNR| <= 1e-3 dB.
+    * plain random weights (11 frames, reset_branch = 9): the recurrence is chaotic IN THE REFERENCE (any perturbation
+      grows ~1.4x per frame -- 27 frames end at 37 dB vs the oracle with the output saturated at 6 dB vs GT,
+      profiles/r02_gpu_parity_report.txt), so the direct distance to the oracle at depth measures the network's
+      conditioning; required here: |dPSNR| <= 1e-3 dB at every depth and, after the restart, the distance of a first
+      frame again."""
+    from oracle import refvsr_oracle as orc
+    from refvsr_amd import make_state_dict
+    from refvsr_amd.synth import make_clip, window_indices
+    for variant, nfr, R in (('plausible', 27, 26), (None, 11, 9)):
+        lr, rf, gt = make_clip(nfr, 64, 96, seed=5)
+        net, cfg, sd = make_net('config_RefVSR_small_L1', 5, dev, save_sample=False, reset=R)
+        assert get_config_reset('config_RefVSR_small_L1') == 26
+        if variant:
+            sd = make_state_dict(cfg, 1234, variant=variant)
+            net.load_state_dict(sd)
+        o = orc.OracleNetwork(cfg, sd)
+        worst_d, worst_e, low_p = 0.0, 0.0, 1e9
+        first = None
+        for f in range(nfr):
+            w = window_indices(f, nfr, 5)
+            a = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+            want = o.forward(lr[w][None], rf[w][None], f == 0)['result']
+            assert net.Network.frame_itr_num == o.frame_itr_num == (f % R) + 1
+            d = abs(psnr(a, gt[f][None]) - psnr(want, gt[f][None]))
+            e, pp = maxdiff(a, want), psnr(a, want)
+            worst_d, worst_e, low_p = max(worst_d, d), max(worst_e, e), min(low_p, pp)
+            first = first if first is not None else e
+            if f in (0, 1, 2, 4, 8, 9, 10, 12, 16, 20, 25, 26):
+                report('recurrence %s f%02d' % (variant or 'random', f), res=e, psnr_vs_oracle=float(pp), dPSNR_vs_gt=float(d),
+                       psnr_vs_gt=float(psnr(a, gt[f][None])))
+            assert d < 1e-3, '%s frame %d: dPSNR %.2e' % (variant, f, d)
+            if variant:
+                assert e < 4e-3 and pp > 70.0, '%s frame %d: %.2e / %.1f dB' % (variant, f, e, pp)
+                assert psnr(a, gt[f][None]) > 24.0
+            if f == R:
+                assert e < 2.0 * first + 1e-3, 'the restart at reset_branch did not restore first-frame accuracy'
+        report('recurrence %s worst of %d frames' % (variant or 'random', nfr), res=worst_e, psnr_vs_oracle=float(low_p), dPSNR_vs_gt=float(worst_d))
 
 
 def test_hd_midsize_against_live_oracle(dev):
@@ -294,27 +346,57 @@ def test_full_size_properties(dev):
     assert torch.equal(nxt(lr[w][None], rf[w][None], False)['result'], outs[3])
 
 
-def test_full_size_against_reference_fixture(dev):
-    """270x480 t=5 first-frame + steady-state call vs the reference (strided sub-sample + PSNR scalars
-    recorded by tools/gen_golden.py --full)."""
+@pytest.mark.parametrize('variant', [None, 'plausible'])
+def test_full_size_against_reference_fixture(dev, variant):
+    """270x480 t=5 first-frame + steady-state call vs the REFERENCE at the headline size (tools/gen_golden.py --full):
+    PSNR scalars, a strided sub-sample, two full-resolution 128x128 crops and -- where fp16 near-ties would show -- the
+    index map and confidence map of the window's centre frame (129 600 columns x 32 400 candidates).  Twice: with the
+    random weights, and with the 'plausible' head (output = bicubic base + a residual of the size of the bicubic error,
+    PSNR vs GT 27-28 dB) where a PSNR difference is as sensitive to the build's error as for a trained model."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'e2e_full_S_270x480_t5.npz')
     if not os.path.exists(path):
         pytest.skip('full-size fixture not generated')
+    from refvsr_amd import make_state_dict
     from refvsr_amd.synth import make_clip, window_indices
     g = load_golden('e2e_full_S_270x480_t5')
     nfr = int(g['nframes'])
     lr, rf, gt = make_clip(nfr, 270, 480, seed=0)
     net, cfg, sd = make_net('config_RefVSR_small_L1', 5, dev, save_sample=False)
+    tag = ''
+    if variant:
+        net.load_state_dict(make_state_dict(cfg, 1234, variant=variant))
+        tag = 'p_'
     st = int(g['stride'])
+    crops = g['crops'].tolist()
     for f in range(nfr):
         w = window_indices(f, nfr, 5)
         res = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
-        sub = res[0, :, ::st, ::st]
         p = psnr(res, gt[f][None])
-        report('full-size vs reference f%d' % f, sub_err=maxdiff(sub, g['sub_%d' % f]), psnr=float(p),
-               ref_psnr=float(g['psnr_%d' % f]), dPSNR=float(abs(p - float(g['psnr_%d' % f]))))
-        assert maxdiff(sub, g['sub_%d' % f]) < 3e-2
-        assert abs(p - float(g['psnr_%d' % f])) < 1e-3
+        d_psnr = abs(p - float(g[tag + 'psnr_%d' % f]))
+        e_crop = max(maxdiff(res[0, :, y0:y0 + 128, x0:x0 + 128], g[tag + 'crop%d_%d' % (ci, f)]) for ci, (y0, x0) in enumerate(crops))
+        p_crop = min(psnr(res[0, :, y0:y0 + 128, x0:x0 + 128], g[tag + 'crop%d_%d' % (ci, f)]) for ci, (y0, x0) in enumerate(crops))
+        report('full-size %s vs reference f%d' % (variant or 'random', f), crop_err=e_crop, crop_psnr_vs_ref=float(p_crop), psnr=float(p),
+               ref_psnr=float(g[tag + 'psnr_%d' % f]), dPSNR=float(d_psnr))
+        assert d_psnr < 1e-3                                   # the north-star bar, against the reference itself
+        if variant is None:
+            e_sub = maxdiff(res[0, :, ::st, ::st], g['sub_%d' % f])
+            report('full-size sub-sample f%d' % f, sub_err=e_sub)
+            assert e_sub < 4e-2 and e_crop < 4e-2 and p_crop > 55.0       # measured 1.9e-2 (frame 1) on MI355X
+            # matching of the centre frame: every one of the 129 600 arg-max decisions
+            fr = net.Network.engine(0).prev_window[2]
+            conf, idx = fr.conf.cpu()[0], fr.idx.cpu().view(270, 480)
+            want_c, want_i = g['conf_%d' % f], g['idx_%d' % f].view(270, 480)
+            mism = idx != want_i
+            e_conf = maxdiff(conf, want_c)
+            report('full-size matching f%d' % f, idx_mismatch=int(mism.sum()), conf_err=e_conf,
+                   conf_err_at_mismatch=float((conf - want_c)[mism].abs().max()) if bool(mism.any()) else 0.0)
+            # a different index is acceptable only as an fp32-summation-order tie: the correlation it reaches equals the
+            # reference's maximum to 1e-6; and there may be only a handful of them
+            assert e_conf < 2e-6
+            assert int(mism.sum()) <= 8
+        else:
+            assert p > 25.0                                    # the operating point is a plausible SR result
+            assert e_crop < 4e-3 and p_crop > 70.0
 
 
 # ------------------------------------------------------------------------------------------------

@@ -424,6 +424,81 @@ def test_match_ties_pick_first_index(dev):
     assert maxdiff(conf.cpu(), torch.ones(192)) < 1e-5
 
 
+def test_match_patches_rows32(dev):
+    from refvsr_amd import ops
+    from oracle import refvsr_oracle as orc
+    f = torch.randn(16, 14, 18)
+    rows, inv, rows32 = ops.match_patches(f.to(dev), 256, want_rows32=True)
+    assert torch.equal(rows32.cpu(), orc.patches3x3(f[None])[0].t().contiguous())      # raw patches: pure data movement
+
+
+def test_match_exact_search(dev):
+    """refvsr_match_exact (exhaustive fp32 MFMA search of flagged columns): with margin = inf EVERY column is flagged, the
+    result must then be the exact arg-max and -- where the default margin flags nothing -- identical to the top-2 path."""
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(13)
+    for (h, w) in [(20, 28), (34, 50), (64, 96)]:
+        base = F.interpolate(torch.randn(1, 16, h // 4 + 2, w // 4 + 2, generator=g), size=(h, w), mode='bilinear')[0]
+        lr_f = base + 0.2 * torch.randn(16, h, w, generator=g)
+        ref_f = F.avg_pool2d(base[None], 2)[0] + 0.2 * torch.randn(16, h // 2, w // 2, generator=g)
+        lr_rows, inv_lr = ops.match_patches(lr_f.to(dev), 512)
+        ref_rows, inv_ref, ref32 = ops.match_patches(ref_f.to(dev), 256, want_rows32=True)
+        n_ref = ref_f.shape[1] * ref_f.shape[2]
+        cand, cval = ops.match_top2(ref_rows, n_ref, lr_rows, h * w, 1)
+        conf_a, idx_a, fl_a = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand, cval, float('inf'), ref32)
+        assert int(fl_a[0]) == h * w
+        _check_match(conf_a, idx_a, lr_f, ref_f, '%dx%d exhaustive exact' % (h, w))
+        conf_d, idx_d, fl_d = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand, cval, ops.MATCH_EXACT_MARGIN, ref32)
+        conf_t, idx_t = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand)
+        report('match exact %dx%d' % (h, w), flagged_default=int(fl_d[0]), idx_diff_all_vs_top2=int((idx_a != idx_t).sum()),
+               conf_bitwise_equal=float(torch.equal(conf_a, conf_t)), conf_diff=maxdiff(conf_a.cpu(), conf_t.cpu()))
+        # the exhaustive search and the re-ranked top-2 compute the same fp32 FMA chain: wherever they pick the same
+        # row the confidence is the same number
+        same = idx_a == idx_t
+        assert torch.equal(conf_a[same], conf_t[same])
+        assert torch.equal(idx_d, idx_a) and torch.equal(conf_d, conf_a)      # default margin: same final answer as exhaustive
+
+
+def test_match_near_ties_flat_regions(dev, small_cfg, small_sd):
+    """8-bit frames with large flat areas (+-1 LSB noise, soft gradients, repeated texture): many reference patches are
+    nearly equally similar, the fp16 GEMM's top-2 can miss the true maximum.  Whole FeatureMatching path vs the oracle:
+    per column the correlation reached by the HIP index must be >= the oracle's maximum - 1e-6, and an exact (all
+    constant) region must pick the first index like torch.max."""
+    from oracle import refvsr_oracle as orc
+    from refvsr_amd.engine import Engine, FrameCtx, Weights
+    rs = np.random.RandomState(5)
+    h, w = 96, 128
+    img = np.full((3, h, w), 0.5, np.float32)
+    img[:, :, 64:] = 0.25                                               # two flat halves
+    img[:, 20:50, 10:60] += (rs.randint(-1, 2, (3, 30, 50)) / 255.0)  # +-1 LSB noise patch
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img[:, 60:, :] = 0.3 + 0.2 * (xx[60:] / w)[None]                    # soft gradient (quantised below)
+    img[:, 70:90, 70:120] = 0.5 + 0.25 * np.sign(np.sin(xx[70:90, 70:120] * 0.8))[None]   # repeated stripes
+    lr = torch.from_numpy(np.round(img * 255.0) / 255.0)
+    ref = torch.roll(lr, shifts=(3, -5), dims=(1, 2)).contiguous()
+    eng = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
+    conf, idx, _ = eng.feature_match(FrameCtx(lr.to(dev), ref.to(dev)))
+    ref_p, lr_p, _ = orc.match_features(lr[None], ref[None], small_sd, False)
+    corr = torch.bmm(ref_p.double(), lr_p.double())[0]                  # [n_ref, n_lr] in fp64
+    val, ix = corr.max(0)
+    idx = idx.cpu().long()
+    achieved = corr.gather(0, idx[None])[0]
+    gap = float((val - achieved).max())
+    # how often would the top-2 list alone have missed? (diagnostic: the exhaustive search is what closes the gap)
+    eng2 = Engine(small_cfg, Weights(small_cfg, small_sd, dev))
+    eng2.match_margin = 0.0
+    _, idx2, _ = eng2.feature_match(FrameCtx(lr.to(dev), ref.to(dev)))
+    gap2 = float((val - corr.gather(0, idx2.cpu().long()[None])[0]).max())
+    report('match near-ties', worst_gap=gap, worst_gap_top2_only=gap2, idx_mismatch=int((idx != ix).sum()), n=idx.numel(),
+           conf_err=maxdiff(conf.cpu().view(-1), val.float()))
+    assert gap < 1e-6
+    assert maxdiff(conf.cpu().view(-1), val.float()) < 2e-6
+    # exact ties (identical patches): smallest index, like torch.max
+    o_conf, o_idx = orc.feature_match(lr[None], ref[None], small_sd, False)
+    flat = (o_conf.view(-1) > 1.0 - 1e-6)
+    report('match near-ties exact-tie columns', n=int(flat.sum()), mismatch=int((idx[flat] != o_idx[0][flat]).sum()))
+
+
 def test_feature_match_golden(dev, small_cfg, small_sd):
     """Whole FeatureMatching.forward against the fixture produced by the reference."""
     from refvsr_amd.engine import Engine, FrameCtx, Weights

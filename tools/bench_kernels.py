@@ -45,19 +45,16 @@ def bench_match():
     ref_rows, inv_ref = ops.match_patches(ref_f, 256)
     n_lr, n_ref = h * w, (h // 2) * (w // 2)
     flops = 2.0 * n_lr * n_ref * 144
-    base = None
-    for v in (0, 3, 4):
-        os.environ['REFVSR_MATCH_VARIANT'] = str(v)
-        ci, cv = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1)
-        if base is None:
-            base = (ci.clone(), cv.clone())
-        same = bool(torch.equal(ci, base[0]) and torch.equal(cv, base[1]))
-        us = timeit(lambda: ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1), iters=10)
-        emit('match_top2 variant %d: %.1f us  %.1f TFLOP/s  (%.1f%% of 2.5 PF)  identical=%s' %
-             (v, us, flops / us / 1e6, flops / us / 1e6 / 25.0, same))
-    os.environ["REFVSR_MATCH_VARIANT"] = "4"
+    base = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1)
+    us = timeit(lambda: ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1), iters=10)
+    emit('match_top2: %.1f us  %.1f TFLOP/s  (%.1f%% of 2.5 PF)' % (us, flops / us / 1e6, flops / us / 1e6 / 25.0))
+    _, _, ref32 = ops.match_patches(ref_f, 256, want_rows32=True)
     us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0]), iters=10)
-    emit('match_refine: %.1f us' % us)
+    emit('match_refine (re-rank only): %.1f us' % us)
+    for margin in (ops.MATCH_EXACT_MARGIN, 5e-3, 2e-2):
+        fl = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0], base[1], margin, ref32)[2]
+        us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0], base[1], margin, ref32), iters=10)
+        emit('match_refine + exact search, margin %.1e: %d of %d columns flagged, %.1f us' % (margin, int(fl[0]), n_lr, us))
     us = timeit(lambda: ops.match_patches(lr_f, 512), iters=10)
     emit('match_patches(lr): %.1f us' % us)
 

@@ -267,7 +267,16 @@ def gen_full(nframes=2, stride=8):
     crops = [(300, 500), (700, 1400)]                 # top-left corners of the 128x128 full-resolution crops
     arrs = dict(nframes=np.int64(nframes), stride=np.int64(stride), crops=np.asarray(crops, np.int64),
                 lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
-    for variant in (None, 'plausible'):
+    variants = (None, 'plausible')
+    if '--variant' in sys.argv:                       # regenerate one variant, keep the other from the existing file
+        variants = (sys.argv[sys.argv.index('--variant') + 1],)
+        variants = (None,) if variants[0] == 'random' else variants
+        old = np.load(os.path.join(GOLD, 'e2e_full_S_270x480_t5.npz'))
+        keep = (lambda k: k.startswith('p_')) if variants[0] is None else (lambda k: not k.startswith('p_'))
+        for k in old.files:
+            if keep(k):
+                arrs[k] = old[k]
+    for variant in variants:
         tag = '' if variant is None else 'p_'
         print('== full-size S 270x480 t=5, %d frames, weights: %s ==' % (nframes, variant or 'random'))
         net, cfg, mine, sd = ref_net('config_RefVSR_small_L1', 5, save_sample=False)
