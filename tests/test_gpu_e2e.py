@@ -47,7 +47,8 @@ def make_net(name, t, dev, reset='keep', cache=True, save_sample=True):
 
 E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_small_L1'),
        ('S_24x32_t5_reset3', 'config_RefVSR_small_L1'), ('F_16x24_t3', 'config_RefVSR_MFID'),
-       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1')]
+       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1'),
+       ('HD48_64x96_t3', 'config_RefVSR_MFID_8K')]          # BASELINE configs[4] model: C = 48, 30 blocks, aa1 + aa2 alignment
 
 
 @pytest.mark.parametrize('tag,name', E2E)
@@ -66,8 +67,8 @@ def test_stream_against_reference_fixture(dev, tag, name):
         res = outs['result'].cpu()
         want = g['result_%d' % f]
         st = net.Network.engine(0).export_state()
-        e_res, e_feat = maxdiff(res, want), maxdiff(st['feat'].cpu(), g['state_feat_%d' % f][0])
-        e_up = maxdiff(st['feat_up'].cpu(), g['state_feat_up_%d' % f][0])
+        e_res, e_feat = maxdiff(res, want), maxdiff(st['feat'].cpu(), g['state_feat_%d' % f][0].float())
+        e_up = maxdiff(st['feat_up'].cpu(), g['state_feat_up_%d' % f][0]) if ('state_feat_up_%d' % f) in g else 0.0
         e_conf = maxdiff(st['conf'].cpu(), g['state_conf_%d' % f][0])
         e_flow = maxdiff(st['flow'].cpu(), g['state_flow_%d' % f][0])
         report('e2e %s f%d' % (tag, f), res=e_res, psnr_vs_ref=float(psnr(res, want)), feat=e_feat, feat_up=e_up,
@@ -309,6 +310,54 @@ def test_weight_reload_drops_cached_state(dev):
         net2(lr[w][None], rf[w][None], True)
         net2.load_state_dict(sd2)
         net2(lr[w][None], rf[w][None], False)
+
+
+def test_8k_single_window_at_size(dev):
+    """BASELINE configs[4] at its stated size: config_RefVSR_MFID_8K (C = 48, 30 blocks, flag_HD_in: matching on the
+    half-size frames, aa1 scale 4 + aa2 scale 8 with their stride-4 / stride-8 gather-mode predictor convs), one
+    1080x1920 window -> 4320x7680, whole frame (no spatial tiling: 288 GB of HBM).  No oracle at this size (the CPU
+    restatement needs hours): the run must be finite, in range, deterministic, agree with the bicubic base where the
+    residual head is switched off, and stay inside the HBM budget; the first-frame and a steady-state call are timed."""
+    import time
+    from refvsr_amd import make_state_dict, ops
+    from refvsr_amd.synth import make_clip, window_indices
+    t, h, w = 3, 1080, 1920
+    lr, rf, _ = make_clip(2, h, w, seed=4)
+    lr, rf = lr.to(dev), rf.to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    net, cfg, sd = make_net('config_RefVSR_MFID_8K', t, dev, save_sample=False)
+    assert cfg.mid_channels == 48 and cfg.num_blocks == 30 and cfg.flag_HD_in and cfg.reset_branch is None
+    outs, times = [], []
+    for f in range(2):
+        wi = window_indices(f, 2, t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = net(lr[wi][None], rf[wi][None], f == 0)['result']
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        assert o.shape == (1, 3, 4 * h, 4 * w) and o.dtype == torch.float32
+        assert bool(torch.isfinite(o).all()) and float(o.min()) >= 0.0 and float(o.max()) <= 1.0
+        outs.append(o[0, :, ::8, ::8].clone())                       # keep a strided sub-sample (the frame is 398 MB)
+        del o
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    report('8K 1080x1920 -> 4320x7680', first_frame_s=times[0], steady_frame_s=times[1], peak_hbm_GiB=peak)
+    assert peak < 64.0                                                # measured ~25 GiB; the card has 288
+    # deterministic: a fresh module reproduces the stream bit for bit
+    net2, _, _ = make_net('config_RefVSR_MFID_8K', t, dev, save_sample=False)
+    for f in range(2):
+        wi = window_indices(f, 2, t)
+        o = net2(lr[wi][None], rf[wi][None], f == 0)['result']
+        assert torch.equal(o[0, :, ::8, ::8], outs[f]), 'frame %d is not reproducible' % f
+        del o
+    # with the output head zeroed the network must return exactly the clamped bicubic x4 base (RefVSR.py:288,297)
+    sd0 = dict(sd)
+    sd0['Network.conv_last.weight'] = torch.zeros_like(sd['Network.conv_last.weight'])
+    sd0['Network.conv_last.bias'] = torch.zeros_like(sd['Network.conv_last.bias'])
+    net2.load_state_dict(sd0)
+    wi = window_indices(0, 2, t)
+    o = net2(lr[wi][None], rf[wi][None], True)['result'][0]
+    base = ops.bicubic_scale(lr[wi[t // 2]].contiguous(), 4, clamp01=True)
+    assert torch.equal(o, base)
 
 
 def test_full_size_properties(dev):

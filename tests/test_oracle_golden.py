@@ -97,7 +97,8 @@ def test_compute_up(small_cfg, small_sd):
 
 E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_small_L1'),
        ('S_24x32_t5_reset3', 'config_RefVSR_small_L1'), ('F_16x24_t3', 'config_RefVSR_MFID'),
-       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1')]
+       ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1'),
+       ('HD48_64x96_t3', 'config_RefVSR_MFID_8K')]
 
 
 @pytest.mark.parametrize('tag,name', E2E)
@@ -119,9 +120,11 @@ def test_end_to_end_stream(tag, name):
         outs = o.forward(lr[:, w], rf[:, w], f == 0, is_log=True)
         assert maxdiff(outs['result'], g['result_%d' % f]) < TOL, (tag, f)
         assert o.frame_itr_num == int(g['itr_%d' % f])
-        assert maxdiff(o.forward_feat_prop_prev, g['state_feat_%d' % f]) < TOL
-        up_tol = TOL if g['state_feat_up_%d' % f].dtype == torch.float32 else 2e-3   # big maps stored as fp16
-        assert maxdiff(o.forward_feat_prop_UP_prev, g['state_feat_up_%d' % f]) < up_tol
+        f_tol = TOL if g['state_feat_%d' % f].dtype == torch.float32 else 2e-3       # big maps stored as fp16
+        assert maxdiff(o.forward_feat_prop_prev, g['state_feat_%d' % f]) < f_tol
+        if ('state_feat_up_%d' % f) in g:                                            # (left out of the light fixtures)
+            up_tol = TOL if g['state_feat_up_%d' % f].dtype == torch.float32 else 2e-3
+            assert maxdiff(o.forward_feat_prop_UP_prev, g['state_feat_up_%d' % f]) < up_tol
         assert maxdiff(o.forward_conf_map_prop_prev, g['state_conf_%d' % f]) < TOL
         assert maxdiff(o.forward_flow_prev, g['state_flow_%d' % f]) < TOL
         for k, v in outs['eval_vis'].items():

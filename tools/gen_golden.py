@@ -212,7 +212,7 @@ def windows(nframes, t):
     return out
 
 
-def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep'):
+def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep', light=False):
     print('== end-to-end %s: %s t=%d %dx%d, %d frames ==' % (tag, name, t, h, w, nframes))
     net, cfg, mine, sd = ref_net(name, t)
     if reset_override != 'keep':
@@ -245,8 +245,9 @@ def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep'):
                       float(N.forward_feat_prop_UP_prev.abs().mean())))
             assert N.frame_itr_num == o.frame_itr_num
             arrs['result_%d' % f] = outs['result']
-            arrs['state_feat_%d' % f] = N.forward_feat_prop_prev
-            arrs['state_feat_up_%d' % f] = N.forward_feat_prop_UP_prev.to(torch.float16) if h * w > 600 else N.forward_feat_prop_UP_prev
+            arrs['state_feat_%d' % f] = N.forward_feat_prop_prev.to(torch.float16) if light else N.forward_feat_prop_prev
+            if not light:             # (light fixtures of the big models: the 2x state map alone is 2.4 MB per frame)
+                arrs['state_feat_up_%d' % f] = N.forward_feat_prop_UP_prev.to(torch.float16) if h * w > 600 else N.forward_feat_prop_UP_prev
             arrs['state_conf_%d' % f] = N.forward_conf_map_prop_prev
             arrs['state_flow_%d' % f] = N.forward_flow_prev
             arrs['itr_%d' % f] = np.int64(N.frame_itr_num)
@@ -321,16 +322,18 @@ def main():
            ('F_16x24_t3', 'config_RefVSR_MFID', 3, 16, 24, 3, 'keep'),
            ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K', 3, 32, 48, 3, 'keep'),
            # 7-frame windows on a 5-frame clip: every window replicates frames at a clip edge (datasets.py:233-234)
-           ('S_16x24_t7', 'config_RefVSR_small_L1', 7, 16, 24, 5, 'keep')]
+           ('S_16x24_t7', 'config_RefVSR_small_L1', 7, 16, 24, 5, 'keep'),
+           # BASELINE configs[4] model: C = 48, 30 blocks, flag_HD_in (aa1 scale 4 + align, aa2 scale 8 + align), no reset
+           ('HD48_64x96_t3', 'config_RefVSR_MFID_8K', 3, 64, 96, 2, 'keep')]
     if '--only' in sys.argv:                     # regenerate one end-to-end fixture: --only S_16x24_t7
         tag = sys.argv[sys.argv.index('--only') + 1]
         for e in E2E:
             if e[0] == tag:
-                gen_e2e(*e[:6], reset_override=e[6])
+                gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'))
         return
     gen_ops()
     for e in E2E:
-        gen_e2e(*e[:6], reset_override=e[6])
+        gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'))
     # state-dict contract checksums for all six configs
     sums = {}
     for name in ('config_RefVSR_small_L1', 'config_RefVSR_small_MFID', 'config_RefVSR_L1', 'config_RefVSR_MFID',
