@@ -192,9 +192,10 @@ int refvsr_match_naive(const float* lr_feat, int h, int w, const float* ref_feat
  * out[s*y+ky][s*x+kx][:] = value[s*ry+ky][s*rx+kx][:], (ry,rx) = divmod(idx[y*gw+x], wv/s). */
 int refvsr_block_gather_nhwc16(const void* value, int hv, int wv, int cs, const int32_t* idx, int gh, int gw,
                                int s, void* out, void* stream);
-/* same gather on a planar fp32 RGB frame, written as nhwc16 [gh*s][gw*s][8] (3 valid channels). */
+/* same gather on a planar fp32 RGB frame, written as nhwc16 [gh*s][gw*s][8] (3 valid channels; out8, may be NULL)
+ * and / or as an exact planar fp32 copy [3][gh*s][gw*s] (out_planar, may be NULL: the `vis` samples RefVSR.py:305-309). */
 int refvsr_block_gather_rgb(const float* value, int hv, int wv, const int32_t* idx, int gh, int gw, int s,
-                            void* out8, void* stream);
+                            void* out8, float* out_planar, void* stream);
 /* affine-deformable bilinear patch sampler (alignment.py:53-100,102-178).
  * x: nhwc16 [h*ks][w*ks][cs]; affine: planar fp32 [3][h][w] already (+1, clamped to [-3,3]). */
 int refvsr_aligned_sample(const void* x, int h, int w, int ks, int cs, const float* affine, void* out,

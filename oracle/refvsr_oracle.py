@@ -602,6 +602,7 @@ class OracleNetwork(object):
                     conf_maps[i], index_maps[i] = self._feature_match(lrs[:, i], refs[:, i])
         else:
             range_start = ctr
+        fw_flow_in = self.forward_flow_prev
         for i in range(range_start, ctr + 1):
             if i > range_start:
                 fl = ff[i - 1]
@@ -636,6 +637,33 @@ class OracleNetwork(object):
                          conf_maps=conf_maps, index_maps=index_maps, backward_feat_UP=bw_up,
                          conf_map_prop_backward=conf_bw, conf_map_prop_forward=conf,
                          forward_feat_UP=feat_up, is_first_frame=is_first_frame)
+        if is_log:                                                           # debugging samples, RefVSR.py:219-221,262-263,301-316
+            vis = collections.OrderedDict()
+            if ctr < t - 1:                                                  # :219-221 (backward loop, i == t//2)
+                vis['BW_LR_next_warp'] = warp(lrs[:, ctr + 1], pa['bf'][ctr])
+            # :262-263 -- `flow` is whatever the forward loop assigned last at i == t//2
+            fl_fw = ff[ctr - 1] if ctr > range_start else (None if is_first_frame else fw_flow_in)
+            if fl_fw is not None:
+                vis['FW_LR_prev_warp'] = warp(lrs[:, ctr - 1], fl_fw)
+            if self.cfg.save_sample:                                         # :301-316
+                lr_c, ref_c, idx_c = lrs[:, ctr], refs[:, ctr], index_maps[ctr]
+                lr_down = bicubic_scale(lr_c, 0.5, clamp=True)
+                ref_down = bicubic_scale(ref_c, 0.5, clamp=True)
+                s1, s2 = self.ks // 2, self.ks
+                o1 = (lr_down.shape[-2] * 2, lr_down.shape[-1] * 2)
+                o2 = (lr_c.shape[-2] * 2, lr_c.shape[-1] * 2)
+                fm1 = block_gather(ref_down, idx_c, s1, o1)
+                vis['FW_aa1_fm_ref_aligned'] = fm1
+                if s1 > 1:                                                   # aa1.align exists (HD configs)
+                    vis['FW_aa1_ref_aligned'] = aligned_conv(fm1, lr_down, block_gather(ref_c, idx_c, s1, o1), W, 'Network.aa1.align', s1)
+                fm2 = block_gather(ref_c, idx_c, s2, o2)
+                vis['FW_aa2_fm_ref_aligned'] = fm2
+                vis['FW_aa2_ref_aligned'] = aligned_conv(fm2, lr_c, fm2, W, 'Network.aa2.align', s2)
+                vis['conf_map_norm'] = norm_res_vis(conf_maps[ctr])
+                vis['conf_map_prop_backward_norm'] = norm_res_vis(conf_bw)
+                vis['conf_map_prop_forward_norm'] = norm_res_vis(conf)
+                vis['conf_map_prop_norm'] = norm_res_vis(torch.maximum(conf_bw, conf))
+            outs['vis'] = vis
         if is_log and self.cfg.save_sample:                                  # :318-322
             ev = collections.OrderedDict()
             ev['conf_map'] = conf_maps[ctr]
@@ -653,6 +681,15 @@ class OracleNetwork(object):
         return self.phase_b(self.phase_a(lrs, refs, first_hint=first), is_first_frame, is_log=is_log, trace=trace)
 
     __call__ = forward
+
+
+def norm_res_vis(res):
+    """models/utils.py:23-32: per-sample min/max normalisation of a debug map."""
+    b = res.shape[0]
+    r = res.reshape(b, -1)
+    r = r - r.min(1, keepdim=True)[0]
+    r = r / r.max(1, keepdim=True)[0]
+    return r.view(res.shape)
 
 
 def psnr(a, b):

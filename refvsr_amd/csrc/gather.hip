@@ -36,7 +36,7 @@ extern "C" int refvsr_block_gather_nhwc16(const void* value, int hv, int wv, int
 }
 
 __global__ void block_gather_rgb_kernel(const float* __restrict__ value, int hv, int wv, const int32_t* __restrict__ idx,
-                                        int gh, int gw, int s, f16* __restrict__ out8) {
+                                        int gh, int gw, int s, f16* __restrict__ out8, float* __restrict__ out_planar) {
     const int ow = gw * s;
     const int ox = blockIdx.x * blockDim.x + threadIdx.x;
     const int oy = blockIdx.y;
@@ -50,16 +50,23 @@ __global__ void block_gather_rgb_kernel(const float* __restrict__ value, int hv,
     const int sx = min(rx * s + kx, wv - 1);
     const size_t plane = (size_t)hv * wv;
     const size_t sp = (size_t)sy * wv + sx;
-    f16x8 o = {(f16)value[sp], (f16)value[plane + sp], (f16)value[2 * plane + sp], 0, 0, 0, 0, 0};
-    *reinterpret_cast<f16x8*>(out8 + ((size_t)oy * ow + ox) * 8) = o;
+    const float r = value[sp], g = value[plane + sp], b = value[2 * plane + sp];
+    if (out8) {
+        f16x8 o = {(f16)r, (f16)g, (f16)b, 0, 0, 0, 0, 0};
+        *reinterpret_cast<f16x8*>(out8 + ((size_t)oy * ow + ox) * 8) = o;
+    }
+    if (out_planar) {                                   // exact copy (the `vis` debugging samples, RefVSR.py:305-309)
+        const size_t op = (size_t)gh * s * ow, o = (size_t)oy * ow + ox;
+        out_planar[o] = r; out_planar[op + o] = g; out_planar[2 * op + o] = b;
+    }
 }
 
 extern "C" int refvsr_block_gather_rgb(const float* value, int hv, int wv, const int32_t* idx, int gh, int gw, int s,
-                                       void* out8, void* stream) {
-    RV_CHECK(value && idx && out8 && hv > 0 && wv > 0 && gh > 0 && gw > 0 && s >= 1 && wv / s > 0,
+                                       void* out8, float* out_planar, void* stream) {
+    RV_CHECK(value && idx && (out8 || out_planar) && hv > 0 && wv > 0 && gh > 0 && gw > 0 && s >= 1 && wv / s > 0,
              "block_gather_rgb: bad args");
     hipLaunchKernelGGL(block_gather_rgb_kernel, dim3(rv_cdiv(gw * s, 128), gh * s), dim3(128), 0, (hipStream_t)stream,
-                       value, hv, wv, idx, gh, gw, s, (f16*)out8);
+                       value, hv, wv, idx, gh, gw, s, (f16*)out8, out_planar);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -682,7 +682,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
+    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False):
         """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None).
         frame_ids (optional): one hashable id per window frame -> the window cache is keyed by id instead of by
         content comparison; together with set_pipelined(True) it enables cross-call stream pipelining."""
@@ -691,10 +691,10 @@ class Engine(object):
             # of a running clip keeps the cache -- same clip, same ids)
             self.id_cache, self.flow_cache = {}, {}
         with torch.cuda.device(lrs.device):          # launches go to the tensors' device, whatever the current device is
-            if self.pipelined and frame_ids is not None and self.cache and self.overlap:
+            if self.pipelined and frame_ids is not None and self.cache and self.overlap and not want_log:
                 return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids)
             with ops.on_stream(torch.cuda.current_stream()):
-                return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
+                return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids, want_log)
 
     # ------------------------------------------------------------------ two-phase forward (multi-GPU wavefront)
     def _check_window(self, lrs, refs):
@@ -770,7 +770,43 @@ class Engine(object):
                 vis['conf_map_prop_forward'] = conf
         return out, vis
 
-    def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None):
+    def _debug_vis(self, fr, t, is_first_frame, range_start, fw_flow_in, flow, conf_bw, conf_fw, save_sample):
+        """The `vis` debugging samples of Network.forward (RefVSR.py:219-221,262-263,301-316), is_log only; planar fp32
+        [C,H,W] maps.  (The min/max normalisation of the four confidence maps, models/utils.py:23-32, uses torch
+        reductions: debug output, not the hot path.)"""
+        ctr = t // 2
+        vis = collections.OrderedDict()
+        if ctr < t - 1:
+            vis['BW_LR_next_warp'] = ops.warp_planar(fr[ctr + 1].lr, flow(ctr, ctr + 1))
+        fl = flow(ctr, ctr - 1) if ctr > range_start else (None if is_first_frame else fw_flow_in)
+        if fl is not None:
+            vis['FW_LR_prev_warp'] = ops.warp_planar(fr[ctr - 1].lr, fl)
+        if save_sample:
+            f = fr[ctr]
+            h, w = f.lr.shape[1:]
+            gh, gw = (h, w) if not self.hd else (h // self.cfg.scale, w // self.cfg.scale)
+            s1, s2 = self.ks // 2, self.ks
+            lr_down = ops.bicubic_scale(f.lr, 0.5, clamp01=True)
+            ref_down = ops.bicubic_scale(f.ref, 0.5, clamp01=True)
+            vis['FW_aa1_fm_ref_aligned'] = ops.block_gather_rgb(ref_down, f.idx, gh, gw, s1, planar=True)
+            if s1 > 1:
+                fm8 = ops.block_gather_rgb(ref_down, f.idx, gh, gw, s1)
+                rgb8 = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s1)
+                vis['FW_aa1_ref_aligned'] = ops.unpack_nhwc16(self.aligned_conv(fm8, lr_down, rgb8, 'aa1.align', s1), 3)
+            vis['FW_aa2_fm_ref_aligned'] = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s2, planar=True)
+            rgb8 = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s2)
+            vis['FW_aa2_ref_aligned'] = ops.unpack_nhwc16(self.aligned_conv(rgb8, f.lr, rgb8, 'aa2.align', s2), 3)
+
+            def norm(x):
+                x = x - x.min()
+                return x / x.max()
+            vis['conf_map_norm'] = norm(f.conf)
+            vis['conf_map_prop_backward_norm'] = norm(conf_bw)
+            vis['conf_map_prop_forward_norm'] = norm(conf_fw)
+            vis['conf_map_prop_norm'] = norm(ops.max2(conf_bw, conf_fw))
+        return vis
+
+    def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False):
         t, h, w = self._check_window(lrs, refs)
         ctr = t // 2
         dev = lrs.device
@@ -796,6 +832,7 @@ class Engine(object):
         # first one's tensor out of the cache -- from the other stream
         share = (main, self._side_stream(dev)) if overlap else None
         flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b], share))   # :183-191
+        fw_flow_in = self.fw_flow
         if overlap:
             for i in range(ctr, t):
                 self.pyramid(fr[i])                        # shared by both streams: build on main before the fork
@@ -829,4 +866,7 @@ class Engine(object):
             vis['conf_map_prop'] = ops.max2(conf_bw, conf)
             vis['conf_map_prop_backward'] = conf_bw
             vis['conf_map_prop_forward'] = conf
+        if want_log:
+            dbg = self._debug_vis(fr, t, is_first_frame, range_start, fw_flow_in, flow, conf_bw, conf, want_vis)
+            return out, (vis, dbg)
         return out, vis

@@ -69,7 +69,7 @@ SIGNATURES = {
     'refvsr_match_exact': [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     'refvsr_match_naive': [_P, _I, _I, _P, _I, _I, _P, _P, _P],
     'refvsr_block_gather_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
-    'refvsr_block_gather_rgb': [_P, _I, _I, _P, _I, _I, _I, _P, _P],
+    'refvsr_block_gather_rgb': [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P],
     'refvsr_aligned_sample': [_P, _I, _I, _I, _I, _P, _P, _P],
 }
 _SPECIAL = {'refvsr_abi_version': (C.c_int, []), 'refvsr_last_error': (C.c_char_p, [])}

@@ -132,14 +132,18 @@ class Network(nn.Module):
         self.ensure_engines(n, lrs.device)
         want_vis = bool(is_log and self.config.save_sample)
         results, vis_all = [], []
+        dbg_all = []
         for b in range(n):
             out, vis = self._engines[b].forward(lrs[b], refs[b], bool(is_first_frame), want_vis,
-                                                None if frame_ids is None else [(b, f) for f in frame_ids])
+                                                None if frame_ids is None else [(b, f) for f in frame_ids], want_log=bool(is_log))
+            if is_log:
+                vis, dbg = vis
+                dbg_all.append(dbg)
             results.append(out)
             vis_all.append(vis)
         outs = collections.OrderedDict()
-        if is_log:
-            outs['vis'] = collections.OrderedDict()
+        if is_log:                                             # RefVSR.py:162-164,219-221,262-263,301-316
+            outs['vis'] = collections.OrderedDict((k, torch.stack([d[k] for d in dbg_all], 0)) for k in dbg_all[0])
         outs['result'] = torch.stack(results, 0)
         if want_vis:
             ev = collections.OrderedDict()

@@ -415,12 +415,18 @@ def block_gather_nhwc16(value, idx, gh, gw, s):
     return out
 
 
-def block_gather_rgb(value, idx, gh, gw, s):
+def block_gather_rgb(value, idx, gh, gw, s, planar=False):
+    """nhwc16 [gh*s, gw*s, 8] (3 valid channels), or with planar=True an exact planar fp32 copy [3, gh*s, gw*s]."""
     _planar(value, 3)
     hv, wv = value.shape[1:]
     assert idx.dtype == torch.int32 and idx.numel() == gh * gw and idx.is_contiguous()
+    if planar:
+        out = torch.empty((3, gh * s, gw * s), dtype=torch.float32, device=value.device)
+        hip.check(hip.lib().refvsr_block_gather_rgb(_ptr(value), hv, wv, _ptr(idx), gh, gw, s, None, _ptr(out), _stream()),
+                  'block_gather_rgb')
+        return out
     out = torch.empty((gh * s, gw * s, 8), dtype=torch.float16, device=value.device)
-    hip.check(hip.lib().refvsr_block_gather_rgb(_ptr(value), hv, wv, _ptr(idx), gh, gw, s, _ptr(out), _stream()),
+    hip.check(hip.lib().refvsr_block_gather_rgb(_ptr(value), hv, wv, _ptr(idx), gh, gw, s, _ptr(out), None, _stream()),
               'block_gather_rgb')
     return out
 

@@ -82,6 +82,15 @@ def test_stream_against_reference_fixture(dev, tag, name):
         assert e_feat < 2.5e-2 and e_up < 2.1e-2 and e_conf < 2.5e-4 and e_flow < 5e-4
         for k, v in outs['eval_vis'].items():
             assert maxdiff(v.cpu(), g['ev_%s_%d' % (k, f)]) < 1e-3, k
+        # the `vis` debugging samples (RefVSR.py:219-221,262-263,301-316): same keys as the reference, values for the streams
+        # whose fixture stores them
+        vkeys = sorted(k[4:-len('_%d' % f)] for k in g if k.startswith('vis_') and k.endswith('_%d' % f))
+        if vkeys:
+            assert sorted(outs['vis'].keys()) == vkeys, (sorted(outs['vis'].keys()), vkeys)
+            ev = {k: maxdiff(outs['vis'][k].cpu(), g['vis_%s_%d' % (k, f)]) for k in vkeys}
+            report('e2e %s f%d vis' % (tag, f), **ev)
+            for k, e in ev.items():
+                assert e < (1e-6 if k == 'FW_aa2_fm_ref_aligned' else 5e-3), (k, e)      # a pure gather of the frame: exact
         worst = max(worst, e_res)
     report('e2e %s worst' % tag, res=worst)
 
@@ -451,30 +460,15 @@ def test_full_size_against_reference_fixture(dev, variant):
 # ------------------------------------------------------------------------------------------------
 # N > 1 with the real engine: two processes share the one GPU of the test box (gloo for the hand-off)
 # ------------------------------------------------------------------------------------------------
-class _HipExec(object):
-    def __init__(self, reset):
-        self.net, self.cfg, self.sd = make_net('config_RefVSR_small_L1', 3, torch.device('cuda:0'), reset=reset,
-                                               save_sample=False)
-        self.eng = self.net.Network.ensure_engines(1, torch.device('cuda:0'))[0]
-
-    def __call__(self, lrs, refs, first):
-        return self.net(lrs[None].cuda(), refs[None].cuda(), first)['result'][0].cpu()
-
-    def phase_a(self, lrs, refs, f, hint):
-        return self.net.Network.phase_a(lrs[None].cuda(), refs[None].cuda(), first_hint=hint)
-
-    def phase_b(self, handles, first):
-        return self.net.Network.phase_b(handles, first)['result'][0].cpu()
-
-    def export_state(self):
-        st = self.eng.export_state()
-        return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
-
-    def import_state(self, st):
-        self.eng.import_state({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in st.items()})
+def _make_exec(reset, name='config_RefVSR_small_L1', nframes=6):
+    """The engine behind refvsr_amd.shard.EngineExecutor: packed single-message fp16 state hand-off, id-keyed window cache."""
+    from refvsr_amd import shard
+    dev = torch.device('cuda:0')
+    net, cfg, sd = make_net(name, 3, dev, reset=reset, save_sample=False)
+    return shard.EngineExecutor(net, dev, 32, 48, nframes, 3, keep_on_device=False), cfg
 
 
-def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False):
+def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='config_RefVSR_small_L1'):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -483,22 +477,26 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False):
     from refvsr_amd.synth import make_clip, window_indices
     lr, rf, _ = make_clip(6, 32, 48, seed=3)
     get = lambda f: (lr[window_indices(f, 6, 3)], rf[window_indices(f, 6, 3)])
-    ex = _HipExec(reset)
+    ex, cfg = _make_exec(reset, name)
     if wavefront:
-        res = shard.run_wavefront(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu')
+        res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu')
     else:
-        res = shard.run_sharded(ex, get, 6, 3, reset, ex.cfg.mid_channels, 'cpu', aligned=aligned)
+        res = shard.run_sharded(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', aligned=aligned)
     q.put((rank, {f: v.clone().numpy() for f, v in res.items()}))     # by value: no fd passing after exit
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('reset,aligned,wavefront', [(None, False, False), (3, True, False), (None, False, True),
-                                                     (4, False, True)])
-def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront):
-    """Frame sharding across two ranks (state hand-off, the exchange-free reset-aligned partition, and the
-    phase-A / phase-B wavefront -- also with a reset inside a shard) must reproduce the single-process stream
-    bit-for-bit on the HIP engine."""
+@pytest.mark.parametrize('reset,aligned,wavefront,name', [(None, False, False, 'config_RefVSR_small_L1'),
+                                                          (3, True, False, 'config_RefVSR_small_L1'),
+                                                          (None, False, True, 'config_RefVSR_small_L1'),
+                                                          (4, False, True, 'config_RefVSR_small_MFID'),
+                                                          ('keep', False, True, 'config_RefVSR_small_MFID')])
+def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront, name):
+    """Frame sharding across two ranks (state hand-off as ONE packed fp16 buffer, the exchange-free reset-aligned
+    partition, and the phase-A / phase-B wavefront with the early send -- also with a reset inside a shard, also on
+    config_RefVSR_small_MFID, the model of BASELINE configs[3]) must reproduce the single-process stream bit-for-bit on
+    the HIP engine."""
     import socket
     import torch.multiprocessing as mp
     from refvsr_amd.synth import make_clip, window_indices
@@ -508,7 +506,7 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront)
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, reset, aligned, q, wavefront)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, reset, aligned, q, wavefront, name)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -519,7 +517,31 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront)
         p.join(120)
         assert p.exitcode == 0
     lr, rf, _ = make_clip(6, 32, 48, seed=3)
-    ex = _HipExec(reset)
+    ex, _ = _make_exec(reset, name)
     for f in range(6):
         w = window_indices(f, 6, 3)
         assert torch.equal(got[f], ex(lr[w], rf[w], f == 0)), 'frame %d differs from the sequential run' % f
+
+
+def test_packed_state_roundtrip(dev):
+    """export_state_packed / import_state_packed (the hand-off message: header + fp16 HWC maps + fp32 flow / conf in one
+    buffer) restores the engine's state bit for bit, and its size is the documented (10 C + 12) h w + 16 bytes."""
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, _ = make_clip(3, 32, 48, seed=23)
+    lr, rf = lr.to(dev), rf.to(dev)
+    a, cfg, _ = make_net('config_RefVSR_small_L1', 3, dev, save_sample=False)
+    b, _, _ = make_net('config_RefVSR_small_L1', 3, dev, save_sample=False)
+    for f in range(2):
+        a(lr[window_indices(f, 3, 3)][None], rf[window_indices(f, 3, 3)][None], f == 0)
+    ea = a.Network.engine(0)
+    buf = ea.export_state_packed()
+    assert buf.dtype == torch.uint8 and buf.numel() == ea.state_nbytes(32, 48) == 16 + 32 * 48 * (10 * cfg.mid_channels + 12)
+    b(lr[window_indices(0, 3, 3)][None], rf[window_indices(0, 3, 3)][None], True)       # allocate b's engine
+    eb = b.Network.engine(0)
+    eb.reset_state()
+    eb.import_state_packed(buf.clone())
+    assert eb.frame_itr_num == ea.frame_itr_num
+    for k in ('fw_feat', 'fw_feat_up', 'fw_flow', 'fw_conf'):
+        assert torch.equal(getattr(ea, k), getattr(eb, k)), k
+    w2 = window_indices(2, 3, 3)
+    assert torch.equal(a(lr[w2][None], rf[w2][None], False)['result'], b(lr[w2][None], rf[w2][None], False)['result'])

@@ -29,6 +29,7 @@ from refvsr_amd.config import get_config as my_get_config  # noqa: E402
 from oracle import refvsr_oracle as orc  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
+VIS_FIXTURES = ('S_18x26_t5', 'HD_32x48_t3')
 SEED_W = 1234
 
 
@@ -253,6 +254,14 @@ def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep', light=False):
             arrs['itr_%d' % f] = np.int64(N.frame_itr_num)
             for k, v in outs['eval_vis'].items():
                 arrs['ev_%s_%d' % (k, f)] = v
+            # the `vis` debugging samples (RefVSR.py:219-221,262-263,301-316): oracle delta for every stream, values stored
+            # for the streams listed in VIS_FIXTURES (the maps are 2x-size RGB, they would double the other fixtures)
+            dv = {k: md(v, oo['vis'][k]) for k, v in outs['vis'].items()}
+            assert set(outs['vis']) == set(oo['vis']), (sorted(outs['vis']), sorted(oo['vis']))
+            print('    vis: ' + ' '.join('%s=%.1e' % kv for kv in dv.items()))
+            if tag in VIS_FIXTURES:
+                for k, v in outs['vis'].items():
+                    arrs['vis_%s_%d' % (k, f)] = v
     save('e2e_' + tag, **arrs)
 
 
