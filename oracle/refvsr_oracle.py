@@ -333,8 +333,9 @@ def match_features(lr, ref, W, hd, scale=4):
         oh, ow = int(math.floor(lr.shape[-2] * f)), int(math.floor(lr.shape[-1] * f))
         lr = resize(lr, (oh, ow), 'nearest', 1.0 / f)
         ref = resize(ref, (oh, ow), 'nearest', 1.0 / f)
-    lr_f = feature_extract(lr, W, hd)
-    ref_f = feature_extract(avg_pool2(ref), W, hd)
+    vgg7 = hd or scale != 4                          # attention.py:31-35
+    lr_f = feature_extract(lr, W, vgg7)
+    ref_f = feature_extract(avg_pool2(ref), W, vgg7)
     lr_p = patches3x3(lr_f)
     ref_p = patches3x3(ref_f).permute(0, 2, 1)
     ref_p = ref_p / ref_p.norm(dim=2, keepdim=True).clamp_min(1e-12)

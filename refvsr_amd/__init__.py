@@ -5,7 +5,7 @@
     net = SRNet(cfg).cuda().eval(); net.load_state_dict(ckpt)
     out = net(lr_window, ref_window, is_first_frame)['result']
 """
-from .config import CONFIG_NAMES, get_config, set_data_path  # noqa: F401
+from .config import CONFIG_NAMES, get_config, set_data_path, set_scale  # noqa: F401
 from .weights import make_state_dict, state_spec  # noqa: F401
 
 

@@ -113,6 +113,18 @@ def get_config(project='', mode='', config='', data='', LRS='', batch_size=8):
     return c
 
 
+def set_scale(c, scale):
+    """The reference's config files hard-code `config.scale = 4 # SR scale (2 | 4)` and derive the matching patch size
+    from it (configs/config_RefVSR_small_L1.py:30-39); x2 is selected by editing that line.  This does the same edit on a
+    built config: scale, matching_ksize (4 for x2, 2 for x4; times scale with flag_HD_in)."""
+    assert scale in (2, 4)
+    c.scale = scale
+    c.matching_ksize = 4 if scale == 2 else 2
+    if c.flag_HD_in:
+        c.matching_ksize *= scale
+    return c
+
+
 def set_data_path(config, data, is_train=False):
     """RealMCVSR folder layout for evaluation (reference configs/config.py:120-152)."""
     if data != 'RealMCVSR':

@@ -65,9 +65,15 @@ struct ConvArgs {
     int prefetch;                    // resident kernels: 1 = next tile prefetched into registers during the K loop
 };
 
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT>
+// EPI = 0: general epilogue (every output mode, fp16 / fp32 maps).  EPI = 1: the fp16 HWC store with optional alpha
+// multiply / residual and activations given as slopes in [0, 1] -- the path of ~90 % of the launches -- written for a low
+// instruction count: the PMC split of round 1 (33 % of wave cycles issuing at 3 waves per SIMD = a saturated issue
+// port, MFMA 19-30 % busy) says these kernels are bound by the NUMBER of instructions around the K loop, not by memory
+// or the matrix pipe.
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
     static_assert(!(GATHER && RESIDENT), "gather mode streams its weights");
+    static_assert(EPI == 0 || (RESIDENT && !F32), "the lean epilogue is built for the resident fp16 kernels");
     constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tab = reinterpret_cast<int*>(smem);
@@ -288,20 +294,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
     };
 
+    // ---- EPI = 1: bias, activation as max(y, slope*y), optional alpha multiply / residual, fp16 HWC store; 32-bit element
+    // offsets (the host checks the map sizes) ---------------------------------------------------------------------------
+    auto epilogue_lean = [&](const int ty0, const int tx0, const int tide) {
+        const int lane_e = tide & 63, wave_e = tide >> 6, q_e = lane_e >> 4;
+        const int lp_e = (p.stride == 1) ? rv_pix16(lane_e & 15) : (lane_e & 15);
+        const f16* mulp = reinterpret_cast<const f16*>(p.mul);
+        const f16* resp = reinterpret_cast<const f16*>(p.res);
+        f16* outp = reinterpret_cast<f16*>(p.out);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int ti = wave_e * TILES + t;
+            const int oy = ty0 + (ti >> 1);
+            const int ox = tx0 + (ti & 1) * 16 + lp_e;
+            if (oy >= p.h_out || ox >= p.w_out) continue;
+            const unsigned opix = (unsigned)(oy * p.w_out + ox);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = (zg * MT + m) * 16 + q_e * 4;
+                if (co0 >= p.cout) continue;
+                const float4 bv = bias_r[m];
+                float y0 = acc[m][t][0] + bv.x, y1 = acc[m][t][1] + bv.y, y2 = acc[m][t][2] + bv.z, y3 = acc[m][t][3] + bv.w;
+                y0 = fmaxf(y0, y0 * p.act_slope); y1 = fmaxf(y1, y1 * p.act_slope);
+                y2 = fmaxf(y2, y2 * p.act_slope); y3 = fmaxf(y3, y3 * p.act_slope);
+                if (mulp) {
+                    const f16x4 t4 = *reinterpret_cast<const f16x4*>(mulp + (opix * (unsigned)p.mul_c + (unsigned)co0));
+                    y0 *= (float)t4[0]; y1 *= (float)t4[1]; y2 *= (float)t4[2]; y3 *= (float)t4[3];
+                }
+                if (resp) {
+                    const f16x4 t4 = *reinterpret_cast<const f16x4*>(resp + (opix * (unsigned)p.res_c + (unsigned)co0));
+                    y0 += (float)t4[0]; y1 += (float)t4[1]; y2 += (float)t4[2]; y3 += (float)t4[3];
+                }
+                if (p.post_slope != 1.0f) {
+                    y0 = fmaxf(y0, y0 * p.post_slope); y1 = fmaxf(y1, y1 * p.post_slope);
+                    y2 = fmaxf(y2, y2 * p.post_slope); y3 = fmaxf(y3, y3 * p.post_slope);
+                }
+                const f16x4 o = {(f16)y0, (f16)y1, (f16)y2, (f16)y3};
+                *reinterpret_cast<f16x4*>(outp + (opix * (unsigned)p.out_c + (unsigned)co0)) = o;
+            }
+        }
+    };
+
     if constexpr (RESIDENT) {
         // ================= persistent workgroup: resident weights, register-prefetched tiles =====================
+        // weights -> LDS in batches of eight 16-byte loads per thread: every load of a batch is in flight before the first
+        // LDS store (a plain copy loop costs one memory round trip per 4 KB)
         {
             const int n16 = p.S * MT * WFR * 64;
             uint4* d = reinterpret_cast<uint4*>(wl);
-            for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];
+            for (int i0 = 0; i0 < n16; i0 += 8 * 256) {
+                uint4 w0, w1, w2, w3, w4, w5, w6, w7;
+                const int last = n16 - 1, i = i0 + tid;
+                w0 = wsrc[min(i, last)];            w1 = wsrc[min(i + 256, last)];
+                w2 = wsrc[min(i + 512, last)];      w3 = wsrc[min(i + 768, last)];
+                w4 = wsrc[min(i + 1024, last)];     w5 = wsrc[min(i + 1280, last)];
+                w6 = wsrc[min(i + 1536, last)];     w7 = wsrc[min(i + 1792, last)];
+                asm volatile("" ::: "memory");
+                if (i < n16) d[i] = w0;
+                if (i + 256 < n16) d[i + 256] = w1;
+                if (i + 512 < n16) d[i + 512] = w2;
+                if (i + 768 < n16) d[i + 768] = w3;
+                if (i + 1024 < n16) d[i + 1024] = w4;
+                if (i + 1280 < n16) d[i + 1280] = w5;
+                if (i + 1536 < n16) d[i + 1536] = w6;
+                if (i + 1792 < n16) d[i + 1792] = w7;
+            }
         }
         int tl, k_hi;                                              // this workgroup's tiles (common.h:rv_tile_range)
         rv_tile_range(p.n_xy, tl, k_hi);
         constexpr int k_step = 1;
-        // input-tile chunk k of this thread: 16 bytes = (row r, column c, channel group cg) of the LH x LW tile
+        // input-tile chunk k of this thread: 16 bytes = (row r, column c, channel group cg) of the LH x LW tile.  Everything
+        // that does not depend on the tile origin is computed ONCE per thread: xq = r | c << 5 | (cg within its source) << 12 |
+        // src1 << 19 | cg << 20 (-1 past the tile).  Per tile a chunk then costs ~20 instructions (bounds, offset from the tile's
+        // origin pixel, base select, 64-bit add, load) instead of ~58.
         const int row_chunks = p.LW * p.ncg;
         const int total = p.LH * row_chunks;                       // <= CONV_XPF * 256 (host)
-        int xq[CONV_XPF];                                          // r << 16 | c << 8 | cg, or -1 past the tile
+        int xq[CONV_XPF];
         {
             const float inv_rc = 1.0f / (float)row_chunks;
 #pragma unroll
@@ -310,7 +378,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 const int r = (int)(((float)idx + 0.5f) * inv_rc);
                 const int i = idx - r * row_chunks;
                 const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
-                xq[k] = idx < total ? ((r << 16) | (c << 8) | (i - c * p.ncg)) : -1;
+                const int cg = i - c * p.ncg;
+                const bool s1 = cg >= p.ncg0;
+                xq[k] = idx < total ? (r | (c << 5) | ((s1 ? cg - p.ncg0 : cg) << 12) | (s1 ? (1 << 19) : 0) | (cg << 20)) : -1;
             }
         }
         uint4 xv[CONV_XPF];
@@ -318,16 +388,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             const int tyi = t / p.tiles_x;
             const int iy0 = tyi * TH * p.stride - p.pad;
             const int ix0 = (t - tyi * p.tiles_x) * CONV_TW * p.stride - p.pad;
+            const long long org = (long long)iy0 * p.w_in + ix0;   // origin pixel (may lie outside the frame): uniform
+            const unsigned char* b0 = p.src0 + org * p.pixb0;
+            const unsigned char* b1 = p.src1 + org * p.pixb1;
 #pragma unroll
             for (int k = 0; k < CONV_XPF; ++k) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 int e = xq[k];
-                asm volatile("" : "+v"(e));                        // decode per tile: keeps (r, c, cg, addresses) x 8 out of
-                const int iy = iy0 + (e >> 16), ix = ix0 + ((e >> 8) & 0xff), cg = e & 0xff;   // the registers live across the K loop
-                if (e >= 0 && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
-                    const size_t pix = (size_t)iy * p.w_in + ix;
-                    v = (cg < p.ncg0) ? *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16)
-                                      : *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
+                asm volatile("" : "+v"(e));                        // decode per tile: keeps the decoded fields x 8 out of the
+                const int iy = iy0 + (e & 31), ix = ix0 + ((e >> 5) & 127);   // registers that live across the K loop
+                if (e >= 0 && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) {
+                    const bool s1 = (e >> 19) & 1;
+                    const int off = ((e & 31) * p.w_in + ((e >> 5) & 127)) * (s1 ? p.pixb1 : p.pixb0) + ((e >> 12) & 127) * 16;
+                    v = *reinterpret_cast<const uint4*>((s1 ? b1 : b0) + off);
                 }
                 xv[k] = v;
             }
@@ -338,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 int e = xq[k];
                 asm volatile("" : "+v"(e));
                 if (e >= 0)
-                    *reinterpret_cast<uint4*>(tile + ((size_t)((e >> 16) * p.LW + ((e >> 8) & 0xff)) * p.ps + (e & 0xff)) * 16) = xv[k];
+                    *reinterpret_cast<uint4*>(tile + (((e & 31) * p.LW + ((e >> 5) & 127)) * p.ps + ((e >> 20) & 127)) * 16) = xv[k];
             }
         };
         // Schedule per tile i:  fetch tile i+1 into registers | K loop(i) | barrier | park tile i+1 | epilogue(i) | barrier.
@@ -362,7 +435,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             int tide = tid;
             asm volatile("" : "+v"(tide));
             const int tyi = tl / p.tiles_x;
-            epilogue(tyi * TH, (tl - tyi * p.tiles_x) * CONV_TW, tide);
+            if constexpr (EPI == 1) epilogue_lean(tyi * TH, (tl - tyi * p.tiles_x) * CONV_TW, tide);
+            else epilogue(tyi * TH, (tl - tyi * p.tiles_x) * CONV_TW, tide);
             __syncthreads();                                       // next tile visible
         }
     } else {
@@ -455,13 +529,13 @@ extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg);
 
 // RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
 // the XCD banding) and walk the tiles; the others launch one workgroup per tile.
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0>
 static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy table (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
@@ -474,7 +548,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         for (int i = 0; i < 4; ++i)
             if (occ_lds[dev][i] == lds && occ_val[dev][i] > 0) occ = occ_val[dev][i];
         if (occ == 0) {
-            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>, 256, lds));
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI>, 256, lds));
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
@@ -483,7 +557,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT>), dim3(gx, 1, nz), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI>), dim3(gx, 1, nz), dim3(256), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -559,6 +633,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
             const int chunks = a.LH * a.LW * a.ncg;
             const int wg = need <= LDS_MAX ? (int)(LDS_MAX / need) : 0;
             if (chunks > CONV_XPF * 256 || wg == 0) continue;
+            if (a.LH > 31 || a.LW > 127 || a.ncg > 127) continue;   // packed chunk descriptor of the tile staging (r:5, c:7, cg:7 + 7 bits)
             if (best_wg == 0 || (best_wg < 2 && wg > best_wg)) { best_wg = wg; tiles = tl; lds = need; resident = true; }
         }
         if (resident) { a.wl_bytes = a.S * wfr_kb; tile_bytes(tiles); }
@@ -594,10 +669,18 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         if (MT == 2) return launch_conv<2, 4, false, true, false>(a, nz, lds, st);
         return launch_conv<3, 4, false, true, false>(a, nz, lds, st);
     }
+    // lean epilogue: fp16 HWC output, slopes in [0, 1], maps addressable with 32-bit element offsets, tile coordinates in
+    // the packed chunk descriptor's range
+    static const bool no_lean = getenv("REFVSR_CONV_NO_LEAN_EPI") != nullptr;      // A/B knob, read once
+    const bool lean = resident && !f32 && !no_lean && d->out_mode == REFVSR_OUT_NHWC16 && d->act_slope >= 0.f && d->act_slope <= 1.f &&
+                      d->post_slope >= 0.f && d->post_slope <= 1.f &&
+                      (long long)d->h_out * d->w_out * (long long)(d->out_c > d->mul_c ? (d->out_c > d->res_c ? d->out_c : d->res_c)
+                                                                                       : (d->mul_c > d->res_c ? d->mul_c : d->res_c)) < (1ll << 31);
 #define RV_CONV_CASE(M, T)                                                                                \
     if (MT == M && tiles == T) {                                                                          \
         if (f32) return resident ? launch_conv<M, T, true, false, true>(a, nz, lds, st)                   \
                                  : launch_conv<M, T, true, false, false>(a, nz, lds, st);                 \
+        if (lean) return launch_conv<M, T, false, false, true, 1>(a, nz, lds, st);                        \
         return resident ? launch_conv<M, T, false, false, true>(a, nz, lds, st)                           \
                         : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
     }

@@ -77,10 +77,11 @@ class Weights(object):
                 mf('FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j), [ci])
         fe = 'feature_match.feature_extract.'
         self.hd = bool(config.flag_HD_in)
+        self.vgg7 = self.hd or config.scale != 4          # attention.py:31-35
         dr('feature_match.sub_mean')
         mf32(fe + '0', [3])
         mf32(fe + '2', [64])
-        if self.hd:                       # VGG19[0:7] + map128 (attention.py:33-40)
+        if self.vgg7:                     # VGG19[0:7] + map128 (attention.py:33-40)
             mf32(fe + '5', [64])
             mf32(fe + 'map128.0', [128])
         else:
@@ -127,7 +128,8 @@ class Weights(object):
                 mf('%s.main.2.%d.conv2' % (br, i), [C])
         mf('fusion_UP', [C, C])
         mf('upsample1.upsample_conv', [C], shuffle=True)
-        mf('upsample2.upsample_conv', [C], shuffle=True)
+        if config.scale == 4:                             # RefVSR.py:89-90
+            mf('upsample2.upsample_conv', [C], shuffle=True)
         mf('conv_hr', [C])
         mf('conv_last', [C])
 
@@ -137,14 +139,15 @@ class Engine(object):
     instance: RefVSR.py:96-101,279-283)."""
 
     def __init__(self, config, weights):
-        if config.scale != 4:
-            raise NotImplementedError('only scale 4 is built')
+        if config.scale not in (2, 4):
+            raise NotImplementedError('SR scale must be 2 or 4 (configs/config_RefVSR_*.py: "SR scale (2 | 4)")')
         self.cfg = config
         self.W = weights
         self.C = config.mid_channels
         self.nb = config.num_blocks
         self.ks = config.matching_ksize
         self.hd = bool(config.flag_HD_in)
+        self.vgg7 = self.hd or config.scale != 4           # matching on VGG19[0:7] features: grid = half the (resized) frame
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
         self.match_margin = float(getattr(config, 'match_exact_margin', ops.MATCH_EXACT_MARGIN))
@@ -323,7 +326,7 @@ class Engine(object):
         def extract(x):       # VGG19 head + 1x1 map in exact fp32 on v_mfma_f32_16x16x4_f32 (attention.py:31-42)
             x = ops.pack_nhwc32(x, 4)
             x = ops.conv(self.cw(fe + '0'), x, act=0.0)
-            if not self.hd:
+            if not self.vgg7:
                 x = ops.conv(self.cw(fe + '2'), x, act=0.0)
                 return ops.conv(self.cw(fe + 'map64.0'), x, act=0.2, planar_out=True)
             x = ops.conv(self.cw(fe + '2'), x, act=0.0, planar_out=True)
@@ -449,9 +452,10 @@ class Engine(object):
         t = ops.conv(self.cw('feat_fusion_BWFW.0.0'), bw_up, fw_up, act=0.2)
         out = ops.conv(self.cw('feat_fusion_BWFW.1.0'), t, act=0.2, mul=alpha, res=fus)
         out = self.res_list(out, 'feat_decoder_BWFW', 4)
-        out = ops.conv(self.cw('upsample2.upsample_conv'), out, act=0.1)      # lrelu commutes with pixel_shuffle
+        if self.cfg.scale == 4:                                               # :114-115
+            out = ops.conv(self.cw('upsample2.upsample_conv'), out, act=0.1)  # lrelu commutes with pixel_shuffle
         out = ops.conv(self.cw('conv_hr'), out, act=0.1)
-        base = ops.bicubic_scale(lr_center, 4, clamp01=True)
+        base = ops.bicubic_scale(lr_center, self.cfg.scale, clamp01=True)
         return ops.conv(self.cw('conv_last'), out, planar_out=True, res_planar=base, clamp=(0.0, 1.0))
 
     # ------------------------------------------------------------------ window bookkeeping
@@ -702,6 +706,7 @@ class Engine(object):
         t, _, h, w = lrs.shape
         assert t >= 3 and t % 2 == 1 and h % 2 == 0 and w % 2 == 0, 'need odd t >= 3 and even h, w'
         assert not self.hd or (h % 8 == 0 and w % 8 == 0), 'flag_HD_in needs h, w divisible by 8'
+        assert not self.vgg7 or (h % 4 == 0 and w % 4 == 0), 'x2 / HD matching needs h, w divisible by 4'
         return t, h, w
 
     @torch.no_grad()
@@ -784,7 +789,8 @@ class Engine(object):
         if save_sample:
             f = fr[ctr]
             h, w = f.lr.shape[1:]
-            gh, gw = (h, w) if not self.hd else (h // self.cfg.scale, w // self.cfg.scale)
+            hm, wm = (h // (self.cfg.scale // 2), w // (self.cfg.scale // 2)) if self.hd else (h, w)
+            gh, gw = (hm // 2, wm // 2) if self.vgg7 else (hm, wm)
             s1, s2 = self.ks // 2, self.ks
             lr_down = ops.bicubic_scale(f.lr, 0.5, clamp01=True)
             ref_down = ops.bicubic_scale(f.ref, 0.5, clamp01=True)

@@ -28,6 +28,10 @@ def matching(cfg, h, w):
         vgg = lambda px: _conv(3, 64, 3, px) + _conv(64, 64, 3, px) + _conv(64, 128, 3, px // 4) + _conv(128, 16, 1, px // 4)
         n_lr, n_ref = (hl // 2) * (wl // 2), (hl // 4) * (wl // 4)
         return 2.0 * n_lr * n_ref * 144, vgg(hl * wl) + vgg((hl // 2) * (wl // 2))
+    if cfg.scale != 4:                                # x2: VGG19[0:7] features, matching grid = half the frame
+        vgg = lambda px: _conv(3, 64, 3, px) + _conv(64, 64, 3, px) + _conv(64, 128, 3, px // 4) + _conv(128, 16, 1, px // 4)
+        n_lr, n_ref = (h // 2) * (w // 2), (h // 4) * (w // 4)
+        return 2.0 * n_lr * n_ref * 144, vgg(h * w) + vgg((h // 2) * (w // 2))
     vgg = lambda px: _conv(3, 64, 3, px) + _conv(64, 64, 3, px) + _conv(64, 16, 1, px)
     n_lr, n_ref = h * w, (h // 2) * (w // 2)
     return 2.0 * n_lr * n_ref * 144, vgg(n_lr) + vgg(n_ref)
@@ -63,9 +67,10 @@ def propagation_step(cfg, h, w):
 
 
 def upsampler(cfg, h, w):
-    C, X2, HR = cfg.mid_channels, 4 * h * w, 16 * h * w
+    C, X2 = cfg.mid_channels, 4 * h * w
+    HR = 16 * h * w if cfg.scale == 4 else X2
     f = _conv(2 * C, C, 1, X2) + _conv(2, 16, 3, X2) + _conv(16, C, 3, X2) + _conv(2 * C, C, 3, X2) + _conv(C, C, 3, X2)
-    f += 9 * _conv(C, C, 3, X2) + _conv(C, 4 * C, 3, X2) + _conv(C, C, 3, HR) + _conv(C, 3, 3, HR)
+    f += 9 * _conv(C, C, 3, X2) + (_conv(C, 4 * C, 3, X2) if cfg.scale == 4 else 0.0) + _conv(C, C, 3, HR) + _conv(C, 3, 3, HR)
     return f
 
 

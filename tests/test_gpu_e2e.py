@@ -31,9 +31,11 @@ def get_config_reset(name):
     return get_config('p', 'm', name).reset_branch
 
 
-def make_net(name, t, dev, reset='keep', cache=True, save_sample=True):
-    from refvsr_amd import SRNet, get_config, make_state_dict
+def make_net(name, t, dev, reset='keep', cache=True, save_sample=True, scale=4):
+    from refvsr_amd import SRNet, get_config, make_state_dict, set_scale
     cfg = get_config('p', 'm', name)
+    if scale != 4:
+        set_scale(cfg, scale)
     cfg.frame_num = t
     cfg.save_sample = save_sample
     cfg.cache_windows = cache
@@ -48,7 +50,8 @@ def make_net(name, t, dev, reset='keep', cache=True, save_sample=True):
 E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_small_L1'),
        ('S_24x32_t5_reset3', 'config_RefVSR_small_L1'), ('F_16x24_t3', 'config_RefVSR_MFID'),
        ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1'),
-       ('HD48_64x96_t3', 'config_RefVSR_MFID_8K')]          # BASELINE configs[4] model: C = 48, 30 blocks, aa1 + aa2 alignment
+       ('HD48_64x96_t3', 'config_RefVSR_MFID_8K'),          # BASELINE configs[4] model: C = 48, 30 blocks, aa1 + aa2 alignment
+       ('S2_16x24_t3', 'config_RefVSR_small_L1')]           # x2 SR: config.scale = 2 (matching_ksize 4, VGG19[0:7] matching)
 
 
 @pytest.mark.parametrize('tag,name', E2E)
@@ -57,7 +60,7 @@ def test_stream_against_reference_fixture(dev, tag, name):
     g = load_golden('e2e_' + tag)
     t = int(g['t'])
     rb = int(g['reset_branch'])
-    net, cfg, sd = make_net(name, t, dev, reset=None if rb < 0 else rb)
+    net, cfg, sd = make_net(name, t, dev, reset=None if rb < 0 else rb, scale=int(g.get('scale', 4)))
     lr, rf = g['lr'], g['ref']
     nframes = lr.shape[1]
     worst = 0.0

@@ -98,7 +98,7 @@ def test_compute_up(small_cfg, small_sd):
 E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_small_L1'),
        ('S_24x32_t5_reset3', 'config_RefVSR_small_L1'), ('F_16x24_t3', 'config_RefVSR_MFID'),
        ('HD_32x48_t3', 'config_RefVSR_small_MFID_8K'), ('S_16x24_t7', 'config_RefVSR_small_L1'),
-       ('HD48_64x96_t3', 'config_RefVSR_MFID_8K')]
+       ('HD48_64x96_t3', 'config_RefVSR_MFID_8K'), ('S2_16x24_t3', 'config_RefVSR_small_L1')]
 
 
 @pytest.mark.parametrize('tag,name', E2E)
@@ -112,6 +112,9 @@ def test_end_to_end_stream(tag, name):
     cfg.save_sample = True
     rb = int(g['reset_branch'])
     cfg.reset_branch = None if rb < 0 else rb
+    if int(g.get('scale', 4)) != 4:                      # x2 fixtures: the reference ran with `config.scale = 2`
+        from refvsr_amd import set_scale
+        set_scale(cfg, int(g['scale']))
     o = orc.OracleNetwork(cfg, make_state_dict(cfg, 1234))
     lr, rf = g['lr'], g['ref']
     nframes = lr.shape[1]

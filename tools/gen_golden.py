@@ -33,8 +33,11 @@ VIS_FIXTURES = ('S_18x26_t5', 'HD_32x48_t3')
 SEED_W = 1234
 
 
-def ref_net(name, frame_num, save_sample=True):
+def ref_net(name, frame_num, save_sample=True, scale=4):
     cfg = importlib.import_module('configs.' + name).get_config('p', 'm', name)
+    if scale != 4:            # what editing `config.scale = 4 # SR scale (2 | 4)` in the reference's config file does (:30-39)
+        cfg.scale = scale
+        cfg.matching_ksize = (4 if scale == 2 else 2) * (scale if cfg.flag_HD_in else 1)
     cfg.cuda = False
     cfg.device = 'cpu'
     cfg.dist = False
@@ -45,6 +48,9 @@ def ref_net(name, frame_num, save_sample=True):
     mine = my_get_config('p', 'm', name)
     mine.frame_num = frame_num
     mine.save_sample = save_sample
+    if scale != 4:
+        from refvsr_amd.config import set_scale
+        set_scale(mine, scale)
     # the build's config mirror must agree with the reference on every model field
     for k in ('scale', 'flag_HD_in', 'matching_ksize', 'num_blocks', 'mid_channels', 'reset_branch',
               'is_amp', 'network'):
@@ -213,9 +219,9 @@ def windows(nframes, t):
     return out
 
 
-def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep', light=False):
-    print('== end-to-end %s: %s t=%d %dx%d, %d frames ==' % (tag, name, t, h, w, nframes))
-    net, cfg, mine, sd = ref_net(name, t)
+def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep', light=False, scale=4):
+    print('== end-to-end %s: %s t=%d %dx%d, %d frames, x%d ==' % (tag, name, t, h, w, nframes, scale))
+    net, cfg, mine, sd = ref_net(name, t, scale=scale)
     if reset_override != 'keep':
         cfg.reset_branch = reset_override
         mine.reset_branch = reset_override
@@ -223,7 +229,8 @@ def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep', light=False):
     rs = np.random.RandomState(abs(hash(tag)) % (2 ** 31) if False else sum(map(ord, tag)))
     lr, rf = synth_clip(rs, nframes, h, w)
     o = orc.OracleNetwork(mine, sd)
-    arrs = dict(lr=lr, ref=rf, t=np.int64(t), reset_branch=np.int64(-1 if mine.reset_branch is None else mine.reset_branch))
+    arrs = dict(lr=lr, ref=rf, t=np.int64(t), reset_branch=np.int64(-1 if mine.reset_branch is None else mine.reset_branch),
+                scale=np.int64(scale))
     with torch.no_grad():
         for f, win in enumerate(windows(nframes, t)):
             x, r = lr[:, win], rf[:, win]
@@ -333,16 +340,18 @@ def main():
            # 7-frame windows on a 5-frame clip: every window replicates frames at a clip edge (datasets.py:233-234)
            ('S_16x24_t7', 'config_RefVSR_small_L1', 7, 16, 24, 5, 'keep'),
            # BASELINE configs[4] model: C = 48, 30 blocks, flag_HD_in (aa1 scale 4 + align, aa2 scale 8 + align), no reset
-           ('HD48_64x96_t3', 'config_RefVSR_MFID_8K', 3, 64, 96, 2, 'keep')]
+           ('HD48_64x96_t3', 'config_RefVSR_MFID_8K', 3, 64, 96, 2, 'keep'),
+           # x2 SR (config.scale = 2: matching_ksize 4, VGG19[0:7] matching features, aa1 + aa2 alignment, one pixel shuffle)
+           ('S2_16x24_t3', 'config_RefVSR_small_L1', 3, 16, 24, 3, 'keep')]
     if '--only' in sys.argv:                     # regenerate one end-to-end fixture: --only S_16x24_t7
         tag = sys.argv[sys.argv.index('--only') + 1]
         for e in E2E:
             if e[0] == tag:
-                gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'))
+                gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'), scale=2 if e[0].startswith('S2_') else 4)
         return
     gen_ops()
     for e in E2E:
-        gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'))
+        gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'), scale=2 if e[0].startswith('S2_') else 4)
     # state-dict contract checksums for all six configs
     sums = {}
     for name in ('config_RefVSR_small_L1', 'config_RefVSR_small_MFID', 'config_RefVSR_L1', 'config_RefVSR_MFID',
