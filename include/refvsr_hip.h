@@ -89,6 +89,9 @@ int refvsr_resblock_mfma(const void* src, int c, int h, int w, const void* w1, c
  * the intermediate map overwrites the input tile): two workgroups per CU, so one's epilogue runs under the other's
  * MFMAs.  Bit-identical to refvsr_resblock_mfma.  Slopes must lie in [0, 1]. */
 int refvsr_resblock_lean_fits(int c);
+/* Tuning knob: waves per workgroup of the lean kernel, 8 (default: half the tiles per wave, <= 128 VGPRs, four waves per
+ * SIMD) or 4.  Results do not depend on it. */
+int refvsr_set_resblock_waves(int waves);
 int refvsr_resblock_lean(const void* src, int c, int h, int w, const void* w1, const float* b1,
                          const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
                          void* out, void* stream);

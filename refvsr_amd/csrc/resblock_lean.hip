@@ -29,8 +29,7 @@
 #define RL_IW (RL_TW + 2)
 #define RL_NI (RL_IH * RL_IW)             // 340 intermediate pixels
 #define RL_T1 ((RL_NI + 15) / 16)         // 22 phase-1 tiles
-#define RL_T1W ((RL_T1 + 3) / 4)          // 6 per wave
-#define RL_T2W (RL_TH * 2 / 4)            // 4 per wave
+// tiles per wave are template constants of the kernel: NWV = 4 waves -> 6 / 4, NWV = 8 waves -> 3 / 2
 
 struct ResLeanArgs {
     const f16* src; f16* out;
@@ -86,10 +85,15 @@ __device__ __forceinline__ void rl_kloop(f32x4 (&acc)[MT][T], const unsigned cha
     }
 }
 
-// XP = staging passes of the x tile: 256 threads cover (256 / CPR) rows x CPR 16-byte chunk slots per pass,
-// CPR = 128 (XP = 6, up to 3 channel groups) or 256 (XP = 12, up to 7).
-template <int MT, int XP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_lean_kernel(ResLeanArgs p) {
+// NWV = waves per workgroup (4 or 8).  WIDE = false: a staged row has 128 chunk slots (up to 3 channel groups),
+// true: 256 (up to 7).  With 8 waves each wave holds half the tiles (3 + 2 instead of 6 + 4): <= 128 VGPRs, so the two
+// workgroups of a CU put FOUR waves on every SIMD -- the VALU-only stretches (epilogues, staging) issue at twice the
+// rate of the 2-waves-per-SIMD shapes, which is what bounds them (tools/probe_resblock.py).
+template <int MT, bool WIDE, int NWV>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 2, NWV / 2))) void resblock_lean_kernel(ResLeanArgs p) {
+    constexpr int NT = NWV * 64;                                  // threads
+    constexpr int RL_T1W = (RL_T1 + NWV - 1) / NWV;               // phase-1 tiles per wave
+    constexpr int RL_T2W = RL_TH * 2 / NWV;                       // phase-2 tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tab1 = reinterpret_cast<int*>(smem);                    // K-slot -> byte offset in the x tile (pitch RL_XW)
     int* tab2 = tab1 + p.S * 4;                                   // K-slot -> byte offset in the t tile (pitch RL_IW)
@@ -97,8 +101,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* wl2 = wl1 + p.w_bytes;
     unsigned char* xt = wl2 + p.w_bytes;                          // x tile [RL_XH][RL_XW][ps*16], then t [RL_IH][RL_IW][ps*16]
 
-    constexpr int CPR = (XP == 6) ? 128 : 256;                    // chunk slots per staged row
-    constexpr int RPP = 256 / CPR;                                // rows per staging pass
+    constexpr int CPR = WIDE ? 256 : 128;                         // chunk slots per staged row
+    constexpr int RPP = NT / CPR;                                 // rows per staging pass
+    constexpr int XP = RL_XH / RPP;                               // staging passes of the x tile
     static_assert(XP * RPP == RL_XH, "staging passes must cover the x tile");
 
     const int tid = threadIdx.x;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lp = rv_pix16(lane & 15);       // pixel (of a 16-pixel MFMA tile) held by this lane's column
     const int psb = p.ps * 16;
 
-    for (int g = tid; g < p.S * 4; g += 256) {                    // K order: common.h:rv_kslot
+    for (int g = tid; g < p.S * 4; g += NT) {                     // K order: common.h:rv_kslot
         int o1, o2, slot;
         if (g < p.G) {
             const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
@@ -168,23 +173,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // Start-up: every global load of the prologue (w1, first x tile, w2, biases) is issued before the first LDS store, so
     // the workgroup pays ONE memory round trip; both weight sets then stay resident for the workgroup's whole life.
     // (named registers, not arrays: hipcc keeps conditionally stored register ARRAYS in scratch memory)
-    constexpr int NW = (MT == 1) ? 3 : 9;           // uint4 per thread and weight set (C <= 16: 640, C = 24 / 32: 1792 / 2304)
+    constexpr int NW = ((MT == 1 ? 640 : 2304) + NT - 1) / NT;   // uint4 per thread and weight set (C <= 16: 640, C = 24 / 32: 1792 / 2304)
     const int n16w = p.S * MT * 2 * 64;
     uint4 wa0, wa1, wa2, wa3, wa4, wa5, wa6, wa7, wa8, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8;
 #define RL_W_ALL(OP, P) OP(P, 0) OP(P, 1) OP(P, 2) OP(P, 3) OP(P, 4) OP(P, 5) OP(P, 6) OP(P, 7) OP(P, 8)
-#define RL_W_LOAD(P, k) if constexpr (NW > k) P##k = src_[min(tid + k * 256, n16w - 1)];
-#define RL_W_STORE(P, k) if constexpr (NW > k) { if (tid + k * 256 < n16w) dst_[tid + k * 256] = P##k; }
+#define RL_W_LOAD(P, k) if constexpr (NW > k) P##k = src_[min(tid + k * NT, n16w - 1)];
+#define RL_W_STORE(P, k) if constexpr (NW > k) { if (tid + k * NT < n16w) dst_[tid + k * NT] = P##k; }
     { const uint4* src_ = p.w1; RL_W_ALL(RL_W_LOAD, wa) }
     if (tl < k_hi) x_fetch(tl);
     { const uint4* src_ = p.w2; RL_W_ALL(RL_W_LOAD, wb) }
-    float4 b1r[MT], b2r[MT];                        // biases of this lane's output channels: fetched once
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int co0 = min(m * 16 + q * 4, p.c - 4);
-        b1r[m] = *reinterpret_cast<const float4*>(p.b1 + co0);
-        b2r[m] = *reinterpret_cast<const float4*>(p.b2 + co0);
-    }
+    // biases: 2 x 32 floats parked in LDS behind the tables (in registers they cost 16 VGPRs for the kernel's whole life)
+    float* bl = reinterpret_cast<float*>(tab2 + p.S * 4);
+    float bias_v = 0.f;
+    if (tid < 64) bias_v = (tid & 31) < p.c ? ((tid < 32) ? p.b1[tid] : p.b2[tid - 32]) : 0.f;
     asm volatile("" ::: "memory");                  // loads above, LDS stores below
+    if (tid < 64) bl[tid] = bias_v;
     { uint4* dst_ = reinterpret_cast<uint4*>(wl1); RL_W_ALL(RL_W_STORE, wa) }
     if (tl < k_hi) x_park();
     { uint4* dst_ = reinterpret_cast<uint4*>(wl2); RL_W_ALL(RL_W_STORE, wb) }
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int m = 0; m < MT; ++m) {
                 const int co0 = m * 16 + q_e * 4;
                 if (co0 >= p.c) continue;
-                const float4 bv = b1r[m];
+                const float4 bv = *reinterpret_cast<const float4*>(bl + m * 16 + q_e * 4);
                 float y0 = acc1[m][t][0] + bv.x, y1 = acc1[m][t][1] + bv.y, y2 = acc1[m][t][2] + bv.z, y3 = acc1[m][t][3] + bv.w;
                 y0 = fmaxf(y0, y0 * p.act_slope); y1 = fmaxf(y1, y1 * p.act_slope);       // (leaky) ReLU, 0 <= slope <= 1
                 y2 = fmaxf(y2, y2 * p.act_slope); y3 = fmaxf(y3, y3 * p.act_slope);
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int m = 0; m < MT; ++m) {
                 const int co0 = m * 16 + q_e * 4;
                 if (co0 >= p.c) continue;
-                const float4 bv = b2r[m];
+                const float4 bv = *reinterpret_cast<const float4*>(bl + 32 + m * 16 + q_e * 4);
                 const f16x4 xv4 = xres[m][t];
                 float y[4] = {acc2[m][t][0] + bv.x + (float)xv4[0], acc2[m][t][1] + bv.y + (float)xv4[1],
                               acc2[m][t][2] + bv.z + (float)xv4[2], acc2[m][t][3] + bv.w + (float)xv4[3]};
@@ -299,7 +302,7 @@ static size_t rl_lds_bytes(int c) {
     const int ncg = c / 8, ps = ncg | 1;
     const int S = rv_ksteps(3, ncg);
     const int MT = (c + 15) / 16;
-    return (size_t)((S * 4 * 2 * 4 + 15) / 16 * 16) + 2 * (size_t)S * MT * 2 * 1024 + (size_t)RL_XH * RL_XW * ps * 16;
+    return (size_t)((S * 4 * 2 * 4 + 256 + 15) / 16 * 16) + 2 * (size_t)S * MT * 2 * 1024 + (size_t)RL_XH * RL_XW * ps * 16;
 }
 
 extern "C" int refvsr_resblock_lean_fits(int c) {
@@ -309,7 +312,14 @@ extern "C" int refvsr_resblock_lean_fits(int c) {
     return rl_lds_bytes(c) <= 160 * 1024 ? 1 : 0;
 }
 
-template <int MT, int XP>
+static int g_lean_waves = 8;               // A/B knob (refvsr_set_resblock_waves): 4 or 8 waves per workgroup
+extern "C" int refvsr_set_resblock_waves(int waves) {
+    if (waves != 4 && waves != 8) return 1;
+    g_lean_waves = waves;
+    return 0;
+}
+
+template <int MT, bool WIDE, int NWV>
 static int launch_lean(const ResLeanArgs& a, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
@@ -317,20 +327,20 @@ static int launch_lean(const ResLeanArgs& a, size_t lds, hipStream_t st) {
     static size_t occ_lds[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_lean_kernel<MT, XP>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_lean_kernel<MT, WIDE, NWV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
     if (occ_dev[dev] == 0 || occ_lds[dev] != lds) {
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_lean_kernel<MT, XP>, 256, lds));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_lean_kernel<MT, WIDE, NWV>, NWV * 64, lds));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         occ_lds[dev] = lds;
     }
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     const int gx = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((resblock_lean_kernel<MT, XP>), dim3(gx), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((resblock_lean_kernel<MT, WIDE, NWV>), dim3(gx), dim3(NWV * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -354,16 +364,18 @@ extern "C" int refvsr_resblock_lean(const void* src, int c, int h, int w, const 
     a.w1 = (const uint4*)w1; a.b1 = b1; a.w2 = (const uint4*)w2; a.b2 = b2;
     a.act_slope = act_slope; a.post_slope = post_slope;
     const int MT = (c + 15) / 16;
-    a.tab_bytes = (a.S * 4 * 2 * 4 + 15) / 16 * 16;
+    a.tab_bytes = (a.S * 4 * 2 * 4 + 256 + 15) / 16 * 16;         // two K-slot tables + 2 x 32 bias floats
     a.w_bytes = a.S * MT * 2 * 1024;
     a.tiles_x = rv_cdiv(w, RL_TW);
     a.n_tiles = a.tiles_x * rv_cdiv(h, RL_TH);
     const size_t lds = rl_lds_bytes(c);
     hipStream_t st = (hipStream_t)stream;
-    if (RL_XW * a.ncg <= 128) {
-        if (MT == 1) return launch_lean<1, 6>(a, lds, st);
-        return launch_lean<2, 6>(a, lds, st);
-    }
-    if (MT == 1) return launch_lean<1, 12>(a, lds, st);
-    return launch_lean<2, 12>(a, lds, st);
+    const bool wide = RL_XW * a.ncg > 128;
+#define RL_CASE(M, WD, NW_)                                                          \
+    if (MT == M && wide == WD && g_lean_waves == NW_) return launch_lean<M, WD, NW_>(a, lds, st);
+    RL_CASE(1, false, 8) RL_CASE(2, false, 8) RL_CASE(1, true, 8) RL_CASE(2, true, 8)
+    RL_CASE(1, false, 4) RL_CASE(2, false, 4) RL_CASE(1, true, 4) RL_CASE(2, true, 4)
+#undef RL_CASE
+    refvsr_set_error("resblock_lean: no kernel for MT=%d wide=%d waves=%d", MT, (int)wide, g_lean_waves);
+    return 1;
 }

@@ -150,6 +150,7 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
 # Two kernels implement the fused block with identical results: 'lean' (4 waves, 8x32 tile, 77 KB LDS at C = 24, two
 # workgroups per CU -- resblock_lean.hip) and 'wide' (8 waves, 16x32 tile, one 154 KB workgroup per CU -- resblock_mfma.hip).
 RESBLOCK_KERNEL = os.environ.get('REFVSR_RESBLOCK', 'lean')
+_WAVES_SET = False
 
 
 def resblock_fits(c):
@@ -166,6 +167,11 @@ def resblock(cw1, cw2, x, act, post=1.0, kernel=None):
     assert not cw1.f32 and not cw1.shuffle and cw1.wpack.shape[0] == 1
     out = torch.empty_like(x)
     kernel = kernel or RESBLOCK_KERNEL
+    global _WAVES_SET
+    if not _WAVES_SET:                     # A/B knob of the lean kernel's workgroup shape (default 8 waves)
+        _WAVES_SET = True
+        if os.environ.get('REFVSR_RESBLOCK_WAVES'):
+            hip.check(hip.lib().refvsr_set_resblock_waves(int(os.environ['REFVSR_RESBLOCK_WAVES'])), 'set_resblock_waves')
     if kernel == 'lean' and hip.lib().refvsr_resblock_lean_fits(c):
         hip.check(hip.lib().refvsr_resblock_lean(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
                                                  _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_lean')

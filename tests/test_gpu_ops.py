@@ -226,7 +226,13 @@ def test_resblock_fused(dev, C, h, w, act):
     assert same < 4e-3            # both round the intermediate and the output to fp16; summation order differs
     fused_p = ops.resblock(c1, c2, xin, act=act, post=0.2)
     assert rel(planar(fused_p), F.leaky_relu(want, 0.2)) < 1e-3
-    # the two fused kernels (4-wave 8x32-tile 'lean', 8-wave 16x32-tile 'wide') agree bit for bit
+    # both workgroup shapes of the lean kernel (8 waves / 4 waves) agree bit for bit
+    if ops.hip.lib().refvsr_resblock_lean_fits(C):
+        ops.hip.lib().refvsr_set_resblock_waves(4)
+        four = ops.resblock(c1, c2, xin, act=act, kernel='lean')
+        ops.hip.lib().refvsr_set_resblock_waves(8)
+        assert torch.equal(four, ops.resblock(c1, c2, xin, act=act, kernel='lean')), 'lean 4 waves != 8 waves'
+    # the two fused kernels (8x32-tile 'lean', 8-wave 16x32-tile 'wide') agree bit for bit
     if ops.hip.lib().refvsr_resblock_fits(C) and ops.hip.lib().refvsr_resblock_lean_fits(C):
         for post in (1.0, 0.2):
             assert torch.equal(ops.resblock(c1, c2, xin, act=act, post=post, kernel='lean'),
