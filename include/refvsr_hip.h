@@ -204,6 +204,27 @@ int refvsr_block_gather_rgb(const float* value, int hv, int wv, const int32_t* i
 int refvsr_aligned_sample(const void* x, int h, int w, int ks, int cs, const float* affine, void* out,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * RefVSR_IR: EDVR-M feature extractor pieces that are not convolutions (models/archs/edvr_net.py)
+ * ------------------------------------------------------------------------------------------ */
+/* Sampling half of mmcv's modulated deformable convolution (edvr_net.py:49-56, ModulatedDCNPack; 3x3, stride 1, pad 1):
+ * cols[y][x][k*c + ch] = sigmoid(mask) * bilinear(x, tap position + offset) for tap k, 8 channels per deformable group;
+ * offset_mask = raw conv_offset output, planar fp32 [3*groups*9][h][w] ([o1 | o2 | mask]).  The contraction with the
+ * [cout][c*9] weight is a 1x1 refvsr_conv_mfma over cols. */
+int refvsr_dcn_sample(const void* x, int h, int w, int c, const float* offset_mask, int deform_groups, void* cols,
+                      void* stream);
+/* TSAFusion temporal attention (edvr_net.py:259-272): out[.., i*c + ch] = aligned_i * sigmoid(sum_ch emb_i * emb_ref);
+ * aligned / emb: HOST arrays of t device pointers (nhwc16 [npix][c]). */
+int refvsr_tsa_weight(const void* const* aligned, const void* const* emb, const void* emb_ref, int t, int c, int npix,
+                      void* out, void* stream);
+/* MaxPool2d / AvgPool2d(3, stride 2, padding 1) of an nhwc16 map into channels [c_off, c_off + c) of out (channel
+ * stride out_c) (edvr_net.py:214-215,277-279). */
+int refvsr_pool3s2_nhwc16(const void* x, int h, int w, int c, void* out, int out_c, int c_off, int is_max, void* stream);
+/* nn.Upsample(x2, bilinear, align_corners=False) * mul of an nhwc16 map (edvr_net.py:131,179-181,246). */
+int refvsr_up2_bilinear_nhwc16(const void* x, int h, int w, int c, float mul, void* out, void* stream);
+/* out = feat * sigmoid(attn) * 2 + add on n halfs (edvr_net.py:294-299). */
+int refvsr_tsa_blend(const void* feat, const void* attn, const void* add, size_t n, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,11 @@ _MODELS = {
     'config_RefVSR_MFID':          dict(mid_channels=48, num_blocks=30, flag_HD_in=False, frame_itr_num=9, frame_num=7, reset='itr', is_amp=False),
     'config_RefVSR_MFID_8K':       dict(mid_channels=48, num_blocks=30, flag_HD_in=True, frame_itr_num=9, frame_num=7, reset=None, is_amp=False),
     'config_RefVSR_small_MFID_8K': dict(mid_channels=24, num_blocks=24, flag_HD_in=True, frame_itr_num=9, frame_num=3, reset='itr', is_amp=True),
+    # RefVSR_IR (IconVSR-style: information refill from an EDVR-M feature extractor, configs/config_RefVSR_IR_{L1,MFID}.py)
+    'config_RefVSR_IR_L1':         dict(mid_channels=36, num_blocks=30, flag_HD_in=False, frame_itr_num=26, frame_num=13, reset='itr', is_amp=False,
+                                        network='RefVSR_IR', keyframe_stride=5),
+    'config_RefVSR_IR_MFID':       dict(mid_channels=36, num_blocks=30, flag_HD_in=False, frame_itr_num=5, frame_num=9, reset='itr', is_amp=False,
+                                        network='RefVSR_IR', keyframe_stride=5),
 }
 
 CONFIG_NAMES = tuple(_MODELS)
@@ -106,7 +111,9 @@ def get_config(project='', mode='', config='', data='', LRS='', batch_size=8):
     if c.flag_HD_in:
         c.matching_ksize *= c.scale
     c.trainer = 'trainer'
-    c.network = 'RefVSR'
+    c.network = m.get('network', 'RefVSR')
+    if 'keyframe_stride' in m:
+        c.keyframe_stride = m['keyframe_stride']
     c.num_blocks = m['num_blocks']
     c.mid_channels = m['mid_channels']
     c.reset_branch = c.frame_itr_num if m['reset'] == 'itr' else None

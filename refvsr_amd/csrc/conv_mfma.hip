@@ -225,7 +225,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co0 = (zg * MT + m) * 16 + q_e * 4;
-            if (co0 >= p.cout) continue;
+            if (co0 >= p.cout) {
+                // channel padding of an HWC map whose channel count is not a multiple of 8 (C = 36 of RefVSR_IR -> stride
+                // 40): consumers multiply the padding by zero weights, so it must hold zeros, not allocator garbage
+                if (p.out_mode == REFVSR_OUT_NHWC16 && co0 < p.out_c) {
+                    if constexpr (F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + opix * p.out_c + co0) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    else *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + opix * p.out_c + co0) = (f16x4){0, 0, 0, 0};
+                }
+                continue;
+            }
             float y[4];
             const float4 bv = bias_r[m];
             y[0] = acc[m][t][0] + bv.x; y[1] = acc[m][t][1] + bv.y;
@@ -276,6 +284,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 const size_t op = (size_t)(2 * oy + (sub >> 1)) * (2 * p.w_out) + (2 * ox + (sub & 1));
                 f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
                 *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + op * p.out_c + c) = o;
+                if (c + 4 == C && p.out_c > C)             // zero the channel padding of the shuffled map (see above)
+                    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + op * p.out_c + C) = (f16x4){0, 0, 0, 0};
             } else {
                 const size_t plane = (size_t)p.h_out * p.w_out;
 #pragma unroll
@@ -312,7 +322,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int co0 = (zg * MT + m) * 16 + q_e * 4;
-                if (co0 >= p.cout) continue;
+                if (co0 >= p.cout) {
+                    if (co0 < p.out_c) *reinterpret_cast<f16x4*>(outp + (opix * (unsigned)p.out_c + (unsigned)co0)) = (f16x4){0, 0, 0, 0};
+                    continue;
+                }
                 const float4 bv = bias_r[m];
                 float y0 = acc[m][t][0] + bv.x, y1 = acc[m][t][1] + bv.y, y2 = acc[m][t][2] + bv.z, y3 = acc[m][t][3] + bv.w;
                 y0 = fmaxf(y0, y0 * p.act_slope); y1 = fmaxf(y1, y1 * p.act_slope);
@@ -579,7 +592,8 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         RV_CHECK(d->res_planar == nullptr, "conv: res_planar only with planar output");
     }
     if (d->out_mode == REFVSR_OUT_NHWC16_SHUFFLE2)
-        RV_CHECK(d->cout % 16 == 0 && !d->mul && !d->res && !f32, "conv: pixel-shuffle output constraints");
+        RV_CHECK(d->cout % 16 == 0 && !d->mul && !d->res && !f32 && d->out_c >= d->cout / 4 && d->out_c - d->cout / 4 <= 4,
+                 "conv: pixel-shuffle output constraints");
     RV_CHECK(refvsr_init() == 0, "init failed");
 
     ConvArgs a;

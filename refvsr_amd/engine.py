@@ -122,7 +122,14 @@ class Weights(object):
         reslist('feat_decoder2', 4)
         reslist('feat_decoder_BWFW', 4)
         for br in ('backward_resblocks', 'forward_resblocks'):
-            mf(br + '.main.0', [3, C])
+            cin = sd['Network.' + br + '.main.0.weight'].shape[1]
+            if cin == C + 3:
+                mf(br + '.main.0', [3, C])
+            else:                        # RefVSR_IR forward branch: cat([lr, backward features, state]) (RefVSR_IR.py:354); the
+                assert cin == 2 * C + 3  # kernel takes two maps, so [lr | backward features] are handed over as one HWC map
+                mf(br + '.main.0', [3, C, C])
+                cw = self.conv[br + '.main.0']
+                cw.cpads = [cw.cpads[0] + cw.cpads[1], cw.cpads[2]]
             for i in range(self.nb):
                 mf('%s.main.2.%d.conv1' % (br, i), [C])
                 mf('%s.main.2.%d.conv2' % (br, i), [C])
@@ -188,7 +195,7 @@ class Engine(object):
         """Forward-branch state as planar fp32 tensors (what RefVSR.py:279-283 keeps)."""
         if self.fw_feat is None:
             return None
-        return dict(feat=ops.unpack_nhwc16(self.fw_feat), flow=self.fw_flow, feat_up=ops.unpack_nhwc16(self.fw_feat_up),
+        return dict(feat=ops.unpack_nhwc16(self.fw_feat, self.C), flow=self.fw_flow, feat_up=ops.unpack_nhwc16(self.fw_feat_up, self.C),
                     conf=self.fw_conf, frame_itr_num=self.frame_itr_num)
 
     def import_state(self, st):

@@ -72,6 +72,11 @@ SIGNATURES = {
     'refvsr_block_gather_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     'refvsr_block_gather_rgb': [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P],
     'refvsr_aligned_sample': [_P, _I, _I, _I, _I, _P, _P, _P],
+    'refvsr_dcn_sample': [_P, _I, _I, _I, _P, _I, _P, _P],
+    'refvsr_tsa_weight': [_P, _P, _P, _I, _I, _I, _P, _P],
+    'refvsr_pool3s2_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _I, _P],
+    'refvsr_up2_bilinear_nhwc16': [_P, _I, _I, _I, _F, _P, _P],
+    'refvsr_tsa_blend': [_P, _P, _P, _Z, _P, _P],
 }
 _SPECIAL = {'refvsr_abi_version': (C.c_int, []), 'refvsr_last_error': (C.c_char_p, [])}
 EXPORTS = tuple(sorted(list(SIGNATURES) + list(_SPECIAL)))

@@ -48,6 +48,8 @@ class _FlowNetHandle(nn.Module):
 
 class Network(nn.Module):
     """HIP implementation of models/archs/RefVSR.py:Network (inference path)."""
+    _engine_cls = Engine
+    _weights_cls = Weights
 
     def __init__(self, config):
         super().__init__()
@@ -83,7 +85,7 @@ class Network(nn.Module):
         key = (self._weights_key(), str(device))
         if self._packed is None or self._packed_key != key:
             sd = collections.OrderedDict(('Network.' + k, v.detach()) for k, v in self.named_parameters())
-            self._packed = Weights(self.config, sd, device)
+            self._packed = self._weights_cls(self.config, sd, device)
             self._packed_key = key
             for e in self._engines:
                 # everything an engine caches (per-frame matching / encodings / flows, the forward-branch state) was
@@ -114,7 +116,7 @@ class Network(nn.Module):
     def ensure_engines(self, n, device):
         W = self._weights(device)
         while len(self._engines) < n:
-            self._engines.append(Engine(self.config, W))
+            self._engines.append(self._engine_cls(self.config, W))
         return self._engines
 
     def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, frame_ids=None):

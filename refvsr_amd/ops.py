@@ -66,6 +66,10 @@ def _nhwc(t, f32=False):
     return t
 
 
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
 def _farr(vals):
     if vals is None:
         return None
@@ -136,12 +140,13 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         if clamp is not None:
             d.clamp_lo, d.clamp_hi = clamp
     elif cw.shuffle:
-        co = cw.cout // 4
+        co = _round_up(cw.cout // 4, 8)             # channel stride of the map (padding channels are written as zeros)
         out = torch.empty((2 * ho, 2 * wo, co), dtype=torch.float16, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16_SHUFFLE2, co
     else:
-        out = torch.empty((ho, wo, cw.cout), dtype=cw.odtype, device=src0.device)
-        d.out_mode, d.out_c = OUT_NHWC16, cw.cout
+        co = _round_up(cw.cout, 4 if f32 else 8)
+        out = torch.empty((ho, wo, co), dtype=cw.odtype, device=src0.device)
+        d.out_mode, d.out_c = OUT_NHWC16, co
     d.out = out.data_ptr()
     hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
     return out
@@ -336,10 +341,6 @@ def spynet_level_input(ref, supp, flow_prev):
     return out8, fup
 
 
-def _round_up(a, b):
-    return (a + b - 1) // b * b
-
-
 def match_patches(feat, row_pad, want_rows32=False):
     """feat planar [16,h,w] -> (rows fp16 [pad(h*w), KP] zero padded, inv_norm fp32 [h*w][, rows32 fp32 [h*w,144]])."""
     _planar(feat, 16)
@@ -445,4 +446,60 @@ def aligned_sample(x, affine, ks):
     out = torch.empty_like(x)
     hip.check(hip.lib().refvsr_aligned_sample(_ptr(x), h, w, ks, x.shape[2], _ptr(affine), _ptr(out), _stream()),
               'aligned_sample')
+    return out
+
+
+# ---- RefVSR_IR / EDVR-M pieces (csrc/edvr.hip) -------------------------------------------------------------------------
+def dcn_sample(x, offset_mask, deform_groups=8):
+    """Sampling half of the modulated deformable conv: x nhwc16 [h,w,c], offset_mask planar fp32 [3*dg*9,h,w] (raw
+    conv_offset output) -> columns nhwc16 [h,w,9*c] in (tap, channel) order."""
+    _nhwc(x)
+    h, w, c = x.shape
+    _planar(offset_mask, 3 * deform_groups * 9)
+    assert tuple(offset_mask.shape[1:]) == (h, w)
+    cols = torch.empty((h, w, 9 * c), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().refvsr_dcn_sample(_ptr(x), h, w, c, _ptr(offset_mask), deform_groups, _ptr(cols), _stream()), 'dcn_sample')
+    return cols
+
+
+def tsa_weight(aligned, emb, emb_ref):
+    """TSAFusion temporal attention: t aligned maps weighted by sigmoid(<emb_i, emb_ref>), side by side -> [h,w,t*c]."""
+    t = len(aligned)
+    h, w, c = aligned[0].shape
+    for m in list(aligned) + list(emb) + [emb_ref]:
+        _nhwc(m)
+        assert tuple(m.shape) == (h, w, c)
+    out = torch.empty((h, w, t * c), dtype=torch.float16, device=emb_ref.device)
+    pa = (C.c_void_p * t)(*[m.data_ptr() for m in aligned])
+    pe = (C.c_void_p * t)(*[m.data_ptr() for m in emb])
+    hip.check(hip.lib().refvsr_tsa_weight(pa, pe, _ptr(emb_ref), t, c, h * w, _ptr(out), _stream()), 'tsa_weight')
+    return out
+
+
+def pool3s2_pair(x):
+    """cat([MaxPool2d(3, 2, 1)(x), AvgPool2d(3, 2, 1)(x)], channel) on an nhwc16 map -> [ho, wo, 2c]."""
+    _nhwc(x)
+    h, w, c = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((ho, wo, 2 * c), dtype=torch.float16, device=x.device)
+    for off, is_max in ((0, 1), (c, 0)):
+        hip.check(hip.lib().refvsr_pool3s2_nhwc16(_ptr(x), h, w, c, _ptr(out), 2 * c, off, is_max, _stream()), 'pool3s2')
+    return out
+
+
+def up2_bilinear_nhwc16(x, mul=1.0):
+    _nhwc(x)
+    h, w, c = x.shape
+    out = torch.empty((2 * h, 2 * w, c), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().refvsr_up2_bilinear_nhwc16(_ptr(x), h, w, c, mul, _ptr(out), _stream()), 'up2_bilinear')
+    return out
+
+
+def tsa_blend(feat, attn, add):
+    """feat * sigmoid(attn) * 2 + add."""
+    for m in (feat, attn, add):
+        _nhwc(m)
+        assert m.shape == feat.shape
+    out = torch.empty_like(feat)
+    hip.check(hip.lib().refvsr_tsa_blend(_ptr(feat), _ptr(attn), _ptr(add), feat.numel(), _ptr(out), _stream()), 'tsa_blend')
     return out

@@ -46,8 +46,73 @@ def _aligned_conv(spec, name):          # alignment.py:18-24
     _resblock(spec, name + '.conv1.2', 32)
 
 
+def _edvr(spec, P):
+    """EDVRFeatureExtractor (RefVSR_IR.py:424-546: EDVR-M, 64 channels, 5 frames, 8 deformable groups) with PCDAlignment
+    and TSAFusion (edvr_net.py:62-330)."""
+    M = 64
+    _conv(spec, P + 'conv_first', M, 3, 3)
+    for i in range(5):
+        _resblock(spec, P + 'feature_extraction.%d' % i, M)
+    for nm in ('feat_l2_conv1', 'feat_l2_conv2', 'feat_l3_conv1', 'feat_l3_conv2'):
+        _conv(spec, P + nm + '.conv', M, M, 3)
+    A = P + 'pcd_alignment.'
+    for lvl in ('l3', 'l2', 'l1'):
+        _conv(spec, A + 'offset_conv1.%s.conv' % lvl, M, 2 * M, 3)
+    _conv(spec, A + 'offset_conv2.l3.conv', M, M, 3)
+    _conv(spec, A + 'offset_conv2.l2.conv', M, 2 * M, 3)
+    _conv(spec, A + 'offset_conv2.l1.conv', M, 2 * M, 3)
+    _conv(spec, A + 'offset_conv3.l2.conv', M, M, 3)
+    _conv(spec, A + 'offset_conv3.l1.conv', M, M, 3)
+    for lvl in ('l3', 'l2', 'l1'):
+        _conv(spec, A + 'dcn_pack.%s' % lvl, M, M, 3)
+        _conv(spec, A + 'dcn_pack.%s.conv_offset' % lvl, 216, M, 3)
+    _conv(spec, A + 'feat_conv.l2.conv', M, 2 * M, 3)
+    _conv(spec, A + 'feat_conv.l1.conv', M, 2 * M, 3)
+    _conv(spec, A + 'cas_offset_conv1.conv', M, 2 * M, 3)
+    _conv(spec, A + 'cas_offset_conv2.conv', M, M, 3)
+    _conv(spec, A + 'cas_dcnpack', M, M, 3)
+    _conv(spec, A + 'cas_dcnpack.conv_offset', 216, M, 3)
+    F_ = P + 'fusion.'
+    _conv(spec, F_ + 'temporal_attn1', M, M, 3)
+    _conv(spec, F_ + 'temporal_attn2', M, M, 3)
+    _conv(spec, F_ + 'feat_fusion.conv', M, 5 * M, 1)
+    _conv(spec, F_ + 'spatial_attn1.conv', M, 5 * M, 1)
+    _conv(spec, F_ + 'spatial_attn2.conv', M, 2 * M, 1)
+    _conv(spec, F_ + 'spatial_attn3.conv', M, M, 3)
+    _conv(spec, F_ + 'spatial_attn4.conv', M, M, 1)
+    _conv(spec, F_ + 'spatial_attn5', M, M, 3)
+    _conv(spec, F_ + 'spatial_attn_l1.conv', M, M, 1)
+    _conv(spec, F_ + 'spatial_attn_l2.conv', M, 2 * M, 3)
+    _conv(spec, F_ + 'spatial_attn_l3.conv', M, M, 3)
+    _conv(spec, F_ + 'spatial_attn_add1.conv', M, M, 1)
+    _conv(spec, F_ + 'spatial_attn_add2', M, M, 1)
+
+
 def state_spec(config):
     """OrderedDict name -> shape for `SRNet(config).state_dict()` (keys start with `Network.`)."""
+    if getattr(config, 'network', 'RefVSR') == 'RefVSR_IR':
+        return _state_spec_ir(config)
+    return _state_spec_refvsr(config)
+
+
+def _state_spec_ir(config):
+    """models/archs/RefVSR_IR.py:20-123: the RefVSR modules plus the EDVR extractor (registered first), the two
+    information-refill fusion convs, and a forward branch whose input conv also takes the backward features."""
+    base = _state_spec_refvsr(config)
+    C = config.mid_channels
+    s = collections.OrderedDict()
+    _edvr(s, 'Network.edvr.')
+    for k, v in base.items():
+        if k == 'Network.forward_resblocks.main.0.weight':
+            v = (C, 2 * C + 3, 3, 3)
+        s[k] = v
+        if k == 'Network.feat_decoder_BWFW.conv_tail.bias':
+            _conv(s, 'Network.backward_fusion', C, 64 + C, 3)
+            _conv(s, 'Network.forward_fusion', C, 64 + C, 3)
+    return s
+
+
+def _state_spec_refvsr(config):
     C = config.mid_channels
     nb = config.num_blocks
     hd = bool(config.flag_HD_in)
@@ -119,8 +184,10 @@ def num_params(config):
 
 def _gain(name):
     """Per-family weight gain: residual bodies are damped so deep chains stay bounded."""
-    if '.main.2.' in name or '.RBs.' in name or '.p_conv.2.' in name or '.conv1.2.' in name:
+    if '.main.2.' in name or '.RBs.' in name or '.p_conv.2.' in name or '.conv1.2.' in name or 'feature_extraction.' in name:
         return 0.35
+    if 'conv_offset' in name:            # DCN offsets of a few pixels, masks around sigmoid(0)
+        return 0.5
     if 'FlowNet' in name:
         return 0.8
     if name.endswith('p_conv.4.weight'):

@@ -98,6 +98,33 @@ def test_stream_against_reference_fixture(dev, tag, name):
     report('e2e %s worst' % tag, res=worst)
 
 
+def test_refvsr_ir_stream_against_reference_fixture(dev):
+    """RefVSR_IR (config_RefVSR_IR_MFID: C = 36, 30 blocks, EDVR-M information refill with modulated deformable convs, key
+    frames every 5th frame) against the fixture produced by the reference: first-frame call, steady call, reset_branch
+    rollover; result, carried state, iteration counter and the key-frame bookkeeping."""
+    from refvsr_amd.synth import window_indices
+    g = load_golden('e2e_IR_64x64_t5_reset2')
+    t, rb = int(g['t']), int(g['reset_branch'])
+    net, cfg, sd = make_net('config_RefVSR_IR_MFID', t, dev, reset=rb, save_sample=False)
+    assert cfg.network == 'RefVSR_IR' and cfg.mid_channels == 36 and type(net.Network).__name__ == 'Network'
+    lr, rf = g['lr'], g['ref']
+    nframes = lr.shape[1]
+    for f in range(nframes):
+        w = window_indices(f, nframes, t)
+        res = net(lr[:, w].to(dev), rf[:, w].to(dev), f == 0)['result'].cpu()
+        want = g['result_%d' % f]
+        eng = net.Network.engine(0)
+        st = eng.export_state()
+        e_res = maxdiff(res, want)
+        e_feat = maxdiff(st['feat'].cpu(), g['state_feat_%d' % f][0].float())
+        e_conf, e_flow = maxdiff(st['conf'].cpu(), g['state_conf_%d' % f][0]), maxdiff(st['flow'].cpu(), g['state_flow_%d' % f][0])
+        report('e2e IR_64x64 f%d' % f, res=e_res, psnr_vs_ref=float(psnr(res, want)), feat=e_feat, conf=e_conf, flow=e_flow)
+        assert net.Network.frame_itr_num == int(g['itr_%d' % f])
+        assert [int(k) for k in eng.keyframe_idx] == g['keyframes_%d' % f].tolist()
+        assert res.shape == want.shape and float(res.min()) >= 0.0 and float(res.max()) <= 1.0
+        assert e_res < 2e-2 and psnr(res, want) > 55.0 and e_feat < 3e-2 and e_conf < 1e-3 and e_flow < 1e-3
+
+
 def test_midsize_against_live_oracle_and_cache_equivalence(dev):
     """64x96, t=5: 4 frames against the oracle; the cross-window cache must not change a single bit."""
     from oracle import refvsr_oracle as orc

@@ -590,3 +590,86 @@ def test_compute_up_golden(dev, small_cfg, small_sd):
                          lr[0].to(dev)).cpu()
     report('compute_up', abs=maxdiff(got, want))
     assert maxdiff(got, want) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# RefVSR_IR / EDVR-M pieces (csrc/edvr.hip) against the IR oracle's restatements
+# ------------------------------------------------------------------------------------------------
+def test_dcn_modulated_deformable_conv(dev):
+    """conv_offset -> dcn_sample -> 1x1 contraction == ModulatedDCNPack of the oracle (edvr_net.py:49-56), incl. samples
+    that leave the map (zero outside, partial corners) and large offsets."""
+    from oracle import refvsr_ir_oracle as iro
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(41)
+    M, h, w = 64, 23, 31
+    x = torch.randn(1, M, h, w, generator=g)
+    extra = torch.randn(1, M, h, w, generator=g)
+    W = {'d.weight': torch.randn(M, M, 3, 3, generator=g) / 24.0, 'd.bias': torch.randn(M, generator=g) * 0.1,
+         'd.conv_offset.weight': torch.randn(216, M, 3, 3, generator=g) / 12.0, 'd.conv_offset.bias': torch.randn(216, generator=g)}
+    want = iro.dcn_pack(x, extra, W, 'd')[0]
+    co = ops.ConvWeights(pack_conv(W['d.conv_offset.weight'], W['d.conv_offset.bias'], [M]), dev)
+    cd = ops.ConvWeights(pack_conv(W['d.weight'].permute(0, 2, 3, 1).reshape(M, 9 * M, 1, 1), W['d.bias'], [9 * M]), dev)
+    om = ops.conv(co, nhwc(extra[0], dev), planar_out=True)
+    got = planar(ops.conv(cd, ops.dcn_sample(nhwc(x[0], dev), om, 8)))
+    # offsets reach several pixels here: their fp16-operand error (1e-3 px) times the map's gradient dominates
+    report('dcn', rel=rel(got, want), off_mag=float(om[:144].abs().max()))
+    assert rel(got, want) < 1e-2
+    # zero offsets / zero mask logits: the op is 0.5 x the plain 3x3 convolution
+    W0 = dict(W)
+    W0['d.conv_offset.weight'] = torch.zeros(216, M, 3, 3)
+    W0['d.conv_offset.bias'] = torch.zeros(216)
+    om0 = torch.zeros(216, h, w, device=dev)
+    got0 = planar(ops.conv(cd, ops.dcn_sample(nhwc(x[0], dev), om0, 8)))
+    want0 = 0.5 * F.conv2d(x.half().float(), W['d.weight'], None, padding=1)[0] + W['d.bias'].view(-1, 1, 1)
+    assert rel(got0, want0) < 1e-3
+
+
+def test_edvr_pool_upsample_tsa(dev):
+    from oracle import refvsr_ir_oracle as iro
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(1, 64, 22, 30, generator=g)
+    pp = planar(ops.pool3s2_pair(nhwc(x[0], dev)))
+    xh = x.half().float()
+    assert maxdiff(pp[:64], iro.pool3s2(xh, 'max')[0]) == 0.0                    # exact on the fp16 values
+    assert maxdiff(pp[64:], iro.pool3s2(xh, 'avg')[0]) < 2e-3
+    up = planar(ops.up2_bilinear_nhwc16(nhwc(x[0], dev), 2.0))
+    assert maxdiff(up, iro.up2_bilinear(xh)[0] * 2) < 4e-3
+    al = torch.randn(1, 5, 64, 12, 16, generator=g)
+    em = torch.randn(1, 5, 64, 12, 16, generator=g) * 0.3
+    er = torch.randn(1, 64, 12, 16, generator=g) * 0.3
+    got = planar(ops.tsa_weight([nhwc(al[0, i], dev) for i in range(5)], [nhwc(em[0, i], dev) for i in range(5)], nhwc(er[0], dev)))
+    corr = torch.sigmoid((em.half().float() * er.half().float()[:, None]).sum(2))
+    want = (al.half().float() * corr[:, :, None]).reshape(1, 320, 12, 16)[0]
+    assert maxdiff(got, want) < 4e-3
+    f, a, d = [torch.randn(64, 12, 16, generator=g) for _ in range(3)]
+    got = planar(ops.tsa_blend(nhwc(f, dev), nhwc(a, dev), nhwc(d, dev)))
+    want = f.half().float() * torch.sigmoid(a.half().float()) * 2 + d.half().float()
+    assert maxdiff(got, want) < 6e-3
+
+
+def test_conv_channel_padding_is_zeroed(dev):
+    """C = 36 maps (RefVSR_IR) have channel stride 40: the conv epilogues must write zeros into the padding (also through
+    the pixel-shuffle store), consumers rely on it."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(36, 19, 27, generator=g)
+    xin = nhwc(x, dev)
+    assert xin.shape[2] == 40 and float(xin[:, :, 36:].abs().max()) == 0.0
+    wt, b = torch.randn(36, 36, 3, 3, generator=g) / 18.0, torch.randn(36, generator=g) * 0.1
+    cw = ops.ConvWeights(pack_conv(wt, b, [36]), dev)
+    torch.full((64, 64, 64), float('nan'), device=dev).half()              # poison the allocator's free blocks
+    torch.cuda.empty_cache()
+    for kw in (dict(act=0.2), dict(act=0.2, res=xin), dict(act=1.0, mul=xin, res=xin)):
+        y = ops.conv(cw, xin, **kw)
+        assert y.shape == (19, 27, 40) and float(y[:, :, 36:].float().abs().max()) == 0.0 and bool(torch.isfinite(y.float()).all())
+    want = F.leaky_relu(F.conv2d(x.half().float()[None], wt, b, padding=1), 0.2)[0]
+    assert rel(planar(ops.conv(cw, xin, act=0.2))[:36], want) < 1e-3
+    ws, bs = torch.randn(144, 36, 3, 3, generator=g) / 18.0, torch.randn(144, generator=g) * 0.1
+    cs = ops.ConvWeights(pack_conv(ws, bs, [36], shuffle=True), dev)
+    y = ops.conv(cs, xin)
+    assert y.shape == (38, 54, 40) and float(y[:, :, 36:].float().abs().max()) == 0.0
+    want = F.pixel_shuffle(F.conv2d(x.half().float()[None], ws, bs, padding=1), 2)[0]
+    assert rel(planar(y)[:36], want) < 1e-3

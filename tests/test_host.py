@@ -35,7 +35,7 @@ def test_config_modules_importable_like_reference():
     import importlib
     for name in CONFIG_NAMES:
         m = importlib.import_module('refvsr_amd.configs.' + name)
-        assert m.get_config('p', 'm', name).network == 'RefVSR'
+        assert m.get_config('p', 'm', name).network == ('RefVSR_IR' if '_IR_' in name else 'RefVSR')
 
 
 def test_param_counts():

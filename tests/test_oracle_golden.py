@@ -132,3 +132,23 @@ def test_end_to_end_stream(tag, name):
         assert maxdiff(o.forward_flow_prev, g['state_flow_%d' % f]) < TOL
         for k, v in outs['eval_vis'].items():
             assert maxdiff(v, g['ev_%s_%d' % (k, f)]) < TOL, (tag, f, k)
+
+
+def test_refvsr_ir_stream():
+    """RefVSR_IR oracle (oracle/refvsr_ir_oracle.py: EDVR-M extractor, PCD alignment, modulated deformable conv, TSA
+    fusion, key-frame refill, the forward branch's stale-flow quirk) against the fixture produced by the reference."""
+    from oracle import refvsr_ir_oracle as iro
+    g = load_golden('e2e_IR_64x64_t5_reset2')
+    cfg = get_config('p', 'm', 'config_RefVSR_IR_MFID')
+    t = int(g['t'])
+    cfg.frame_num = t
+    cfg.reset_branch = int(g['reset_branch'])
+    o = iro.OracleNetworkIR(cfg, make_state_dict(cfg, 1234))
+    lr, rf = g['lr'], g['ref']
+    for f in range(2):                      # first-frame + steady call (the other two repeat them after the reset)
+        w = window_indices(f, lr.shape[1], t)
+        outs = o.forward(lr[:, w], rf[:, w], f == 0)
+        assert maxdiff(outs['result'], g['result_%d' % f]) < TOL
+        assert o.frame_itr_num == int(g['itr_%d' % f]) and list(o.keyframe_idx) == g['keyframes_%d' % f].tolist()
+        assert maxdiff(o.forward_feat_prop_prev, g['state_feat_%d' % f].float()) < 2e-3      # stored as fp16
+        assert maxdiff(o.forward_flow_prev, g['state_flow_%d' % f]) < TOL

@@ -53,7 +53,7 @@ def ref_net(name, frame_num, save_sample=True, scale=4):
         set_scale(mine, scale)
     # the build's config mirror must agree with the reference on every model field
     for k in ('scale', 'flag_HD_in', 'matching_ksize', 'num_blocks', 'mid_channels', 'reset_branch',
-              'is_amp', 'network'):
+              'is_amp', 'network') + (('keyframe_stride',) if 'IR' in name else ()):
         assert cfg[k] == mine[k], (name, k, cfg[k], mine[k])
     sd = wts.make_state_dict(mine, SEED_W)
     ref_sd = net.state_dict()
@@ -272,6 +272,41 @@ def gen_e2e(tag, name, t, h, w, nframes, reset_override='keep', light=False, sca
     save('e2e_' + tag, **arrs)
 
 
+def gen_e2e_ir(tag, name, t, h, w, nframes, reset_override='keep'):
+    """RefVSR_IR (EDVR-M information refill, modulated deformable convs through tools/ref_shims/mmcv/ops): result, carried
+    state, iteration counter and key-frame indices per call."""
+    from oracle import refvsr_ir_oracle as iro
+    print('== end-to-end %s: %s t=%d %dx%d, %d frames ==' % (tag, name, t, h, w, nframes))
+    net, cfg, mine, sd = ref_net(name, t)
+    if reset_override != 'keep':
+        cfg.reset_branch = mine.reset_branch = reset_override
+        net.Network.max_frame_itr_num = reset_override
+    rs = np.random.RandomState(sum(map(ord, tag)))
+    lr, rf = synth_clip(rs, nframes, h, w)
+    o = iro.OracleNetworkIR(mine, sd)
+    arrs = dict(lr=lr, ref=rf, t=np.int64(t), reset_branch=np.int64(-1 if mine.reset_branch is None else mine.reset_branch))
+    with torch.no_grad():
+        for f, win in enumerate(windows(nframes, t)):
+            x, r = lr[:, win], rf[:, win]
+            outs = net(x, r, f == 0, is_log=False, is_train=False)
+            oo = o.forward(x, r, f == 0)
+            N = net.Network
+            d = dict(result=md(outs['result'], oo['result']), feat=md(N.forward_feat_prop_prev, o.forward_feat_prop_prev),
+                     feat_up=md(N.forward_feat_prop_UP_prev, o.forward_feat_prop_UP_prev),
+                     conf=md(N.forward_conf_map_prop_prev, o.forward_conf_map_prop_prev), flow=md(N.forward_flow_prev, o.forward_flow_prev))
+            res = outs['result']
+            print('  frame %d itr=%d keyframes=%s  ' % (f, N.frame_itr_num, list(N.keyframe_idx)) + ' '.join('%s=%.2e' % kv for kv in d.items()) +
+                  '  | result mean %.3f std %.3f sat %.3f' % (float(res.mean()), float(res.std()), float(((res <= 0) | (res >= 1)).float().mean())))
+            assert N.frame_itr_num == o.frame_itr_num and list(N.keyframe_idx) == list(o.keyframe_idx)
+            arrs['result_%d' % f] = res
+            arrs['state_feat_%d' % f] = N.forward_feat_prop_prev.to(torch.float16)
+            arrs['state_conf_%d' % f] = N.forward_conf_map_prop_prev
+            arrs['state_flow_%d' % f] = N.forward_flow_prev
+            arrs['itr_%d' % f] = np.int64(N.frame_itr_num)
+            arrs['keyframes_%d' % f] = np.asarray(N.keyframe_idx, np.int64)
+    save('e2e_' + tag, **arrs)
+
+
 def gen_full(nframes=2, stride=8):
     """Full BASELINE size (270x480 -> 1080x1920, t=5), random AND 'plausible' weights: PSNR scalars, a strided
     sub-sample of the result, two full-resolution 128x128 crops per frame (the full frame is 24.9 MB) and -- the
@@ -324,6 +359,9 @@ def gen_full(nframes=2, stride=8):
 
 
 def main():
+    if '--spec' in sys.argv:
+        gen_spec()
+        return
     if '--full' in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
@@ -343,8 +381,12 @@ def main():
            ('HD48_64x96_t3', 'config_RefVSR_MFID_8K', 3, 64, 96, 2, 'keep'),
            # x2 SR (config.scale = 2: matching_ksize 4, VGG19[0:7] matching features, aa1 + aa2 alignment, one pixel shuffle)
            ('S2_16x24_t3', 'config_RefVSR_small_L1', 3, 16, 24, 3, 'keep')]
+    IR = [('IR_64x64_t5_reset2', 'config_RefVSR_IR_MFID', 5, 64, 64, 4, 2)]
     if '--only' in sys.argv:                     # regenerate one end-to-end fixture: --only S_16x24_t7
         tag = sys.argv[sys.argv.index('--only') + 1]
+        for e in IR:
+            if e[0] == tag:
+                gen_e2e_ir(*e[:6], reset_override=e[6])
         for e in E2E:
             if e[0] == tag:
                 gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'), scale=2 if e[0].startswith('S2_') else 4)
@@ -352,11 +394,17 @@ def main():
     gen_ops()
     for e in E2E:
         gen_e2e(*e[:6], reset_override=e[6], light=e[0].startswith('HD48'), scale=2 if e[0].startswith('S2_') else 4)
-    # state-dict contract checksums for all six configs
+    for e in IR:
+        gen_e2e_ir(*e[:6], reset_override=e[6])
+    gen_spec()
+
+
+def gen_spec():
+    """state-dict contract checksums (from the reference's own modules) for every config, incl. the two RefVSR_IR ones."""
     sums = {}
     for name in ('config_RefVSR_small_L1', 'config_RefVSR_small_MFID', 'config_RefVSR_L1', 'config_RefVSR_MFID',
-                 'config_RefVSR_MFID_8K', 'config_RefVSR_small_MFID_8K'):
-        net, cfg, mine, sd = ref_net(name, 3)
+                 'config_RefVSR_MFID_8K', 'config_RefVSR_small_MFID_8K', 'config_RefVSR_IR_L1', 'config_RefVSR_IR_MFID'):
+        net, cfg, mine, sd = ref_net(name, 5 if 'IR' in name else 3)
         sums[name + '/nparams'] = np.int64(sum(v.numel() for v in net.state_dict().values()))
         sums[name + '/ntensors'] = np.int64(len(net.state_dict()))
         sums[name + '/spec_crc'] = np.int64(wts.spec_checksum(mine))
