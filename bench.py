@@ -262,6 +262,7 @@ def main():
     ap.add_argument('--clip-check', type=int, default=12, help='frames of the sharded clip re-run on one rank and compared')
     ap.add_argument('--wavefront-timeout', type=float, default=180.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--match-margin', type=float, default=None, help='A/B knob: margin of the exact-search flagging (0 = top-2 re-rank only)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-timeout', type=float, default=300.0)
     args = ap.parse_args()
@@ -294,6 +295,8 @@ def main():
     cfg = get_config('bench', 'bench', args.config)
     cfg.frame_num = T
     cfg.cache_windows = not args.no_cache
+    if args.match_margin is not None:
+        cfg.match_exact_margin = args.match_margin
     sd = make_state_dict(cfg, 1234)
     net = SRNet(cfg).to(dev).eval()
     net.load_state_dict(sd)

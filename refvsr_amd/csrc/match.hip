@@ -286,6 +286,10 @@ extern "C" int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr
 // ---------------------------------------------------------------------------------------------
 // exact fp32 re-rank of the candidates
 // ---------------------------------------------------------------------------------------------
+// Summation order of the exact correlation: position p = 16 S + 4 j + q  <->  patch element e = 16 S + 4 q + j (S = 0..8,
+// j, q = 0..3).  It is the order in which v_mfma_f32_16x16x4_f32 consumes K when lane group q holds four CONSECUTIVE
+// elements of a row (one 16-byte load) and MFMA step (S, j) takes component j -- so the exhaustive search
+// (match_exact_kernel) and this re-rank compute bit-identical values.
 __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, int w, const int* ly, const int* lx,
                                            const float* __restrict__ rf, int hr, int wr, int ry, int rx) {
     int yy[3], xx[3];
@@ -293,13 +297,17 @@ __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, 
     for (int k = 0; k < 3; ++k) { yy[k] = rv_reflect(ry + k - 1, hr); xx[k] = rv_reflect(rx + k - 1, wr); }
     const size_t lp = (size_t)h * w, rp = (size_t)hr * wr;
     float d = 0.0f;
-    for (int c = 0; c < 16; ++c) {
+#pragma unroll 1
+    for (int S = 0; S < 9; ++S)                      // (a rolled loop: fully unrolled, the 144 addresses spill)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int q = 0; q < 4; ++q) {
+                const int e = 16 * S + 4 * q + j;
+                const int c = e / 9, t = e - c * 9;
+                const int ky = t / 3, kx = t - ky * 3;
                 d = fmaf(lf[c * lp + (size_t)ly[ky] * w + lx[kx]], rf[c * rp + (size_t)yy[ky] * wr + xx[kx]], d);
-    }
+            }
     return d;
 }
 
@@ -357,7 +365,7 @@ extern "C" int refvsr_match_refine(const float* lr_feat, int h, int w, const flo
 // candidates are further apart than that, the top-2 + fp32 re-rank is provably the exact arg-max; where they are not
 // (flat or repetitive image regions: many reference patches nearly equally similar) a THIRD row may be the true maximum.
 // Those columns -- flagged by match_refine -- are searched exhaustively here on v_mfma_f32_16x16x4_f32 (bitwise an fp32
-// FMA chain over k = 0..143 in order, i.e. the same value patch_dot computes): 64 flagged columns per workgroup pass,
+// FMA chain over the 144 patch elements in the order documented at patch_dot, i.e. the same value patch_dot computes): 64 flagged columns per workgroup pass,
 // the reference rows (fp32 [n_ref][144], written by match_patches) split over the 4 waves x gridDim.y; per column
 // (value, first index) maxima are merged through a 64-bit atomicMax key.  The list is read on the device: no host sync.
 #define EX_COLS 64
@@ -377,15 +385,15 @@ __global__ __launch_bounds__(256) void match_exact_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
     const int n_tiles = (n_ref + 15) >> 4;
-    // work item = (column group, row part): with few flagged columns the reference rows are split further so that the
-    // whole chip works on them (the count is only known here, on the device)
-    const int nsplit = max(1, min(64, (2 * (int)gridDim.x) / max(ngroups, 1)));
+    // work item = (column group, row part): the reference rows are split so that there are about as many items as
+    // workgroups (the flagged count is only known here, on the device)
+    const int nsplit = max(1, min(64, (int)gridDim.x / max(ngroups, 1)));
     const int nparts = nsplit * 4;
     const size_t plane = (size_t)h * w;
     for (int item = blockIdx.x; item < ngroups * nsplit; item += gridDim.x) {
         const int g = item / nsplit;
         const int part = (item - g * nsplit) * 4 + wave;
-        // B operand: 4 tiles of 16 flagged columns, K-step s supplies k = 4s + kq
+        // B operand: 4 tiles of 16 flagged columns; MFMA step (S, j) takes patch element 16 S + 4 kq + j from lane group kq
         float b[4][36];
         float il[4];
         int colv[4];
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void match_exact_kernel(const float* __restric
             il[ct] = col >= 0 ? inv_lr[cc] : 0.0f;
 #pragma unroll
             for (int s = 0; s < 36; ++s) {
-                const int e = 4 * s + kq;
+                const int e = 16 * (s >> 2) + 4 * kq + (s & 3);
                 const int c = e / 9, t = e - c * 9;
                 const int ky = t / 3, kx = t - ky * 3;
                 b[ct][s] = lf[c * plane + (size_t)rv_reflect(y + ky - 1, h) * w + rv_reflect(x + kx - 1, w)];
@@ -410,15 +418,22 @@ __global__ __launch_bounds__(256) void match_exact_kernel(const float* __restric
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) { best[ct] = -INFINITY; besti[ct] = 0x7fffffff; }
         for (int tile = part; tile < n_tiles; tile += nparts) {
-            const float* arow = ref32 + (size_t)min(tile * 16 + n16, n_ref - 1) * 144 + kq;
+            // A operand: lane (row n16, group kq) reads 16 bytes = elements 16 S + 4 kq .. + 3 of its row, nine times
+            const float4* arow = reinterpret_cast<const float4*>(ref32 + (size_t)min(tile * 16 + n16, n_ref - 1) * 144 + 4 * kq);
+            float4 a[9];
+#pragma unroll
+            for (int S = 0; S < 9; ++S) a[S] = arow[S * 4];
             f32x4 acc[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 36; ++s) {
-                const float a = arow[4 * s];
+            for (int S = 0; S < 9; ++S) {
+                const float av[4] = {a[S].x, a[S].y, a[S].z, a[S].w};
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[ct][s], acc[ct], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[ct][S * 4 + j], acc[ct], 0, 0, 0);
             }
             // lane holds rows 4*kq + j (j = 0..3) of column n16: increasing j == increasing row, strict > keeps the first
 #pragma unroll
