@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 3   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
-                                  3: exact matching (match_patches rows32, match_refine flagging, match_exact), lean ResBlock */
+#define REFVSR_ABI_VERSION 4   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+                                  3: exact matching (match_refine flagging, match_exact), lean ResBlock;
+                                  4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -163,9 +164,10 @@ int refvsr_spynet_level_input(const float* ref, const float* supp, const float* 
 #define REFVSR_MATCH_ROWCHUNK 256 /* reference rows are padded to a multiple of this               */
 #define REFVSR_MATCH_COLBLOCK 512 /* LR columns are padded to a multiple of this                    */
 /* feat: planar fp32 [16][h][w].  Writes rows [h*w][KP] fp16 of L2-normalised reflect-padded 3x3
- * patches (channel order c*9+ky*3+kx, RefVSR_/utils.py:29-57), inv_norm[h*w] = 1/max(|p|,1e-12) and, when rows32 != NULL,
- * the un-normalised fp32 patches [h*w][144] (operand of refvsr_match_exact). */
-int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, float* rows32, void* stream);
+ * patches (channel order c*9+ky*3+kx, RefVSR_/utils.py:29-57), inv_norm[h*w] = 1/max(|p|,1e-12) and, when rows_lo != NULL,
+ * the low halves of the fp16 hi + lo split of the same normalised patches, rows_lo [h*w][KP] fp16 =
+ * fp16((p - rows) * 2^11) (second operand of refvsr_match_exact; allocate it padded like rows). */
+int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, void* rows_lo, void* stream);
 /* Fused cosine GEMM + column top-2 (never materialises the [n_ref x n_lr] matrix).
  * ref_rows: [n_ref_pad][KP], lr_rows: [n_lr_pad][KP] (pads zero).  row_splits >= 1 partitions the
  * reference rows over blockIdx.y.  cand_idx / cand_val: [n_lr][2*row_splits] (first-max-wins order). */
@@ -178,12 +180,15 @@ int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr_rows, int 
 int refvsr_match_refine(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
                         const float* inv_lr, const float* inv_ref, const int32_t* cand_idx, const float* cand_val,
                         int ncand, float margin, int32_t* flagged, float* conf, int32_t* idx, void* stream);
-/* Exhaustive exact-fp32 arg-max (v_mfma_f32_16x16x4_f32 = an fp32 FMA chain) for the flagged columns; overwrites their
- * conf / idx.  ref_rows32: fp32 [n_ref][144] from refvsr_match_patches; keys: uint64 [h*w] zeroed scratch.  The flagged
- * count is read on the device (no host synchronisation); with no flagged column the launch is a no-op. */
-int refvsr_match_exact(const float* lr_feat, int h, int w, const float* ref_rows32, int n_ref,
-                       const float* inv_lr, const float* inv_ref, const int32_t* flagged, void* keys,
-                       float* conf, int32_t* idx, void* stream);
+/* Exhaustive fp32-grade arg-max for the flagged columns: both operands split into fp16 hi + lo, three fp16 MFMAs with fp32
+ * accumulation per product (dropped term 2^-22).  The winner of every flagged column is re-evaluated with the exact fp32
+ * dot product of refvsr_match_refine and replaces that column's conf / idx if it is better (smaller index on ties).
+ * lr_rows / lr_rows_lo, ref_rows / ref_rows_lo: the fp16 hi / lo patch rows of refvsr_match_patches (reference rows padded
+ * to a multiple of 256); keys: uint64 [h*w] zeroed scratch.  The flagged count is read on the device (no host
+ * synchronisation); with no flagged column the launches are no-ops. */
+int refvsr_match_exact(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr, const void* lr_rows,
+                       const void* lr_rows_lo, const void* ref_rows, const void* ref_rows_lo, const float* inv_lr,
+                       const float* inv_ref, const int32_t* flagged, void* keys, float* conf, int32_t* idx, void* stream);
 /* Unfused fp32 reference kernel of the same op (test / debugging aid, O(n_ref*n_lr*144) VALU). */
 int refvsr_match_naive(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
                        float* conf, int32_t* idx, void* stream);

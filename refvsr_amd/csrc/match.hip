@@ -1,4 +1,5 @@
-// Reference matching on CDNA4 matrix cores  (FeatureMatching.forward, RefVSR_/attention.py:72-91).
+// Reference matching on CDNA4 matrix cores  (FeatureMatching.forward, RefVSR_/attention.py:72-91): patch rows, exact
+// re-rank and the exhaustive search of ambiguous columns.  The fused GEMM + top-2 kernel lives in match_top2.hip.
 //
 //   corr[r][p] = < ref_patch r , lr_patch p >   (144-dim, both L2-normalised)
 //   conf[p], idx[p] = max / argmax over r        (first maximal index wins, like torch.max)
@@ -17,40 +18,50 @@
 //    candidates are re-ranked with an exact fp32 dot product by match_refine.
 #include <stdlib.h>
 
-#include "common.h"
-
-#define KP REFVSR_MATCH_KP            // halfs per row (152)
-#define ROWB (KP * 2)                 // bytes per row (304)
-#define COLB REFVSR_MATCH_COLBLOCK    // LR columns per workgroup
-#define KSTEPS 9
+#include "match_common.h"
 
 // ---------------------------------------------------------------------------------------------
 // patch rows: reflect-pad 3x3 unfold + L2 normalise -> fp16 [L][KP], plus 1/norm
 // ---------------------------------------------------------------------------------------------
-__global__ void match_patches_kernel(const float* __restrict__ feat, int h, int w, f16* __restrict__ rows,
-                                     float* __restrict__ inv_norm, float* __restrict__ rows32) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= h * w) return;
-    const int y = p / w, x = p - y * w;
-    int yy[3], xx[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { yy[k] = rv_reflect(y + k - 1, h); xx[k] = rv_reflect(x + k - 1, w); }
+// Scale of the low half of the fp16 hi + lo operand split (exact search): lo = fp16((v - hi) * 2^11), so that it is a
+// normal fp16 number wherever hi is (no precision lost to fp16 subnormals).
+#define LO_SCALE 2048.0f
+#define LO_UNSCALE (1.0f / 2048.0f)
+
+__global__ __launch_bounds__(128) void match_patches_kernel(const float* __restrict__ feat, int h, int w,
+                                                            f16* __restrict__ rows, float* __restrict__ inv_norm,
+                                                            f16* __restrict__ rows_lo) {
+    __shared__ float s_inv[128];
+    const int tid = threadIdx.x, p0 = blockIdx.x * 128, n = h * w;
     const size_t plane = (size_t)h * w;
-    float ss = 0.0f;
-    for (int c = 0; c < 16; ++c) {
-        const float* f = feat + c * plane;
+    {   // phase 1: one pixel per thread, 1 / |patch|
+        const int p = min(p0 + tid, n - 1);
+        const int y = p / w, x = p - y * w;
+        int yy[3], xx[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int k = 0; k < 3; ++k) { yy[k] = rv_reflect(y + k - 1, h) * w; xx[k] = rv_reflect(x + k - 1, w); }
+        float ss = 0.0f;
+        for (int c = 0; c < 16; ++c) {
+            const float* f = feat + c * plane;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) { const float v = f[(size_t)yy[ky] * w + xx[kx]]; ss = fmaf(v, v, ss); }
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) { const float v = f[yy[ky] + xx[kx]]; ss = fmaf(v, v, ss); }
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        s_inv[tid] = inv;
+        if (p0 + tid < n) inv_norm[p0 + tid] = inv;
     }
-    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-    inv_norm[p] = inv;
-    f16* row = rows + (size_t)p * KP;
-    // 144 = 18 groups of 8 halfs; element e = c*9 + ky*3 + kx
-    for (int g = 0; g < 19; ++g) {
-        f16x8 o;
-        float raw[8];
+    __syncthreads();
+    // phase 2: the block's 128 rows = 128 x 19 sixteen-byte slots, consecutive threads -> consecutive slots (coalesced
+    // stores); slot g of a row holds elements 8 g .. 8 g + 7, element e = c*9 + ky*3 + kx (slot 18 is the zero pad)
+    const int n_slots = min(128, n - p0) * 19;
+    for (int i = tid; i < n_slots; i += 128) {
+        const int pl = i / 19, g = i - pl * 19;
+        const int p = p0 + pl;
+        const int y = p / w, x = p - y * w;
+        const float inv = s_inv[pl];
+        f16x8 o, lo;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = g * 8 + k;
@@ -58,227 +69,26 @@ __global__ void match_patches_kernel(const float* __restrict__ feat, int h, int 
             if (e < 144) {
                 const int c = e / 9, t = e - c * 9;
                 const int ky = t / 3, kx = t - ky * 3;
-                v = feat[c * plane + (size_t)yy[ky] * w + xx[kx]];
+                v = feat[c * plane + (size_t)rv_reflect(y + ky - 1, h) * w + rv_reflect(x + kx - 1, w)];
             }
-            raw[k] = v;
-            o[k] = (f16)(v * inv);
+            float vn = v * inv;
+            // (opaque: otherwise hipcc re-derives the hi half for the subtraction with a fused multiply-convert whose
+            //  single rounding can differ from the stored double-rounded one by an fp16 ulp)
+            asm volatile("" : "+v"(vn));
+            o[k] = (f16)vn;
+            lo[k] = (f16)((vn - (float)o[k]) * LO_SCALE);
         }
-        *reinterpret_cast<f16x8*>(row + g * 8) = o;
-        if (rows32 && g < 18) {                                // un-normalised fp32 patch (the exact search's operand)
-            float4* d = reinterpret_cast<float4*>(rows32 + (size_t)p * 144 + g * 8);
-            d[0] = make_float4(raw[0], raw[1], raw[2], raw[3]);
-            d[1] = make_float4(raw[4], raw[5], raw[6], raw[7]);
-        }
+        const size_t off = (size_t)p0 * KP + (size_t)i * 8;
+        *reinterpret_cast<f16x8*>(rows + off) = o;
+        if (rows_lo) *reinterpret_cast<f16x8*>(rows_lo + off) = lo;    // second half of the split operand
     }
 }
 
-extern "C" int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, float* rows32,
+extern "C" int refvsr_match_patches(const float* feat, int h, int w, void* rows, float* inv_norm, void* rows_lo,
                                     void* stream) {
     RV_CHECK(feat && rows && inv_norm && h >= 2 && w >= 2, "match_patches: bad args");
     hipLaunchKernelGGL(match_patches_kernel, dim3(rv_cdiv(h * w, 128)), dim3(128), 0, (hipStream_t)stream,
-                       feat, h, w, (f16*)rows, inv_norm, rows32);
-    RV_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// fused GEMM + column top-2
-// ---------------------------------------------------------------------------------------------
-struct Top2 { float m1, m2; int i1, i2; };
-
-__device__ __forceinline__ bool rv_better(float va, int ia, float vb, int ib) {
-    return va > vb || (va == vb && ia < ib);
-}
-
-__device__ __forceinline__ float acc_max(const f32x16& a) {
-    float t0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), t1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
-    float t2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), t3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
-    return fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
-}
-
-__device__ __forceinline__ void top2_insert(Top2& s, const f32x16& acc, int rowbase, int n_ref) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {                      // increasing r == increasing row index; branch-free selects
-        const int row = rowbase + (r & 3) + 8 * (r >> 2);
-        const float v = (row < n_ref) ? acc[r] : -INFINITY;
-        const bool g1 = v > s.m1;
-        const bool g2 = v > s.m2;
-        s.m2 = g1 ? s.m1 : (g2 ? v : s.m2);
-        s.i2 = g1 ? s.i1 : (g2 ? row : s.i2);
-        s.m1 = g1 ? v : s.m1;
-        s.i1 = g1 ? row : s.i1;
-    }
-}
-
-// Schedule history (round 1, identical outputs, MI355X): plain loop 2.0 ms -> prefetch pinned around the MFMA loop 1.95 ->
-// A-fragment double buffering 1.69 -> accumulator double buffering + branch-free top-2 (the VALU max-trees run under the
-// matrix pipe) 1.26 -> 256-row stages (below) 1.17 ms.  The earlier variants were removed from the library in round 2.
-// Accumulator double buffering on 256-row stages: one barrier per 288
-// MFMAs/wave, LDS 2 x 76 KiB, the next stage fetched in two halves so only 20 VGPRs are pinned.
-// (Keeping a second A-fragment set in flight as well needs > 256 VGPRs at 2 waves/SIMD and spills.)
-#define CHUNK4 REFVSR_MATCH_ROWCHUNK
-#define CHUNK4_U4 (CHUNK4 * ROWB / 16)
-#define PF4 ((CHUNK4_U4 + 511) / 512)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void match_top2_kernel_v4(
-    const f16* __restrict__ ref_rows, int n_ref, const f16* __restrict__ lr_rows, int n_lr,
-    int chunks_per_split, int n_chunks, int row_splits, int32_t* __restrict__ cand_idx, float* __restrict__ cand_val) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][CHUNK4 * ROWB];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int l31 = lane & 31;
-    const int hi = lane >> 5;
-    const int col0 = blockIdx.x * COLB + wave * 64;
-    const int c_begin = blockIdx.y * chunks_per_split;
-    const int c_end = min(c_begin + chunks_per_split, n_chunks);
-
-    f16x8 bfrag[2][KSTEPS];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const f16* src = lr_rows + (size_t)(col0 + ct * 32 + l31) * KP + hi * 8;
-#pragma unroll
-        for (int k = 0; k < KSTEPS; ++k) bfrag[ct][k] = *reinterpret_cast<const f16x8*>(src + k * 16);
-    }
-    Top2 st[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) { st[ct].m1 = st[ct].m2 = -INFINITY; st[ct].i1 = st[ct].i2 = 0; }
-
-    const uint4* gsrc = reinterpret_cast<const uint4*>(ref_rows);
-    // the next stage is fetched in two halves (HALF_U4 uint4 each) so only PF4H x 4 VGPRs are pinned
-    constexpr int HALF_U4 = CHUNK4_U4 / 2;                       // 2432
-    constexpr int PF4H = (HALF_U4 + 511) / 512;                  // 5
-    static_assert(PF4H == 5, "prefetch macros assume 5 slots");
-    uint4 pf0, pf1, pf2, pf3, pf4;
-#define PF_LOAD(base) do { pf0 = gsrc[(base) + pfi[0]]; pf1 = gsrc[(base) + pfi[1]]; pf2 = gsrc[(base) + pfi[2]]; \
-                           pf3 = gsrc[(base) + pfi[3]]; pf4 = gsrc[(base) + pfi[4]]; } while (0)
-#define PF_STORE(dst, off) do { uint4* d_ = reinterpret_cast<uint4*>(dst) + (off); d_[pfi[0]] = pf0; d_[pfi[1]] = pf1; \
-                                d_[pfi[2]] = pf2; d_[pfi[3]] = pf3; if (last_ok) d_[pfi[4]] = pf4; } while (0)
-    int pfi[PF4H];
-#pragma unroll
-    for (int k = 0; k < PF4H; ++k) pfi[k] = min(tid + k * 512, HALF_U4 - 1);
-    const bool last_ok = (tid + (PF4H - 1) * 512) < HALF_U4;
-
-    if (c_begin < c_end) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            PF_LOAD((size_t)c_begin * CHUNK4_U4 + hf * HALF_U4);
-            PF_STORE(lds[0], hf * HALF_U4);
-        }
-    }
-    __syncthreads();
-
-    constexpr int NRT = CHUNK4 / 32;
-    int buf = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-        const bool has_next = (c + 1 < c_end);
-        if (has_next) PF_LOAD((size_t)(c + 1) * CHUNK4_U4);
-        asm volatile("" ::: "memory");
-        const unsigned char* ap = lds[buf] + (size_t)l31 * ROWB + hi * 16;
-        f16x8 afA[KSTEPS], afB[KSTEPS];
-        f32x16 accA0, accA1, accB0, accB1;
-#pragma unroll
-        for (int k = 0; k < KSTEPS; ++k) afA[k] = *reinterpret_cast<const f16x8*>(ap + k * 32);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accA0[r] = 0.0f; accA1[r] = 0.0f; }
-#pragma unroll
-        for (int k = 0; k < KSTEPS; ++k) {
-            accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[0][k], accA0, 0, 0, 0);
-            accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[1][k], accA1, 0, 0, 0);
-        }
-        auto run_pairs = [&](const int rp_begin, const int rp_end) {
-#pragma unroll 1
-        for (int rp = rp_begin; rp < rp_end; ++rp) {         // two tiles per iteration: roles of the A/B sets are static
-            const bool more = (rp + 1 < NRT / 2);
-            const unsigned char* an = ap + (size_t)(2 * rp + 2) * 32 * ROWB;
-            // -- tile e = 2rp is finished (or in flight) in accA; start tile o = 2rp+1
-#pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) afB[k] = *reinterpret_cast<const f16x8*>(an - (size_t)32 * ROWB + k * 32);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accB0[r] = 0.0f; accB1[r] = 0.0f; }
-#pragma unroll
-            for (int k = 0; k < KSTEPS; ++k) {
-                accB0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afB[k], bfrag[0][k], accB0, 0, 0, 0);
-                accB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afB[k], bfrag[1][k], accB1, 0, 0, 0);
-            }
-            {
-                const float t0 = acc_max(accA0), t1 = acc_max(accA1);
-                if (t0 > st[0].m2 || t1 > st[1].m2) {
-                    const int rowbase = c * CHUNK4 + (2 * rp) * 32 + 4 * hi;
-                    if (t0 > st[0].m2) top2_insert(st[0], accA0, rowbase, n_ref);
-                    if (t1 > st[1].m2) top2_insert(st[1], accA1, rowbase, n_ref);
-                }
-            }
-            // -- tile o is in flight in accB; start tile e+2
-            if (more) {
-#pragma unroll
-                for (int k = 0; k < KSTEPS; ++k) afA[k] = *reinterpret_cast<const f16x8*>(an + k * 32);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { accA0[r] = 0.0f; accA1[r] = 0.0f; }
-#pragma unroll
-                for (int k = 0; k < KSTEPS; ++k) {
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[0][k], accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afA[k], bfrag[1][k], accA1, 0, 0, 0);
-                }
-            }
-            {
-                const float t0 = acc_max(accB0), t1 = acc_max(accB1);
-                if (t0 > st[0].m2 || t1 > st[1].m2) {
-                    const int rowbase = c * CHUNK4 + (2 * rp + 1) * 32 + 4 * hi;
-                    if (t0 > st[0].m2) top2_insert(st[0], accB0, rowbase, n_ref);
-                    if (t1 > st[1].m2) top2_insert(st[1], accB1, rowbase, n_ref);
-                }
-            }
-        }
-        };
-        run_pairs(0, NRT / 4);
-        asm volatile("" ::: "memory");        // mid-stage: park the first half of the next stage, fetch the second
-        if (has_next) {
-            PF_STORE(lds[buf ^ 1], 0);
-            PF_LOAD((size_t)(c + 1) * CHUNK4_U4 + HALF_U4);
-        }
-        asm volatile("" ::: "memory");
-        run_pairs(NRT / 4, NRT / 2);
-        asm volatile("" ::: "memory");
-        if (has_next) PF_STORE(lds[buf ^ 1], HALF_U4);
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        Top2 a = st[ct], b;
-        b.m1 = __shfl_xor(a.m1, 32); b.m2 = __shfl_xor(a.m2, 32);
-        b.i1 = __shfl_xor(a.i1, 32); b.i2 = __shfl_xor(a.i2, 32);
-        Top2 o;
-        if (rv_better(a.m1, a.i1, b.m1, b.i1)) {
-            o.m1 = a.m1; o.i1 = a.i1;
-            if (rv_better(a.m2, a.i2, b.m1, b.i1)) { o.m2 = a.m2; o.i2 = a.i2; } else { o.m2 = b.m1; o.i2 = b.i1; }
-        } else {
-            o.m1 = b.m1; o.i1 = b.i1;
-            if (rv_better(b.m2, b.i2, a.m1, a.i1)) { o.m2 = b.m2; o.i2 = b.i2; } else { o.m2 = a.m1; o.i2 = a.i1; }
-        }
-        const int col = col0 + ct * 32 + l31;
-        if (hi == 0 && col < n_lr) {
-            const size_t o2 = ((size_t)col * row_splits + blockIdx.y) * 2;
-            cand_idx[o2] = o.i1; cand_idx[o2 + 1] = o.i2;
-            cand_val[o2] = o.m1; cand_val[o2 + 1] = o.m2;
-        }
-    }
-}
-
-#undef PF_LOAD
-#undef PF_STORE
-
-extern "C" int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr_rows, int n_lr, int row_splits,
-                                 int32_t* cand_idx, float* cand_val, void* stream) {
-    RV_CHECK(ref_rows && lr_rows && cand_idx && cand_val && n_ref >= 2 && n_lr >= 1 && row_splits >= 1,
-             "match_top2: bad args");
-    const int n_chunks = rv_cdiv(n_ref, CHUNK4);
-    RV_CHECK(row_splits <= n_chunks, "match_top2: row_splits (%d) > row chunks (%d)", row_splits, n_chunks);
-    const int cps = rv_cdiv(n_chunks, row_splits);
-    RV_CHECK((row_splits - 1) * cps < n_chunks, "match_top2: empty row split (use fewer splits)");
-    dim3 grid(rv_cdiv(n_lr, COLB), row_splits);
-    hipLaunchKernelGGL(match_top2_kernel_v4, grid, dim3(512), 0, (hipStream_t)stream, (const f16*)ref_rows, n_ref,
-                       (const f16*)lr_rows, n_lr, cps, n_chunks, row_splits, cand_idx, cand_val);
+                       feat, h, w, (f16*)rows, inv_norm, (f16*)rows_lo);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -286,10 +96,6 @@ extern "C" int refvsr_match_top2(const void* ref_rows, int n_ref, const void* lr
 // ---------------------------------------------------------------------------------------------
 // exact fp32 re-rank of the candidates
 // ---------------------------------------------------------------------------------------------
-// Summation order of the exact correlation: position p = 16 S + 4 j + q  <->  patch element e = 16 S + 4 q + j (S = 0..8,
-// j, q = 0..3).  It is the order in which v_mfma_f32_16x16x4_f32 consumes K when lane group q holds four CONSECUTIVE
-// elements of a row (one 16-byte load) and MFMA step (S, j) takes component j -- so the exhaustive search
-// (match_exact_kernel) and this re-rank compute bit-identical values.
 __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, int w, const int* ly, const int* lx,
                                            const float* __restrict__ rf, int hr, int wr, int ry, int rx) {
     int yy[3], xx[3];
@@ -298,16 +104,12 @@ __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, 
     const size_t lp = (size_t)h * w, rp = (size_t)hr * wr;
     float d = 0.0f;
 #pragma unroll 1
-    for (int S = 0; S < 9; ++S)                      // (a rolled loop: fully unrolled, the 144 addresses spill)
+    for (int c = 0; c < 16; ++c)                     // (a rolled loop: fully unrolled, the 144 addresses spill)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = 16 * S + 4 * q + j;
-                const int c = e / 9, t = e - c * 9;
-                const int ky = t / 3, kx = t - ky * 3;
+            for (int kx = 0; kx < 3; ++kx)
                 d = fmaf(lf[c * lp + (size_t)ly[ky] * w + lx[kx]], rf[c * rp + (size_t)yy[ky] * wr + xx[kx]], d);
-            }
     return d;
 }
 
@@ -359,132 +161,203 @@ extern "C" int refvsr_match_refine(const float* lr_feat, int h, int w, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// exhaustive exact-fp32 search for the columns the fp16 GEMM cannot decide
+// exhaustive fp32-grade search for the columns the fp16 GEMM cannot decide
 // ---------------------------------------------------------------------------------------------
 // The fp16 operands of match_top2 perturb a correlation by ~3e-5 (up to ~1e-4 for peaky patches).  Where the best two
 // candidates are further apart than that, the top-2 + fp32 re-rank is provably the exact arg-max; where they are not
 // (flat or repetitive image regions: many reference patches nearly equally similar) a THIRD row may be the true maximum.
-// Those columns -- flagged by match_refine -- are searched exhaustively here on v_mfma_f32_16x16x4_f32 (bitwise an fp32
-// FMA chain over the 144 patch elements in the order documented at patch_dot, i.e. the same value patch_dot computes): 64 flagged columns per workgroup pass,
-// the reference rows (fp32 [n_ref][144], written by match_patches) split over the 4 waves x gridDim.y; per column
-// (value, first index) maxima are merged through a 64-bit atomicMax key.  The list is read on the device: no host sync.
-#define EX_COLS 64
+// Those columns -- flagged by match_refine -- are searched exhaustively here with both operands split into fp16
+// hi + lo (lo scaled by 2^11): <a, b> = <ah, bh> + 2^-11 (<ah, bl> + <al, bh>), three fp16 MFMAs with fp32 accumulation,
+// dropped term 2^-22 -- the accuracy of an fp32 dot product at 4.8x the rate of v_mfma_f32_16x16x4_f32.
+// Workgroup item = 256 flagged columns (64 per wave, B operand = their LR patch rows, in registers) x one part of the
+// reference rows, which stream through LDS in 64-row stages shared by the four waves; K = 144 = 4 x 32 + 16
+// (v_mfma_f32_16x16x32_f16 x 4 + v_mfma_f32_16x16x16_f16).  Per column the (value, first index) maxima are merged through
+// a 64-bit atomicMax key; match_exact_finish re-evaluates the winner with patch_dot (the SAME fp32 expression
+// match_refine uses) and keeps it only if it beats the re-ranked candidates, so flagged and unflagged columns carry
+// values of one definition.  The flagged list is read on the device: no host synchronisation.
+#define EX_CT 4                     // 16-column tiles per wave
+#define EX_COLS (64 * EX_CT)         // flagged columns per workgroup item (4 waves)
+#define EX_ROWS 64
 __device__ __forceinline__ unsigned long long ex_key(float v, int row) {
     unsigned u = __float_as_uint(v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                // order-preserving float -> uint
     return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)row);   // ties: smaller row wins
 }
 
-__global__ __launch_bounds__(256) void match_exact_kernel(const float* __restrict__ lf, int h, int w,
-                                                          const float* __restrict__ ref32, int n_ref,
-                                                          const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
-                                                          const int32_t* __restrict__ flagged,
-                                                          unsigned long long* __restrict__ keys) {
+#define EX_STAGE_BYTES (EX_ROWS * ROWB)           // one array (hi or lo) of one stage: 19 x 1 KiB
+#define EX_CHUNKS (2 * EX_STAGE_BYTES / 1024)     // 1 KiB wave-chunks per stage (hi then lo)
+
+// Stage st of the reference rows (64 rows x 304 bytes, hi and lo arrays) -> LDS, asynchronously: global_load_lds writes
+// wave-uniform LDS base + lane * 16, i.e. a flat copy of 1 KiB per wave instruction -- exactly this layout (the LDS image
+// of a stage IS its global image).  No staging registers; completion is tracked by vmcnt.
+__device__ __forceinline__ void ex_issue_stage(const f16* __restrict__ ref_hi, const f16* __restrict__ ref_lo, int st,
+                                               unsigned char* buf, int wave, int lane) {
+    const unsigned char* gh = reinterpret_cast<const unsigned char*>(ref_hi + (size_t)st * EX_ROWS * KP);
+    const unsigned char* gl = reinterpret_cast<const unsigned char*>(ref_lo + (size_t)st * EX_ROWS * KP);
+#pragma unroll
+    for (int i = 0; i < (EX_CHUNKS + 3) / 4; ++i) {
+        const int c = wave + 4 * i;
+        if (c < EX_CHUNKS) {
+            const bool lo = c >= EX_CHUNKS / 2;
+            const int cc = lo ? c - EX_CHUNKS / 2 : c;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)((lo ? gl : gh) + cc * 1024 + lane * 16),
+                (__attribute__((address_space(3))) void*)(buf + c * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// 64 staged rows x (EX_CT x 16) columns of one wave: 4 row tiles x EX_CT x 15 MFMAs; running (value, first row) maxima.
+__device__ __forceinline__ void ex_compute_stage(const unsigned char* buf, int st, int n_ref, int n16, int kq,
+                                                 const f16x8 (&bh)[EX_CT][4], const f16x8 (&bl)[EX_CT][4],
+                                                 const f16x4 (&bht)[EX_CT], const f16x4 (&blt)[EX_CT],
+                                                 float (&best)[EX_CT], int (&besti)[EX_CT]) {
+#pragma unroll 1
+    for (int rt = 0; rt < EX_ROWS / 16; ++rt) {
+        const unsigned char* ah_p = buf + (rt * 16 + n16) * ROWB + kq * 16;
+        const unsigned char* al_p = ah_p + EX_STAGE_BYTES;
+        f32x4 acc[EX_CT], acx[EX_CT];
+#pragma unroll
+        for (int ct = 0; ct < EX_CT; ++ct) { acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ah_p + s * 64);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(al_p + s * 64);
+#pragma unroll
+            for (int ct = 0; ct < EX_CT; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct][s], acc[ct], 0, 0, 0);
+                acx[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct][s], acx[ct], 0, 0, 0);
+                acx[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct][s], acx[ct], 0, 0, 0);
+            }
+        }
+        {
+            const f16x4 ah = *reinterpret_cast<const f16x4*>(ah_p + 256 - kq * 8);
+            const f16x4 al = *reinterpret_cast<const f16x4*>(al_p + 256 - kq * 8);
+#pragma unroll
+            for (int ct = 0; ct < EX_CT; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bht[ct], acc[ct], 0, 0, 0);
+                acx[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, blt[ct], acx[ct], 0, 0, 0);
+                acx[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bht[ct], acx[ct], 0, 0, 0);
+            }
+        }
+        // lane holds rows 4*kq + j (j = 0..3) of column n16: increasing j == increasing row, strict > keeps the first
+        const int row0 = st * EX_ROWS + rt * 16 + 4 * kq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = row0 + j < n_ref;
+#pragma unroll
+            for (int ct = 0; ct < EX_CT; ++ct) {
+                const float v = fmaf(acx[ct][j], LO_UNSCALE, acc[ct][j]);
+                if (ok && v > best[ct]) { best[ct] = v; besti[ct] = row0 + j; }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void match_exact_kernel(
+    const f16* __restrict__ lr_hi, const f16* __restrict__ lr_lo, const f16* __restrict__ ref_hi,
+    const f16* __restrict__ ref_lo, int n_ref, const int32_t* __restrict__ flagged, unsigned long long* __restrict__ keys) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds0[2 * EX_STAGE_BYTES];     // stage buffers: [hi | lo][row][KP]
+    __shared__ __attribute__((aligned(16))) unsigned char lds1[2 * EX_STAGE_BYTES];
     const int count = flagged[0];
     const int ngroups = (count + EX_COLS - 1) / EX_COLS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
-    const int n_tiles = (n_ref + 15) >> 4;
+    const int n_stages = (n_ref + EX_ROWS - 1) / EX_ROWS;
     // work item = (column group, row part): the reference rows are split so that there are about as many items as
     // workgroups (the flagged count is only known here, on the device)
-    const int nsplit = max(1, min(64, (int)gridDim.x / max(ngroups, 1)));
-    const int nparts = nsplit * 4;
-    const size_t plane = (size_t)h * w;
+    const int nsplit = max(1, min(n_stages, (int)gridDim.x / max(ngroups, 1)));
     for (int item = blockIdx.x; item < ngroups * nsplit; item += gridDim.x) {
-        const int g = item / nsplit;
-        const int part = (item - g * nsplit) * 4 + wave;
-        // B operand: 4 tiles of 16 flagged columns; MFMA step (S, j) takes patch element 16 S + 4 kq + j from lane group kq
-        float b[4][36];
-        float il[4];
-        int colv[4];
+        const int g = item / nsplit, part = item - g * nsplit;
+        const int s_begin = (int)((long long)n_stages * part / nsplit), s_end = (int)((long long)n_stages * (part + 1) / nsplit);
+        __syncthreads();                                            // the previous item's readers are done with lds0
+        ex_issue_stage(ref_hi, ref_lo, s_begin, lds0, wave, lane);
+        // B operand: EX_CT tiles of 16 flagged columns per wave, straight from the LR patch rows (hi / lo): lane group kq
+        // holds elements 32 s + 8 kq .. + 7 (s < 4) and 128 + 4 kq .. + 3 (tail) of its column
+        f16x8 bh[EX_CT][4], bl[EX_CT][4];
+        f16x4 bht[EX_CT], blt[EX_CT];
+        int colv[EX_CT];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int fi = g * EX_COLS + ct * 16 + n16;
-            const int col = fi < count ? flagged[1 + fi] : -1;
-            colv[ct] = col;
-            const int cc = max(col, 0);
-            const int y = cc / w, x = cc - y * w;
-            il[ct] = col >= 0 ? inv_lr[cc] : 0.0f;
-#pragma unroll
-            for (int s = 0; s < 36; ++s) {
-                const int e = 16 * (s >> 2) + 4 * kq + (s & 3);
-                const int c = e / 9, t = e - c * 9;
-                const int ky = t / 3, kx = t - ky * 3;
-                b[ct][s] = lf[c * plane + (size_t)rv_reflect(y + ky - 1, h) * w + rv_reflect(x + kx - 1, w)];
-            }
+        for (int ct = 0; ct < EX_CT; ++ct) {                        // (all four list reads in flight before the row loads)
+            const int fi = g * EX_COLS + (wave * EX_CT + ct) * 16 + n16;
+            colv[ct] = flagged[1 + min(fi, count - 1)] | (fi < count ? 0 : 0x80000000);      // < 0: no column
         }
-        float best[4];
-        int besti[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { best[ct] = -INFINITY; besti[ct] = 0x7fffffff; }
-        for (int tile = part; tile < n_tiles; tile += nparts) {
-            // A operand: lane (row n16, group kq) reads 16 bytes = elements 16 S + 4 kq .. + 3 of its row, nine times
-            const float4* arow = reinterpret_cast<const float4*>(ref32 + (size_t)min(tile * 16 + n16, n_ref - 1) * 144 + 4 * kq);
-            float4 a[9];
+        for (int ct = 0; ct < EX_CT; ++ct) {
+            const int col = colv[ct] & 0x7fffffff;
+            const f16* bp0 = lr_hi + (size_t)col * KP + kq * 8;
+            const f16* bp1 = lr_lo + (size_t)col * KP + kq * 8;
 #pragma unroll
-            for (int S = 0; S < 9; ++S) a[S] = arow[S * 4];
-            f32x4 acc[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int S = 0; S < 9; ++S) {
-                const float av[4] = {a[S].x, a[S].y, a[S].z, a[S].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[ct][S * 4 + j], acc[ct], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                bh[ct][s] = *reinterpret_cast<const f16x8*>(bp0 + s * 32);
+                bl[ct][s] = *reinterpret_cast<const f16x8*>(bp1 + s * 32);
             }
-            // lane holds rows 4*kq + j (j = 0..3) of column n16: increasing j == increasing row, strict > keeps the first
+            bht[ct] = *reinterpret_cast<const f16x4*>(bp0 + 128 - kq * 4);
+            blt[ct] = *reinterpret_cast<const f16x4*>(bp1 + 128 - kq * 4);
+        }
+        float best[EX_CT];
+        int besti[EX_CT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = tile * 16 + 4 * kq + j;
-                if (row < n_ref) {
-                    const float ir = inv_ref[row];
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        const float v = acc[ct][j] * il[ct] * ir;
-                        if (v > best[ct]) { best[ct] = v; besti[ct] = row; }
-                    }
-                }
+        for (int ct = 0; ct < EX_CT; ++ct) { best[ct] = -INFINITY; besti[ct] = 0x7fffffff; }
+        // double-buffered stages, one barrier each: the barrier's vmcnt(0) lands stage st (issued one stage earlier, under
+        // the previous stage's MFMAs) and frees the other buffer for stage st + 1
+        for (int st = s_begin; st < s_end; st += 2) {
+            __syncthreads();
+            if (st + 1 < s_end) ex_issue_stage(ref_hi, ref_lo, st + 1, lds1, wave, lane);
+            ex_compute_stage(lds0, st, n_ref, n16, kq, bh, bl, bht, blt, best, besti);
+            if (st + 1 < s_end) {
+                __syncthreads();
+                if (st + 2 < s_end) ex_issue_stage(ref_hi, ref_lo, st + 2, lds0, wave, lane);
+                ex_compute_stage(lds1, st + 1, n_ref, n16, kq, bh, bl, bht, blt, best, besti);
             }
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int ct = 0; ct < EX_CT; ++ct) {
             unsigned long long k = besti[ct] == 0x7fffffff ? 0ull : ex_key(best[ct], besti[ct]);
             const unsigned long long k1 = __shfl_xor(k, 16);
             k = k1 > k ? k1 : k;
             const unsigned long long k2 = __shfl_xor(k, 32);
             k = k2 > k ? k2 : k;
-            if (kq == 0 && colv[ct] >= 0 && k != 0ull) atomicMax(&keys[g * EX_COLS + ct * 16 + n16], k);
+            if (kq == 0 && colv[ct] >= 0 && k != 0ull) atomicMax(&keys[g * EX_COLS + (wave * EX_CT + ct) * 16 + n16], k);
         }
     }
 }
 
-__global__ void match_exact_finish_kernel(const int32_t* __restrict__ flagged, const unsigned long long* __restrict__ keys,
+__global__ void match_exact_finish_kernel(const float* __restrict__ lf, int h, int w, const float* __restrict__ rf, int hr,
+                                          int wr, const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
+                                          const int32_t* __restrict__ flagged, const unsigned long long* __restrict__ keys,
                                           float* __restrict__ conf, int32_t* __restrict__ idx) {
     const int count = flagged[0];
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < count; f += gridDim.x * blockDim.x) {
         const unsigned long long k = keys[f];
-        unsigned u = (unsigned)(k >> 32);
-        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        if (k == 0ull) continue;
+        const int r = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
         const int col = flagged[1 + f];
-        conf[col] = __uint_as_float(u);
-        idx[col] = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+        const int y = col / w, x = col - y * w;
+        int ly[3], lx[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { ly[t] = rv_reflect(y + t - 1, h); lx[t] = rv_reflect(x + t - 1, w); }
+        const float v = patch_dot(lf, h, w, ly, lx, rf, hr, wr, r / wr, r % wr) * inv_lr[col] * inv_ref[r];
+        const float c0 = conf[col];
+        const int i0 = idx[col];
+        if (v > c0 || (v == c0 && r < i0)) { conf[col] = v; idx[col] = r; }
     }
 }
 
-extern "C" int refvsr_match_exact(const float* lr_feat, int h, int w, const float* ref_rows32, int n_ref,
+extern "C" int refvsr_match_exact(const float* lr_feat, int h, int w, const float* ref_feat, int hr, int wr,
+                                  const void* lr_rows, const void* lr_rows_lo, const void* ref_rows, const void* ref_rows_lo,
                                   const float* inv_lr, const float* inv_ref, const int32_t* flagged, void* keys,
                                   float* conf, int32_t* idx, void* stream) {
-    RV_CHECK(lr_feat && ref_rows32 && inv_lr && inv_ref && flagged && keys && conf && idx, "match_exact: null pointer");
-    RV_CHECK(h >= 2 && w >= 2 && n_ref >= 2, "match_exact: bad sizes");
-    // fixed grid, one workgroup per CU (the flagged count lives on the device; the kernel sizes its work items from it)
-    hipLaunchKernelGGL(match_exact_kernel, dim3(rv_num_cus()), dim3(256), 0, (hipStream_t)stream, lr_feat, h, w, ref_rows32, n_ref,
-                       inv_lr, inv_ref, flagged, (unsigned long long*)keys);
+    RV_CHECK(lr_feat && ref_feat && lr_rows && lr_rows_lo && ref_rows && ref_rows_lo && inv_lr && inv_ref && flagged &&
+             keys && conf && idx, "match_exact: null pointer");
+    RV_CHECK(h >= 2 && w >= 2 && hr >= 2 && wr >= 2, "match_exact: bad sizes");
+    // fixed grid, two workgroups per CU (the flagged count lives on the device; the kernel sizes its work items from it)
+    hipLaunchKernelGGL(match_exact_kernel, dim3(2 * rv_num_cus()), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)lr_rows, (const f16*)lr_rows_lo, (const f16*)ref_rows, (const f16*)ref_rows_lo, hr * wr,
+                       flagged, (unsigned long long*)keys);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_exact_finish_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, flagged,
-                       (const unsigned long long*)keys, conf, idx);
+    hipLaunchKernelGGL(match_exact_finish_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, lr_feat, h, w, ref_feat, hr,
+                       wr, inv_lr, inv_ref, flagged, (const unsigned long long*)keys, conf, idx);
     RV_LAUNCH_CHECK();
     return 0;
 }

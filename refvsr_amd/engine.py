@@ -349,8 +349,8 @@ class Engine(object):
             ref_n = ops.resize(ref_n, (oh, ow), ops.RS_NEAREST, (1.0 / f, 1.0 / f))
         lr_f = extract(lr_n)
         ref_f = extract(ops.avgpool2(ref_n))
-        lr_rows, inv_lr = ops.match_patches(lr_f, ops.hip.MATCH_COLBLOCK)
-        ref_rows, inv_ref, ref_rows32 = ops.match_patches(ref_f, ops.hip.MATCH_ROWCHUNK, want_rows32=True)
+        lr_rows, inv_lr, lr_lo = ops.match_patches(lr_f, ops.hip.MATCH_COLBLOCK, want_lo=True)
+        ref_rows, inv_ref, ref_lo = ops.match_patches(ref_f, ops.hip.MATCH_ROWCHUNK, want_lo=True)
         n_lr = lr_f.shape[1] * lr_f.shape[2]
         n_ref = ref_f.shape[1] * ref_f.shape[2]
         if self.kernel_events is not None:
@@ -361,7 +361,8 @@ class Engine(object):
             e1.record()
             self.kernel_events.append((e0, e1))
         # exact fp32 re-rank of the top-2 + exhaustive fp32 search of the columns the fp16 GEMM cannot decide
-        conf, idx, _ = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand, cand_val, self.match_margin, ref_rows32)
+        conf, idx, _ = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand, cand_val, self.match_margin, (lr_rows, lr_lo),
+                                        (ref_rows, ref_lo))
         conf = conf.view(1, lr_f.shape[1], lr_f.shape[2])
         grid = (lr_f.shape[1], lr_f.shape[2])
         if grid[0] != h:                                                           # attention.py:96-98 (HD)

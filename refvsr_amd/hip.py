@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RefvsrConv(C.Structure):
@@ -67,7 +67,7 @@ SIGNATURES = {
     'refvsr_match_patches': [_P, _I, _I, _P, _P, _P, _P],
     'refvsr_match_top2': [_P, _I, _P, _I, _I, _P, _P, _P],
     'refvsr_match_refine': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P],
-    'refvsr_match_exact': [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    'refvsr_match_exact': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'refvsr_match_naive': [_P, _I, _I, _P, _I, _I, _P, _P, _P],
     'refvsr_block_gather_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     'refvsr_block_gather_rgb': [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P],

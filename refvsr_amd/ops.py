@@ -341,16 +341,17 @@ def spynet_level_input(ref, supp, flow_prev):
     return out8, fup
 
 
-def match_patches(feat, row_pad, want_rows32=False):
-    """feat planar [16,h,w] -> (rows fp16 [pad(h*w), KP] zero padded, inv_norm fp32 [h*w][, rows32 fp32 [h*w,144]])."""
+def match_patches(feat, row_pad, want_lo=False):
+    """feat planar [16,h,w] -> (rows fp16 [pad(h*w), KP] zero padded, inv_norm fp32 [h*w][, rows_lo fp16 like rows: the
+    low halves of the hi + lo operand split, scaled by 2^11 -- the exact search's second operand])."""
     _planar(feat, 16)
     h, w = feat.shape[1:]
     n = h * w
     rows = torch.zeros((_round_up(n, row_pad), hip.MATCH_KP), dtype=torch.float16, device=feat.device)
     inv = torch.empty((n,), dtype=torch.float32, device=feat.device)
-    rows32 = torch.empty((n, 144), dtype=torch.float32, device=feat.device) if want_rows32 else None
-    hip.check(hip.lib().refvsr_match_patches(_ptr(feat), h, w, _ptr(rows), _ptr(inv), _ptr(rows32), _stream()), 'match_patches')
-    return (rows, inv, rows32) if want_rows32 else (rows, inv)
+    lo = torch.zeros_like(rows) if want_lo else None
+    hip.check(hip.lib().refvsr_match_patches(_ptr(feat), h, w, _ptr(rows), _ptr(inv), _ptr(lo), _stream()), 'match_patches')
+    return (rows, inv, lo) if want_lo else (rows, inv)
 
 
 def match_top2(ref_rows, n_ref, lr_rows, n_lr, row_splits=1):
@@ -364,14 +365,14 @@ def match_top2(ref_rows, n_ref, lr_rows, n_lr, row_splits=1):
 
 
 # fp16-GEMM scores of rows outside the candidate list are trusted to this margin; columns whose exact maximum does not
-# clear the runner-up's fp16 score by it are searched exhaustively in fp32 (refvsr_match_exact).  The fp16 operand
+# clear the runner-up's fp16 score by it are searched exhaustively at fp32 accuracy (refvsr_match_exact).  The fp16 operand
 # rounding perturbs a correlation by ~3e-5 (measured), bounded by 2^-10 = 9.8e-4 in the worst case.
 MATCH_EXACT_MARGIN = 2.5e-4
 
 
-def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cand_val=None, margin=None, ref_rows32=None):
-    """Exact re-rank of the candidates; with cand_val / margin / ref_rows32 also the exhaustive exact search of the
-    columns the fp16 GEMM cannot decide.  margin = inf searches EVERY column exhaustively (test aid).
+def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cand_val=None, margin=None, lr_split=None, ref_split=None):
+    """Exact re-rank of the candidates; with cand_val / margin / lr_split = (lr_rows, lr_rows_lo) / ref_split = (ref_rows, ref_rows_lo) also the exhaustive
+    search of the columns the fp16 GEMM cannot decide.  margin = inf searches EVERY column exhaustively (test aid).
     Returns (conf, idx) or (conf, idx, flagged int32 [1 + n], [0] = count) when flagging is on."""
     _planar(lr_feat, 16)
     _planar(ref_feat, 16)
@@ -385,8 +386,12 @@ def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cand_val=None, margin
                                                 _ptr(cand), None, cand.shape[1], 0.0, None, _ptr(conf), _ptr(idx), _stream()),
                   'match_refine')
         return conf, idx
-    assert cand_val is not None and ref_rows32 is not None and cand_val.shape == cand.shape and cand_val.is_contiguous()
-    assert ref_rows32.dtype == torch.float32 and tuple(ref_rows32.shape) == (hr * wr, 144) and ref_rows32.is_contiguous()
+    assert cand_val is not None and ref_split is not None and lr_split is not None
+    assert cand_val.shape == cand.shape and cand_val.is_contiguous()
+    (lr_rows, lr_lo), (ref_rows, ref_lo) = lr_split, ref_split
+    for r, n_, pad in ((lr_rows, h * w, 1), (lr_lo, h * w, 1), (ref_rows, hr * wr, hip.MATCH_ROWCHUNK), (ref_lo, hr * wr, hip.MATCH_ROWCHUNK)):
+        assert r.dtype == torch.float16 and r.is_contiguous() and r.shape[1] == hip.MATCH_KP
+        assert r.shape[0] >= n_ and r.shape[0] % pad == 0
     # one zeroed scratch allocation: [flag count + list (int32 1 + n, padded to 8 bytes)] [merge keys uint64 n]
     n = h * w
     fl_words = (n + 2) // 2 * 2
@@ -395,8 +400,9 @@ def match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cand_val=None, margin
     hip.check(hip.lib().refvsr_match_refine(_ptr(lr_feat), h, w, _ptr(ref_feat), hr, wr, _ptr(inv_lr), _ptr(inv_ref),
                                             _ptr(cand), _ptr(cand_val), cand.shape[1], float(margin), _ptr(flagged), _ptr(conf),
                                             _ptr(idx), _stream()), 'match_refine')
-    hip.check(hip.lib().refvsr_match_exact(_ptr(lr_feat), h, w, _ptr(ref_rows32), hr * wr, _ptr(inv_lr), _ptr(inv_ref),
-                                           _ptr(flagged), _ptr(keys), _ptr(conf), _ptr(idx), _stream()), 'match_exact')
+    hip.check(hip.lib().refvsr_match_exact(_ptr(lr_feat), h, w, _ptr(ref_feat), hr, wr, _ptr(lr_rows), _ptr(lr_lo), _ptr(ref_rows), _ptr(ref_lo),
+                                           _ptr(inv_lr), _ptr(inv_ref), _ptr(flagged), _ptr(keys), _ptr(conf), _ptr(idx),
+                                           _stream()), 'match_exact')
     return conf, idx, flagged
 
 

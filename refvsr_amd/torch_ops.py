@@ -100,11 +100,11 @@ def register():
 
     @op('match_argmax')
     def match_argmax(lr_feat: torch.Tensor, ref_feat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        lr_rows, inv_lr = ops.match_patches(lr_feat, hip.MATCH_COLBLOCK)
-        ref_rows, inv_ref, ref32 = ops.match_patches(ref_feat, hip.MATCH_ROWCHUNK, want_rows32=True)
+        lr_rows, inv_lr, lr_lo = ops.match_patches(lr_feat, hip.MATCH_COLBLOCK, want_lo=True)
+        ref_rows, inv_ref, ref_lo = ops.match_patches(ref_feat, hip.MATCH_ROWCHUNK, want_lo=True)
         n_lr, n_ref = lr_feat.shape[1] * lr_feat.shape[2], ref_feat.shape[1] * ref_feat.shape[2]
         cand, cval = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1)
-        conf, idx, _ = ops.match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cval, ops.MATCH_EXACT_MARGIN, ref32)
+        conf, idx, _ = ops.match_refine(lr_feat, ref_feat, inv_lr, inv_ref, cand, cval, ops.MATCH_EXACT_MARGIN, (lr_rows, lr_lo), (ref_rows, ref_lo))
         return conf.view(1, lr_feat.shape[1], lr_feat.shape[2]), idx
 
     @match_argmax.register_fake

@@ -430,38 +430,47 @@ def test_match_ties_pick_first_index(dev):
     assert maxdiff(conf.cpu(), torch.ones(192)) < 1e-5
 
 
-def test_match_patches_rows32(dev):
+def test_match_patches_split_rows(dev):
+    """hi + lo operand split of the normalised patch rows: hi + lo * 2^-11 reproduces the fp32 normalised patch to 2^-22."""
     from refvsr_amd import ops
     from oracle import refvsr_oracle as orc
     f = torch.randn(16, 14, 18)
-    rows, inv, rows32 = ops.match_patches(f.to(dev), 256, want_rows32=True)
-    assert torch.equal(rows32.cpu(), orc.patches3x3(f[None])[0].t().contiguous())      # raw patches: pure data movement
+    rows, inv, lo = ops.match_patches(f.to(dev), 256, want_lo=True)
+    n = 14 * 18
+    want = F.normalize(orc.patches3x3(f[None])[0].t().contiguous().double(), dim=1)          # [n, 144]
+    got = rows[:n, :144].cpu().double() + lo[:n, :144].cpu().double() / 2048.0
+    report('match split rows', err=float((got - want).abs().max()), hi_only=float((rows[:n, :144].cpu().double() - want).abs().max()))
+    assert float((got - want).abs().max()) < 2e-7
+    assert float(rows[n:].abs().max()) == 0 and float(lo[:, 144:].abs().max()) == 0 and float(rows[:, 144:].abs().max()) == 0
 
 
 def test_match_exact_search(dev):
-    """refvsr_match_exact (exhaustive fp32 MFMA search of flagged columns): with margin = inf EVERY column is flagged, the
-    result must then be the exact arg-max and -- where the default margin flags nothing -- identical to the top-2 path."""
+    """refvsr_match_exact (exhaustive split-fp16 MFMA search of flagged columns): with margin = inf EVERY column is flagged,
+    the result must then be the exact arg-max and -- where the default margin flags nothing -- identical to the top-2
+    path; conf values of both paths come from the same fp32 expression."""
     from refvsr_amd import ops
     g = torch.Generator().manual_seed(13)
     for (h, w) in [(20, 28), (34, 50), (64, 96)]:
         base = F.interpolate(torch.randn(1, 16, h // 4 + 2, w // 4 + 2, generator=g), size=(h, w), mode='bilinear')[0]
         lr_f = base + 0.2 * torch.randn(16, h, w, generator=g)
         ref_f = F.avg_pool2d(base[None], 2)[0] + 0.2 * torch.randn(16, h // 2, w // 2, generator=g)
-        lr_rows, inv_lr = ops.match_patches(lr_f.to(dev), 512)
-        ref_rows, inv_ref, ref32 = ops.match_patches(ref_f.to(dev), 256, want_rows32=True)
+        lr_rows, inv_lr, lr_lo = ops.match_patches(lr_f.to(dev), 512, want_lo=True)
+        ref_rows, inv_ref, ref_lo = ops.match_patches(ref_f.to(dev), 256, want_lo=True)
         n_ref = ref_f.shape[1] * ref_f.shape[2]
         cand, cval = ops.match_top2(ref_rows, n_ref, lr_rows, h * w, 1)
-        conf_a, idx_a, fl_a = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand, cval, float('inf'), ref32)
+        split = ((lr_rows, lr_lo), (ref_rows, ref_lo))
+        conf_a, idx_a, fl_a = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand, cval, float('inf'), *split)
         assert int(fl_a[0]) == h * w
         _check_match(conf_a, idx_a, lr_f, ref_f, '%dx%d exhaustive exact' % (h, w))
-        conf_d, idx_d, fl_d = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand, cval, ops.MATCH_EXACT_MARGIN, ref32)
+        conf_d, idx_d, fl_d = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand, cval, ops.MATCH_EXACT_MARGIN, *split)
         conf_t, idx_t = ops.match_refine(lr_f.to(dev), ref_f.to(dev), inv_lr, inv_ref, cand)
         report('match exact %dx%d' % (h, w), flagged_default=int(fl_d[0]), idx_diff_all_vs_top2=int((idx_a != idx_t).sum()),
                conf_bitwise_equal=float(torch.equal(conf_a, conf_t)), conf_diff=maxdiff(conf_a.cpu(), conf_t.cpu()))
-        # the exhaustive search and the re-ranked top-2 compute the same fp32 FMA chain: wherever they pick the same
-        # row the confidence is the same number
+        # the search winner is re-evaluated with the re-rank's fp32 expression and only replaces a candidate it beats:
+        # same row => same number, different row => a larger (or equal, smaller index) value
         same = idx_a == idx_t
         assert torch.equal(conf_a[same], conf_t[same])
+        assert bool((conf_a[~same] >= conf_t[~same]).all())
         assert torch.equal(idx_d, idx_a) and torch.equal(conf_d, conf_a)      # default margin: same final answer as exhaustive
 
 

@@ -65,10 +65,10 @@ def test_torch_library_ops_match_direct_calls():
     assert torch.equal(R.warp(x, fl), ops.warp_nhwc16(x, fl))
     lr_f, ref_f = torch.randn(16, h, w, generator=g).to(dev), torch.randn(16, h // 2, w // 2, generator=g).to(dev)
     conf, idx = R.match_argmax(lr_f, ref_f)
-    lr_rows, inv_lr = ops.match_patches(lr_f, 512)
-    ref_rows, inv_ref, r32 = ops.match_patches(ref_f, 256, want_rows32=True)
+    lr_rows, inv_lr, l_lo = ops.match_patches(lr_f, 512, want_lo=True)
+    ref_rows, inv_ref, r_lo = ops.match_patches(ref_f, 256, want_lo=True)
     cand, cv = ops.match_top2(ref_rows, (h // 2) * (w // 2), lr_rows, h * w, 1)
-    c0, i0, _ = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand, cv, ops.MATCH_EXACT_MARGIN, r32)
+    c0, i0, _ = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand, cv, ops.MATCH_EXACT_MARGIN, (lr_rows, l_lo), (ref_rows, r_lo))
     assert torch.equal(conf.view(-1), c0) and torch.equal(idx, i0)
     assert torch.equal(R.block_gather(x, idx, h, w, 2), ops.block_gather_nhwc16(x, idx, h, w, 2))
     with pytest.raises(RuntimeError, match='ksteps mismatch'):          # the library's own argument check surfaces as RuntimeError

@@ -48,15 +48,19 @@ def bench_match():
     base = ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1)
     us = timeit(lambda: ops.match_top2(ref_rows, n_ref, lr_rows, n_lr, 1), iters=10)
     emit('match_top2: %.1f us  %.1f TFLOP/s  (%.1f%% of 2.5 PF)' % (us, flops / us / 1e6, flops / us / 1e6 / 25.0))
-    _, _, ref32 = ops.match_patches(ref_f, 256, want_rows32=True)
+    _, _, ref_lo = ops.match_patches(ref_f, 256, want_lo=True)
+    _, _, lr_lo = ops.match_patches(lr_f, 512, want_lo=True)
+    split = ((lr_rows, lr_lo), (ref_rows, ref_lo))
     us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0]), iters=10)
     emit('match_refine (re-rank only): %.1f us' % us)
     for margin in (ops.MATCH_EXACT_MARGIN, 5e-3, 2e-2):
-        fl = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0], base[1], margin, ref32)[2]
-        us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0], base[1], margin, ref32), iters=10)
+        fl = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0], base[1], margin, *split)[2]
+        us = timeit(lambda: ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, base[0], base[1], margin, *split), iters=10)
         emit('match_refine + exact search, margin %.1e: %d of %d columns flagged, %.1f us' % (margin, int(fl[0]), n_lr, us))
     us = timeit(lambda: ops.match_patches(lr_f, 512), iters=10)
     emit('match_patches(lr): %.1f us' % us)
+    us = timeit(lambda: ops.match_patches(lr_f, 512, want_lo=True), iters=10)
+    emit('match_patches(lr) with lo rows: %.1f us' % us)
 
 
 # NOTE: timeit() launches back to back from Python; anything below ~12 us per call is bounded by the host launch rate,
