@@ -70,8 +70,12 @@ struct ConvArgs {
 // instruction count: the PMC split of round 1 (33 % of wave cycles issuing at 3 waves per SIMD = a saturated issue
 // port, MFMA 19-30 % busy) says these kernels are bound by the NUMBER of instructions around the K loop, not by memory
 // or the matrix pipe.
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
+// NW: waves per workgroup.  4 by default; 8 (with half the pixel tiles per wave, i.e. the same 8 x 32 output tile) where LDS
+// admits ONE workgroup per CU -- the C = 48 weight sets of RefVSR_MFID(_8K): 84 KB resident, or a 65 KB two-source tile next
+// to the streamed chunk -- so that a SIMD still has two waves to interleave instead of one.
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
+    constexpr int NT = NW * 64;                      // threads per workgroup
     static_assert(!(GATHER && RESIDENT), "gather mode streams its weights");
     static_assert(EPI == 0 || (RESIDENT && !F32), "the lean epilogue is built for the resident fp16 kernels");
     constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
@@ -86,11 +90,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const int q = lane >> 4;
     const int lr = lane & 15;
     const int lp = (p.stride == 1) ? rv_pix16(lr) : lr;      // pixel of the 16-pixel tile this lane's MFMA column holds
-    constexpr int TH = TILES * 2;
+    constexpr int TH = NW * TILES / 2;               // output rows of the workgroup's tile (two 16-pixel groups per row)
     const int zg = blockIdx.z;
 
     // ---- K-slot -> LDS byte offset table (K order: common.h:rv_kslot) ---------------------------
-    for (int g = tid; g < p.S * 4; g += 256) {
+    for (int g = tid; g < p.S * 4; g += NT) {
         int off, slot;
         if (g < p.G) {
             const int tap = (int)(((float)g + 0.5f) * p.inv_ncg);
@@ -355,22 +359,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         {
             const int n16 = p.S * MT * WFR * 64;
             uint4* d = reinterpret_cast<uint4*>(wl);
-            for (int i0 = 0; i0 < n16; i0 += 8 * 256) {
+            for (int i0 = 0; i0 < n16; i0 += 8 * NT) {
                 uint4 w0, w1, w2, w3, w4, w5, w6, w7;
                 const int last = n16 - 1, i = i0 + tid;
-                w0 = wsrc[min(i, last)];            w1 = wsrc[min(i + 256, last)];
-                w2 = wsrc[min(i + 512, last)];      w3 = wsrc[min(i + 768, last)];
-                w4 = wsrc[min(i + 1024, last)];     w5 = wsrc[min(i + 1280, last)];
-                w6 = wsrc[min(i + 1536, last)];     w7 = wsrc[min(i + 1792, last)];
+                w0 = wsrc[min(i, last)];              w1 = wsrc[min(i + NT, last)];
+                w2 = wsrc[min(i + 2 * NT, last)];     w3 = wsrc[min(i + 3 * NT, last)];
+                w4 = wsrc[min(i + 4 * NT, last)];     w5 = wsrc[min(i + 5 * NT, last)];
+                w6 = wsrc[min(i + 6 * NT, last)];     w7 = wsrc[min(i + 7 * NT, last)];
                 asm volatile("" ::: "memory");
                 if (i < n16) d[i] = w0;
-                if (i + 256 < n16) d[i + 256] = w1;
-                if (i + 512 < n16) d[i + 512] = w2;
-                if (i + 768 < n16) d[i + 768] = w3;
-                if (i + 1024 < n16) d[i + 1024] = w4;
-                if (i + 1280 < n16) d[i + 1280] = w5;
-                if (i + 1536 < n16) d[i + 1536] = w6;
-                if (i + 1792 < n16) d[i + 1792] = w7;
+                if (i + NT < n16) d[i + NT] = w1;
+                if (i + 2 * NT < n16) d[i + 2 * NT] = w2;
+                if (i + 3 * NT < n16) d[i + 3 * NT] = w3;
+                if (i + 4 * NT < n16) d[i + 4 * NT] = w4;
+                if (i + 5 * NT < n16) d[i + 5 * NT] = w5;
+                if (i + 6 * NT < n16) d[i + 6 * NT] = w6;
+                if (i + 7 * NT < n16) d[i + 7 * NT] = w7;
             }
         }
         int tl, k_hi;                                              // this workgroup's tiles (common.h:rv_tile_range)
@@ -382,12 +386,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         // origin pixel, base select, 64-bit add, load) instead of ~58.
         const int row_chunks = p.LW * p.ncg;
         const int total = p.LH * row_chunks;                       // <= CONV_XPF * 256 (host)
-        int xq[CONV_XPF];
+        constexpr int XPF = CONV_XPF * 256 / NT;                   // chunk slots per thread
+        int xq[XPF];
         {
             const float inv_rc = 1.0f / (float)row_chunks;
 #pragma unroll
-            for (int k = 0; k < CONV_XPF; ++k) {
-                const int idx = tid + k * 256;
+            for (int k = 0; k < XPF; ++k) {
+                const int idx = tid + k * NT;
                 const int r = (int)(((float)idx + 0.5f) * inv_rc);
                 const int i = idx - r * row_chunks;
                 const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 xq[k] = idx < total ? (r | (c << 5) | ((s1 ? cg - p.ncg0 : cg) << 12) | (s1 ? (1 << 19) : 0) | (cg << 20)) : -1;
             }
         }
-        uint4 xv[CONV_XPF];
+        uint4 xv[XPF];
         auto x_fetch = [&](const int t) {                          // global -> registers (zero padded at the frame border)
             const int tyi = t / p.tiles_x;
             const int iy0 = tyi * TH * p.stride - p.pad;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             const unsigned char* b0 = p.src0 + org * p.pixb0;
             const unsigned char* b1 = p.src1 + org * p.pixb1;
 #pragma unroll
-            for (int k = 0; k < CONV_XPF; ++k) {
+            for (int k = 0; k < XPF; ++k) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 int e = xq[k];
                 asm volatile("" : "+v"(e));                        // decode per tile: keeps the decoded fields x 8 out of the
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         };
         auto x_park = [&]() {                                      // registers -> LDS tile
 #pragma unroll
-            for (int k = 0; k < CONV_XPF; ++k) {
+            for (int k = 0; k < XPF; ++k) {
                 int e = xq[k];
                 asm volatile("" : "+v"(e));
                 if (e >= 0)
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             const int row_chunks = p.LW * p.ncg;
             const float inv_rc = 1.0f / (float)row_chunks;
             const int total = p.LH * row_chunks;
-            for (int idx = tid; idx < total; idx += 256) {
+            for (int idx = tid; idx < total; idx += NT) {
                 const int r = (int)(((float)idx + 0.5f) * inv_rc);
                 const int i = idx - r * row_chunks;
                 const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
@@ -490,19 +495,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
         }
         // Weight chunks: chunk c+1 is fetched into registers while chunk c feeds the MFMAs and parked afterwards.
-        constexpr int WPT = (CONV_CH * MT * WFR * 64) / 256;         // uint4 per thread per chunk (4 * MT * WFR)
+        constexpr int WPT = (CONV_CH * MT * WFR * 64) / NT;          // uint4 per thread per chunk (4 * MT * WFR with 4 waves)
         const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
         // named registers, not an array: hipcc keeps a prefetch *array* in scratch memory here (scratch_store right
         // behind every load), which serialises the whole prefetch
         static_assert(WPT <= 12, "prefetch register set");
         uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
 #define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
-#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * 256, n16n - 1)];
-#define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * 256 < n16n) d[tid + k * 256] = w##k; }
+#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * NT, n16n - 1)];
+#define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * NT < n16n) d[tid + k * NT] = w##k; }
         {
             const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
             uint4* d = reinterpret_cast<uint4*>(wl);
-            for (int i = tid; i < n16; i += 256) d[i] = wsrc[i];     // chunk 0, issued together with the tile staging
+            for (int i = tid; i < n16; i += NT) d[i] = wsrc[i];      // chunk 0, issued together with the tile staging
         }
         zero_acc();
         __syncthreads();
@@ -542,13 +547,13 @@ extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg);
 
 // RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
 // the XCD banding) and walk the tiles; the others launch one workgroup per tile.
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4>
 static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy table (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
@@ -561,7 +566,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         for (int i = 0; i < 4; ++i)
             if (occ_lds[dev][i] == lds && occ_val[dev][i] > 0) occ = occ_val[dev][i];
         if (occ == 0) {
-            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI>, 256, lds));
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>, NW * 64, lds));
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
@@ -570,7 +575,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI>), dim3(gx, 1, nz), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -635,7 +640,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     // RESIDENT: whole weight set in LDS, persistent workgroups with a register-prefetched input tile.  Needs few enough
     // K-steps, a tile that fits the prefetch registers, and LDS for >= 2 workgroups per CU (8 x 32 pixels preferred,
     // 4 x 32 when that buys a second / third workgroup).
-    bool resident = false;
+    bool resident = false, one_wg = false;             // one_wg: LDS admits a single workgroup per CU
     static const int res_max = getenv("REFVSR_CONV_RES_MAX") ? atoi(getenv("REFVSR_CONV_RES_MAX")) : CONV_RES_MAX;   // A/B knob
     if (!no_resident && a.S <= res_max && a.S <= CONV_RES_MAX) {
         int best_wg = 0;
@@ -650,7 +655,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
             if (a.LH > 31 || a.LW > 127 || a.ncg > 127) continue;   // packed chunk descriptor of the tile staging (r:5, c:7, cg:7 + 7 bits)
             if (best_wg == 0 || (best_wg < 2 && wg > best_wg)) { best_wg = wg; tiles = tl; lds = need; resident = true; }
         }
-        if (resident) { a.wl_bytes = a.S * wfr_kb; tile_bytes(tiles); }
+        if (resident) { a.wl_bytes = a.S * wfr_kb; tile_bytes(tiles); one_wg = best_wg == 1; }
     }
     if (!resident) {
         // chunked weights (one CONV_CH-step buffer): 8 x 32 pixels if the staged input fits, else 4 x 32, else gather mode
@@ -671,7 +676,11 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
             const size_t lds2 = lds_for(2);
             if (lds2 <= LDS_MAX / 2) { tiles = 2; lds = lds2; } else { lds = lds_for(4); }
         }
+        one_wg = !a.gather && lds > LDS_MAX / 2;
     }
+    // one workgroup per CU: eight waves on the same 8 x 32 tile (two pixel groups per wave) keep two waves per SIMD
+    static const bool no_nw8 = getenv("REFVSR_CONV_NO_NW8") != nullptr;             // A/B knob, read once
+    const bool nw8 = one_wg && tiles == 4 && !f32 && !a.gather && !no_nw8;
     static const bool no_prefetch = getenv("REFVSR_CONV_NO_PREFETCH") != nullptr;   // A/B knob, read once
     a.prefetch = no_prefetch ? 0 : 1;
     a.tiles_x = rv_cdiv(d->w_out, CONV_TW);
@@ -697,6 +706,16 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         if (lean) return launch_conv<M, T, false, false, true, 1>(a, nz, lds, st);                        \
         return resident ? launch_conv<M, T, false, false, true>(a, nz, lds, st)                           \
                         : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
+    }
+    if (nw8) {
+#define RV_CONV_CASE8(M)                                                                                  \
+        if (MT == M) {                                                                                    \
+            if (lean) return launch_conv<M, 2, false, false, true, 1, 8>(a, nz, lds, st);                 \
+            return resident ? launch_conv<M, 2, false, false, true, 0, 8>(a, nz, lds, st)                 \
+                            : launch_conv<M, 2, false, false, false, 0, 8>(a, nz, lds, st);               \
+        }
+        RV_CONV_CASE8(1) RV_CONV_CASE8(2) RV_CONV_CASE8(3)
+#undef RV_CONV_CASE8
     }
     RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
     RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)

@@ -96,6 +96,9 @@ extern "C" int refvsr_match_patches(const float* feat, int h, int w, void* rows,
 // ---------------------------------------------------------------------------------------------
 // exact fp32 re-rank of the candidates
 // ---------------------------------------------------------------------------------------------
+// UNROLL: channels per trip of the (otherwise rolled) channel loop.  Fully unrolled, the 144 addresses spill; rolled, a lone
+// thread pays one memory round trip per channel -- match_exact_finish (a few thousand threads, latency-bound) takes 4.
+template <int UNROLL = 1>
 __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, int w, const int* ly, const int* lx,
                                            const float* __restrict__ rf, int hr, int wr, int ry, int rx) {
     int yy[3], xx[3];
@@ -104,12 +107,20 @@ __device__ __forceinline__ float patch_dot(const float* __restrict__ lf, int h, 
     const size_t lp = (size_t)h * w, rp = (size_t)hr * wr;
     float d = 0.0f;
 #pragma unroll 1
-    for (int c = 0; c < 16; ++c)                     // (a rolled loop: fully unrolled, the 144 addresses spill)
+    for (int c0 = 0; c0 < 16; c0 += UNROLL) {
+        float a[UNROLL][9], b[UNROLL][9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                d = fmaf(lf[c * lp + (size_t)ly[ky] * w + lx[kx]], rf[c * rp + (size_t)yy[ky] * wr + xx[kx]], d);
+            for (int t = 0; t < 9; ++t) {
+                a[u][t] = lf[(c0 + u) * lp + (size_t)ly[t / 3] * w + lx[t % 3]];
+                b[u][t] = rf[(c0 + u) * rp + (size_t)yy[t / 3] * wr + xx[t % 3]];
+            }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d = fmaf(a[u][t], b[u][t], d);     // same order for every UNROLL: c, ky, kx
+    }
     return d;
 }
 
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-__global__ void match_exact_finish_kernel(const float* __restrict__ lf, int h, int w, const float* __restrict__ rf, int hr,
+__global__ __launch_bounds__(256) void match_exact_finish_kernel(const float* __restrict__ lf, int h, int w, const float* __restrict__ rf, int hr,
                                           int wr, const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
                                           const int32_t* __restrict__ flagged, const unsigned long long* __restrict__ keys,
                                           float* __restrict__ conf, int32_t* __restrict__ idx) {
@@ -337,7 +348,7 @@ __global__ void match_exact_finish_kernel(const float* __restrict__ lf, int h, i
         int ly[3], lx[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) { ly[t] = rv_reflect(y + t - 1, h); lx[t] = rv_reflect(x + t - 1, w); }
-        const float v = patch_dot(lf, h, w, ly, lx, rf, hr, wr, r / wr, r % wr) * inv_lr[col] * inv_ref[r];
+        const float v = patch_dot<4>(lf, h, w, ly, lx, rf, hr, wr, r / wr, r % wr) * inv_lr[col] * inv_ref[r];
         const float c0 = conf[col];
         const int i0 = idx[col];
         if (v > c0 || (v == c0 && r < i0)) { conf[col] = v; idx[col] = r; }
