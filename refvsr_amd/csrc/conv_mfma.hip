@@ -70,9 +70,10 @@ struct ConvArgs {
 // instruction count: the PMC split of round 1 (33 % of wave cycles issuing at 3 waves per SIMD = a saturated issue
 // port, MFMA 19-30 % busy) says these kernels are bound by the NUMBER of instructions around the K loop, not by memory
 // or the matrix pipe.
-// NW: waves per workgroup.  4 by default; 8 (with half the pixel tiles per wave, i.e. the same 8 x 32 output tile) where LDS
-// admits ONE workgroup per CU -- the C = 48 weight sets of RefVSR_MFID(_8K): 84 KB resident, or a 65 KB two-source tile next
-// to the streamed chunk -- so that a SIMD still has two waves to interleave instead of one.
+// NW: waves per workgroup.  4 by default.  Where LDS admits ONE workgroup per CU -- the C = 48 weight sets of
+// RefVSR_MFID(_8K): 84 KB resident, or a 65 KB two-source tile next to the streamed chunk -- a 4-wave workgroup leaves a
+// SIMD with a single wave and nothing to interleave: those launches use 16 waves on a 16 x 32 tile (resident, where it fits)
+// or 8 waves on the same 8 x 32 tile (two pixel groups per wave).
 template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
     constexpr int NT = NW * 64;                      // threads per workgroup
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
         // origin pixel, base select, 64-bit add, load) instead of ~58.
         const int row_chunks = p.LW * p.ncg;
         const int total = p.LH * row_chunks;                       // <= CONV_XPF * 256 (host)
-        constexpr int XPF = CONV_XPF * 256 / NT;                   // chunk slots per thread
+        constexpr int XPF = NW == 4 ? CONV_XPF : (NW == 8 ? 8 : 4);   // chunk slots per thread (capacity 2048 | 4096 | 4096)
         int xq[XPF];
         {
             const float inv_rc = 1.0f / (float)row_chunks;
@@ -641,6 +642,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     // K-steps, a tile that fits the prefetch registers, and LDS for >= 2 workgroups per CU (8 x 32 pixels preferred,
     // 4 x 32 when that buys a second / third workgroup).
     bool resident = false, one_wg = false;             // one_wg: LDS admits a single workgroup per CU
+    bool w16 = false;                                  // 16 x 32 tile, 16 waves
     static const int res_max = getenv("REFVSR_CONV_RES_MAX") ? atoi(getenv("REFVSR_CONV_RES_MAX")) : CONV_RES_MAX;   // A/B knob
     if (!no_resident && a.S <= res_max && a.S <= CONV_RES_MAX) {
         int best_wg = 0;
@@ -656,6 +658,17 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
             if (best_wg == 0 || (best_wg < 2 && wg > best_wg)) { best_wg = wg; tiles = tl; lds = need; resident = true; }
         }
         if (resident) { a.wl_bytes = a.S * wfr_kb; tile_bytes(tiles); one_wg = best_wg == 1; }
+        // One workgroup per CU (the C = 48 weight sets): a 16 x 32 tile walked by SIXTEEN waves (two pixel groups each) keeps
+        // four waves per SIMD next to the 84 KB weight set and halves the halo; 8 waves on 8 x 32 where that does not fit.
+        // (same box, frames/s: RefVSR_MFID 60.6 [4 waves] / 68.9 [8 x 2] / 70.1 [8 x 4] / 72.2 [16 x 2]; MFID_8K 1080p 5.04 / 5.80 / 6.24 / 6.25)
+        static const bool no_w16 = getenv("REFVSR_CONV_NO_W16") != nullptr;          // A/B knob, read once
+        if (resident && one_wg && tiles == 4 && !f32 && !no_w16 && (MT == 2 || MT == 3)) {
+            const size_t tb = tile_bytes(8);
+            const size_t need = (size_t)a.tab_bytes + (size_t)a.S * wfr_kb + tb;
+            const int chunks = a.LH * a.LW * a.ncg;
+            if (need <= LDS_MAX && chunks <= 4096 && a.LH <= 31 && a.LW <= 127) { tiles = 8; lds = need; w16 = true; }
+            else tile_bytes(tiles);
+        }
     }
     if (!resident) {
         // chunked weights (one CONV_CH-step buffer): 8 x 32 pixels if the staged input fits, else 4 x 32, else gather mode
@@ -706,6 +719,10 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         if (lean) return launch_conv<M, T, false, false, true, 1>(a, nz, lds, st);                        \
         return resident ? launch_conv<M, T, false, false, true>(a, nz, lds, st)                           \
                         : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
+    }
+    if (w16) {
+        if (MT == 3) return lean ? launch_conv<3, 2, false, false, true, 1, 16>(a, nz, lds, st) : launch_conv<3, 2, false, false, true, 0, 16>(a, nz, lds, st);
+        return lean ? launch_conv<2, 2, false, false, true, 1, 16>(a, nz, lds, st) : launch_conv<2, 2, false, false, true, 0, 16>(a, nz, lds, st);
     }
     if (nw8) {
 #define RV_CONV_CASE8(M)                                                                                  \
