@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
         // origin pixel, base select, 64-bit add, load) instead of ~58.
         const int row_chunks = p.LW * p.ncg;
         const int total = p.LH * row_chunks;                       // <= CONV_XPF * 256 (host)
-        constexpr int XPF = NW == 4 ? CONV_XPF : (NW == 8 ? 8 : 4);   // chunk slots per thread (capacity 2048 | 4096 | 4096)
+        constexpr int XPF = NW == 4 ? CONV_XPF : 4;                // chunk slots per thread (capacity 2048 | 2048 | 4096)
         int xq[XPF];
         {
             const float inv_rc = 1.0f / (float)row_chunks;
@@ -693,7 +693,10 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     }
     // one workgroup per CU: eight waves on the same 8 x 32 tile (two pixel groups per wave) keep two waves per SIMD
     static const bool no_nw8 = getenv("REFVSR_CONV_NO_NW8") != nullptr;             // A/B knob, read once
-    const bool nw8 = one_wg && tiles == 4 && !f32 && !a.gather && !no_nw8;
+    // ... and eight waves (two pixel groups each) on every other 8 x 32 fp16 tile as well: 2 workgroups x 8 waves = 4 waves per
+    // SIMD instead of 3 x 4 = 3 (same box: 156.7 -> 159.3 frames/s on RefVSR_small; forcing <= 80 VGPRs for 6 waves spills)
+    const bool nw8 = tiles == 4 && !f32 && !a.gather && !no_nw8;
+    (void)one_wg;
     static const bool no_prefetch = getenv("REFVSR_CONV_NO_PREFETCH") != nullptr;   // A/B knob, read once
     a.prefetch = no_prefetch ? 0 : 1;
     a.tiles_x = rv_cdiv(d->w_out, CONV_TW);
