@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-__global__ __launch_bounds__(256) void match_exact_finish_kernel(const float* __restrict__ lf, int h, int w, const float* __restrict__ rf, int hr,
+__global__ __launch_bounds__(64) void match_exact_finish_kernel(const float* __restrict__ lf, int h, int w, const float* __restrict__ rf, int hr,
                                           int wr, const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
                                           const int32_t* __restrict__ flagged, const unsigned long long* __restrict__ keys,
                                           float* __restrict__ conf, int32_t* __restrict__ idx) {
@@ -367,7 +367,9 @@ extern "C" int refvsr_match_exact(const float* lr_feat, int h, int w, const floa
                        (const f16*)lr_rows, (const f16*)lr_rows_lo, (const f16*)ref_rows, (const f16*)ref_rows_lo, hr * wr,
                        flagged, (unsigned long long*)keys);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_exact_finish_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, lr_feat, h, w, ref_feat, hr,
+    // one wave per workgroup, as many workgroups as there can be flagged columns (the count lives on the device; idle ones exit
+    // at once): the gathers of a wave are fully divergent, so the few thousand columns are spread over as many CUs as possible
+    hipLaunchKernelGGL(match_exact_finish_kernel, dim3(rv_cdiv(h * w, 64)), dim3(64), 0, (hipStream_t)stream, lr_feat, h, w, ref_feat, hr,
                        wr, inv_lr, inv_ref, flagged, (const unsigned long long*)keys, conf, idx);
     RV_LAUNCH_CHECK();
     return 0;
