@@ -693,10 +693,12 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     }
     // one workgroup per CU: eight waves on the same 8 x 32 tile (two pixel groups per wave) keep two waves per SIMD
     static const bool no_nw8 = getenv("REFVSR_CONV_NO_NW8") != nullptr;             // A/B knob, read once
-    // ... and eight waves (two pixel groups each) on every other 8 x 32 fp16 tile as well: 2 workgroups x 8 waves = 4 waves per
-    // SIMD instead of 3 x 4 = 3 (same box: 156.7 -> 159.3 frames/s on RefVSR_small; forcing <= 80 VGPRs for 6 waves spills)
-    const bool nw8 = tiles == 4 && !f32 && !a.gather && !no_nw8;
-    (void)one_wg;
+    // ... and eight waves (two pixel groups each) on the other 8 x 32 fp16 tiles as well, unless the map is large: 2 workgroups x
+    // 8 waves = 4 waves per SIMD instead of 3 x 4 = 3 hides more latency (24->24 at 270p 9.7 -> 9.2 us, at 540p 24.3 -> 23.0 us,
+    // same box 156.7 -> 159.3 frames/s on RefVSR_small); at 1080p (4080 tiles, 8 per workgroup) the better weight-fragment
+    // reuse of four pixel groups per wave wins (75.5 vs 78.5 us).  (Forcing <= 80 VGPRs for 6 waves per SIMD spills.)
+    const int n_tiles8 = rv_cdiv(d->w_out, CONV_TW) * rv_cdiv(d->h_out, 8);
+    const bool nw8 = tiles == 4 && !f32 && !a.gather && !no_nw8 && (one_wg || n_tiles8 <= 2048);
     static const bool no_prefetch = getenv("REFVSR_CONV_NO_PREFETCH") != nullptr;   // A/B knob, read once
     a.prefetch = no_prefetch ? 0 : 1;
     a.tiles_x = rv_cdiv(d->w_out, CONV_TW);

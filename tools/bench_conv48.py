@@ -33,7 +33,10 @@ def main():
     cases = [('LR270 48->48', 48, [48], 270, 480), ('LR270 48+48->48', 48, [48, 48], 270, 480),
              ('2x540 48->48', 48, [48], 540, 960), ('2x540 48+48->48', 48, [48, 48], 540, 960),
              ('LR1080 48->48', 48, [48], 1080, 1920), ('2x2160 48+48->48', 48, [48, 48], 2160, 3840),
-             ('LR270 64->64', 64, [64], 270, 480)]
+             ('LR270 64->64', 64, [64], 270, 480),
+             ('S LR270 24->24', 24, [24], 270, 480), ('S LR270 24+24->24', 24, [24, 24], 270, 480),
+             ('S 2x540 24->24', 24, [24], 540, 960), ('S 2x540 24+24->24', 24, [24, 24], 540, 960),
+             ('S HR1080 24->24', 24, [24], 1080, 1920), ('S LR135 24->24', 24, [24], 135, 240)]
     only = os.environ.get('CONV48_ONLY')
     for name, co, cins, h, w in cases:
         if only and only not in name:
