@@ -90,6 +90,12 @@ int refvsr_resblock_mfma(const void* src, int c, int h, int w, const void* w1, c
  * the intermediate map overwrites the input tile): two workgroups per CU, so one's epilogue runs under the other's
  * MFMAs.  Bit-identical to refvsr_resblock_mfma.  Slopes must lie in [0, 1]. */
 int refvsr_resblock_lean_fits(int c);
+/* n fused blocks behind one call (n launches, intermediates ping-pong between scratch0 / scratch1: each [h][w][c] fp16,
+ * scratch0 needed for n >= 2, scratch1 for n >= 3; src, scratch*, out pairwise distinct).  w1 / b1 / w2 / b2: host arrays of
+ * n device pointers.  Same results as n calls of refvsr_resblock_lean; saves n - 1 FFI crossings and n - 2 allocations. */
+int refvsr_resblock_chain(const void* src, int c, int h, int w, int n, const void* const* w1, const float* const* b1,
+                          const void* const* w2, const float* const* b2, int ksteps, float act_slope, float post_slope,
+                          void* scratch0, void* scratch1, void* out, void* stream);
 /* Tuning knob: waves per workgroup of the lean kernel, 8 (default: half the tiles per wave, <= 128 VGPRs, four waves per
  * SIMD) or 4.  Results do not depend on it. */
 int refvsr_set_resblock_waves(int waves);

@@ -379,3 +379,26 @@ extern "C" int refvsr_resblock_lean(const void* src, int c, int h, int w, const 
     refvsr_set_error("resblock_lean: no kernel for MT=%d wide=%d waves=%d", MT, (int)wide, g_lean_waves);
     return 1;
 }
+
+// A run of n fused blocks x <- post(x + conv2(act(conv1 x))) behind ONE call: n launches of the kernel above on the caller's
+// stream, intermediate maps ping-ponging between two scratch buffers (the blocks cannot run in place: neighbouring tiles read
+// the input halo).  Same results as n calls of refvsr_resblock_lean; what it saves is the host: one FFI crossing and two
+// allocations instead of n of each (156 of the ~330 launches of a RefVSR_small frame are fused blocks).
+extern "C" int refvsr_resblock_chain(const void* src, int c, int h, int w, int n, const void* const* w1,
+                                     const float* const* b1, const void* const* w2, const float* const* b2, int ksteps,
+                                     float act_slope, float post_slope, void* scratch0, void* scratch1, void* out,
+                                     void* stream) {
+    RV_CHECK(n >= 1 && w1 && b1 && w2 && b2 && out, "resblock_chain: bad args");
+    RV_CHECK(n == 1 || scratch0, "resblock_chain: n >= 2 needs scratch0");
+    RV_CHECK(n <= 2 || scratch1, "resblock_chain: n >= 3 needs scratch1");
+    RV_CHECK(src != out && scratch0 != out && scratch1 != out && (n < 2 || scratch0 != src) && (n < 3 || scratch1 != src) &&
+             (n < 3 || scratch0 != scratch1), "resblock_chain: buffers must be distinct");
+    const void* cur = src;
+    for (int i = 0; i < n; ++i) {
+        void* dst = (i == n - 1) ? out : ((i & 1) ? scratch1 : scratch0);
+        if (refvsr_resblock_lean(cur, c, h, w, w1[i], b1[i], w2[i], b2[i], ksteps, act_slope, post_slope, dst, stream)) return 1;
+        cur = dst;
+    }
+    return 0;
+}
+

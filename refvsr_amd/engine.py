@@ -158,6 +158,7 @@ class Engine(object):
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
         self.match_margin = float(getattr(config, 'match_exact_margin', ops.MATCH_EXACT_MARGIN))
+        self.chain_calls = bool(getattr(config, 'chain_calls', os.environ.get('REFVSR_NO_CHAIN_CALLS') is None))
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
@@ -256,6 +257,14 @@ class Engine(object):
         One launch per block (fused kernel) or two launches per block (fuse_resblocks off / unsupported channel count).
         (A kernel chaining TWO blocks per launch with halo recomputation was built in round 1 and measured in round 2:
         29.3 us vs 2 x 14.7 us on the LR maps, slower on the 2x maps and 4 % slower end to end -- removed.)"""
+        if self.fuse_resblocks and self.chain_calls and ops.resblock_chain_ok(x.shape[2]):
+            # one library call per run (same launches, same results): 156 of the ~330 launches of a frame
+            chains = self.W.__dict__.setdefault('_chains', {})      # lives and dies with the packed weights it points into
+            key = tuple(id(c1) for c1, _ in pairs)
+            ch = chains.get(key)
+            if ch is None:
+                ch = chains[key] = ops.ResblockChain(pairs)
+            return ops.resblock_chain(ch, x, act)
         for c1, c2 in pairs:
             if self.fuse_resblocks:
                 x = ops.resblock(c1, c2, x, act=act)

@@ -52,6 +52,7 @@ SIGNATURES = {
     'refvsr_resblock_lean_fits': [_I],
     'refvsr_set_resblock_waves': [_I],
     'refvsr_resblock_lean': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
+    'refvsr_resblock_chain': [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     'refvsr_pack_nhwc16': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_pack_nhwc32': [_P, _I, _I, _I, _P, _I, _P],

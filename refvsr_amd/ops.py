@@ -164,6 +164,14 @@ def resblock_fits(c):
     return bool(hip.lib().refvsr_resblock_fits(int(c)))
 
 
+def _apply_resblock_knobs():
+    global _WAVES_SET
+    if not _WAVES_SET:                     # A/B knob of the lean kernel's workgroup shape (default 8 waves)
+        _WAVES_SET = True
+        if os.environ.get('REFVSR_RESBLOCK_WAVES'):
+            hip.check(hip.lib().refvsr_set_resblock_waves(int(os.environ['REFVSR_RESBLOCK_WAVES'])), 'set_resblock_waves')
+
+
 def resblock(cw1, cw2, x, act, post=1.0, kernel=None):
     """refvsr_resblock_lean / refvsr_resblock_mfma: post(x + conv2(act(conv1(x)))) in one launch (3x3, C->C)."""
     _nhwc(x)
@@ -172,11 +180,7 @@ def resblock(cw1, cw2, x, act, post=1.0, kernel=None):
     assert not cw1.f32 and not cw1.shuffle and cw1.wpack.shape[0] == 1
     out = torch.empty_like(x)
     kernel = kernel or RESBLOCK_KERNEL
-    global _WAVES_SET
-    if not _WAVES_SET:                     # A/B knob of the lean kernel's workgroup shape (default 8 waves)
-        _WAVES_SET = True
-        if os.environ.get('REFVSR_RESBLOCK_WAVES'):
-            hip.check(hip.lib().refvsr_set_resblock_waves(int(os.environ['REFVSR_RESBLOCK_WAVES'])), 'set_resblock_waves')
+    _apply_resblock_knobs()
     if kernel == 'lean' and hip.lib().refvsr_resblock_lean_fits(c):
         hip.check(hip.lib().refvsr_resblock_lean(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
                                                  _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_lean')
@@ -184,6 +188,41 @@ def resblock(cw1, cw2, x, act, post=1.0, kernel=None):
         hip.check(hip.lib().refvsr_resblock_mfma(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
                                                  _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_mfma')
     return out
+
+
+class ResblockChain(object):
+    """Pointer tables of a run of fused blocks (built once per run of packed weights, reused by every call)."""
+
+    def __init__(self, pairs):
+        self.pairs = list(pairs)
+        n = self.n = len(self.pairs)
+        c1 = self.pairs[0][0]
+        self.c, self.ksteps = c1.cout, c1.ksteps
+        for a, b in self.pairs:
+            assert a.cpads == [self.c] and b.cpads == [self.c] and a.cout == self.c and b.cout == self.c and a.ksize == 3
+            assert not a.f32 and not a.shuffle and a.wpack.shape[0] == 1 and a.ksteps == self.ksteps
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self.w1, self.b1 = arr([a.wpack for a, _ in self.pairs]), arr([a.bias for a, _ in self.pairs])
+        self.w2, self.b2 = arr([b.wpack for _, b in self.pairs]), arr([b.bias for _, b in self.pairs])
+
+
+def resblock_chain(chain, x, act, post=1.0):
+    """refvsr_resblock_chain: chain.n fused blocks behind ONE library call (same launches and results as chain.n calls of
+    resblock(); two scratch maps instead of n - 1 intermediates).  Lean kernel only (resblock_fits_lean)."""
+    _nhwc(x)
+    h, w, c = x.shape
+    assert c == chain.c
+    out = torch.empty_like(x)
+    s0 = torch.empty_like(x) if chain.n >= 2 else None
+    s1 = torch.empty_like(x) if chain.n >= 3 else None
+    hip.check(hip.lib().refvsr_resblock_chain(_ptr(x), c, h, w, chain.n, chain.w1, chain.b1, chain.w2, chain.b2, chain.ksteps,
+                                              act, post, _ptr(s0), _ptr(s1), _ptr(out), _stream()), 'resblock_chain')
+    return out
+
+
+def resblock_chain_ok(c):
+    _apply_resblock_knobs()
+    return RESBLOCK_KERNEL == 'lean' and bool(hip.lib().refvsr_resblock_lean_fits(int(c)))
 
 
 def conv_direct(x, w, b, stride=1, pad=None, act=1.0, nhwc16_out=False):

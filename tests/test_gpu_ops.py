@@ -239,6 +239,36 @@ def test_resblock_fused(dev, C, h, w, act):
                                ops.resblock(c1, c2, xin, act=act, post=post, kernel='wide')), 'lean != wide'
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 8])
+def test_resblock_chain_call(dev, n):
+    """refvsr_resblock_chain (n fused blocks behind one library call, scratch ping-pong) == n calls of the fused block, bit for
+    bit; the input map is left untouched; bad buffer aliasing is refused by the library."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    C, h, w = 24, 37, 70
+    g = torch.Generator().manual_seed(n)
+    pairs = []
+    for _ in range(n):
+        ws = [torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5 for _ in range(2)]
+        bs = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+        pairs.append(tuple(ops.ConvWeights(pack_conv(ws[i], bs[i], [C]), dev) for i in range(2)))
+    x = nhwc(torch.randn(C, h, w, generator=g), dev)
+    x0 = x.clone()
+    want = x
+    for c1, c2 in pairs:
+        want = ops.resblock(c1, c2, want, act=0.2, kernel='lean')
+    assert ops.resblock_chain_ok(C)
+    got = ops.resblock_chain(ops.ResblockChain(pairs), x, 0.2)
+    assert torch.equal(got, want) and torch.equal(x, x0)
+    if n >= 2:
+        ch = ops.ResblockChain(pairs)
+        lib = ops.hip.lib()
+        out, s1 = torch.empty_like(x), torch.empty_like(x)
+        rc = lib.refvsr_resblock_chain(x.data_ptr(), C, h, w, n, ch.w1, ch.b1, ch.w2, ch.b2, ch.ksteps, 0.2, 1.0,
+                                       x.data_ptr(), s1.data_ptr(), out.data_ptr(), None)  # scratch0 aliases the input
+        assert rc != 0 and b'distinct' in lib.refvsr_last_error()
+
+
 def test_conv_mfma_f32_mode(dev):
     """Exact-fp32 MFMA mode (v_mfma_f32_16x16x4_f32) used for the VGG feature extractor."""
     from refvsr_amd import ops
