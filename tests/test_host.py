@@ -223,10 +223,22 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
     class E(object):
         _block_chain = engine.Engine._block_chain
         fuse_resblocks = True
+        chain_calls = False                      # per-block launches from Python
     e = E()
     for n in (1, 2, 5, 24):
         pairs = [('a%d' % i, 'b%d' % i) for i in range(n)]
         assert e._block_chain(X((270, 480, 24)), pairs, 0.2).hist == tuple((a, b, 0.2) for a, b in pairs)
+    # chain_calls: the whole run goes to ONE library call, with a pointer table cached on the packed weights
+    calls = []
+    monkeypatch.setattr(ops, 'resblock_chain_ok', lambda c: True)
+    monkeypatch.setattr(ops, 'ResblockChain', lambda pairs: ('chain', tuple(pairs)))
+    monkeypatch.setattr(ops, 'resblock_chain', lambda ch, x, act, post=1.0: calls.append((ch, act)) or X(x.shape, x.hist + (ch,)))
+    e.chain_calls = True
+    e.W = type('W', (), {})()
+    out = e._block_chain(X((270, 480, 24)), pairs, 0.2)
+    out2 = e._block_chain(X((270, 480, 24)), pairs, 0.2)
+    assert out.hist == (('chain', tuple(pairs)),) and out2.hist == out.hist and len(calls) == 2 and len(e.W._chains) == 1
+    e.chain_calls = False
     e.fuse_resblocks = False
     want = tuple(x for a, b in pairs for x in ((a, 0.0, False), (b, 1.0, True)))
     assert e._block_chain(X((270, 480, 24)), pairs, 0.0).hist == want
