@@ -55,6 +55,7 @@ class Weights(object):
         self.nb = config.num_blocks
         self.conv = {}
         self.raw = {}
+        self.chains = {}            # runs of fused blocks -> ops.ResblockChain pointer tables (Engine._block_chain)
         C = self.C
         g = lambda n: (sd['Network.' + n + '.weight'], sd['Network.' + n + '.bias'])
 
@@ -259,7 +260,7 @@ class Engine(object):
         29.3 us vs 2 x 14.7 us on the LR maps, slower on the 2x maps and 4 % slower end to end -- removed.)"""
         if self.fuse_resblocks and self.chain_calls and ops.resblock_chain_ok(x.shape[2]):
             # one library call per run (same launches, same results): 156 of the ~330 launches of a frame
-            chains = self.W.__dict__.setdefault('_chains', {})      # lives and dies with the packed weights it points into
+            chains = self.W.chains                                  # lives and dies with the packed weights it points into
             key = tuple(id(c1) for c1, _ in pairs)
             ch = chains.get(key)
             if ch is None:

@@ -234,10 +234,10 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
     monkeypatch.setattr(ops, 'ResblockChain', lambda pairs: ('chain', tuple(pairs)))
     monkeypatch.setattr(ops, 'resblock_chain', lambda ch, x, act, post=1.0: calls.append((ch, act)) or X(x.shape, x.hist + (ch,)))
     e.chain_calls = True
-    e.W = type('W', (), {})()
+    e.W = type('W', (), {'chains': {}})()
     out = e._block_chain(X((270, 480, 24)), pairs, 0.2)
     out2 = e._block_chain(X((270, 480, 24)), pairs, 0.2)
-    assert out.hist == (('chain', tuple(pairs)),) and out2.hist == out.hist and len(calls) == 2 and len(e.W._chains) == 1
+    assert out.hist == (('chain', tuple(pairs)),) and out2.hist == out.hist and len(calls) == 2 and len(e.W.chains) == 1
     e.chain_calls = False
     e.fuse_resblocks = False
     want = tuple(x for a, b in pairs for x in ((a, 0.0, False), (b, 1.0, True)))
