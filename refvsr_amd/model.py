@@ -146,7 +146,7 @@ class Network(nn.Module):
         outs = collections.OrderedDict()
         if is_log:                                             # RefVSR.py:162-164,219-221,262-263,301-316
             outs['vis'] = collections.OrderedDict((k, torch.stack([d[k] for d in dbg_all], 0)) for k in dbg_all[0])
-        outs['result'] = torch.stack(results, 0)
+        outs['result'] = results[0].unsqueeze(0) if n == 1 else torch.stack(results, 0)     # (n == 1: a view, no 25 MB copy)
         if want_vis:
             ev = collections.OrderedDict()
             for k in vis_all[0]:
@@ -174,7 +174,7 @@ class Network(nn.Module):
         outs = collections.OrderedDict()
         if is_log:
             outs['vis'] = collections.OrderedDict()
-        outs['result'] = torch.stack([r[0] for r in res], 0)
+        outs['result'] = res[0][0].unsqueeze(0) if len(res) == 1 else torch.stack([r[0] for r in res], 0)
         if want_vis:
             ev = collections.OrderedDict()
             for k in res[0][1]:

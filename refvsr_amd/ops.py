@@ -386,9 +386,14 @@ def match_patches(feat, row_pad, want_lo=False):
     _planar(feat, 16)
     h, w = feat.shape[1:]
     n = h * w
-    rows = torch.zeros((_round_up(n, row_pad), hip.MATCH_KP), dtype=torch.float16, device=feat.device)
+    # the kernel writes every slot of the n valid rows (incl. the zero pad of each row); only the pad ROWS need clearing
+    rows = torch.empty((_round_up(n, row_pad), hip.MATCH_KP), dtype=torch.float16, device=feat.device)
     inv = torch.empty((n,), dtype=torch.float32, device=feat.device)
-    lo = torch.zeros_like(rows) if want_lo else None
+    lo = torch.empty_like(rows) if want_lo else None
+    if rows.shape[0] > n:
+        rows[n:].zero_()
+        if lo is not None:
+            lo[n:].zero_()
     hip.check(hip.lib().refvsr_match_patches(_ptr(feat), h, w, _ptr(rows), _ptr(inv), _ptr(lo), _stream()), 'match_patches')
     return (rows, inv, lo) if want_lo else (rows, inv)
 
