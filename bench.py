@@ -390,7 +390,7 @@ def main():
                        'call_surface': ('extended: frame_ids= + set_pipelined(True)' if pipelined else
                                         'extended: frame_ids=' if use_ids else 'reference call surface'),
                        'precision': 'fp16 HWC feature maps + fp16 hi+lo MFMA weights, fp32 accumulate; fp32 matching features / flows / '
-                                    'output; exact fp32 arg-max'},
+                                    'output; arg-max decided at fp32 accuracy (fp16 GEMM top-2 + fp32 re-rank + split-fp16 search of ambiguous columns)'},
             'dropin_surface': dropin,
         }
         # ---- roofline of the dominant kernel (match_top2) from the events recorded in the timed region

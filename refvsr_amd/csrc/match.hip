@@ -7,7 +7,7 @@
 // The reference materialises corr ([32400 x 129600] fp32 = 16.8 GB at 270p) with one GEMM and then
 // reduces it.  Here the GEMM and the column reduction are fused: a workgroup owns 512 LR columns,
 // keeps their fp16 operand fragments in registers for its whole lifetime, streams the reference
-// rows through LDS in 128-row chunks (register-prefetched, double buffered) and keeps a running
+// rows through LDS in 256-row stages (register-prefetched, double buffered) and keeps a running
 // top-2 per column in registers -- corr never leaves the accumulators.
 //
 //  * v_mfma_f32_32x32x16_f16: K = 144 = 9 steps exactly (no K padding).  The 32x32 accumulator
@@ -15,7 +15,8 @@
 //  * LDS rows are 304 bytes (K padded to 152 halfs on the host side of the ABI): 19 sixteen-byte
 //    slots per row, odd => the 16 lanes of a ds_read_b128 group hit 16 distinct slots.
 //  * top-2 (not top-1) is kept so that the fp16 operand rounding cannot change the winner: the
-//    candidates are re-ranked with an exact fp32 dot product by match_refine.
+//    candidates are re-ranked with an exact fp32 dot product by match_refine, and the columns whose
+//    margin is inside the fp16 error are searched exhaustively at fp32 accuracy (match_exact).
 #include <stdlib.h>
 
 #include "match_common.h"

@@ -370,7 +370,7 @@ class Engine(object):
         if self.kernel_events is not None:
             e1.record()
             self.kernel_events.append((e0, e1))
-        # exact fp32 re-rank of the top-2 + exhaustive fp32 search of the columns the fp16 GEMM cannot decide
+        # exact fp32 re-rank of the top-2 + exhaustive fp32-grade (split-fp16) search of the columns the fp16 GEMM cannot decide
         conf, idx, _ = ops.match_refine(lr_f, ref_f, inv_lr, inv_ref, cand, cand_val, self.match_margin, (lr_rows, lr_lo),
                                         (ref_rows, ref_lo))
         conf = conf.view(1, lr_f.shape[1], lr_f.shape[2])
