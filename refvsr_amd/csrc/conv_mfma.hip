@@ -739,6 +739,12 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         RV_CONV_CASE8(1) RV_CONV_CASE8(2) RV_CONV_CASE8(3)
 #undef RV_CONV_CASE8
     }
+    // the exact-fp32 convs (VGG head of the matching) on 4 x 32 tiles: eight waves with one pixel group each (fp32 MFMAs are
+    // slow enough that the lost fragment reuse costs nothing: 64->64 at 270p 115 -> 105 us)
+    if (!no_nw8 && f32 && tiles == 2 && !a.gather && (MT == 1 || MT == 2)) {
+        if (MT == 1) return resident ? launch_conv<1, 1, true, false, true, 0, 8>(a, nz, lds, st) : launch_conv<1, 1, true, false, false, 0, 8>(a, nz, lds, st);
+        return resident ? launch_conv<2, 1, true, false, true, 0, 8>(a, nz, lds, st) : launch_conv<2, 1, true, false, false, 0, 8>(a, nz, lds, st);
+    }
     RV_CONV_CASE(1, 2) RV_CONV_CASE(1, 4)
     RV_CONV_CASE(2, 2) RV_CONV_CASE(2, 4)
     RV_CONV_CASE(3, 2) RV_CONV_CASE(3, 4)

@@ -30,6 +30,7 @@ def timeit(fn, iters=30):
 
 def main():
     g = torch.Generator().manual_seed(1)
+    f32_cases = [('vgg f32 3->64', 64, [3], 270, 480), ('vgg f32 64->64', 64, [64], 270, 480), ('vgg f32 64->64 ref', 64, [64], 135, 240)]
     cases = [('LR270 48->48', 48, [48], 270, 480), ('LR270 48+48->48', 48, [48, 48], 270, 480),
              ('2x540 48->48', 48, [48], 540, 960), ('2x540 48+48->48', 48, [48, 48], 540, 960),
              ('LR1080 48->48', 48, [48], 1080, 1920), ('2x2160 48+48->48', 48, [48, 48], 2160, 3840),
@@ -38,6 +39,15 @@ def main():
              ('S 2x540 24->24', 24, [24], 540, 960), ('S 2x540 24+24->24', 24, [24, 24], 540, 960),
              ('S HR1080 24->24', 24, [24], 1080, 1920), ('S LR135 24->24', 24, [24], 135, 240)]
     only = os.environ.get('CONV48_ONLY')
+    for name, co, cins, h, w in f32_cases:
+        if only and only not in name:
+            continue
+        cin = sum(cins)
+        wt = torch.randn(co, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        cw = ops.ConvWeights(pack_conv(wt, torch.zeros(co), cins, False, f32=True), dev)
+        x = ops.pack_nhwc32(torch.randn(cin, h, w, generator=g).to(dev))
+        us = timeit(lambda: ops.conv(cw, x, act=0.0), iters=int(os.environ.get('CONV48_ITERS', '30')))
+        print('conv %-20s %9.1f us  %6.1f TFLOP/s (fp32 MFMA peak 157)' % (name, us, 2.0 * h * w * co * cin * 9 / us / 1e6), flush=True)
     for name, co, cins, h, w in cases:
         if only and only not in name:
             continue
