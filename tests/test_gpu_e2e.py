@@ -305,6 +305,24 @@ def test_batch_and_api_contract(dev):
     assert not torch.equal(single(x[:1], r[:1], True)['result'], outs['result'][:1])
 
 
+def test_trainer_wrappers_dataparallel_and_autocast(dev):
+    """The reference's eval call site wraps the module in nn.DataParallel and runs it under amp autocast
+    (trainers/trainer.py:67,237-241): same stream, bit for bit, as the bare module called directly."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 4, 3
+    lr, rf, _ = make_clip(nfr, 32, 48, seed=23)
+    lr, rf = lr.to(dev), rf.to(dev)
+    bare, _, _ = make_net('config_RefVSR_small_L1', t, dev, save_sample=False)
+    wrapped, _, _ = make_net('config_RefVSR_small_L1', t, dev, save_sample=False)
+    dp = torch.nn.DataParallel(wrapped, device_ids=[dev.index or 0])
+    for f in range(nfr):
+        w = window_indices(f, nfr, t)
+        want = bare(lr[w][None], rf[w][None], f == 0)['result']
+        with torch.autocast('cuda', dtype=torch.float16):
+            got = dp(lr[w][None], rf[w][None], f == 0, is_log=False, is_train=False)['result']
+        assert got.dtype == torch.float32 and torch.equal(got, want), 'frame %d differs under DataParallel + autocast' % f
+
+
 def test_static_input_buffer_refilled_in_place(dev):
     """A caller that keeps ONE pair of input buffers and refills them in place for every window (a common serving
     pattern) must get the same stream as a caller that passes fresh tensors: the window cache owns its frames, it must
