@@ -60,16 +60,22 @@ static inline int rv_num_cus() {
 // workgroup has floor or ceil(n/g) tiles (a strided walk inside fixed eighths of the frame left single workgroups with
 // twice the tiles of the others whenever g ~ n) and the tiles in flight on one XCD are neighbours sharing halo rows in
 // that XCD's L2.
-__device__ __forceinline__ void rv_tile_range(const int n_tiles, int& t_begin, int& t_end) {
-    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+// (g = gridDim.x, passed in the kernel's own argument struct: read from the hidden dispatch arguments it costs a
+// separate scalar-load round trip)
+__device__ __forceinline__ void rv_tile_range(const int n_tiles, const int g, int& t_begin, int& t_end) {
+    const int b = (int)blockIdx.x;
     int rank = b;
     if (g >= 8) {
         const int xcd = b & 7;
         rank = b >> 3;
         for (int y = 0; y < xcd; ++y) rank += (g - y + 7) >> 3;
     }
-    t_begin = (int)(((long long)rank * n_tiles) / g);
-    t_end = (int)(((long long)(rank + 1) * n_tiles) / g);
+    // 32-bit unsigned divisions (~30 instructions each; the 64-bit ones hipcc expands to several hundred instructions
+    // PER WAVE, at the head of every persistent launch: an s_memtime probe put ~4 000 cycles between kernel entry and the
+    // first x-tile load).  rank * n_tiles < 2^31: at most 1 024 workgroups x 2 M tiles -- checked by the callers' hosts.
+    const unsigned un = (unsigned)n_tiles, ug = (unsigned)g;
+    t_begin = (int)(((unsigned)rank * un) / ug);
+    t_end = (int)(((unsigned)(rank + 1) * un) / ug);
 }
 
 // ReflectionPad2d index (no edge repeat): -1 -> 1, n -> n-2.  Valid for -n < i < 2n-1.

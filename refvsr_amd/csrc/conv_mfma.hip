@@ -63,6 +63,7 @@ struct ConvArgs {
     int gather;                      // 1: no LDS input tile, B fragments gathered from global memory
     int tiles_x, n_xy;               // pixel tiles per row / per frame
     int prefetch;                    // resident kernels: 1 = next tile prefetched into registers during the K loop
+    int grid;                        // gridDim.x (resident kernels: rv_tile_range)
 };
 
 // EPI = 0: general epilogue (every output mode, fp16 / fp32 maps).  EPI = 1: the fp16 HWC store with optional alpha
@@ -85,6 +86,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
     unsigned char* wl = smem + p.tab_bytes;
     unsigned char* tile = wl + p.wl_bytes;           // [table][weights: resident set | one chunk][input tile]
 
+    // the kernel arguments, fetched by ONE batch of scalar loads (hipcc otherwise loads the fields of the by-value struct where
+    // they are first used: a chain of dependent s_load / s_waitcnt round trips at the head of every launch)
+    asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.wpack), "s"(p.bias), "s"(p.out), "s"(p.mul), "s"(p.res), "s"(p.c0),
+                 "s"(p.ncg0), "s"(p.ncg), "s"(p.ps), "s"(p.pixb0), "s"(p.pixb1), "s"(p.h_in), "s"(p.w_in), "s"(p.h_out),
+                 "s"(p.w_out), "s"(p.ks), "s"(p.stride), "s"(p.pad), "s"(p.LH), "s"(p.LW), "s"(p.G), "s"(p.S), "s"(p.inv_ncg),
+                 "s"(p.cout), "s"(p.tab_bytes), "s"(p.wl_bytes), "s"(p.tiles_x), "s"(p.n_xy), "s"(p.grid));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
             }
         }
         int tl, k_hi;                                              // this workgroup's tiles (common.h:rv_tile_range)
-        rv_tile_range(p.n_xy, tl, k_hi);
+        rv_tile_range(p.n_xy, p.grid, tl, k_hi);
         constexpr int k_step = 1;
         // input-tile chunk k of this thread: 16 bytes = (row r, column c, channel group cg) of the LH x LW tile.  Everything
         // that does not depend on the tile origin is computed ONCE per thread: xq = r | c << 5 | (cg within its source) << 12 |
@@ -576,6 +583,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;
     }
+    a.grid = gx;
     hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;

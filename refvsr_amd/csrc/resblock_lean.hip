@@ -41,6 +41,9 @@ struct ResLeanArgs {
     float act_slope, post_slope;
     int tab_bytes, w_bytes;               // LDS carve
     int tiles_x, n_tiles;
+    int grid;                             // gridDim.x
+    unsigned long long* probe;           // debug: per-workgroup s_memtime stamps (refvsr_set_probe), normally null
+    int probe_iter;                      // which tile iteration of the workgroup is stamped
 };
 
 // Software-pipelined K loop (two fragment sets, unrolled by two) -- the same walk as conv_mfma.hip / resblock_mfma.hip.
@@ -112,6 +115,32 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
     const int q = lane >> 4;
     const int lp = rv_pix16(lane & 15);       // pixel (of a 16-pixel MFMA tile) held by this lane's column
     const int psb = p.ps * 16;
+    // every kernel argument the prologue needs, fetched by ONE batch of scalar loads: hipcc otherwise loads the fields of the
+    // by-value argument struct where they are first used -- six dependent s_load / s_waitcnt round trips before the first
+    // x-tile load could leave (s_memtime probe + ISA)
+    asm volatile("" :: "s"(p.src), "s"(p.out), "s"(p.w1), "s"(p.w2), "s"(p.b1), "s"(p.b2), "s"(p.c), "s"(p.ncg), "s"(p.ps),
+                 "s"(p.h), "s"(p.w), "s"(p.G), "s"(p.S), "s"(p.inv_ncg), "s"(p.tab_bytes), "s"(p.w_bytes), "s"(p.tiles_x),
+                 "s"(p.n_tiles), "s"(p.grid), "s"(p.probe), "s"(p.probe_iter));
+#define RL_STAMP(i) do { if (p.probe && tid == 0) p.probe[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    RL_STAMP(0);
+    if (p.probe && tid == 0) p.probe[blockIdx.x * 12 + 8] = __builtin_amdgcn_s_memrealtime();
+
+    // Start-up: both weight sets go global -> LDS with global_load_lds_dwordx4 (1 KiB per wave instruction, no staging
+    // registers, no ds_write pass: the LDS image of a packed weight set IS its global image), issued first; the x tile and the
+    // biases follow through registers (they need masking / re-layout).  Everything lands behind ONE barrier; the weights then
+    // stay resident for the workgroup's whole life.  An s_memtime probe showed the prologue to be instruction-bound (~300
+    // instructions per wave x 16 waves per CU), not latency-bound: the register-staged copy alone was ~80 of them.
+    {
+        const int nch = p.S * MT * 2;                             // 1 KiB chunks per weight set
+        for (int c = wave; c < 2 * nch; c += NWV) {
+            const bool second = c >= nch;
+            const int cc = second ? c - nch : c;
+            const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(second ? p.w2 : p.w1) + cc * 1024 + lane * 16;
+            unsigned char* ldst = (second ? wl2 : wl1) + cc * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                             (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+        }
+    }
 
     for (int g = tid; g < p.S * 4; g += NT) {                     // K order: common.h:rv_kslot
         int o1, o2, slot;
@@ -168,32 +197,20 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
     };
 
     int tl, k_hi;                                                 // this workgroup's tiles (common.h:rv_tile_range)
-    rv_tile_range(p.n_tiles, tl, k_hi);
+    rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
     constexpr int k_step = 1;
-    // Start-up: every global load of the prologue (w1, first x tile, w2, biases) is issued before the first LDS store, so
-    // the workgroup pays ONE memory round trip; both weight sets then stay resident for the workgroup's whole life.
-    // (named registers, not arrays: hipcc keeps conditionally stored register ARRAYS in scratch memory)
-    constexpr int NW = ((MT == 1 ? 640 : 2304) + NT - 1) / NT;   // uint4 per thread and weight set (C <= 16: 640, C = 24 / 32: 1792 / 2304)
-    const int n16w = p.S * MT * 2 * 64;
-    uint4 wa0, wa1, wa2, wa3, wa4, wa5, wa6, wa7, wa8, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8;
-#define RL_W_ALL(OP, P) OP(P, 0) OP(P, 1) OP(P, 2) OP(P, 3) OP(P, 4) OP(P, 5) OP(P, 6) OP(P, 7) OP(P, 8)
-#define RL_W_LOAD(P, k) if constexpr (NW > k) P##k = src_[min(tid + k * NT, n16w - 1)];
-#define RL_W_STORE(P, k) if constexpr (NW > k) { if (tid + k * NT < n16w) dst_[tid + k * NT] = P##k; }
-    { const uint4* src_ = p.w1; RL_W_ALL(RL_W_LOAD, wa) }
     if (tl < k_hi) x_fetch(tl);
-    { const uint4* src_ = p.w2; RL_W_ALL(RL_W_LOAD, wb) }
     // biases: 2 x 32 floats parked in LDS behind the tables (in registers they cost 16 VGPRs for the kernel's whole life)
     float* bl = reinterpret_cast<float*>(tab2 + p.S * 4);
-    float bias_v = 0.f;
-    if (tid < 64) bias_v = (tid & 31) < p.c ? ((tid < 32) ? p.b1[tid] : p.b2[tid - 32]) : 0.f;
+    // (unconditional clamped loads + select: a load under a lane condition is waited for on the spot -- together with
+    //  everything else in flight, i.e. the weight and x-tile loads above)
+    const int bi_ = min(tid & 31, p.c - 1);
+    const float b1v_ = p.b1[bi_], b2v_ = p.b2[bi_];
+    const float bias_v = (tid & 31) < p.c ? ((tid & 32) ? b2v_ : b1v_) : 0.f;
+    RL_STAMP(1);
     asm volatile("" ::: "memory");                  // loads above, LDS stores below
     if (tid < 64) bl[tid] = bias_v;
-    { uint4* dst_ = reinterpret_cast<uint4*>(wl1); RL_W_ALL(RL_W_STORE, wa) }
     if (tl < k_hi) x_park();
-    { uint4* dst_ = reinterpret_cast<uint4*>(wl2); RL_W_ALL(RL_W_STORE, wb) }
-#undef RL_W_ALL
-#undef RL_W_LOAD
-#undef RL_W_STORE
     // per-lane pixel bookkeeping, independent of the tile origin
     int pb1[RL_T1W], pb2[RL_T2W];
 #pragma unroll
@@ -208,8 +225,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
         pb2[t] = ((ti >> 1) * RL_IW + (ti & 1) * 16 + lp) * psb;
     }
     __syncthreads();                                // tables, weights, first tile
+    RL_STAMP(2);
 
-    for (; tl < k_hi; tl += k_step) {
+    for (int iter = 0; tl < k_hi; tl += k_step, ++iter) {
         const bool has_next = tl + k_step < k_hi;
         const int tyi = tl / p.tiles_x;
         const int ty0 = tyi * RL_TH, tx0 = (tl - tyi * p.tiles_x) * RL_TW;
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
 #pragma unroll
             for (int t = 0; t < RL_T1W; ++t) acc1[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         rl_kloop<MT, RL_T1W>(acc1, wl1, tab1 + q, xt, pb1, p.S, lane);
+        if (iter == p.probe_iter) RL_STAMP(3);
         // residual x of this lane's phase-2 outputs: the x tile is about to be overwritten by t
         f16x4 xres[MT][RL_T2W];
 #pragma unroll
@@ -259,7 +278,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
             }
         }
         if (has_next) x_fetch(tl + k_step);         // in flight during conv2
+        if (iter == p.probe_iter) RL_STAMP(4);
         __syncthreads();                            // B: t complete
+        if (iter == p.probe_iter) RL_STAMP(5);
 
         // ---------------- phase 2: out = post(x + conv2(t) + b2) ----------------------------------------------------
         f32x4 acc2[MT][RL_T2W];
@@ -268,6 +289,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
 #pragma unroll
             for (int t = 0; t < RL_T2W; ++t) acc2[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         rl_kloop<MT, RL_T2W>(acc2, wl2, tab2 + q, xt, pb2, p.S, lane);
+        if (iter == p.probe_iter) RL_STAMP(6);
         if (has_next) {
             __syncthreads();                        // C: every wave is done reading t
             x_park();
@@ -294,9 +316,18 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
                 *reinterpret_cast<f16x4*>(dst + co0) = o;
             }
         }
+        if (iter == p.probe_iter) RL_STAMP(7);
         if (has_next) __syncthreads();              // D: next x tile visible
     }
+    if (p.probe && tid == 0) {
+        p.probe[blockIdx.x * 12 + 9] = __builtin_amdgcn_s_memrealtime();
+        p.probe[blockIdx.x * 12 + 10] = __builtin_amdgcn_s_memtime();
+    }
+#undef RL_STAMP
 }
+
+extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
+extern int g_rb_probe_iter;
 
 static size_t rl_lds_bytes(int c) {
     const int ncg = c / 8, ps = ncg | 1;
@@ -320,7 +351,7 @@ extern "C" int refvsr_set_resblock_waves(int waves) {
 }
 
 template <int MT, bool WIDE, int NWV>
-static int launch_lean(const ResLeanArgs& a, size_t lds, hipStream_t st) {
+static int launch_lean(ResLeanArgs& a, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
@@ -340,6 +371,7 @@ static int launch_lean(const ResLeanArgs& a, size_t lds, hipStream_t st) {
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     const int gx = a.n_tiles < cap ? a.n_tiles : cap;
+    a.grid = gx;
     hipLaunchKernelGGL((resblock_lean_kernel<MT, WIDE, NWV>), dim3(gx), dim3(NWV * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
@@ -363,6 +395,7 @@ extern "C" int refvsr_resblock_lean(const void* src, int c, int h, int w, const 
     a.inv_ncg = 1.0f / (float)a.ncg;
     a.w1 = (const uint4*)w1; a.b1 = b1; a.w2 = (const uint4*)w2; a.b2 = b2;
     a.act_slope = act_slope; a.post_slope = post_slope;
+    a.probe = g_rb_probe; a.probe_iter = g_rb_probe_iter;
     const int MT = (c + 15) / 16;
     a.tab_bytes = (a.S * 4 * 2 * 4 + 256 + 15) / 16 * 16;         // two K-slot tables + 2 x 32 bias floats
     a.w_bytes = a.S * MT * 2 * 1024;

@@ -301,8 +301,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef RB_STAMP
 }
 
-static unsigned long long* g_rb_probe = nullptr;
-static int g_rb_probe_iter = 0;
+unsigned long long* g_rb_probe = nullptr;          // shared with resblock_lean.hip
+int g_rb_probe_iter = 0;
 extern "C" int refvsr_set_probe(void* buf, int iter) {
     g_rb_probe = (unsigned long long*)buf;
     g_rb_probe_iter = iter;

@@ -15,7 +15,7 @@ from refvsr_amd import hip, ops  # noqa: E402
 from refvsr_amd.packing import pack_conv  # noqa: E402
 
 dev = torch.device('cuda:0')
-STAGES = ['entry->loads issued', 'loads issued->landed (sync)', 'conv1 K loop', 'conv1 epilogue (+w2/x park)', 'barrier',
+STAGES = ['entry->loads issued', 'loads issued->landed (sync)', 'conv1 K loop', 'conv1 epilogue (t -> LDS)', 'barrier',
           'conv2 K loop', 'conv2 epilogue (stores issued)']
 
 
@@ -25,8 +25,8 @@ def main():
     w1 = torch.randn(Cc, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5
     c1 = ops.ConvWeights(pack_conv(w1, torch.zeros(Cc), [Cc]), dev)
     c2 = ops.ConvWeights(pack_conv(w1.flip(0), torch.zeros(Cc), [Cc]), dev)
-    probe = torch.zeros(256 * 12, dtype=torch.int64, device=dev)
-    for name, h, w, it in (('LR', 270, 480, 0), ('LR/2', 135, 240, 0), ('2x first tile', 540, 960, 0), ('2x 4th tile', 540, 960, 3), ('2x 7th tile', 540, 960, 6)):
+    probe = torch.zeros(512 * 12, dtype=torch.int64, device=dev)     # one slot set per workgroup (the lean kernel launches up to 512)
+    for name, h, w, it in (('LR', 270, 480, 0), ('LR/2', 135, 240, 0), ('2x first tile', 540, 960, 0), ('2x 4th tile', 540, 960, 3)):
         x = ops.pack_nhwc16(torch.randn(Cc, h, w, generator=g).to(dev))
         y = x
         for _ in range(5):
@@ -42,7 +42,7 @@ def main():
             y = ops.resblock(c1, c2, y, act=0.0)
             e1.record()
             torch.cuda.synchronize()
-            p = probe.view(256, 12).cpu()
+            p = probe.view(512, 12).cpu()
             p = p[(p[:, 0] > 0) & (p[:, 7] > 0)].double()
             reps.append((e0.elapsed_time(e1) * 1e3, p))
         hip.lib().refvsr_set_probe(None, 0)
