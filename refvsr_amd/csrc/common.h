@@ -9,6 +9,7 @@
 #include "../../include/refvsr_hip.h"
 
 typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

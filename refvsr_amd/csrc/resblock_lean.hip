@@ -19,6 +19,8 @@
 //           residual x values of this lane's outputs -> registers;  barrier;  t = act(acc1 + b1) (0 outside the
 //           frame = conv2's zero padding) -> LDS over the x tile;  barrier
 //   phase 2 out = post(x + conv2(t) + b2) on the 8 x 32 tile -> global (8-byte HWC channel vectors)
+#include <type_traits>
+
 #include "common.h"
 
 #define RL_TH 8
@@ -253,30 +255,41 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
             for (int m = 0; m < MT; ++m) xres[m][t] = *reinterpret_cast<const f16x4*>(xr_ + min(m * 16 + q_e * 4, p.c - 4) * 2);
         }
         __syncthreads();                            // A: every wave is done reading the x tile
-        // t = act(acc1 + b1), zero outside the frame, over the x tile
+        // t = act(acc1 + b1), zero outside the frame, over the x tile.  (This epilogue costs as many cycles as the K loop
+        // before it -- 16 waves share four vector ALUs -- so it is written for instruction count: the ReLU blocks, 128 of the
+        // 156 fused launches of a RefVSR_small frame, skip the slope multiply, and the fp16 pairs are converted with two
+        // packed conversions -- through a 4-vector + mask union hipcc emits two scalar conversions and a permute.)
+        auto epi1 = [&](auto relu_c) {
+            constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-        for (int t = 0; t < RL_T1W; ++t) {
-            const int tile1 = wave_e * RL_T1W + t;
-            const int pix = tile1 * 16 + lp_e;
-            if (tile1 >= RL_T1 || pix >= RL_NI) continue;
-            const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RL_IW));
-            const int iy = ty0 - 1 + r, ix = tx0 - 1 + (pix - r * RL_IW);
-            const unsigned keep = (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? 0xffffffffu : 0u;
-            unsigned char* dst = xt + (size_t)pix * psb;
+            for (int t = 0; t < RL_T1W; ++t) {
+                const int tile1 = wave_e * RL_T1W + t;
+                const int pix = tile1 * 16 + lp_e;
+                if (tile1 >= RL_T1 || pix >= RL_NI) continue;
+                const int r = (int)(((float)pix + 0.5f) * (1.0f / (float)RL_IW));
+                const int iy = ty0 - 1 + r, ix = tx0 - 1 + (pix - r * RL_IW);
+                const unsigned keep = (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? 0xffffffffu : 0u;
+                unsigned char* dst = xt + (size_t)pix * psb;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co0 = m * 16 + q_e * 4;
-                if (co0 >= p.c) continue;
-                const float4 bv = *reinterpret_cast<const float4*>(bl + m * 16 + q_e * 4);
-                float y0 = acc1[m][t][0] + bv.x, y1 = acc1[m][t][1] + bv.y, y2 = acc1[m][t][2] + bv.z, y3 = acc1[m][t][3] + bv.w;
-                y0 = fmaxf(y0, y0 * p.act_slope); y1 = fmaxf(y1, y1 * p.act_slope);       // (leaky) ReLU, 0 <= slope <= 1
-                y2 = fmaxf(y2, y2 * p.act_slope); y3 = fmaxf(y3, y3 * p.act_slope);
-                union { f16x4 h; uint2 u; } o;
-                o.h = (f16x4){(f16)y0, (f16)y1, (f16)y2, (f16)y3};
-                o.u.x &= keep; o.u.y &= keep;
-                *reinterpret_cast<uint2*>(dst + co0 * 2) = o.u;
+                for (int m = 0; m < MT; ++m) {
+                    const int co0 = m * 16 + q_e * 4;
+                    if (co0 >= p.c) continue;
+                    const float4 bv = *reinterpret_cast<const float4*>(bl + m * 16 + q_e * 4);
+                    float y0 = acc1[m][t][0] + bv.x, y1 = acc1[m][t][1] + bv.y, y2 = acc1[m][t][2] + bv.z, y3 = acc1[m][t][3] + bv.w;
+                    if constexpr (RELU) {
+                        y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f);
+                    } else {                                                                   // leaky ReLU, 0 < slope <= 1
+                        y0 = fmaxf(y0, y0 * p.act_slope); y1 = fmaxf(y1, y1 * p.act_slope);
+                        y2 = fmaxf(y2, y2 * p.act_slope); y3 = fmaxf(y3, y3 * p.act_slope);
+                    }
+                    union { f16x2 h; unsigned u; } a, b;
+                    a.h = (f16x2){(f16)y0, (f16)y1};
+                    b.h = (f16x2){(f16)y2, (f16)y3};
+                    *reinterpret_cast<uint2*>(dst + co0 * 2) = make_uint2(a.u & keep, b.u & keep);
+                }
             }
-        }
+        };
+        if (p.act_slope == 0.f) epi1(std::true_type{}); else epi1(std::false_type{});
         if (has_next) x_fetch(tl + k_step);         // in flight during conv2
         if (iter == p.probe_iter) RL_STAMP(4);
         __syncthreads();                            // B: t complete
