@@ -243,3 +243,41 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
     want = tuple(x for a, b in pairs for x in ((a, 0.0, False), (b, 1.0, True)))
     assert e._block_chain(X((270, 480, 24)), pairs, 0.0).hist == want
 
+
+def test_split_fp16_dot_product_is_fp32_grade():
+    """The arithmetic of the exhaustive arg-max search (match.hip: match_patches lo rows + match_exact_kernel), restated in
+    numpy: a = a_h + 2^-11 a_l with a_h = fp16(a), a_l = fp16((a - a_h) * 2^11); <a, b> ~ <a_h, b_h> + 2^-11 (<a_h, b_l> +
+    <a_l, b_h>) with fp32 accumulation.  On normalised 144-element patches the result must be as close to the exact
+    correlation as an fp32 dot product is (the claim DESIGN.md 4.1 makes), and far closer than the fp16 GEMM's score."""
+    rs = np.random.RandomState(7)
+    n, k = 4000, 144
+    a = np.abs(rs.randn(n, k)).astype(np.float32)            # ReLU features are non-negative
+    b = (a + 0.3 * np.abs(rs.randn(n, k))).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    exact = np.sum(a.astype(np.float64) * b.astype(np.float64), axis=1)
+
+    def split(x):
+        hi = x.astype(np.float16)
+        lo = ((x - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        return hi.astype(np.float32), lo.astype(np.float32)
+    ah, al = split(a)
+    bh, bl = split(b)
+    assert np.abs((ah + al / 2048.0) - a).max() < 2.0 ** -22 * 1.01 * np.abs(a).max() + 1e-9      # representation: 22 bits
+    assert np.all(np.abs(al) >= 0) and np.abs(al).max() <= 1.0 + 1e-3                              # lo * 2^11 stays a normal fp16
+    f32 = lambda x: x.astype(np.float32)
+    hh = np.zeros(n, np.float32)
+    cross = np.zeros(n, np.float32)
+    for j in range(k):                                        # fp32 accumulation, term by term
+        hh = f32(hh + ah[:, j] * bh[:, j])
+        cross = f32(cross + f32(ah[:, j] * bl[:, j]) + f32(al[:, j] * bh[:, j]))
+    got = f32(hh + cross * np.float32(1.0 / 2048.0))
+    fp32_dot = np.zeros(n, np.float32)
+    for j in range(k):
+        fp32_dot = f32(fp32_dot + a[:, j] * b[:, j])
+    gemm16 = np.sum(ah.astype(np.float64) * bh.astype(np.float64), axis=1)                          # what match_top2 ranks by
+    e_split, e_f32, e_16 = np.abs(got - exact).max(), np.abs(fp32_dot - exact).max(), np.abs(gemm16 - exact).max()
+    # (term-by-term fp32 accumulation of 144 products near 1.0 is itself ~6e-7 off; the MFMA's blocked sums are tighter)
+    assert e_split < 1e-6 and e_split < 1.5 * e_f32, (e_split, e_f32)
+    assert e_16 > 20.0 * e_split, (e_16, e_split)              # the fp16 GEMM alone is two orders of magnitude coarser
+
