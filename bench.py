@@ -237,7 +237,7 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                'schedule': 'phase A (flows, matching, encoders, alignment, backward branch) of all frames concurrently on all ranks; '
                            'phase B (forward-branch step + upsampler) rank 0 -> 1 -> ... behind the hand-off',
                'handoff': {'backend': backend, 'messages': sum(1 for r in range(1, world) if shard.needs_handoff(shard.partition(nfr, world)[r][0], cfg.reset_branch)),
-                           'bytes_per_message': 16 + h * w * (10 * C + 12), 'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
+                           'bytes_per_message': 64 + h * w * (10 * C + 12), 'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
                            'overlap': 'isend issued when the last frame\'s state is final, under its upsampler'},
                'frames_checked_against_single_rank_run': ncheck, 'frames_equal': bool(ok)}
     dist.barrier()

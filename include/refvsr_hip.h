@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 4   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 5   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
-                                  4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact */
+                                  4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
+                                  5: compile-time-specialised 24-channel ResBlock (resblock24 blob) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -102,6 +103,21 @@ int refvsr_set_resblock_waves(int waves);
 int refvsr_resblock_lean(const void* src, int c, int h, int w, const void* w1, const float* b1,
                          const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
                          void* out, void* stream);
+/* The 24-channel fused block of RefVSR_small (mid_channels = 24: configs/config_RefVSR_small_*.py) with every geometry
+ * constant fixed at compile time -- ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97, act_slope 0 = ReLU) and ResBlock
+ * (RefVSR_/common.py:25-39, act_slope 0.2), out = x + conv2(act(conv1 x)), n blocks behind one call like
+ * refvsr_resblock_chain.  Block i's parameters are ONE blob of REFVSR_RESBLOCK24_BLOB_BYTES at blobs + i * blob_stride
+ * (device memory, 16-byte aligned): [conv1: 7 K-steps x 3 fragments x 64 lanes x 8 halfs][conv2: same][b1: 32 floats,
+ * 24..31 = 0][b2: 32 floats]; fragments 0 / 1 = hi / lo halves of output channels 0-15, fragment 2 = rows 0-7 hi, rows 8-15
+ * lo of channels 16-23; lane l = (q = l >> 4, row r = l & 15) holds K-block refvsr_resblock24_kblock(s, q) of row r
+ * (refvsr_amd/packing.py:pack_resblock24 builds it).  Same arithmetic as refvsr_resblock_lean up to fp32 summation order. */
+#define REFVSR_RESBLOCK24_BLOB_BYTES 43264
+int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
+                            void* scratch0, void* scratch1, void* out, void* stream);
+/* (ty << 16 | tx << 8 | cg) of K-block (K-step s = 0..6, quarter q = 0..3) of the blob's K order, -1 for the zero block. */
+int refvsr_resblock24_kblock(int s, int q);
+/* Tuning knob: waves per workgroup of the 24-channel kernel, 8 (default) or 4.  Results do not depend on it. */
+int refvsr_set_resblock24_waves(int waves);
 /* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
  * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its
  * iter-th tile at buf[12 * workgroup + i] (uint64; [8], [9] = 100 MHz s_memrealtime at entry / exit, [10] = s_memtime at exit) -- tools/probe_resblock.py.  NULL switches it off (default). */

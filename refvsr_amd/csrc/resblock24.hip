@@ -1,0 +1,426 @@
+// Fused residual block for the C = 24 maps of RefVSR_small:  out = x + conv2( act( conv1(x) ) ),  3x3, 24 -> 24,
+// with EVERYTHING a compile-time constant.  Replaces the per-block body of ResidualBlockNoBN
+// (mmedit/models/common/sr_backbone_utils.py:42-97: 96 launches per frame in backward/forward_resblocks,
+// models/archs/RefVSR.py:327-360) and of ResBlock (models/archs/RefVSR_/common.py:25-39: 60 launches per frame in the
+// ResLists of AA_AF_conf_prop / compute_up).
+//
+// Why a second kernel next to resblock_lean.hip (which stays as the runtime-generic kernel for C = 8 / 16 / 32): the SQ
+// counters of the round-2 kernel (profiles/r02_pmc_sq_match_top2.txt) show it bound by INSTRUCTION ISSUE, not by the matrix
+// pipe or by memory -- per wave and tile 609 vector-ALU + 166 LDS + 140 MFMA instructions, 26 % of the wave cycles issuing
+// x 4 waves per SIMD = a saturated issue port, matrix pipe 19-36 % busy.  Most of those instructions are index arithmetic
+// that exists only because channel count, K order and tile geometry were runtime values.  Here:
+//
+//   * K order chosen so that a B-fragment address is  (per-lane base) + (immediate):  the K-blocks of one 3x3 window row are
+//     nine consecutive 16-byte slots u = 3*tx + cg of the x tile (pixel stride = 3 slots, no padding slot), K-step
+//     s = 2*ty + a (a = 0|1) takes u = 4a + {0,2,1,3}[q] (q = lane >> 4: the two K-blocks a ds_read_b128 lane group mixes
+//     have slot offsets of equal parity => bank-conflict free, common.h), K-step 6 takes u = 8 of rows ty = q (q = 3: a zero
+//     block).  No K-slot table, no per-step address arithmetic: a K-step is 3 + T ds_read_b128 and 3T MFMAs, nothing else;
+//   * hi + lo weights in THREE 16-row fragments instead of four: rows [hi 0-15], [lo 0-15], [hi 16-23 | lo 16-23] -- the
+//     third accumulator holds the hi sums of channels 16-23 in lanes 0-31 and their lo sums in lanes 32-63, folded with one
+//     v_permlane32_swap + add per register after the K loop (25 % fewer MFMAs and weight-fragment reads, 42 KB of weights);
+//   * bias (and, for conv2, bias + residual) are the accumulators' initial values; ReLU runs on the packed fp16 pair;
+//   * the x tile (12 x 36 pixels x 48 bytes) is a contiguous image of 12 row segments of the HWC map: three 16-byte loads
+//     per thread at offsets computed once per kernel, zero masking only in tiles that touch the frame border (uniform branch);
+//   * weights + biases of a block are ONE 43 264-byte blob that goes global -> LDS with global_load_lds_dwordx4.
+//
+// Layout of the blob (host: refvsr_amd/packing.py:pack_resblock24):  [conv1: 7 K-steps x 3 fragments x 1 KiB][conv2: same]
+// [b1: 32 floats, 24..31 = 0][b2: 32 floats].  Fragment f of K-step s, lane l = (q, r): 8 halfs = K-block (s, q) of row r.
+//
+//   stage   x tile                                                            global -> registers -> LDS
+//   phase 1 acc1 = b1 + conv1(x) on the 10 x 34 halo region (22 sixteen-pixel groups over the waves), residual x values
+//           -> registers;  barrier;  t = act(acc1) (0 outside the frame) -> LDS over the x tile, shifted by (1, 1);  barrier
+//   phase 2 out = (b2 + x) + conv2(t) on the 8 x 32 tile -> global (8-byte HWC channel vectors)
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+constexpr int RB_TH = 8, RB_TW = 32;
+constexpr int RB_XH = RB_TH + 4, RB_XW = RB_TW + 4;       // x tile: 12 x 36 pixels
+constexpr int RB_IH = RB_TH + 2, RB_IW = RB_TW + 2;       // intermediate: 10 x 34
+constexpr int RB_NI = RB_IH * RB_IW;                      // 340 intermediate pixels
+constexpr int RB_G1 = (RB_NI + 15) / 16;                  // 22 sixteen-pixel groups of phase 1
+constexpr int RB_PXB = 48;                                // bytes per pixel (24 halfs)
+constexpr int RB_ROWB = RB_XW * RB_PXB;                   // 1728 bytes per tile row
+constexpr int RB_XBYTES = RB_XH * RB_ROWB;                // 20736
+constexpr int RB_XCH = RB_XBYTES / 16;                    // 1296 sixteen-byte chunks
+constexpr int RB_RCH = RB_ROWB / 16;                      // 108 chunks per tile row
+constexpr int RB_S = 7, RB_NF = 3;
+constexpr int RB_WB = RB_S * RB_NF * 1024;                // 21504 bytes of fragments per conv
+constexpr int RB_BIAS = 2 * RB_WB;                        // 43008
+constexpr int RB_BLOB = RB_BIAS + 256;                    // 43264
+constexpr int RB_XT = RB_BLOB;                            // LDS offset of the x tile
+constexpr int RB_LDS = RB_XT + RB_XBYTES;                 // 64000 -> two workgroups per CU
+static_assert(RB_BLOB == REFVSR_RESBLOCK24_BLOB_BYTES, "blob size is part of the C-ABI");
+}  // namespace
+
+struct RB24Args {
+    const unsigned char* src; unsigned char* out; const unsigned char* blob;
+    int h, w, tiles_x, n_tiles, grid;
+    float act_slope;
+};
+
+// lane l: a[l] + a[l ^ 32]   (v_mov, v_permlane32_swap, v_add per register).  The two results are taken out of the builtin's
+// vector as plain unsigned values first: __builtin_bit_cast on `pr[1]` directly made hipcc (ROCm 7.2) read element 0 twice.
+__device__ __forceinline__ float rb_fold1(const float a) {
+    const unsigned u = __float_as_uint(a);
+    const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned x0 = pr[0], x1 = pr[1];
+    return __uint_as_float(x0) + __uint_as_float(x1);
+}
+__device__ __forceinline__ f32x4 rb_fold_halves(const f32x4 a) {
+    f32x4 r;
+    r[0] = rb_fold1(a[0]); r[1] = rb_fold1(a[1]); r[2] = rb_fold1(a[2]); r[3] = rb_fold1(a[3]);
+    return r;
+}
+
+// K loop of one conv: T pixel groups of this wave, fragments at smem + wofs, B windows at smem + pb[t] (+ immediates).
+// Software pipelined over two fragment sets (the reads of step s+1 are issued above the MFMAs of step s).
+template <int T, int TA>
+__device__ __forceinline__ void rb_kloop(f32x4 (&acc0)[TA], f32x4 (&acc1)[TA], const unsigned char* smem, const int wofs,
+                                         const int la, const int (&pb)[TA], const int delta6) {
+    static_assert(T <= TA, "group count");
+    uint4 a[2][RB_NF], b[2][T];
+    auto load = [&](auto sc, uint4 (&af)[RB_NF], uint4 (&bf)[T]) {
+        constexpr int s = decltype(sc)::value;
+#pragma unroll
+        for (int f = 0; f < RB_NF; ++f) af[f] = *reinterpret_cast<const uint4*>(smem + wofs + (s * RB_NF + f) * 1024 + la);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if constexpr (s < 6) bf[t] = *reinterpret_cast<const uint4*>(smem + pb[t] + (s >> 1) * RB_ROWB + (s & 1) * 64);
+            else bf[t] = *reinterpret_cast<const uint4*>(smem + pb[t] + delta6);
+        }
+    };
+    auto mfma = [&](const uint4 (&af)[RB_NF], const uint4 (&bf)[T]) {
+        const f16x8 a_hi = *reinterpret_cast<const f16x8*>(&af[0]);
+        const f16x8 a_lo = *reinterpret_cast<const f16x8*>(&af[1]);
+        const f16x8 a_mx = *reinterpret_cast<const f16x8*>(&af[2]);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, *reinterpret_cast<const f16x8*>(&bf[t]), acc0[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_mx, *reinterpret_cast<const f16x8*>(&bf[t]), acc1[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, *reinterpret_cast<const f16x8*>(&bf[t]), acc0[t], 0, 0, 0);
+    };
+    load(std::integral_constant<int, 0>{}, a[0], b[0]);
+    load(std::integral_constant<int, 1>{}, a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+    load(std::integral_constant<int, 2>{}, a[0], b[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[1], b[1]);
+    load(std::integral_constant<int, 3>{}, a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+    load(std::integral_constant<int, 4>{}, a[0], b[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[1], b[1]);
+    load(std::integral_constant<int, 5>{}, a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+    load(std::integral_constant<int, 6>{}, a[0], b[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+}
+
+// act(y) of four fp32 values -> two packed fp16 pairs.  RELU: conversion first, v_pk_max_f16 on the pairs (ReLU commutes with
+// the rounding); leaky ReLU (0 < slope <= 1): max(y, slope * y) in fp32.
+template <bool RELU>
+__device__ __forceinline__ uint2 rb_act_pack(const f32x4 y, const float slope) {
+    union { f16x2 h; unsigned u; } a, b;
+    if constexpr (RELU) {
+        const f16x2 z = {(f16)0.f, (f16)0.f};
+        a.h = __builtin_elementwise_max((f16x2){(f16)y[0], (f16)y[1]}, z);
+        b.h = __builtin_elementwise_max((f16x2){(f16)y[2], (f16)y[3]}, z);
+    } else {
+        a.h = (f16x2){(f16)fmaxf(y[0], y[0] * slope), (f16)fmaxf(y[1], y[1] * slope)};
+        b.h = (f16x2){(f16)fmaxf(y[2], y[2] * slope), (f16)fmaxf(y[3], y[3] * slope)};
+    }
+    return make_uint2(a.u, b.u);
+}
+
+__device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
+    union { f16x2 h; unsigned u; } a, b;
+    a.h = (f16x2){(f16)y[0], (f16)y[1]};
+    b.h = (f16x2){(f16)y[2], (f16)y[3]};
+    return make_uint2(a.u, b.u);
+}
+
+// NWV = waves per workgroup (8: three + two pixel groups per wave, <= 128 VGPRs, four waves per SIMD with the two workgroups
+// of a CU; 4: six + four groups per wave, twice the weight-fragment reuse, two waves per SIMD).
+template <bool RELU, int NWV>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 2, NWV / 2))) void resblock24_kernel(RB24Args p) {
+    constexpr int NT = NWV * 64;
+    constexpr int T1 = (RB_G1 + NWV - 1) / NWV;                  // phase-1 groups of a "full" wave (3 | 6)
+    constexpr int T1REM = RB_G1 % NWV;                           // waves below this index are full, the others have T1 - 1
+    constexpr int T2 = 16 / NWV;                                 // phase-2 groups per wave (2 | 4)
+    constexpr int KCH = (RB_XCH + NT - 1) / NT;                  // x-tile chunks per thread (3 | 6)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    asm volatile("" :: "s"(p.src), "s"(p.out), "s"(p.blob), "s"(p.h), "s"(p.w), "s"(p.tiles_x), "s"(p.n_tiles), "s"(p.grid),
+                 "s"(p.act_slope));                             // one batch of scalar argument loads
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- weights + biases: global -> LDS, 1 KiB per wave instruction, issued before anything else --------------------------
+    {
+        constexpr int NCH = RB_BIAS / 1024;                      // 42 full chunks + the 256-byte bias tail
+        const unsigned char* g = p.blob + lane * 16;
+#pragma unroll
+        for (int j = 0; j < (NCH + NWV - 1) / NWV; ++j) {
+            const int c = wave + j * NWV;
+            if (c < NCH)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024),
+                                                 (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
+        }
+        if (wave == NCH % NWV && lane < 16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + NCH * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + NCH * 1024), 16, 0, 0);
+    }
+
+    // ---- per-lane constants ---------------------------------------------------------------------------------------------
+    const int q = lane >> 4;
+    const int lp = rv_pix16(lane & 15);                          // pixel of a 16-pixel group held by this lane's MFMA column
+    const int permq = ((q & 1) << 1) | (q >> 1);                 // {0, 2, 1, 3}
+    const int la = lane * 16;
+    const int delta6 = min(q, 2) * RB_ROWB + 128 - permq * 16;   // K-step 6 (u = 8 of window row q) relative to a window base
+    const int dq = RB_ROWB + RB_PXB + q * 8 - permq * 16;        // channels 4q.. of the window's centre pixel, same base
+    const bool full1 = T1REM == 0 || wave < T1REM;
+    const int g1 = full1 ? wave * T1 : T1REM * T1 + (wave - T1REM) * (T1 - 1);
+    int pb1[T1];                                                 // phase 1: LDS byte offset of each group's window origin (+ permq slot)
+#pragma unroll
+    for (int t = 0; t < T1; ++t) {
+        const int pix = min((g1 + t) * 16 + lp, RB_NI - 1);      // lanes past the region repeat its last pixel (same value, same address)
+        const int r = pix / RB_IW;
+        pb1[t] = RB_XT + r * RB_ROWB + (pix - r * RB_IW) * RB_PXB + permq * 16;
+    }
+    const int oy0 = (wave * T2) >> 1;                            // first output row of this wave
+    int pb2[T2];                                                 // phase 2 windows: one VGPR + immediates
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+        pb2[t] = RB_XT + (oy0 + (t >> 1) + 1) * RB_ROWB + ((t & 1) * 16 + lp + 1) * RB_PXB + permq * 16;
+    const int rowb_g = p.w * RB_PXB;                             // bytes per row of the HWC maps
+    const unsigned oo = (unsigned)(oy0 * rowb_g + lp * RB_PXB + q * 8);   // output offset of group 0 relative to the tile origin
+    unsigned xg[KCH];                                            // x-tile chunk k of this thread: global offset relative to the tile origin
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+        const int i = min(tid + k * NT, RB_XCH - 1);
+        const int r = i / RB_RCH;
+        xg[k] = (unsigned)(r * rowb_g + (i - r * RB_RCH) * 16);
+    }
+    uint4 xv[KCH];
+    // tile origin (top-left pixel of the x tile) may lie outside the frame: only in-frame chunks are dereferenced
+    auto x_fetch = [&](const int t) {
+        const int tyi = t / p.tiles_x;
+        const int ty0 = tyi * RB_TH, tx0 = (t - tyi * p.tiles_x) * RB_TW;
+        const bool interior = ty0 >= 2 && ty0 + RB_TH + 2 <= p.h && tx0 >= 2 && tx0 + RB_TW + 2 <= p.w;
+        const long long org = ((long long)(ty0 - 2) * p.w + (tx0 - 2)) * RB_PXB;
+        if (interior) {
+            const unsigned char* b = p.src + org;
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) xv[k] = *reinterpret_cast<const uint4*>(b + xg[k]);
+        } else {
+            // (thread id made opaque: hipcc otherwise hoists this path's index arithmetic out of the tile loop and keeps it
+            //  in registers that live across the K loops)
+            int tide = tid;
+            asm volatile("" : "+v"(tide));
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const int i = min(tide + k * NT, RB_XCH - 1);
+                const int r = i / RB_RCH;
+                const int px = (i - r * RB_RCH) / 3;
+                const int iy = ty0 - 2 + r, ix = tx0 - 2 + px;
+                const bool ok = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
+                const unsigned off = (unsigned)((min(max(iy, 0), p.h - 1) * p.w + min(max(ix, 0), p.w - 1)) * RB_PXB + ((i - r * RB_RCH) - px * 3) * 16);
+                uint4 v = *reinterpret_cast<const uint4*>(p.src + off);          // clamped address, masked value (32-bit offsets: host check)
+                const unsigned keep = ok ? 0xffffffffu : 0u;
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                xv[k] = v;
+            }
+        }
+    };
+    auto x_park = [&]() {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+            if (k * NT + NT <= RB_XCH || tid + k * NT < RB_XCH)
+                *reinterpret_cast<uint4*>(smem + RB_XT + tid * 16 + k * NT * 16) = xv[k];
+    };
+
+    int tl, k_hi;
+    rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
+    if (tl < k_hi) { x_fetch(tl); x_park(); }
+    __syncthreads();                                             // weights, biases, first tile
+
+    for (; tl < k_hi; ++tl) {
+        const bool has_next = tl + 1 < k_hi;
+        const int tyi = tl / p.tiles_x;
+        const int ty0 = tyi * RB_TH, tx0 = (tl - tyi * p.tiles_x) * RB_TW;
+        const bool interior = ty0 >= 2 && ty0 + RB_TH + 2 <= p.h && tx0 >= 2 && tx0 + RB_TW + 2 <= p.w;
+
+        // ---------------- phase 1: acc = b1 + conv1(x) on the halo region -------------------------------------------------
+        f32x4 a0[T1], a1[T1];
+        {
+            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(smem + RB_BIAS + q * 16);          // channels 4q ..
+            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(smem + RB_BIAS + 64 + q * 16);     // channels 16 + 4q .. (24..31: zeros)
+#pragma unroll
+            for (int t = 0; t < T1; ++t) { a0[t] = bv0; a1[t] = bv1; }
+        }
+        if (full1) rb_kloop<T1, T1>(a0, a1, smem, 0, la, pb1, delta6);
+        else rb_kloop<T1 - 1, T1>(a0, a1, smem, 0, la, pb1, delta6);
+        // residual x values of this lane's outputs: the x tile is about to be overwritten by t
+        f16x4 xr0[T2], xr1[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+            xr0[t] = *reinterpret_cast<const f16x4*>(smem + pb2[t] + dq);
+            // lanes 32-63 of the third accumulator collect lo sums only: they start from zeros (the pad of b1)
+            xr1[t] = *reinterpret_cast<const f16x4*>(smem + (q < 2 ? pb2[t] + dq + 32 : RB_BIAS + 96));
+        }
+#pragma unroll
+        for (int t = 0; t < T1; ++t) a1[t] = rb_fold_halves(a1[t]);
+        __syncthreads();                                         // A: every wave is done reading the x tile
+        // t = act(acc), zero outside the frame (conv2's zero padding), written over the x tile at (+1, +1)
+        auto epi1 = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                uint2 v0 = rb_act_pack<RELU>(a0[t], p.act_slope);
+                uint2 v1 = rb_act_pack<RELU>(a1[t], p.act_slope);
+                if (!interior) {
+                    int lpe = lp;
+                    asm volatile("" : "+v"(lpe));                 // see x_fetch
+                    const int pix = min((g1 + t) * 16 + lpe, RB_NI - 1);
+                    const int r = pix / RB_IW;
+                    const int iy = ty0 - 1 + r, ix = tx0 - 1 + (pix - r * RB_IW);
+                    const unsigned keep = ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w) ? 0xffffffffu : 0u;
+                    v0.x &= keep; v0.y &= keep; v1.x &= keep; v1.y &= keep;
+                }
+                unsigned char* d = smem + pb1[t] + dq;
+                *reinterpret_cast<uint2*>(d) = v0;
+                if (q < 2) *reinterpret_cast<uint2*>(d + 32) = v1;
+            }
+        };
+        if (full1) epi1(std::integral_constant<int, T1>{}); else epi1(std::integral_constant<int, T1 - 1>{});
+        if (has_next) x_fetch(tl + 1);                           // in flight during conv2
+        __syncthreads();                                         // B: t complete
+
+        // ---------------- phase 2: out = (b2 + x) + conv2(t): the accumulators start as bias + residual ------------------------
+        f32x4 c0[T2], c1[T2];
+        {
+            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(smem + RB_BIAS + 128 + q * 16);
+            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(smem + RB_BIAS + 192 + q * 16);
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                const f16x4 x0 = xr0[t], x1 = xr1[t];
+                c0[t] = (f32x4){bv0[0] + (float)x0[0], bv0[1] + (float)x0[1], bv0[2] + (float)x0[2], bv0[3] + (float)x0[3]};
+                c1[t] = (f32x4){bv1[0] + (float)x1[0], bv1[1] + (float)x1[1], bv1[2] + (float)x1[2], bv1[3] + (float)x1[3]};
+            }
+        }
+        rb_kloop<T2, T2>(c0, c1, smem, RB_WB, la, pb2, delta6);
+        if (has_next) {
+            __syncthreads();                                     // C: every wave is done reading t
+            x_park();
+        }
+        {
+            unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                const f32x4 m = rb_fold_halves(c1[t]);
+                const uint2 v0 = rb_pack(c0[t]), v1 = rb_pack(m);
+                bool ok = true;
+                if (!interior) {
+                    int lpe = lp;
+                    asm volatile("" : "+v"(lpe));
+                    ok = ty0 + oy0 + (t >> 1) < p.h && tx0 + (t & 1) * 16 + lpe < p.w;
+                }
+                unsigned char* d = ob + (unsigned)((t >> 1) * rowb_g) + oo + (t & 1) * 16 * RB_PXB;
+                if (ok) {
+                    *reinterpret_cast<uint2*>(d) = v0;
+                    if (q < 2) *reinterpret_cast<uint2*>(d + 32) = v1;
+                }
+            }
+        }
+        if (has_next) __syncthreads();                           // D: next x tile visible
+    }
+}
+
+static int g_rb24_waves = 8;                 // A/B knob (refvsr_set_resblock24_waves): 4 or 8 waves per workgroup
+extern "C" int refvsr_set_resblock24_waves(int waves) {
+    if (waves != 4 && waves != 8) return 1;
+    g_rb24_waves = waves;
+    return 0;
+}
+
+template <bool RELU, int NWV>
+static int launch_rb24(RB24Args& a, hipStream_t st) {
+    static bool attr_done[RV_MAX_DEVICES] = {};
+    static int occ_dev[RV_MAX_DEVICES] = {};
+    const int dev = rv_device();
+    if (!attr_done[dev]) {
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS));
+        int occ = 0;
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV>, NWV * 64, RB_LDS));
+        occ_dev[dev] = occ < 1 ? 1 : occ;
+        attr_done[dev] = true;
+    }
+    int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
+    if (cap < 8) cap = 8;
+    a.grid = a.n_tiles < cap ? a.n_tiles : cap;
+    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// n fused blocks x <- x + conv2(act(conv1 x)) on a 24-channel fp16 HWC map; block i's weights are the blob at
+// blobs + i * blob_stride (refvsr_amd/packing.py:pack_resblock24).  n launches on the caller's stream, intermediates ping-pong
+// between scratch0 / scratch1 (blocks cannot run in place: neighbouring tiles read the input halo).
+extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride,
+                                       float act_slope, void* scratch0, void* scratch1, void* out, void* stream) {
+    RV_CHECK(src && out && blobs && h > 0 && w > 0 && n >= 1, "resblock24_chain: bad args");
+    RV_CHECK(blob_stride >= (size_t)RB_BLOB && blob_stride % 16 == 0 && ((uintptr_t)blobs & 15) == 0,
+             "resblock24_chain: blobs must be 16-byte aligned, stride >= %d", RB_BLOB);
+    RV_CHECK(act_slope >= 0.f && act_slope <= 1.f, "resblock24_chain: activation slope must lie in [0, 1]");
+    RV_CHECK(n == 1 || scratch0, "resblock24_chain: n >= 2 needs scratch0");
+    RV_CHECK(n <= 2 || scratch1, "resblock24_chain: n >= 3 needs scratch1");
+    RV_CHECK(src != out && scratch0 != out && scratch1 != out && (n < 2 || scratch0 != src) && (n < 3 || scratch1 != src) &&
+             (n < 3 || scratch0 != scratch1), "resblock24_chain: buffers must be distinct");
+    RV_CHECK((long long)h * w * RB_PXB < (1ll << 31), "resblock24_chain: map too large for 32-bit offsets");
+    RV_CHECK(refvsr_init() == 0, "init failed");
+    RB24Args a;
+    memset(&a, 0, sizeof(a));
+    a.h = h; a.w = w; a.act_slope = act_slope;
+    a.tiles_x = rv_cdiv(w, RB_TW);
+    a.n_tiles = a.tiles_x * rv_cdiv(h, RB_TH);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char* cur = (const unsigned char*)src;
+    for (int i = 0; i < n; ++i) {
+        unsigned char* dst = (unsigned char*)((i == n - 1) ? out : ((i & 1) ? scratch1 : scratch0));
+        a.src = cur; a.out = dst; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
+        int rc;
+        if (act_slope == 0.f) rc = g_rb24_waves == 8 ? launch_rb24<true, 8>(a, st) : launch_rb24<true, 4>(a, st);
+        else rc = g_rb24_waves == 8 ? launch_rb24<false, 8>(a, st) : launch_rb24<false, 4>(a, st);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return 0;
+}
+
+// K-block (K-step s, quarter q) of the blob's fragment order -> (ty, tx, cg) of the 3x3 x 24-channel window, or -1 for the
+// zero block: the single source of truth for the host packer (refvsr_amd/packing.py checks itself against it).
+extern "C" int refvsr_resblock24_kblock(int s, int q) {
+    if (s < 0 || s >= RB_S || q < 0 || q > 3) return -2;
+    int ty, u;
+    if (s < 6) {
+        const int perm[4] = {0, 2, 1, 3};
+        ty = s >> 1;
+        u = 4 * (s & 1) + perm[q];
+    } else {
+        if (q == 3) return -1;
+        ty = q;
+        u = 8;
+    }
+    return (ty << 16) | ((u / 3) << 8) | (u % 3);
+}

@@ -162,6 +162,7 @@ class Engine(object):
         self.chain_calls = bool(getattr(config, 'chain_calls', os.environ.get('REFVSR_NO_CHAIN_CALLS') is None))
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
+        self.rb24 = not os.environ.get('REFVSR_NO_RB24')         # A/B knob: the generic lean kernel for C = 24 as well
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
         self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
@@ -194,32 +195,53 @@ class Engine(object):
         self.pipelined = bool(on)
 
     def export_state(self):
-        """Forward-branch state as planar fp32 tensors (what RefVSR.py:279-283 keeps)."""
+        """Forward-branch state as planar fp32 tensors (what RefVSR.py:279-283 keeps; RefVSR_IR adds its key-frame indices,
+        RefVSR_IR.py:262-272)."""
         if self.fw_feat is None:
             return None
-        return dict(feat=ops.unpack_nhwc16(self.fw_feat, self.C), flow=self.fw_flow, feat_up=ops.unpack_nhwc16(self.fw_feat_up, self.C),
-                    conf=self.fw_conf, frame_itr_num=self.frame_itr_num)
+        st = dict(feat=ops.unpack_nhwc16(self.fw_feat, self.C), flow=self.fw_flow, feat_up=ops.unpack_nhwc16(self.fw_feat_up, self.C),
+                  conf=self.fw_conf, frame_itr_num=self.frame_itr_num)
+        kf = getattr(self, 'keyframe_idx', None)
+        if kf is not None:
+            st['keyframe_idx'] = [int(k) for k in kf]
+        return st
 
     def import_state(self, st):
-        self.fw_feat = ops.pack_nhwc16(st['feat'].contiguous())
+        cs = (self.C + 7) // 8 * 8                              # channel stride of the maps (C = 36 -> 40, zero padding)
+        self.fw_feat = ops.pack_nhwc16(st['feat'].contiguous(), cs)
         self.fw_flow = st['flow'].contiguous()
-        self.fw_feat_up = ops.pack_nhwc16(st['feat_up'].contiguous())
+        self.fw_feat_up = ops.pack_nhwc16(st['feat_up'].contiguous(), cs)
         self.fw_conf = st['conf'].contiguous()
         self.frame_itr_num = int(st['frame_itr_num'])
+        if st.get('keyframe_idx') is not None and hasattr(self, 'keyframe_idx'):
+            import numpy as np
+            self.keyframe_idx = np.asarray(st['keyframe_idx'], dtype=np.int64)
 
     # ---- the same state as ONE contiguous device buffer in the engine's native layouts (the multi-GPU hand-off message):
-    #      [16-byte header: frame_itr_num, h, w, C as int32][feat fp16 HWC][feat_up fp16 HWC][flow fp32 planar][conf fp32 planar]
-    #      = (5C*2 + 12) * h*w + 16 bytes -- half the bytes of the planar fp32 export, no unpack / pack kernels, one message
+    #      [64-byte header: int32 frame_itr_num, h, w, Cs (channel STRIDE of the maps: 24 / 48 / 40 for C = 36), number of
+    #       key-frame indices, up to 11 key-frame indices (RefVSR_IR)] [feat fp16 HWC] [feat_up fp16 HWC] [flow fp32 planar]
+    #      [conf fp32 planar] = (5 Cs * 2 + 12) * h*w + 64 bytes -- half the bytes of the planar fp32 export, no unpack / pack
+    #      kernels, one message
+    STATE_HEADER = 64
+
+    def _state_cs(self):
+        return (self.C + 7) // 8 * 8
+
     def state_nbytes(self, h, w):
-        return 16 + h * w * (2 * self.C + 8 * self.C + 8 + 4)
+        cs = self._state_cs()
+        return self.STATE_HEADER + h * w * (2 * cs + 8 * cs + 8 + 4)
 
     def export_state_packed(self):
         if self.fw_feat is None:
             return None
-        h, w = self.fw_feat.shape[:2]
+        h, w, cs = self.fw_feat.shape
+        assert cs == self._state_cs() and self.fw_feat_up.shape[2] == cs
         buf = torch.empty(self.state_nbytes(h, w), dtype=torch.uint8, device=self.fw_feat.device)
-        buf[:16].view(torch.int32).copy_(torch.tensor([self.frame_itr_num, h, w, self.C], dtype=torch.int32), non_blocking=False)
-        o = 16
+        kf = [int(k) for k in (getattr(self, 'keyframe_idx', None) if getattr(self, 'keyframe_idx', None) is not None else [])]
+        assert len(kf) <= 11
+        hdr = [self.frame_itr_num, h, w, cs, len(kf)] + kf + [0] * (11 - len(kf))
+        buf[:self.STATE_HEADER].view(torch.int32).copy_(torch.tensor(hdr, dtype=torch.int32), non_blocking=False)
+        o = self.STATE_HEADER
         for t in (self.fw_feat, self.fw_feat_up, self.fw_flow, self.fw_conf):
             n = t.numel() * t.element_size()
             buf[o:o + n].view(t.dtype).copy_(t.reshape(-1))
@@ -227,11 +249,11 @@ class Engine(object):
         return buf
 
     def import_state_packed(self, buf):
-        hdr = buf[:16].view(torch.int32).cpu().tolist()
-        itr, h, w, C = hdr
-        assert C == self.C and buf.numel() == self.state_nbytes(h, w), 'state buffer does not match this model'
+        hdr = buf[:self.STATE_HEADER].view(torch.int32).cpu().tolist()
+        itr, h, w, cs, nk = hdr[:5]
+        assert cs == self._state_cs() and buf.numel() == self.state_nbytes(h, w), 'state buffer does not match this model'
         dev = buf.device
-        o = 16
+        o = self.STATE_HEADER
 
         def take(shape, dtype):
             nonlocal o
@@ -242,11 +264,14 @@ class Engine(object):
             t = buf[o:o + n].view(dtype).view(shape).clone()
             o += n
             return t
-        self.fw_feat = take((h, w, C), torch.float16)
-        self.fw_feat_up = take((2 * h, 2 * w, C), torch.float16)
+        self.fw_feat = take((h, w, cs), torch.float16)
+        self.fw_feat_up = take((2 * h, 2 * w, cs), torch.float16)
         self.fw_flow = take((2, h, w), torch.float32)
         self.fw_conf = take((1, h, w), torch.float32)
         self.frame_itr_num = int(itr)
+        if hasattr(self, 'keyframe_idx') and nk > 0:
+            import numpy as np
+            self.keyframe_idx = np.asarray(hdr[5:5 + nk], dtype=np.int64)
         assert dev == self.fw_feat.device
 
     # ------------------------------------------------------------------ building blocks
@@ -258,9 +283,17 @@ class Engine(object):
         One launch per block (fused kernel) or two launches per block (fuse_resblocks off / unsupported channel count).
         (A kernel chaining TWO blocks per launch with halo recomputation was built in round 1 and measured in round 2:
         29.3 us vs 2 x 14.7 us on the LR maps, slower on the 2x maps and 4 % slower end to end -- removed.)"""
+        if self.fuse_resblocks and self.rb24 and x.shape[2] == 24 and pairs[0][0].raw is not None:
+            # mid_channels = 24 (the RefVSR_small family): the compile-time-specialised kernel, one blob per block
+            chains = self.W.chains                                  # lives and dies with the packed weights it points into
+            key = ('rb24',) + tuple(id(c1) for c1, _ in pairs)
+            ch = chains.get(key)
+            if ch is None:
+                ch = chains[key] = ops.Resblock24Chain(pairs, x.device)
+            return ops.resblock24_chain(ch, x, act)
         if self.fuse_resblocks and self.chain_calls and ops.resblock_chain_ok(x.shape[2]):
             # one library call per run (same launches, same results): 156 of the ~330 launches of a frame
-            chains = self.W.chains                                  # lives and dies with the packed weights it points into
+            chains = self.W.chains
             key = tuple(id(c1) for c1, _ in pairs)
             ch = chains.get(key)
             if ch is None:

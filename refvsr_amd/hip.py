@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 4
+ABI_VERSION = 5
+RESBLOCK24_BLOB_BYTES = 43264
 
 
 class RefvsrConv(C.Structure):
@@ -53,6 +54,9 @@ SIGNATURES = {
     'refvsr_set_resblock_waves': [_I],
     'refvsr_resblock_lean': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
     'refvsr_resblock_chain': [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
+    'refvsr_resblock24_chain': [_P, _I, _I, _I, _P, _Z, _F, _P, _P, _P, _P],
+    'refvsr_resblock24_kblock': [_I, _I],        # returns the packed K-block, not a status
+    'refvsr_set_resblock24_waves': [_I],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     'refvsr_pack_nhwc16': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_pack_nhwc32': [_P, _I, _I, _I, _P, _I, _P],

@@ -78,7 +78,7 @@ def _farr(vals):
 
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'desc', 'odtype')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'desc', 'odtype', 'raw')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
@@ -90,6 +90,7 @@ class ConvWeights(object):
         d.wpack, d.bias = self.wpack.data_ptr(), self.bias.data_ptr()
         d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
         self.odtype = torch.float32 if self.f32 else torch.float16
+        self.raw = pk.get('raw')      # (weight, bias) fp32 cpu tensors when the packer kept them (repacking for specialised kernels)
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
@@ -217,6 +218,44 @@ def resblock_chain(chain, x, act, post=1.0):
     s1 = torch.empty_like(x) if chain.n >= 3 else None
     hip.check(hip.lib().refvsr_resblock_chain(_ptr(x), c, h, w, chain.n, chain.w1, chain.b1, chain.w2, chain.b2, chain.ksteps,
                                               act, post, _ptr(s0), _ptr(s1), _ptr(out), _stream()), 'resblock_chain')
+    return out
+
+
+class Resblock24Chain(object):
+    """A run of 24-channel fused blocks for refvsr_resblock24_chain: one device buffer [n, 43264] of per-block blobs
+    (packing.pack_resblock24).  pairs: [(conv1, conv2)] ConvWeights whose packer kept the raw fp32 weights, or
+    [((w1, b1), (w2, b2))] raw tensors."""
+
+    def __init__(self, pairs, device):
+        from .packing import pack_resblock24
+        blobs = []
+        for a, b in pairs:
+            (w1, b1), (w2, b2) = (a.raw if isinstance(a, ConvWeights) else a), (b.raw if isinstance(b, ConvWeights) else b)
+            blobs.append(pack_resblock24(w1, b1, w2, b2))
+        self.n = len(blobs)
+        self.blobs = torch.stack(blobs, 0).to(device).contiguous()
+        self.stride = self.blobs.shape[1]
+        assert self.stride == hip.RESBLOCK24_BLOB_BYTES and self.blobs.data_ptr() % 16 == 0
+
+
+_RB24_WAVES_SET = False
+
+
+def resblock24_chain(chain, x, act):
+    """refvsr_resblock24_chain: chain.n fused 24-channel blocks x <- x + conv2(act(conv1 x)) behind one library call."""
+    global _RB24_WAVES_SET
+    if not _RB24_WAVES_SET:                # A/B knob of the workgroup shape (default 8 waves)
+        _RB24_WAVES_SET = True
+        if os.environ.get('REFVSR_RESBLOCK24_WAVES'):
+            hip.check(hip.lib().refvsr_set_resblock24_waves(int(os.environ['REFVSR_RESBLOCK24_WAVES'])), 'set_resblock24_waves')
+    _nhwc(x)
+    h, w, c = x.shape
+    assert c == 24
+    out = torch.empty_like(x)
+    s0 = torch.empty_like(x) if chain.n >= 2 else None
+    s1 = torch.empty_like(x) if chain.n >= 3 else None
+    hip.check(hip.lib().refvsr_resblock24_chain(_ptr(x), h, w, chain.n, _ptr(chain.blobs), chain.stride, act, _ptr(s0), _ptr(s1),
+                                                _ptr(out), _stream()), 'resblock24_chain')
     return out
 
 

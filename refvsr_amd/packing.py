@@ -121,4 +121,61 @@ def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False):
     bias = np.zeros(R, np.float32)
     bias[:cout] = b[rows]
     return dict(wpack=wpack, bias=torch.from_numpy(bias), cout=cout, ksteps=S, mt=MT, ksize=ks,
-                cpads=[_padg(c, grp) for c in src_channels], shuffle=shuffle, f32=f32)
+                cpads=[_padg(c, grp) for c in src_channels], shuffle=shuffle, f32=f32,
+                raw=(torch.from_numpy(w.copy()), torch.from_numpy(b.copy())))      # fp32 originals: repacking for specialised kernels
+
+
+# ---- the 24-channel fused residual block (csrc/resblock24.hip) ---------------------------------------------------------
+RB24_S, RB24_NF, RB24_BLOB = 7, 3, 43264          # K-steps, fragments per K-step, bytes per block (REFVSR_RESBLOCK24_BLOB_BYTES)
+
+
+def rb24_kblock(s, q):
+    """K-block (K-step s, quarter q = lane >> 4) of the blob's K order -> (ty, tx, cg) of the 3x3 x 24-channel window, or None
+    for the zero block (csrc/resblock24.hip:refvsr_resblock24_kblock is the same table; tests/test_host.py pins them together).
+    The nine 16-byte slots u = 3*tx + cg of one window row are consecutive in the x tile: K-step 2*ty + a takes
+    u = 4a + {0,2,1,3}[q], K-step 6 takes u = 8 of rows ty = q."""
+    if s < 6:
+        ty, u = s >> 1, 4 * (s & 1) + (0, 2, 1, 3)[q]
+    else:
+        if q == 3:
+            return None
+        ty, u = q, 8
+    return ty, u // 3, u % 3
+
+
+def pack_resblock24(w1, b1, w2, b2):
+    """One fused block -> uint8 [43264]:  [conv1 fragments][conv2 fragments][b1: 32 floats][b2: 32 floats].
+    Fragments of a conv: fp16 [7 K-steps][3][64 lanes][8]; lane l = (q = l >> 4, r = l & 15) holds the 8 input channels of
+    K-block rb24_kblock(s, q) for row r of   f = 0: hi(W[r])   f = 1: lo(W[r])   f = 2: hi(W[16 + r]) if r < 8 else lo(W[8 + r]),
+    hi = fp16(w), lo = fp16(w - hi)."""
+    out = np.zeros(RB24_BLOB, np.uint8)
+    o = 0
+    for w in (w1, w2):
+        w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
+        assert w.shape == (24, 24, 3, 3), w.shape
+        hi = w.astype(np.float16)
+        lo = (w - hi.astype(np.float32)).astype(np.float16)
+        frag = np.zeros((RB24_S, RB24_NF, 4, 16, 8), np.float16)       # [s][f][q][r][8]
+        for s_ in range(RB24_S):
+            for q in range(4):
+                kb = rb24_kblock(s_, q)
+                if kb is None:
+                    continue
+                ty, tx, cg = kb
+                ch = slice(cg * 8, cg * 8 + 8)
+                frag[s_, 0, q] = hi[0:16, ch, ty, tx]
+                frag[s_, 1, q] = lo[0:16, ch, ty, tx]
+                frag[s_, 2, q, 0:8] = hi[16:24, ch, ty, tx]
+                frag[s_, 2, q, 8:16] = lo[16:24, ch, ty, tx]
+        raw = frag.reshape(-1).view(np.uint8)
+        out[o:o + raw.size] = raw
+        o += raw.size
+    assert o == 2 * RB24_S * RB24_NF * 1024
+    for b in (b1, b2):
+        b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
+        bb = np.zeros(32, np.float32)
+        bb[:24] = b
+        out[o:o + 128] = bb.view(np.uint8)
+        o += 128
+    assert o == RB24_BLOB
+    return torch.from_numpy(out)

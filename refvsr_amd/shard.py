@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 STATE_KEYS = ('feat', 'flow', 'feat_up', 'conf')
+MAX_KEYFRAMES = 11
 
 
 def partition(nframes, world, reset_branch=None, aligned=False):
@@ -68,8 +69,10 @@ def send_state(state, dst, device, async_op=False):
             return dist.isend(buf, dst)
         dist.send(buf, dst)
         return None
-    meta = torch.tensor([float(state['frame_itr_num'])] + [float(d) for k in STATE_KEYS for d in state[k].shape[-2:]],
-                        dtype=torch.float32, device=device)
+    kf = [float(k) for k in (state.get('keyframe_idx') or [])]          # RefVSR_IR: key-frame indices travel with the state
+    assert len(kf) <= MAX_KEYFRAMES
+    meta = torch.tensor([float(state['frame_itr_num'])] + [float(d) for k in STATE_KEYS for d in state[k].shape[-2:]] +
+                        [float(len(kf))] + kf + [0.0] * (MAX_KEYFRAMES - len(kf)), dtype=torch.float32, device=device)
     dist.send(meta, dst)
     for k in STATE_KEYS:
         dist.send(state[k].contiguous().to(device), dst)
@@ -82,11 +85,14 @@ def recv_state(src, channels, device, nbytes=None):
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         dist.recv(buf, src)
         return buf
-    meta = torch.empty(1 + 2 * len(STATE_KEYS), dtype=torch.float32, device=device)
+    meta = torch.empty(1 + 2 * len(STATE_KEYS) + 1 + MAX_KEYFRAMES, dtype=torch.float32, device=device)
     dist.recv(meta, src)
     meta = meta.cpu().tolist()
     chans = {'feat': channels, 'flow': 2, 'feat_up': channels, 'conf': 1}
     st = {'frame_itr_num': int(meta[0])}
+    nk = int(meta[1 + 2 * len(STATE_KEYS)])
+    if nk:
+        st['keyframe_idx'] = [int(v) for v in meta[2 + 2 * len(STATE_KEYS):2 + 2 * len(STATE_KEYS) + nk]]
     for i, k in enumerate(STATE_KEYS):
         hh, ww = int(meta[1 + 2 * i]), int(meta[2 + 2 * i])
         buf = torch.empty((chans[k], hh, ww), dtype=torch.float32, device=device)

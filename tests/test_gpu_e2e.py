@@ -573,7 +573,7 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront,
 
 def test_packed_state_roundtrip(dev):
     """export_state_packed / import_state_packed (the hand-off message: header + fp16 HWC maps + fp32 flow / conf in one
-    buffer) restores the engine's state bit for bit, and its size is the documented (10 C + 12) h w + 16 bytes."""
+    buffer) restores the engine's state bit for bit, and its size is the documented (10 Cs + 12) h w + 64 bytes."""
     from refvsr_amd.synth import make_clip, window_indices
     lr, rf, _ = make_clip(3, 32, 48, seed=23)
     lr, rf = lr.to(dev), rf.to(dev)
@@ -583,7 +583,7 @@ def test_packed_state_roundtrip(dev):
         a(lr[window_indices(f, 3, 3)][None], rf[window_indices(f, 3, 3)][None], f == 0)
     ea = a.Network.engine(0)
     buf = ea.export_state_packed()
-    assert buf.dtype == torch.uint8 and buf.numel() == ea.state_nbytes(32, 48) == 16 + 32 * 48 * (10 * cfg.mid_channels + 12)
+    assert buf.dtype == torch.uint8 and buf.numel() == ea.state_nbytes(32, 48) == 64 + 32 * 48 * (10 * cfg.mid_channels + 12)
     b(lr[window_indices(0, 3, 3)][None], rf[window_indices(0, 3, 3)][None], True)       # allocate b's engine
     eb = b.Network.engine(0)
     eb.reset_state()
@@ -593,3 +593,37 @@ def test_packed_state_roundtrip(dev):
         assert torch.equal(getattr(ea, k), getattr(eb, k)), k
     w2 = window_indices(2, 3, 3)
     assert torch.equal(a(lr[w2][None], rf[w2][None], False)['result'], b(lr[w2][None], rf[w2][None], False)['result'])
+
+
+def test_refvsr_ir_state_handoff_roundtrip(dev):
+    """RefVSR_IR (C = 36 maps with channel stride 40) through both hand-off forms: the packed message carries the maps with
+    their channel stride and the key-frame indices (RefVSR_IR.py:262-272); an engine that imports either form continues the
+    stream bit-identically to the engine that produced it (the packed form used C instead of the stride and
+    dropped keyframe_idx)."""
+    from refvsr_amd.synth import window_indices
+    g = load_golden('e2e_IR_64x64_t5_reset2')
+    t = int(g['t'])
+    lr, rf = g['lr'], g['ref']
+    nframes = lr.shape[1]
+    nets = [make_net('config_RefVSR_IR_MFID', t, dev, reset=None, save_sample=False)[0] for _ in range(3)]
+    a, b, c = nets
+    call = lambda net, f, first: net(lr[:, window_indices(f, nframes, t)].to(dev), rf[:, window_indices(f, nframes, t)].to(dev), first)['result']
+    for f in range(2):
+        call(a, f, f == 0)
+    ea = a.Network.engine(0)
+    buf = ea.export_state_packed()
+    assert buf.numel() == ea.state_nbytes(64, 64) == 64 + 64 * 64 * (10 * 40 + 12)
+    st = ea.export_state()
+    assert st['keyframe_idx'] == [int(k) for k in ea.keyframe_idx] and st['feat'].shape[0] == 36
+    for net in (b, c):
+        call(net, 0, True)                                  # allocate the engines
+        net.Network.engine(0).reset_state()
+    eb, ec = b.Network.engine(0), c.Network.engine(0)
+    eb.import_state_packed(buf.clone())
+    ec.import_state({k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()})
+    for e in (eb, ec):
+        assert e.frame_itr_num == ea.frame_itr_num and [int(k) for k in e.keyframe_idx] == [int(k) for k in ea.keyframe_idx]
+        for k in ('fw_feat', 'fw_feat_up', 'fw_flow', 'fw_conf'):
+            assert torch.equal(getattr(ea, k), getattr(e, k)), k
+    want = call(a, 2, False)
+    assert torch.equal(want, call(b, 2, False)) and torch.equal(want, call(c, 2, False))

@@ -269,6 +269,45 @@ def test_resblock_chain_call(dev, n):
         assert rc != 0 and b'distinct' in lib.refvsr_last_error()
 
 
+@pytest.mark.parametrize('h,w,act,n', [(16, 32, 0.0, 1), (45, 83, 0.2, 2), (7, 5, 0.0, 3), (270, 480, 0.0, 3), (61, 130, 0.2, 1),
+                                     (540, 960, 0.2, 2), (8, 32, 0.0, 1), (9, 33, 0.2, 1)])
+def test_resblock24_chain(dev, h, w, act, n):
+    """refvsr_resblock24_chain (compile-time-specialised 24-channel kernel, weights as one blob per block) vs torch fp32 on
+    the same fp16-rounded maps, vs the runtime-generic lean kernel (same arithmetic up to fp32 summation order), with both
+    workgroup shapes (bit-identical), interior and border tiles, maps smaller than one tile."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    C = 24
+    g = torch.Generator().manual_seed(h * 7 + w)
+    raw, pairs = [], []
+    for _ in range(n):
+        ws = [torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5 for _ in range(2)]
+        bs = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+        raw.append(((ws[0], bs[0]), (ws[1], bs[1])))
+        pairs.append(tuple(ops.ConvWeights(pack_conv(ws[i], bs[i], [C]), dev) for i in range(2)))
+    x = torch.randn(C, h, w, generator=g)
+    xin = nhwc(x, dev)
+    x0 = xin.clone()
+    lib = ops.hip.lib()
+    lib.refvsr_set_resblock24_waves(8)
+    got = ops.resblock24_chain(ops.Resblock24Chain(pairs, dev), xin, act)      # blobs repacked from the kept raw weights
+    got_raw = ops.resblock24_chain(ops.Resblock24Chain(raw, dev), xin, act)
+    assert torch.equal(got, got_raw) and torch.equal(xin, x0)
+    lib.refvsr_set_resblock24_waves(4)
+    four = ops.resblock24_chain(ops.Resblock24Chain(raw, dev), xin, act)
+    lib.refvsr_set_resblock24_waves(8)
+    assert torch.equal(got, four), '4-wave and 8-wave workgroups differ'
+    want, lean = x.half().float(), xin
+    for ((w1, b1), (w2, b2)), (c1, c2) in zip(raw, pairs):
+        t = F.leaky_relu(F.conv2d(want[None], w1, b1, padding=1), act).half().float()
+        want = (want + F.conv2d(t, w2, b2, padding=1)[0]).half().float()
+        lean = ops.resblock(c1, c2, lean, act=act, kernel='lean')
+    e, d = rel(planar(got), want), maxdiff(planar(got), planar(lean))
+    report('resblock24 %dx%d act%.1f n%d' % (h, w, act, n), rel=e, vs_lean=d)
+    assert e < 1e-3 * n
+    assert d < 4e-3 * n            # fp16 ulps where the fp32 sums round differently (|x| < 8: ulp 4e-3 .. 8e-3)
+
+
 def test_conv_mfma_f32_mode(dev):
     """Exact-fp32 MFMA mode (v_mfma_f32_16x16x4_f32) used for the VGG feature extractor."""
     from refvsr_amd import ops

@@ -223,6 +223,7 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
     class E(object):
         _block_chain = engine.Engine._block_chain
         fuse_resblocks = True
+        rb24 = False                             # the generic kernels (the 24-channel kernel is dispatched below)
         chain_calls = False                      # per-block launches from Python
     e = E()
     for n in (1, 2, 5, 24):
@@ -238,6 +239,18 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
     out = e._block_chain(X((270, 480, 24)), pairs, 0.2)
     out2 = e._block_chain(X((270, 480, 24)), pairs, 0.2)
     assert out.hist == (('chain', tuple(pairs)),) and out2.hist == out.hist and len(calls) == 2 and len(e.W.chains) == 1
+    # 24-channel maps whose packed weights kept their fp32 originals go to the specialised kernel: one blob table per run
+    CW = collections.namedtuple('CW', 'name raw')
+    pairs24 = [(CW('a%d' % i, ('w', 'b')), CW('b%d' % i, ('w', 'b'))) for i in range(3)]
+    monkeypatch.setattr(ops, 'Resblock24Chain', lambda pairs, dev: ('rb24', tuple(pairs)))
+    monkeypatch.setattr(ops, 'resblock24_chain', lambda ch, x, act: X(x.shape, x.hist + (ch, act)))
+    e.rb24 = True
+    x24 = X((270, 480, 24))
+    x24.device = 'dev'
+    assert e._block_chain(x24, pairs24, 0.0).hist == (('rb24', tuple(pairs24)), 0.0) and len(e.W.chains) == 2
+    x48 = X((270, 480, 48))
+    assert e._block_chain(x48, pairs, 0.2).hist[0][0] == 'chain'            # other channel counts: the generic chain call
+    e.rb24 = False
     e.chain_calls = False
     e.fuse_resblocks = False
     want = tuple(x for a, b in pairs for x in ((a, 0.0, False), (b, 1.0, True)))
@@ -281,3 +294,150 @@ def test_split_fp16_dot_product_is_fp32_grade():
     assert e_split < 1e-6 and e_split < 1.5 * e_f32, (e_split, e_f32)
     assert e_16 > 20.0 * e_split, (e_16, e_split)              # the fp16 GEMM alone is two orders of magnitude coarser
 
+
+
+# ---- the 24-channel fused block (csrc/resblock24.hip): lane- and address-level numpy model of one workgroup ------------------
+def _rb24_model_tile(src, blob, h, w, ty0, tx0, relu, slope, nwv=8):
+    """One 8 x 32 output tile as resblock24_kernel computes it: the SAME byte offsets into a 64 000-byte LDS image, the same
+    K order, fragment rows, lane -> (row, pixel) maps and half-wave folds, written from the kernel's header comment and
+    constants.  What it pins: the blob layout of packing.pack_resblock24 and the address algebra (window bases, K-step
+    immediates, where t lands, where the residual is read, which lane stores which output channels).
+    Returns (t_writes {(row, col, ch) of the x tile: value}, out {(oy, ox, ch): value})."""
+    XW, IW, NI, PXB = 36, 34, 340, 48
+    ROWB, WB, BIAS, XT = XW * PXB, 21504, 43008, 43264
+    lds = np.zeros(64000, np.uint8)
+    lds[:43264] = blob
+    xt = np.zeros((12, XW, 24), np.float16)                       # x tile, zero padded
+    for r in range(12):
+        for c in range(XW):
+            iy, ix = ty0 - 2 + r, tx0 - 2 + c
+            if 0 <= iy < h and 0 <= ix < w:
+                xt[r, c] = src[iy, ix]
+    lds[XT:XT + xt.size * 2] = xt.reshape(-1).view(np.uint8)
+    f16 = lambda off, n: lds[off:off + 2 * n].view(np.float16).astype(np.float32)
+    f32 = lambda off, n: lds[off:off + 4 * n].view(np.float32).copy()
+    pix16 = lambda n: ((n & 7) << 1) if (n < 4 or n >= 12) else (((n - 4) << 1) | 1)
+    perm = (0, 2, 1, 3)
+    lanes = range(64)
+
+    def kloop(acc0, acc1, wofs, pb):           # acc*[lane] = 4 floats (rows 4q + i of column n); pb[lane] = window base
+        for s in range(7):
+            A = [np.stack([f16(wofs + (s * 3 + f) * 1024 + l * 16, 8) for l in lanes]) for f in range(3)]       # [64, 8]
+            B = np.stack([f16(pb[l] + ((s >> 1) * ROWB + (s & 1) * 64 if s < 6
+                                        else min(l >> 4, 2) * ROWB + 128 - perm[l >> 4] * 16), 8) for l in lanes])
+            for f, acc in ((0, acc0), (2, acc1), (1, acc0)):
+                D = np.zeros((16, 16), np.float32)                   # D[row][col] += A[row][k] B[k][col], k = 8 q + j
+                for qq in range(4):
+                    D += A[f][qq * 16:qq * 16 + 16] @ B[qq * 16:qq * 16 + 16].T
+                for l in lanes:
+                    for i in range(4):
+                        acc[l][i] += D[4 * (l >> 4) + i, l & 15]
+
+    fold = lambda acc: [[acc[l][i] + acc[l ^ 32][i] for i in range(4)] for l in lanes]
+    act = (lambda v: max(v, 0.0)) if relu else (lambda v: max(v, v * slope))
+    t1, rem, t2 = (22 + nwv - 1) // nwv, 22 % nwv, 16 // nwv
+    # ---- phase 1 (+ the residual reads, which happen before barrier A)
+    p1, xres = [], {}
+    for wave in range(nwv):
+        full = rem == 0 or wave < rem
+        g1 = wave * t1 if full else rem * t1 + (wave - rem) * (t1 - 1)
+        for t in range(t1 if full else t1 - 1):
+            pb, pixs = [], []
+            for l in lanes:
+                pix = min((g1 + t) * 16 + pix16(l & 15), NI - 1)
+                r = pix // IW
+                pb.append(XT + r * ROWB + (pix - r * IW) * PXB + perm[l >> 4] * 16)
+                pixs.append(pix)
+            a0 = [list(f32(BIAS + (l >> 4) * 16, 4)) for l in lanes]
+            a1 = [list(f32(BIAS + 64 + (l >> 4) * 16, 4)) for l in lanes]
+            kloop(a0, a1, 0, pb)
+            p1.append((pb, pixs, a0, fold(a1)))
+        oy0 = (wave * t2) >> 1
+        for t in range(t2):
+            for l in lanes:
+                q = l >> 4
+                pb2 = XT + (oy0 + (t >> 1) + 1) * ROWB + ((t & 1) * 16 + pix16(l & 15) + 1) * PXB + perm[q] * 16
+                dq = ROWB + PXB + q * 8 - perm[q] * 16
+                xres[(wave, t, l)] = (pb2, f16(pb2 + dq, 4), f16(pb2 + dq + 32 if q < 2 else BIAS + 96, 4))
+    # ---- barrier A; t over the x tile
+    t_writes = {}
+    for pb, pixs, a0, a1 in p1:
+        for l in lanes:
+            q = l >> 4
+            r = pixs[l] // IW
+            iy, ix = ty0 - 1 + r, tx0 - 1 + (pixs[l] - r * IW)
+            keep = 0 <= iy < h and 0 <= ix < w
+            for acc, extra in ((a0, 0), (a1, 32)):
+                if extra and q >= 2:
+                    continue
+                v = np.array([act(np.float32(x)) if keep else 0.0 for x in acc[l]], np.float32).astype(np.float16)
+                o = pb[l] + (ROWB + PXB + q * 8 - perm[q] * 16) + extra
+                lds[o:o + 8] = v.view(np.uint8)
+                rel = o - XT
+                for i in range(4):
+                    t_writes[(rel // ROWB, (rel % ROWB) // PXB, (rel % PXB) // 2 + i)] = float(v[i])
+    # ---- barrier B; phase 2
+    out = {}
+    for wave in range(nwv):
+        oy0 = (wave * t2) >> 1
+        for t in range(t2):
+            pb = [xres[(wave, t, l)][0] for l in lanes]
+            c0 = [list(f32(BIAS + 128 + (l >> 4) * 16, 4) + xres[(wave, t, l)][1]) for l in lanes]
+            c1 = [list(f32(BIAS + 192 + (l >> 4) * 16, 4) + xres[(wave, t, l)][2]) for l in lanes]
+            kloop(c0, c1, WB, pb)
+            c1 = fold(c1)
+            for l in lanes:
+                q = l >> 4
+                oy, ox = ty0 + oy0 + (t >> 1), tx0 + (t & 1) * 16 + pix16(l & 15)
+                if oy >= h or ox >= w:
+                    continue
+                for i in range(4):
+                    out[(oy, ox, 4 * q + i)] = float(np.float16(c0[l][i]))
+                    if q < 2:
+                        out[(oy, ox, 16 + 4 * q + i)] = float(np.float16(c1[l][i]))
+    return t_writes, out
+
+
+@pytest.mark.parametrize('relu', [True, False])
+def test_resblock24_blob_and_address_model(relu):
+    """packing.pack_resblock24 + the address algebra of csrc/resblock24.hip reproduce a 24-channel residual block on tiles that
+    touch every frame border (13 x 40 frame: partial last tile row, partial last tile column); the K-block table equals the
+    library's."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import pack_resblock24, rb24_kblock
+    lib = hip.lib()
+    seen = set()
+    for s in range(7):
+        for q in range(4):
+            kb, v = rb24_kblock(s, q), lib.refvsr_resblock24_kblock(s, q)
+            assert v == (-1 if kb is None else (kb[0] << 16 | kb[1] << 8 | kb[2]))
+            seen.add(kb)
+    assert len(seen - {None}) == 27 and lib.refvsr_resblock24_kblock(7, 0) == -2
+    g = torch.Generator().manual_seed(5)
+    C, h, w = 24, 13, 40
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    blob = pack_resblock24(w1, b1, w2, b2).numpy()
+    assert blob.shape == (hip.RESBLOCK24_BLOB_BYTES,)
+    x = torch.randn(C, h, w, generator=g).half()
+    src = x.permute(1, 2, 0).contiguous().numpy()                   # HWC fp16
+    slope = 0.0 if relu else 0.2
+    t_ref = F.leaky_relu(F.conv2d(x.float()[None], w1, b1, padding=1), slope)
+    o_ref = (x.float() + F.conv2d(t_ref.half().float(), w2, b2, padding=1)[0])
+    t_ref = t_ref[0]
+    covered = set()
+    for ty0, tx0 in ((0, 0), (8, 32), (8, 0)):
+        tw, out = _rb24_model_tile(src, blob, h, w, ty0, tx0, relu, slope)
+        assert len(tw) == 10 * 34 * 24                               # the whole 10 x 34 intermediate, every channel once
+        worst = 0.0
+        for (r, c, ch), v in tw.items():
+            assert 1 <= r <= 10 and 1 <= c <= 34
+            iy, ix = ty0 - 2 + r, tx0 - 2 + c                        # x-tile coordinates -> frame
+            want = float(t_ref[ch, iy, ix]) if (0 <= iy < h and 0 <= ix < w) else 0.0
+            worst = max(worst, abs(v - want))
+        assert worst < 4e-3, worst                                   # fp16 rounding of t (|t| <~ 4)
+        for (oy, ox, ch), v in out.items():
+            assert abs(v - float(o_ref[ch, oy, ox])) < 8e-3, (oy, ox, ch, v, float(o_ref[ch, oy, ox]))
+            covered.add((oy, ox, ch))
+    assert len(covered) == (13 * 32 + 5 * 8) * 24                    # tiles (0,0), (1,0) whole, (1,1): 5 rows x 8 columns
