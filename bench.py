@@ -151,11 +151,12 @@ def kernel_rooflines(cfg, eng, h, w, dev):
     c1, c2 = pair('backward_resblocks.main.2.%d' % (nb // 2))
     d1, d2 = pair('feat_decoder2.RBs.1')
     rb_flops = lambda px: 2 * 2.0 * 9 * C * C * px
-    rb_bytes = lambda px: 2.0 * px * C * 2 + 2 * (c1.wpack.numel() * 2)
-    if eng.fuse_resblocks:
-        add('resblock_fused LR (backward_resblocks)', lambda: ops.resblock(c1, c2, x_lr, act=0.0), rb_flops(h * w), rb_bytes(h * w), 'mfma',
+    rb24 = eng.fuse_resblocks and eng.rb24 and C == 24
+    rb_bytes = lambda px: 2.0 * px * C * 2 + (43264 if rb24 else 2 * (c1.wpack.numel() * 2))
+    if eng.fuse_resblocks:      # through the engine's own dispatch: the kernel the frame uses (resblock24 for C = 24)
+        add('resblock_fused LR (backward_resblocks)', lambda: eng._block_chain(x_lr, [(c1, c2)], 0.0), rb_flops(h * w), rb_bytes(h * w), 'mfma',
             'resblock LR')
-        add('resblock_fused 2x (feat_decoder2)', lambda: ops.resblock(d1, d2, x_2x, act=0.2), rb_flops(4 * h * w), rb_bytes(4 * h * w), 'mfma',
+        add('resblock_fused 2x (feat_decoder2)', lambda: eng._block_chain(x_2x, [(d1, d2)], 0.2), rb_flops(4 * h * w), rb_bytes(4 * h * w), 'mfma',
             'resblock 2x')
     cw = eng.cw('conv_hr')
     x_hr = rnd16(4 * h, 4 * w, C)
@@ -176,6 +177,67 @@ def kernel_rooflines(cfg, eng, h, w, dev):
     return out
 
 
+def wavefront_model(per_frame, nfr, reset_branch):
+    """serial_fraction and predicted strong-scaling speedups of shard.run_wavefront from measured per-frame phase times
+    (shard.predicted_speedup: makespan model, hand-off 0.3 ms = 33 MB over one xGMI link + latency)."""
+    from refvsr_amd import shard
+    ta, tb1, tb2 = per_frame['phase_a_ms'], per_frame['phase_b1_ms'], per_frame['phase_b2_ms']
+    tot = ta + tb1 + tb2
+    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'handoff_ms_assumed': 0.3, 'predicted_speedup': {}}
+    for n in (2, 4, 8):
+        hyb = shard.partition_hybrid(nfr, n, reset_branch) if reset_branch else shard.partition(nfr, n)
+        bal = shard.partition(nfr, n)
+        out['predicted_speedup'][str(n)] = {
+            'hybrid_reset_aligned_partition': round(shard.predicted_speedup(nfr, n, hyb, reset_branch, ta, tb1, tb2, 0.3)[0], 3),
+            'balanced_partition_handoff_at_every_boundary': round(shard.predicted_speedup(nfr, n, bal, reset_branch, ta, tb1, tb2, 0.3)[0], 3),
+            'no_reset_balanced (reset_branch=None, configs[4] regime)': round(shard.predicted_speedup(nfr, n, bal, None, ta, tb1, tb2, 0.3)[0], 3)}
+    return out
+
+
+def wavefront_model_single_gpu(args, dev, h, w):
+    """N = 1: the phases of BASELINE configs[3] (config_RefVSR_small_MFID, reset_branch 9) timed on this GPU over one restart
+    unit, and the speedups the makespan model predicts for 2 / 4 / 8 ranks -- no multi-GPU box needed for the prediction, the
+    driver's SCALE run measures the real thing."""
+    from refvsr_amd import SRNet, get_config, make_state_dict
+    from refvsr_amd.synth import make_clip, window_indices
+    name = 'config_RefVSR_small_MFID'
+    cfg = get_config('bench', 'bench', name)
+    cfg.frame_num = t = 5
+    R = cfg.reset_branch
+    nfr = R + 1
+    net = SRNet(cfg).to(dev).eval()
+    net.load_state_dict(make_state_dict(cfg, 1234))
+    lr, rf, _ = make_clip(nfr, h, w, seed=0)
+    lr, rf = lr.to(dev), rf.to(dev)
+    N = net.Network
+    acc = [0.0, 0.0, 0.0]
+    for rep in range(2):                                   # first repetition = warm-up
+        N.reset()
+        acc = [0.0, 0.0, 0.0]
+        for f in range(nfr - 1):                           # frames 0 .. R-1: one restart unit (incl. its first-frame call)
+            wi = torch.tensor(window_indices(f, nfr, t), device=dev)
+            x, r = lr[wi][None].contiguous(), rf[wi][None].contiguous()
+            ids = window_indices(f, nfr, t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hnd = N.phase_a(x, r, frame_ids=ids, first_hint=(f == 0))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            N.phase_b1(hnd, f == 0)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            N.phase_b2(hnd)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            acc = [acc[0] + t1 - t0, acc[1] + t2 - t1, acc[2] + t3 - t2]
+    per_frame = {'phase_a_ms': 1e3 * acc[0] / (nfr - 1), 'phase_b1_ms': 1e3 * acc[1] / (nfr - 1), 'phase_b2_ms': 1e3 * acc[2] / (nfr - 1)}
+    out = {'workload': '%s %dx%d, frame_num=5, reset_branch=%d: phases of one restart unit (9 frames, host-synchronised per phase) on one GPU; '
+                       'prediction for a 64-frame clip (BASELINE configs[3])' % (name, h, w, R),
+           'phase_ms_per_frame_measured': per_frame}
+    out.update(wavefront_model(per_frame, 64, R))
+    return out
+
+
 def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     """BASELINE configs[3]: an args.clip-frame clip of config_RefVSR_small_MFID (reset_branch = 9), sharded by frame index
     over the ranks with the forward-state hand-off (RCCL send/recv of one packed fp16 buffer per shard boundary)."""
@@ -187,7 +249,11 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     nfr = args.clip
     net = SRNet(cfg).to(dev).eval()
     net.load_state_dict(make_state_dict(cfg, 1234))
-    start, end = shard.partition(nfr, world)[rank]
+    # reset-aligned shards need no hand-off; the short tail is re-balanced over the last two ranks so that ONE boundary still
+    # lies inside a restart unit and the RCCL hand-off is exercised and timed (shard.partition_hybrid); reset_branch = None
+    # (configs[4]) falls back to the balanced partition with a hand-off at every boundary
+    parts = shard.partition_hybrid(nfr, world, cfg.reset_branch) if cfg.reset_branch else shard.partition(nfr, world)
+    start, end = parts[rank]
     lo, hi = max(start - t // 2, 0), min(end + t // 2, nfr)
     lr, rf, _ = make_clip(hi - lo, h, w, seed=0, start=lo)          # this rank's frames (+ input halo), resident in HBM
     lr, rf = lr.to(dev), rf.to(dev)
@@ -207,7 +273,8 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev)
+    tim = {}
+    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=parts, timings=tim)
     torch.cuda.synchronize()
     dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
@@ -218,6 +285,10 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
         rd = r.double()
         sums[f, 0], sums[f, 1] = rd.sum().to(comm_dev), (rd * rd).sum().to(comm_dev)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    # per-rank phase times (host clock after device synchronisation at the phase ends) -> rank 0
+    ph = torch.zeros(world, 4, dtype=torch.float64, device=comm_dev)
+    ph[rank] = torch.tensor([tim.get('phase_a', 0.0), tim.get('phase_b1', 0.0), tim.get('phase_b2', 0.0), float(end - start)], dtype=torch.float64)
+    dist.all_reduce(ph, op=dist.ReduceOp.SUM)
     out = None
     if rank == 0:
         ncheck = min(nfr, args.clip_check)
@@ -231,14 +302,20 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
             r = net(lr0[wi][None], rf0[wi][None], f == 0)['result'][0].double()
             ok = ok and float(r.sum()) == float(sums[f, 0]) and float((r * r).sum()) == float(sums[f, 1])
         C = cfg.mid_channels
-        out = {'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
+        ph = ph.cpu()
+        nloc = ph[:, 3].clamp(min=1.0)
+        per_frame = {'phase_a_ms': float((ph[:, 0] / nloc).mean() * 1e3), 'phase_b1_ms': float((ph[:, 1] / nloc).mean() * 1e3),
+                     'phase_b2_ms': float((ph[:, 2] / nloc).mean() * 1e3)}
+        model = wavefront_model(per_frame, nfr, cfg.reset_branch)
+        out = {'partition': [list(p_) for p_ in parts], 'phase_ms_per_frame_measured': per_frame, 'model': model, 'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
                            '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
                'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
-               'schedule': 'phase A (flows, matching, encoders, alignment, backward branch) of all frames concurrently on all ranks; '
-                           'phase B (forward-branch step + upsampler) rank 0 -> 1 -> ... behind the hand-off',
-               'handoff': {'backend': backend, 'messages': sum(1 for r in range(1, world) if shard.needs_handoff(shard.partition(nfr, world)[r][0], cfg.reset_branch)),
+               'schedule': 'phase A (flows, matching, encoders, alignment, backward branch) of all local frames concurrently on all ranks; '
+                           'B1 (forward-branch steps) along the hand-off chain, state sent right after the last B1; B2 (BW/FW fusion + '
+                           'upsampler) of all local frames afterwards, off the chain',
+               'handoff': {'backend': backend, 'messages': sum(1 for r in range(1, world) if parts[r][1] > parts[r][0] and shard.needs_handoff(parts[r][0], cfg.reset_branch)),
                            'bytes_per_message': 64 + h * w * (10 * C + 12), 'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
-                           'overlap': 'isend issued when the last frame\'s state is final, under its upsampler'},
+                           'overlap': 'isend issued after the last forward-branch step, under the upsamplers'},
                'frames_checked_against_single_rank_run': ncheck, 'frames_equal': bool(ok)}
     dist.barrier()
     return out
@@ -330,7 +407,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        eng.kernel_events = [] if collect_events else None                           # HIP events around the dominant kernel
+        eng.kernel_events = [] if collect_events else None                           # HIP events around match_top2 ...
+        eng.chain_events = [] if collect_events else None                            # ... and around the fused-ResBlock runs
         t0 = time.perf_counter()
         for f in range(args.warmup, nfr):
             out = step(f)
@@ -344,8 +422,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         assert bool(torch.isfinite(out).all())
-        ev = eng.kernel_events
-        eng.kernel_events = None
+        ev = (eng.kernel_events, eng.chain_events)
+        eng.kernel_events = eng.chain_events = None
         net.Network.set_pipelined(False)
         return elapsed, ev
 
@@ -393,7 +471,34 @@ def main():
                                     'output; arg-max decided at fp32 accuracy (fp16 GEMM top-2 + fp32 re-rank + split-fp16 search of ambiguous columns)'},
             'dropin_surface': dropin,
         }
-        # ---- roofline of the dominant kernel (match_top2) from the events recorded in the timed region
+        # ---- rooflines from the HIP events recorded in the timed region.  `roofline` = the time-dominant kernel: the fused
+        # 24-channel ResBlock (resblock24_kernel, 156 launches per frame, ~29 % of the device time; events bracket every run of
+        # >= 8 blocks on the LR map, duration / blocks = per-launch time incl. the gaps between the launches of a run);
+        # `roofline_match_top2` = the matching GEMM (one launch per frame, ~14 %).  Configurations whose blocks do not run on
+        # that kernel (C = 48) report the matching kernel as `roofline`.
+        ev, cev = ev if ev else (None, None)
+        rb_line = None
+        runs = [(a.elapsed_time(b), n) for a, b, n, hh, ww in (cev or []) if (hh, ww) == (H, W_) and n >= 8]
+        if runs:
+            per_launch_ms = sum(m for m, _ in runs) / sum(n for _, n in runs)
+            C_ = cfg.mid_channels
+            flops = 2 * 2.0 * 9 * C_ * C_ * H * W_
+            ach = flops / (per_launch_ms * 1e-3) / 1e12
+            traffic, tsrc = None, None
+            pj = os.path.join(ROOT, 'profiles', 'pmc_kernels.json')
+            if os.path.exists(pj) and (H, W_) == (270, 480):
+                try:
+                    traffic = json.load(open(pj)).get('traffic_bytes_per_launch', {}).get('resblock LR')
+                    tsrc = 'profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
+                except Exception:  # noqa: BLE001
+                    traffic = None
+            rb_line = {'kernel': 'resblock24_kernel (fused conv3x3-ReLU-conv3x3+residual, 24 channels, LR map %dx%d)' % (H, W_), 'bound': 'mfma',
+                       'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
+                       'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': sum(n for _, n in runs),
+                       'mean_launch_ms': per_launch_ms, 'flops_per_launch': flops,
+                       'issued_over_useful_flops': 798.0 * 16384 / (2 * 2.0 * 9 * C_ * C_ * 256),
+                       'note': 'useful FLOPs (2 x 9 x 24 x 24 x 2 convs per pixel); the kernel issues 2.46x that on the matrix pipe: x2 hi + lo '
+                               'weight halves (48 rows in 3 fragments), x1.19 the 10 x 34 halo region of conv1, x1.04 K = 216 padded to 224'}
         ms = [a.elapsed_time(b) for a, b in (ev or [])]
         if ms:
             mean_ms = sum(ms) / len(ms)
@@ -409,12 +514,13 @@ def main():
                     tsrc = 'profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
                 except Exception:  # noqa: BLE001
                     traffic = None
-            line['roofline'] = {'kernel': 'match_top2_kernel (fused cosine GEMM + column top-2)', 'bound': 'mfma',
-                                'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
-                                'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': len(ms),
-                                'mean_launch_ms': mean_ms, 'flops_per_launch': flops}
+            line['roofline_match_top2'] = {'kernel': 'match_top2_kernel (fused cosine GEMM + column top-2)', 'bound': 'mfma',
+                                           'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
+                                           'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': len(ms),
+                                           'mean_launch_ms': mean_ms, 'flops_per_launch': flops}
         else:
-            line['roofline'] = None
+            line['roofline_match_top2'] = None
+        line['roofline'] = rb_line if rb_line is not None else line['roofline_match_top2']
         line['first_frame_ms'] = first_ms
         sv = SURVEY_DEDUP_TFLOP.get(args.config) if (H, W_, T) == (270, 480, 5) else None
         line['whole_path'] = {
@@ -429,6 +535,11 @@ def main():
                 line['kernels'] = kernel_rooflines(cfg, eng, H, W_, dev)
             except Exception as e:  # noqa: BLE001
                 line['kernels'] = {'error': repr(e)[:300]}
+        if world == 1 and not args.no_wavefront and (H, W_) == (270, 480):
+            try:
+                line['wavefront_model'] = wavefront_model_single_gpu(args, dev, H, W_)
+            except Exception as e:  # noqa: BLE001
+                line['wavefront_model'] = {'error': repr(e)[:300]}
     if world > 1 and not args.no_wavefront:
         # The extra leg must never take the headline number down: if it has not returned within the deadline (a hung
         # send / recv, a rank that died) every rank leaves through a watchdog, rank 0 after printing the line.

@@ -582,7 +582,18 @@ class OracleNetwork(object):
         return dict(lrs=lrs, refs=refs, ff=ff, bf=bf, conf_maps=conf_maps, index_maps=index_maps,
                     bw_up=feat_up, conf_bw=conf)
 
-    def phase_b(self, pa, is_first_frame, is_log=False, trace=None):
+    def phase_b1(self, pa, is_first_frame):
+        """Forward-branch step only (:240-283, :292-295): the serial part of phase_b."""
+        return self.phase_b(pa, is_first_frame, stop_after_forward_branch=True)
+
+    def phase_b2(self, pa):
+        """BW/FW fusion + upsampler (:288-297) of a frame whose phase_b1 has run."""
+        ctr = pa['lrs'].shape[1] // 2
+        base = bicubic_scale(pa['lrs'][:, ctr], self.scale, clamp=True)
+        out = self._compute_up(pa['bw_up'], pa['fw_up'], pa['conf_bw'], pa['conf_fw'], base).clamp(0, 1)
+        return collections.OrderedDict(result=out)
+
+    def phase_b(self, pa, is_first_frame, is_log=False, trace=None, stop_after_forward_branch=False):
         """State-dependent rest: forward branch (:240-283), BW/FW fusion + upsampler (:288-297)."""
         W = self.W
         lrs, refs, ff, conf_maps, index_maps = pa['lrs'], pa['refs'], pa['ff'], pa['conf_maps'], pa['index_maps']
@@ -625,11 +636,14 @@ class OracleNetwork(object):
                 self.forward_flow_prev = ff[i].clone() if i < t - 1 else None
                 self.forward_feat_prop_UP_prev = feat_up.clone()
                 self.forward_conf_map_prop_prev = conf.clone()
-        base = bicubic_scale(lrs[:, ctr], self.scale, clamp=True)            # :288
-        out = self._compute_up(bw_up, feat_up, conf_bw, conf, base)
         if is_first_frame:                                                   # :292-295
             self.frame_itr_num = 0
         self.frame_itr_num += 1
+        if stop_after_forward_branch:      # phase_b1 (multi-GPU wavefront test): the carried state is final here
+            pa['fw_up'], pa['conf_fw'] = feat_up, conf
+            return pa
+        base = bicubic_scale(lrs[:, ctr], self.scale, clamp=True)            # :288
+        out = self._compute_up(bw_up, feat_up, conf_bw, conf, base)
         out = out.clamp(0, 1)
         outs = collections.OrderedDict()
         outs['result'] = out

@@ -58,6 +58,8 @@ struct RB24Args {
     const unsigned char* src; unsigned char* out; const unsigned char* blob;
     int h, w, tiles_x, n_tiles, grid;
     float act_slope;
+    unsigned long long* probe;           // PROBE kernels: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
+    int probe_iter;                      // which tile iteration of the workgroup is stamped
 };
 
 // lane l: a[l] + a[l ^ 32]   (v_mov, v_permlane32_swap, v_add per register).  The two results are taken out of the builtin's
@@ -150,8 +152,13 @@ __device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
 
 // NWV = waves per workgroup (8: three + two pixel groups per wave, <= 128 VGPRs, four waves per SIMD with the two workgroups
 // of a CU; 4: six + four groups per wave, twice the weight-fragment reuse, two waves per SIMD).
-template <bool RELU, int NWV>
+template <bool RELU, int NWV, bool PROBE = false>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 2, NWV / 2))) void resblock24_kernel(RB24Args p) {
+    // PROBE: stamps 0 entry, 1 prologue loads issued, 2 first barrier passed; of tile `probe_iter`: 3 conv1 K loop done, 4 fold +
+    // barrier A, 5 t written (+ next tile's loads issued), 6 barrier B, 7 conv2 K loop done, 8 barrier C + next tile parked,
+    // 9 stores issued, 10 barrier D; 11 exit ([8]/[10] = previous stamp when there is no next tile)
+#define RB_STAMP(i) do { if constexpr (PROBE) { if (p.probe && threadIdx.x == 0) p.probe[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    RB_STAMP(0);
     constexpr int NT = NWV * 64;
     constexpr int T1 = (RB_G1 + NWV - 1) / NWV;                  // phase-1 groups of a "full" wave (3 | 6)
     constexpr int T1REM = RB_G1 % NWV;                           // waves below this index are full, the others have T1 - 1
@@ -181,35 +188,20 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
                                              (__attribute__((address_space(3))) void*)(smem + NCH * 1024), 16, 0, 0);
     }
 
-    // ---- per-lane constants ---------------------------------------------------------------------------------------------
-    const int q = lane >> 4;
-    const int lp = rv_pix16(lane & 15);                          // pixel of a 16-pixel group held by this lane's MFMA column
-    const int permq = ((q & 1) << 1) | (q >> 1);                 // {0, 2, 1, 3}
-    const int la = lane * 16;
-    const int delta6 = min(q, 2) * RB_ROWB + 128 - permq * 16;   // K-step 6 (u = 8 of window row q) relative to a window base
-    const int dq = RB_ROWB + RB_PXB + q * 8 - permq * 16;        // channels 4q.. of the window's centre pixel, same base
-    const bool full1 = T1REM == 0 || wave < T1REM;
-    const int g1 = full1 ? wave * T1 : T1REM * T1 + (wave - T1REM) * (T1 - 1);
-    int pb1[T1];                                                 // phase 1: LDS byte offset of each group's window origin (+ permq slot)
-#pragma unroll
-    for (int t = 0; t < T1; ++t) {
-        const int pix = min((g1 + t) * 16 + lp, RB_NI - 1);      // lanes past the region repeat its last pixel (same value, same address)
-        const int r = pix / RB_IW;
-        pb1[t] = RB_XT + r * RB_ROWB + (pix - r * RB_IW) * RB_PXB + permq * 16;
-    }
-    const int oy0 = (wave * T2) >> 1;                            // first output row of this wave
-    int pb2[T2];                                                 // phase 2 windows: one VGPR + immediates
-#pragma unroll
-    for (int t = 0; t < T2; ++t)
-        pb2[t] = RB_XT + (oy0 + (t >> 1) + 1) * RB_ROWB + ((t & 1) * 16 + lp + 1) * RB_PXB + permq * 16;
     const int rowb_g = p.w * RB_PXB;                             // bytes per row of the HWC maps
-    const unsigned oo = (unsigned)(oy0 * rowb_g + lp * RB_PXB + q * 8);   // output offset of group 0 relative to the tile origin
-    unsigned xg[KCH];                                            // x-tile chunk k of this thread: global offset relative to the tile origin
+    // ---- first: the loads.  x-tile chunk k of this thread = 16 bytes at tile row r, row chunk cr (i = tid + k NT = r 108 + cr):
+    // global offset relative to the tile origin, computed once (one division, then i += NT = A 108 + B steps)
+    unsigned xg[KCH];
+    {
+        constexpr int A = NT / RB_RCH, B = NT % RB_RCH;
+        int r = tid / RB_RCH, cr = tid - (tid / RB_RCH) * RB_RCH;
 #pragma unroll
-    for (int k = 0; k < KCH; ++k) {
-        const int i = min(tid + k * NT, RB_XCH - 1);
-        const int r = i / RB_RCH;
-        xg[k] = (unsigned)(r * rowb_g + (i - r * RB_RCH) * 16);
+        for (int k = 0; k < KCH; ++k) {
+            xg[k] = (unsigned)(min(r, RB_XH - 1) * rowb_g + cr * 16);     // (threads past the tile: a valid address, value dropped)
+            const bool wrap = cr + B >= RB_RCH;
+            r += A + (wrap ? 1 : 0);
+            cr += B - (wrap ? RB_RCH : 0);
+        }
     }
     uint4 xv[KCH];
     // tile origin (top-left pixel of the x tile) may lie outside the frame: only in-frame chunks are dereferenced
@@ -251,10 +243,38 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
 
     int tl, k_hi;
     rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
-    if (tl < k_hi) { x_fetch(tl); x_park(); }
-    __syncthreads();                                             // weights, biases, first tile
+    if (tl < k_hi) x_fetch(tl);
+    __builtin_amdgcn_sched_barrier(0);                           // weights and first tile in flight before the rest of the set-up
+    RB_STAMP(1);
 
-    for (; tl < k_hi; ++tl) {
+    // ---- per-lane constants ---------------------------------------------------------------------------------------------
+    const int q = lane >> 4;
+    const int lp = rv_pix16(lane & 15);                          // pixel of a 16-pixel group held by this lane's MFMA column
+    const int permq = ((q & 1) << 1) | (q >> 1);                 // {0, 2, 1, 3}
+    const int la = lane * 16;
+    const int delta6 = min(q, 2) * RB_ROWB + 128 - permq * 16;   // K-step 6 (u = 8 of window row q) relative to a window base
+    const int dq = RB_ROWB + RB_PXB + q * 8 - permq * 16;        // channels 4q.. of the window's centre pixel, same base
+    const bool full1 = T1REM == 0 || wave < T1REM;
+    const int g1 = full1 ? wave * T1 : T1REM * T1 + (wave - T1REM) * (T1 - 1);
+    int pb1[T1];                                                 // phase 1: LDS byte offset of each group's window origin (+ permq slot)
+#pragma unroll
+    for (int t = 0; t < T1; ++t) {
+        const int pix = min((g1 + t) * 16 + lp, RB_NI - 1);      // lanes past the region repeat its last pixel (same value, same address)
+        const int r = pix / RB_IW;
+        pb1[t] = RB_XT + r * RB_ROWB + (pix - r * RB_IW) * RB_PXB + permq * 16;
+    }
+    const int oy0 = (wave * T2) >> 1;                            // first output row of this wave
+    int pb2[T2];                                                 // phase 2 windows: one VGPR + immediates
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+        pb2[t] = RB_XT + (oy0 + (t >> 1) + 1) * RB_ROWB + ((t & 1) * 16 + lp + 1) * RB_PXB + permq * 16;
+    const unsigned oo = (unsigned)(oy0 * rowb_g + lp * RB_PXB + q * 8);   // output offset of group 0 relative to the tile origin
+    if (tl < k_hi) x_park();
+    __syncthreads();                                             // weights, biases, first tile
+    RB_STAMP(2);
+
+    for (int iter = 0; tl < k_hi; ++tl, ++iter) {
+        const bool stamp = PROBE && iter == p.probe_iter;
         const bool has_next = tl + 1 < k_hi;
         const int tyi = tl / p.tiles_x;
         const int ty0 = tyi * RB_TH, tx0 = (tl - tyi * p.tiles_x) * RB_TW;
@@ -270,6 +290,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
         }
         if (full1) rb_kloop<T1, T1>(a0, a1, smem, 0, la, pb1, delta6);
         else rb_kloop<T1 - 1, T1>(a0, a1, smem, 0, la, pb1, delta6);
+        if (stamp) RB_STAMP(3);
+        if (has_next) x_fetch(tl + 1);                           // next tile: in flight from here to the end of conv2
         // residual x values of this lane's outputs: the x tile is about to be overwritten by t
         f16x4 xr0[T2], xr1[T2];
 #pragma unroll
@@ -281,6 +303,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
 #pragma unroll
         for (int t = 0; t < T1; ++t) a1[t] = rb_fold_halves(a1[t]);
         __syncthreads();                                         // A: every wave is done reading the x tile
+        if (stamp) RB_STAMP(4);
         // t = act(acc), zero outside the frame (conv2's zero padding), written over the x tile at (+1, +1)
         auto epi1 = [&](auto tc) {
             constexpr int T = decltype(tc)::value;
@@ -303,8 +326,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
             }
         };
         if (full1) epi1(std::integral_constant<int, T1>{}); else epi1(std::integral_constant<int, T1 - 1>{});
-        if (has_next) x_fetch(tl + 1);                           // in flight during conv2
+        if (stamp) RB_STAMP(5);
         __syncthreads();                                         // B: t complete
+        if (stamp) RB_STAMP(6);
 
         // ---------------- phase 2: out = (b2 + x) + conv2(t): the accumulators start as bias + residual ------------------------
         f32x4 c0[T2], c1[T2];
@@ -319,10 +343,12 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
             }
         }
         rb_kloop<T2, T2>(c0, c1, smem, RB_WB, la, pb2, delta6);
+        if (stamp) RB_STAMP(7);
         if (has_next) {
             __syncthreads();                                     // C: every wave is done reading t
             x_park();
         }
+        if (stamp) RB_STAMP(8);
         {
             unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
 #pragma unroll
@@ -342,9 +368,16 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
                 }
             }
         }
+        if (stamp) RB_STAMP(9);
         if (has_next) __syncthreads();                           // D: next x tile visible
+        if (stamp) RB_STAMP(10);
     }
+    RB_STAMP(11);
+#undef RB_STAMP
 }
+
+extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
+extern int g_rb_probe_iter;
 
 static int g_rb24_waves = 8;                 // A/B knob (refvsr_set_resblock24_waves): 4 or 8 waves per workgroup
 extern "C" int refvsr_set_resblock24_waves(int waves) {
@@ -353,23 +386,23 @@ extern "C" int refvsr_set_resblock24_waves(int waves) {
     return 0;
 }
 
-template <bool RELU, int NWV>
+template <bool RELU, int NWV, bool PROBE = false>
 static int launch_rb24(RB24Args& a, hipStream_t st) {
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV>, NWV * 64, RB_LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE>, NWV * 64, RB_LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
+    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -400,7 +433,9 @@ extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, con
         unsigned char* dst = (unsigned char*)((i == n - 1) ? out : ((i & 1) ? scratch1 : scratch0));
         a.src = cur; a.out = dst; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
         int rc;
-        if (act_slope == 0.f) rc = g_rb24_waves == 8 ? launch_rb24<true, 8>(a, st) : launch_rb24<true, 4>(a, st);
+        a.probe = g_rb_probe; a.probe_iter = g_rb_probe_iter;
+        if (g_rb_probe && act_slope == 0.f && g_rb24_waves == 8) rc = launch_rb24<true, 8, true>(a, st);   // tools/probe_resblock.py
+        else if (act_slope == 0.f) rc = g_rb24_waves == 8 ? launch_rb24<true, 8>(a, st) : launch_rb24<true, 4>(a, st);
         else rc = g_rb24_waves == 8 ? launch_rb24<false, 8>(a, st) : launch_rb24<false, 4>(a, st);
         if (rc) return rc;
         cur = dst;

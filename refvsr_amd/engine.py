@@ -173,6 +173,7 @@ class Engine(object):
         self._pipe = None
         self._inflight = collections.deque()
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
+        self.chain_events = None       # bench.py: list collecting (start, end, blocks, h, w) of the fused-ResBlock runs
         self.reset_state()
 
     # ------------------------------------------------------------------ state
@@ -290,7 +291,14 @@ class Engine(object):
             ch = chains.get(key)
             if ch is None:
                 ch = chains[key] = ops.Resblock24Chain(pairs, x.device)
-            return ops.resblock24_chain(ch, x, act)
+            if self.chain_events is None:
+                return ops.resblock24_chain(ch, x, act)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = ops.resblock24_chain(ch, x, act)
+            e1.record()
+            self.chain_events.append((e0, e1, len(pairs), x.shape[0], x.shape[1]))
+            return out
         if self.fuse_resblocks and self.chain_calls and ops.resblock_chain_ok(x.shape[2]):
             # one library call per run (same launches, same results): 156 of the ~330 launches of a frame
             chains = self.W.chains
@@ -786,11 +794,11 @@ class Engine(object):
         return dict(fr=fr, flows=flows, zero_flow=zero_flow, bw_up=bw_up, conf_bw=conf_bw, t=t, h=h, w=w)
 
     @torch.no_grad()
-    def phase_b(self, pa, is_first_frame, want_vis=False, after_state=None):
-        """The state-dependent rest of forward(): forward-branch step (RefVSR.py:240-283) + BW/FW fusion and upsampler
-        (:288-297).  Must be called in frame order; (phase_a, phase_b) of a frame == forward() of that frame.
-        after_state: callable invoked once the carried state of this frame is final (before the upsampler is enqueued) --
-        the multi-GPU wavefront starts its hand-off send there, under the upsampler."""
+    def phase_b1(self, pa, is_first_frame):
+        """The state-dependent SERIAL part of forward(): the forward-branch step (RefVSR.py:240-283) and the iteration
+        counter (:292-295).  Must be called in frame order; leaves the step's outputs in the handle for phase_b2.  The
+        multi-GPU wavefront runs B1 of all local frames, hands the state over, and only then runs the upsamplers (B2), so
+        that the serial chain over the ranks carries nothing but the forward-branch steps."""
         fr, t, h, w = pa['fr'], pa['t'], pa['h'], pa['w']
         ctr = t // 2
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
@@ -810,21 +818,38 @@ class Engine(object):
             if is_first_frame:
                 for i in range(0, ctr):
                     self.prepare_frame(fr[i])                  # no-op when phase A had the hint
-            feat, feat_up, conf = self._forward_branch(fr, flow, t, h, w, is_first_frame)
+            _, feat_up, conf = self._forward_branch(fr, flow, t, h, w, is_first_frame)
             if is_first_frame:                                                      # :292-295
                 self.frame_itr_num = 0
             self.frame_itr_num += 1
-            if after_state is not None:
-                after_state()
-            out = self.compute_up(pa['bw_up'], feat_up, pa['conf_bw'], conf, fr[ctr].lr)
+        pa['fw_up'], pa['conf_fw'] = feat_up, conf
+        return pa
+
+    @torch.no_grad()
+    def phase_b2(self, pa, want_vis=False):
+        """BW/FW fusion + upsampler (RefVSR.py:288-297) of a frame whose phase_b1 has run: independent of the carried state
+        and of the other frames."""
+        fr, ctr = pa['fr'], pa['t'] // 2
+        with ops.on_stream(torch.cuda.current_stream()):
+            out = self.compute_up(pa['bw_up'], pa['fw_up'], pa['conf_bw'], pa['conf_fw'], fr[ctr].lr)
             vis = None
             if want_vis:
                 vis = collections.OrderedDict()
                 vis['conf_map'] = fr[ctr].conf
-                vis['conf_map_prop'] = ops.max2(pa['conf_bw'], conf)
+                vis['conf_map_prop'] = ops.max2(pa['conf_bw'], pa['conf_fw'])
                 vis['conf_map_prop_backward'] = pa['conf_bw']
-                vis['conf_map_prop_forward'] = conf
+                vis['conf_map_prop_forward'] = pa['conf_fw']
         return out, vis
+
+    @torch.no_grad()
+    def phase_b(self, pa, is_first_frame, want_vis=False, after_state=None):
+        """The state-dependent rest of forward() = phase_b1 + phase_b2; (phase_a, phase_b) of a frame == forward() of that
+        frame.  after_state: callable invoked once the carried state of this frame is final (before the upsampler is
+        enqueued)."""
+        self.phase_b1(pa, is_first_frame)
+        if after_state is not None:
+            after_state()
+        return self.phase_b2(pa, want_vis)
 
     def _debug_vis(self, fr, t, is_first_frame, range_start, fw_flow_in, flow, conf_bw, conf_fw, save_sample):
         """The `vis` debugging samples of Network.forward (RefVSR.py:219-221,262-263,301-316), is_log only; planar fp32

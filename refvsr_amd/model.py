@@ -128,10 +128,18 @@ class Network(nn.Module):
         if not lrs.is_cuda:
             raise RuntimeError('refvsr_amd.Network runs on the GPU only (got a %s tensor); there is no CPU path'
                                % lrs.device)
-        lrs = lrs.float().contiguous()
-        refs = refs.float().contiguous()
         n = lrs.shape[0]
         self.ensure_engines(n, lrs.device)
+        if frame_ids is not None and any(e.pipelined for e in self._engines[:n]):
+            # pipelined mode: the engine's internal streams read the inputs without waiting for the caller's stream (waiting
+            # would serialise consecutive calls, Engine.set_pipelined) -- a dtype / layout conversion here would be exactly such
+            # pending work, so it is refused instead of raced against
+            for t_ in (lrs, refs):
+                if t_.dtype != torch.float32 or not t_.is_contiguous():
+                    raise RuntimeError('pipelined mode needs materialised contiguous float32 inputs (got %s, contiguous=%s): convert '
+                                       'and synchronise before the call, or call set_pipelined(False)' % (t_.dtype, t_.is_contiguous()))
+        lrs = lrs.float().contiguous()
+        refs = refs.float().contiguous()
         want_vis = bool(is_log and self.config.save_sample)
         results, vis_all = [], []
         dbg_all = []
@@ -164,6 +172,27 @@ class Network(nn.Module):
         self.ensure_engines(lrs.shape[0], lrs.device)
         return [self._engines[b].phase_a(lrs[b], refs[b], None if frame_ids is None else [(b, f) for f in frame_ids],
                                          first_hint) for b in range(lrs.shape[0])]
+
+    def phase_b1(self, handles, is_first_frame):
+        """Serial part of phase_b (forward-branch step, carried state); see Engine.phase_b1."""
+        for b, h in enumerate(handles):
+            self._engines[b].phase_b1(h, bool(is_first_frame))
+        return handles
+
+    def phase_b2(self, handles, is_log=False):
+        """State-free rest of phase_b (BW/FW fusion + upsampler); same return value as forward()."""
+        want_vis = bool(is_log and self.config.save_sample)
+        res = [self._engines[b].phase_b2(h, want_vis) for b, h in enumerate(handles)]
+        outs = collections.OrderedDict()
+        if is_log:
+            outs['vis'] = collections.OrderedDict()
+        outs['result'] = res[0][0].unsqueeze(0) if len(res) == 1 else torch.stack([r[0] for r in res], 0)
+        if want_vis:
+            ev = collections.OrderedDict()
+            for k in res[0][1]:
+                ev[k] = torch.stack([r[1][k] for r in res], 0)
+            outs['eval_vis'] = ev
+        return outs
 
     def phase_b(self, handles, is_first_frame, is_log=False, after_state=None):
         """State-dependent rest (forward-branch step + upsampler); same return value as forward().

@@ -142,48 +142,119 @@ def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels
     return results
 
 
-def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None):
-    """Two-phase run of this rank's share (balanced contiguous ranges, any boundary).
+def partition_hybrid(nframes, world, reset_branch):
+    """The partition the wavefront uses when the forward branch restarts every reset_branch frames: boundaries snapped to
+    multiples of reset_branch (those shards need no hand-off and start immediately), except that a short last shard is
+    re-balanced with its predecessor -- ONE boundary then lies inside a restart unit and is served by the hand-off.
+    64 frames, reset 9, 8 ranks: (0,9) (9,18) ... (45,54) (54,59) (59,64): seven exchange-free starts, one hand-off, the longest
+    shard has 9 frames (64 / 9 = 7.1 x over one rank; the balanced partition needs a hand-off at every boundary)."""
+    parts = partition(nframes, world, reset_branch, aligned=True)
+    nz = [i for i, (a, b) in enumerate(parts) if b > a]
+    if len(nz) >= 2:
+        i, j = nz[-2], nz[-1]
+        (a0, a1), (b0, b1) = parts[i], parts[j]
+        if (a1 - a0) - (b1 - b0) >= 2:
+            mid = a0 + (b1 - a0 + 1) // 2
+            parts[i], parts[j] = (a0, mid), (mid, b1)
+    return parts
+
+
+def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
+                  timings=None):
+    """Two-phase run of this rank's share (contiguous ranges, any boundary; default: the balanced partition).
 
     executor.phase_a(lrs, refs, frame_index, first_hint) -> handle   (state-free; all ranks concurrently)
-    executor.phase_b(handle, is_first_frame) -> result               (carries the forward-branch state; in frame order)
-    Results are identical to the sequential run.  Returns {frame: result} for the local frames."""
+    executor.phase_b1(handle, is_first_frame) -> handle              (forward-branch step: carries the state; in frame order)
+    executor.phase_b2(handle) -> result                              (BW/FW fusion + upsampler: state-free)
+    Order on every rank: phase A of all local frames | receive the state | B1 of all local frames | send the state | B2 of
+    all local frames -- the serial chain over the ranks carries only the B1 steps; the upsamplers of rank r run while rank
+    r + 1 walks its B1 chain.  Executors without phase_b1 / phase_b2 run phase_b(handle, first) per frame instead (B2 then
+    sits on the chain).  Results are identical to the sequential run.  Returns {frame: result} for the local frames.
+    timings (optional dict): filled with host-side seconds of the three phases of this rank (after device synchronisation
+    when the executor offers .sync())."""
+    import time
     rank, world = dist.get_rank(), dist.get_world_size()
-    parts = partition(nframes, world)
+    if parts is None:
+        parts = partition(nframes, world)
     start, end = parts[rank]
+    sync = getattr(executor, 'sync', lambda: None)
+    t0 = time.perf_counter()
     handles = {}
     for f in range(start, end):                                   # ---- phase A: no communication, no state
         lrs, refs = get_window(f)
         hint = f == 0 or bool(reset_branch and f % reset_branch == 0) or (f == start and not needs_handoff(start, reset_branch))
         handles[f] = executor.phase_a(lrs, refs, f, hint)
+    if timings is not None:
+        sync()
+        timings['phase_a'] = time.perf_counter() - t0
     results = {}
     if end > start and needs_handoff(start, reset_branch):        # ---- phase B: wavefront behind the hand-off
         _import(executor, rank - 1, channels, device)
         first = False
     else:
         first = True
+    t1 = time.perf_counter()
     nxt = parts[rank + 1] if rank + 1 < world else None
     handoff = nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch)
     pending = []
-
-    def start_send():        # called by phase_b of the LAST local frame as soon as its carried state is final:
-        pending.append(send_state(_export(executor), rank + 1, device, async_op=True))   # the upsampler runs under the send
-    early = handoff and getattr(executor, 'supports_after_state', False)
-    for f in range(start, end):
-        if early and f == end - 1:
-            out = executor.phase_b(handles.pop(f), first, after_state=start_send)
-        else:
-            out = executor.phase_b(handles.pop(f), first)
-        first = False
-        results[f] = out
-        if on_result is not None:
-            on_result(f, out)
-    if handoff and not pending:
-        send_state(_export(executor), rank + 1, device)
+    if hasattr(executor, 'phase_b1'):
+        for f in range(start, end):                               # B1 chain: forward-branch steps only
+            handles[f] = executor.phase_b1(handles[f], first)
+            first = False
+        if handoff:                                               # the next rank's chain starts as soon as this one ends
+            pending.append(send_state(_export(executor), rank + 1, device, async_op=True))
+        if timings is not None:
+            sync()
+            timings['phase_b1'] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        for f in range(start, end):                               # B2: upsamplers, off the chain
+            out = executor.phase_b2(handles.pop(f))
+            results[f] = out
+            if on_result is not None:
+                on_result(f, out)
+        if timings is not None:
+            sync()
+            timings['phase_b2'] = time.perf_counter() - t2
+    else:
+        def start_send():    # called by phase_b of the LAST local frame as soon as its carried state is final:
+            pending.append(send_state(_export(executor), rank + 1, device, async_op=True))   # the upsampler runs under the send
+        early = handoff and getattr(executor, 'supports_after_state', False)
+        for f in range(start, end):
+            if early and f == end - 1:
+                out = executor.phase_b(handles.pop(f), first, after_state=start_send)
+            else:
+                out = executor.phase_b(handles.pop(f), first)
+            first = False
+            results[f] = out
+            if on_result is not None:
+                on_result(f, out)
+        if handoff and not pending:
+            send_state(_export(executor), rank + 1, device)
     for wk in pending:
         if wk is not None:
             wk.wait()
     return results
+
+
+def predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0):
+    """Makespan model of run_wavefront from per-frame phase times: every rank runs its phase A frames, the B1 chain of a
+    shard that starts behind a hand-off begins when its predecessor's chain has ended (+ the hand-off), B2 follows B1 on the
+    same rank.  Returns (speedup over one rank, makespan in the same unit as the inputs)."""
+    end_b1 = []
+    span = 0.0
+    for r, (a, b) in enumerate(parts):
+        n = b - a
+        if n <= 0:
+            end_b1.append(end_b1[-1] if end_b1 else 0.0)
+            continue
+        ready = n * t_a
+        if needs_handoff(a, reset_branch) and r > 0:
+            ready = max(ready, end_b1[r - 1] + t_handoff)
+        e = ready + n * t_b1
+        end_b1.append(e)
+        span = max(span, e + n * t_b2)
+    seq = nframes * (t_a + t_b1 + t_b2)
+    return (seq / span if span > 0 else 0.0), span
 
 
 class EngineExecutor(object):
@@ -195,6 +266,9 @@ class EngineExecutor(object):
         self.net, self.dev, self.h, self.w, self.nframes, self.t = net, device, h, w, nframes, frame_num
         self.keep = keep_on_device
         self.eng = net.Network.ensure_engines(1, device)[0]
+        # the windows are copied to the device on the caller's stream right before each call: cross-call pipelining (whose
+        # internal streams do not wait for the caller's stream, Engine.set_pipelined) stays off here
+        self.eng.set_pipelined(False)
 
     def _ids(self, f):
         return [min(max(f - self.t // 2 + k, 0), self.nframes - 1) for k in range(self.t)]
@@ -211,6 +285,16 @@ class EngineExecutor(object):
 
     def phase_b(self, handles, first, after_state=None):
         return self._out(self.net.Network.phase_b(handles, first, after_state=after_state)['result'][0])
+
+    def phase_b1(self, handles, first):
+        return self.net.Network.phase_b1(handles, first)
+
+    def phase_b2(self, handles):
+        return self._out(self.net.Network.phase_b2(handles)['result'][0])
+
+    def sync(self):
+        import torch as _t
+        _t.cuda.synchronize(self.dev)
 
     def state_nbytes(self):
         return self.eng.state_nbytes(self.h, self.w)

@@ -83,9 +83,10 @@ def register():
         cout, ho, wo, shuffle, f32 = _conv_out_shape(list(meta), src0, stride)
         if planar_out:
             return src0.new_empty((cout, ho, wo), dtype=torch.float32)
+        ru = lambda a, b: (a + b - 1) // b * b          # channel stride of the map, as ops.conv allocates it (C = 36 -> 40)
         if shuffle:
-            return src0.new_empty((2 * ho, 2 * wo, cout // 4), dtype=torch.float16)
-        return src0.new_empty((ho, wo, cout), dtype=torch.float32 if f32 else torch.float16)
+            return src0.new_empty((2 * ho, 2 * wo, ru(cout // 4, 8)), dtype=torch.float16)
+        return src0.new_empty((ho, wo, ru(cout, 4 if f32 else 8)), dtype=torch.float32 if f32 else torch.float16)
 
     @op('resblock')
     def resblock(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, ksteps: int, x: torch.Tensor,

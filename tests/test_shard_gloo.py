@@ -26,11 +26,23 @@ class _Exec(object):
     def phase_b(self, handle, first):
         return self.o.phase_b(handle, first)['result'][0]
 
+    def phase_b1(self, handle, first):
+        return self.o.phase_b1(handle, first)
+
+    def phase_b2(self, handle):
+        return self.o.phase_b2(handle)['result'][0]
+
     def export_state(self):
         return self.o.export_state()
 
     def import_state(self, st):
         self.o.import_state(st)
+
+
+class _ExecNoSplit(_Exec):
+    """An executor without the B1 / B2 split: run_wavefront falls back to phase_b per frame."""
+    phase_b1 = property(lambda self: (_ for _ in ()).throw(AttributeError('phase_b1')))
+    phase_b2 = property(lambda self: (_ for _ in ()).throw(AttributeError('phase_b2')))
 
 
 def _setup(reset, nframes=6, name='config_RefVSR_small_L1'):
@@ -55,7 +67,12 @@ def _worker(rank, world, port, reset, aligned, q, wavefront=False, nframes=6, na
     from refvsr_amd import shard
     cfg, sd, get = _setup(reset, nframes, name)
     reset = cfg.reset_branch
-    if wavefront:
+    if wavefront == 'hybrid':
+        parts = shard.partition_hybrid(nframes, world, reset)
+        res = shard.run_wavefront(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts)
+    elif wavefront == 'nosplit':
+        res = shard.run_wavefront(_ExecNoSplit(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu')
+    elif wavefront:
         res = shard.run_wavefront(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu')
     else:
         res = shard.run_sharded(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', aligned=aligned)
@@ -122,6 +139,23 @@ def test_world8_64_frame_clip_reset9_wavefront():
     ranks (8 frames each: every shard contains a restart, all but the first start behind a hand-off), wavefront schedule
     over gloo -- bit-identical to the sequential stream of all 64 frames."""
     got = _run(reset='keep', aligned=False, wavefront=True, world=8, nframes=64, name='config_RefVSR_small_MFID')
+    assert sorted(got) == list(range(64))
+
+
+def test_wavefront_without_split_executor():
+    """Executors that only offer phase_b keep working (B2 stays on the chain)."""
+    _run(reset=None, aligned=False, wavefront='nosplit')
+
+
+def test_world8_64_frame_clip_reset9_hybrid_partition():
+    """The schedule bench.py uses for BASELINE configs[3]: reset-aligned shards (no hand-off) with the short tail re-balanced
+    over the last two ranks -- exactly one boundary (frame 59) inside a restart unit, served by the hand-off; B1 of all
+    local frames, send, then the upsamplers.  Bit-identical to the sequential stream of all 64 frames."""
+    from refvsr_amd import shard
+    parts = shard.partition_hybrid(64, 8, 9)
+    assert parts == [(0, 9), (9, 18), (18, 27), (27, 36), (36, 45), (45, 54), (54, 59), (59, 64)]
+    assert [shard.needs_handoff(a, 9) for a, _ in parts] == [False] * 7 + [True]
+    got = _run(reset='keep', aligned=False, wavefront='hybrid', world=8, nframes=64, name='config_RefVSR_small_MFID')
     assert sorted(got) == list(range(64))
 
 

@@ -31,6 +31,12 @@ def test_fake_tensor_shape_inference():
         assert y.shape == (3, 20, 30) and y.dtype == torch.float32
         y = torch.ops.refvsr.conv_mfma(w, w, [32, 5, 0, 0, 7, 2, 32, 32], x, x, None, None, None, 2, 0.2, 1.0, False, 0.0, 0.0, 0.0)
         assert y.shape == (10, 15, 32)
+        # C = 36 maps (RefVSR_IR) carry a channel stride of 40: the fake impl rounds like ops.conv
+        x40 = torch.empty((20, 30, 40), dtype=torch.float16, device=dev)
+        y = torch.ops.refvsr.conv_mfma(w, w, [36, 3, 0, 0, 12, 3, 40, 0], x40, None, None, None, None, 1, 1.0, 1.0, False, 0.0, 0.0, 0.0)
+        assert y.shape == (20, 30, 40)
+        y = torch.ops.refvsr.conv_mfma(w, w, [144, 3, 1, 0, 12, 3, 40, 0], x40, None, None, None, None, 1, 1.0, 1.0, False, 0.0, 0.0, 0.0)
+        assert y.shape == (40, 60, 40)                                                                # shuffle: 144 / 4 = 36 -> 40
         conf, idx = torch.ops.refvsr.match_argmax(torch.empty((16, 20, 30), device=dev), torch.empty((16, 10, 15), device=dev))
         assert conf.shape == (1, 20, 30) and idx.shape == (600,) and idx.dtype == torch.int32
         assert torch.ops.refvsr.block_gather(x, idx, 20, 30, 2).shape == (40, 60, 24)

@@ -41,8 +41,8 @@ def main():
     c1, c2 = eng.cw('backward_resblocks.main.2.%d.conv1' % (nb // 2)), eng.cw('backward_resblocks.main.2.%d.conv2' % (nb // 2))
     d1, d2 = eng.cw('feat_decoder2.RBs.1.conv1'), eng.cw('feat_decoder2.RBs.1.conv2')
     fns = {
-        'resblock LR': lambda: ops.resblock(c1, c2, x_lr, act=0.0),
-        'resblock 2x': lambda: ops.resblock(d1, d2, x_2x, act=0.2),
+        'resblock LR': lambda: eng._block_chain(x_lr, [(c1, c2)], 0.0),         # the engine's dispatch: resblock24 for C = 24
+        'resblock 2x': lambda: eng._block_chain(x_2x, [(d1, d2)], 0.2),
         'conv HR': lambda: ops.conv(eng.cw('conv_hr'), x_hr, act=0.1),
         'conv shuffle 2x': lambda: ops.conv(eng.cw('upsample2.upsample_conv'), x_2x, act=0.1),
         'warp LR': lambda: ops.warp_nhwc16(x_lr, flow),
