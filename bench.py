@@ -430,6 +430,19 @@ def main():
     use_ids = not args.no_frame_ids
     pipelined = use_ids and not args.no_pipeline and cfg.cache_windows
     elapsed, ev = timed_pass(use_ids, pipelined, True)
+    # The fused-ResBlock launches are ~10 us each: with four internal streams feeding the GPU the HIP events around a run of
+    # them also bracket the other streams' kernels that get scheduled in between (measured 18.6 us per launch where rocprofv3
+    # reports 9.7).  Their live per-launch time therefore comes from a second, short pass of the same steps on ONE stream
+    # (no cross-call pipelining, no side stream): nothing else is in flight between a run's two events.
+    ev_rb = None
+    if eng.rb24 and cfg.mid_channels == 24:            # (every rank: timed_pass holds barriers)
+        ov = eng.overlap
+        eng.overlap = False
+        try:
+            _, (_, ev_rb) = timed_pass(use_ids, False, True)
+        finally:
+            eng.overlap = ov
+    ev = (ev[0], ev_rb)
     dropin = None
     if not args.no_dropin and (use_ids or pipelined):
         el2, _ = timed_pass(False, False, False)
@@ -471,9 +484,9 @@ def main():
                                     'output; arg-max decided at fp32 accuracy (fp16 GEMM top-2 + fp32 re-rank + split-fp16 search of ambiguous columns)'},
             'dropin_surface': dropin,
         }
-        # ---- rooflines from the HIP events recorded in the timed region.  `roofline` = the time-dominant kernel: the fused
-        # 24-channel ResBlock (resblock24_kernel, 156 launches per frame, ~29 % of the device time; events bracket every run of
-        # >= 8 blocks on the LR map, duration / blocks = per-launch time incl. the gaps between the launches of a run);
+        # ---- rooflines from HIP events.  `roofline` = the time-dominant kernel: the fused 24-channel ResBlock
+        # (resblock24_kernel, 156 launches per frame, ~28 % of the device time; events bracket every run of >= 8 blocks on the
+        # LR map in the single-stream pass above, duration / blocks = per-launch time incl. the gaps between the launches);
         # `roofline_match_top2` = the matching GEMM (one launch per frame, ~14 %).  Configurations whose blocks do not run on
         # that kernel (C = 48) report the matching kernel as `roofline`.
         ev, cev = ev if ev else (None, None)

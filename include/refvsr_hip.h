@@ -23,10 +23,11 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 5   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 6   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
-                                  5: compile-time-specialised 24-channel ResBlock (resblock24 blob) */
+                                  5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
+                                  6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -67,6 +68,14 @@ typedef struct RefvsrConv {
                                              exact fp32 products on v_mfma_f32_16x16x4_f32 (src/mul/res/out all fp32) */
     float add_const;                   /* PLANAR32: constant added after the residual                 */
     float clamp_lo, clamp_hi;          /* PLANAR32: clamp when clamp_lo < clamp_hi                    */
+    /* Fused inter-frame warp (ABI 6): when warp_flow != NULL, source `warp_src` (0 = src0, 1 = src1) is NOT read directly:
+     * the conv consumes warp(src, flow) -- models/utils.py:35-43, the bilinear zero-padded sampling of refvsr_warp_nhwc16 --
+     * evaluated while the input tile is staged (same fp32 blend, same fp16 rounding as the stand-alone kernel: results are
+     * bit-identical to warp + conv).  warp_flow: planar fp32 [2][h_in][w_in] (the conv's input grid); the warped source
+     * map has warp_h x warp_w pixels (it may differ from the grid: RefVSR.py:254 resamples the LR state on the 2x grid).
+     * Supported by the resident 3x3 kernels with fp16 HWC output (the two call sites: ResidualBlocksWithInputConv's input conv,
+     * RefVSR.py:218,227-228 / 253,258-259, and feat_fusion2_1, :220,254,259-260 via :138-139); other shapes are refused. */
+    const float* warp_flow; int warp_src; int warp_h, warp_w;
 } RefvsrConv;
 
 int refvsr_conv_mfma(const RefvsrConv* d, void* stream);

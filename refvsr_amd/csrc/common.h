@@ -93,6 +93,52 @@ __device__ __forceinline__ float rv_linspace_m1p1(int j, int n) {
     return (j < n / 2) ? (-1.0f + step * (float)j) : (1.0f - step * (float)(n - 1 - j));
 }
 
+// warp (models/utils.py:35-43): zeros padding, align_corners=False sampling of a linspace(-1,1) grid displaced by the flow.
+// Shared by the stand-alone warp kernels (resample.hip) and the conv kernels that warp a source while staging it.
+struct WarpCoord { int x0, y0; float w00, w01, w10, w11; bool v00, v01, v10, v11; };
+
+__device__ __forceinline__ WarpCoord warp_coord(const float* flow, int hf, int wf, int hin, int win, int y, int x) {
+    const size_t fp = (size_t)y * wf + x;
+    const float u = flow[fp];
+    const float v = flow[(size_t)hf * wf + fp];
+    const float gx = rv_linspace_m1p1(x, wf) + u / (((float)win - 1.0f) / 2.0f);
+    const float gy = rv_linspace_m1p1(y, hf) + v / (((float)hin - 1.0f) / 2.0f);
+    const float xs = ((gx + 1.0f) * (float)win - 1.0f) / 2.0f;
+    const float ys = ((gy + 1.0f) * (float)hin - 1.0f) / 2.0f;
+    const float fx = floorf(xs), fy = floorf(ys);
+    const float tx = xs - fx, ty = ys - fy;
+    WarpCoord c;
+    // clamp before the int conversion so wild flows cannot overflow; such taps are out of range anyway
+    c.x0 = (int)fminf(fmaxf(fx, -2.0f), (float)win + 1.0f);
+    c.y0 = (int)fminf(fmaxf(fy, -2.0f), (float)hin + 1.0f);
+    const bool xin0 = c.x0 >= 0 && c.x0 < win, xin1 = c.x0 + 1 >= 0 && c.x0 + 1 < win;
+    const bool yin0 = c.y0 >= 0 && c.y0 < hin, yin1 = c.y0 + 1 >= 0 && c.y0 + 1 < hin;
+    c.v00 = xin0 && yin0; c.v01 = xin1 && yin0; c.v10 = xin0 && yin1; c.v11 = xin1 && yin1;
+    c.w00 = (1.0f - ty) * (1.0f - tx); c.w01 = (1.0f - ty) * tx;
+    c.w10 = ty * (1.0f - tx); c.w11 = ty * tx;
+    return c;
+}
+
+// one 16-byte channel group of warp(x, flow) at grid pixel (y, px): fp32 blend in tap order 00, 01, 10, 11, then fp16
+__device__ __forceinline__ uint4 warp_group16(const unsigned char* x, int pixb, int hin, int win, const WarpCoord& c, int goff) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tap = [&](bool valid, int yy, int xx, float wgt) {
+        if (valid) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(x + ((size_t)yy * win + xx) * pixb + goff);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += wgt * (float)v[k];
+        }
+    };
+    tap(c.v00, c.y0, c.x0, c.w00);
+    tap(c.v01, c.y0, c.x0 + 1, c.w01);
+    tap(c.v10, c.y0 + 1, c.x0, c.w10);
+    tap(c.v11, c.y0 + 1, c.x0 + 1, c.w11);
+    union { f16x8 h; uint4 u; } o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.h[k] = (f16)acc[k];
+    return o.u;
+}
+
 // ---- K-block order of the MFMA convolutions (shared with refvsr_amd/packing.py:kslot) --------------------------
 // A K-block is one 16-byte channel group `cg` of one tap (ty, tx).  A wave's ds_read_b128 of the B operand is
 // served in four groups of 16 lanes, each mixing TWO adjacent K-blocks (q = 0|1 or 2|3, MI355X_MICROARCH.md

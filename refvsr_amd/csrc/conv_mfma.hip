@@ -35,6 +35,8 @@
 //   taps) and only the weights go through LDS.
 //
 // Replaces nn.Conv2d call sites listed in include/refvsr_hip.h.
+#include <type_traits>
+
 #include "common.h"
 #include <stdlib.h>
 
@@ -64,6 +66,9 @@ struct ConvArgs {
     int tiles_x, n_xy;               // pixel tiles per row / per frame
     int prefetch;                    // resident kernels: 1 = next tile prefetched into registers during the K loop
     int grid;                        // gridDim.x (resident kernels: rv_tile_range)
+    int ring;                        // streamed kernels: LDS ring slots of CONV_CH K-steps each (2..4)
+    const float* warp_flow;          // WARP kernels: flow on the conv's input grid; the warped source has warp_h x warp_w pixels
+    int warp_h, warp_w;
 };
 
 // EPI = 0: general epilogue (every output mode, fp16 / fp32 maps).  EPI = 1: the fp16 HWC store with optional alpha
@@ -75,8 +80,11 @@ struct ConvArgs {
 // RefVSR_MFID(_8K): 84 KB resident, or a 65 KB two-source tile next to the streamed chunk -- a 4-wave workgroup leaves a
 // SIMD with a single wave and nothing to interleave: those launches use 16 waves on a 16 x 32 tile (resident, where it fits)
 // or 8 waves on the same 8 x 32 tile (two pixel groups per wave).
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4>
+// WARP (resident fp16 kernels): 0 = plain sources; 1 | 2 = source 0 | 1 is warp(source, p.warp_flow), evaluated while the tile is
+// staged (models/utils.py:35-43; the arithmetic of resample.hip:warp_nhwc16_kernel, so warp + conv == this kernel bit for bit).
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
+    static_assert(WARP == 0 || (RESIDENT && !F32), "the fused warp lives in the resident fp16 kernels' tile staging");
     constexpr int NT = NW * 64;                      // threads per workgroup
     static_assert(!(GATHER && RESIDENT), "gather mode streams its weights");
     static_assert(EPI == 0 || (RESIDENT && !F32), "the lean epilogue is built for the resident fp16 kernels");
@@ -425,8 +433,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
                 const int iy = iy0 + (e & 31), ix = ix0 + ((e >> 5) & 127);   // registers that live across the K loop
                 if (e >= 0 && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) {
                     const bool s1 = (e >> 19) & 1;
-                    const int off = ((e & 31) * p.w_in + ((e >> 5) & 127)) * (s1 ? p.pixb1 : p.pixb0) + ((e >> 12) & 127) * 16;
-                    v = *reinterpret_cast<const uint4*>((s1 ? b1 : b0) + off);
+                    if (WARP != 0 && s1 == (WARP == 2)) {             // this chunk = one channel group of warp(source, flow)(iy, ix)
+                        const WarpCoord wc = warp_coord(p.warp_flow, p.h_in, p.w_in, p.warp_h, p.warp_w, iy, ix);
+                        v = warp_group16(s1 ? p.src1 : p.src0, s1 ? p.pixb1 : p.pixb0, p.warp_h, p.warp_w, wc, ((e >> 12) & 127) * 16);
+                    } else {
+                        const int off = ((e & 31) * p.w_in + ((e >> 5) & 127)) * (s1 ? p.pixb1 : p.pixb0) + ((e >> 12) & 127) * 16;
+                        v = *reinterpret_cast<const uint4*>((s1 ? b1 : b0) + off);
+                    }
                 }
                 xv[k] = v;
             }
@@ -471,28 +484,72 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
         const int tyi = tl / p.tiles_x;
         const int tx0 = (tl - tyi * p.tiles_x) * CONV_TW;
         const int ty0 = tyi * TH;
+        // Streamed weights (!GATHER): chunks of CONV_CH K-steps go global -> LDS with global_load_lds_dwordx4 (the LDS image of a
+        // chunk is its global image) through a RING of p.ring slots: chunk c + ring - 1 is issued while chunk c feeds the MFMAs, so
+        // up to ring - 1 chunks are in flight and a chunk costs max(fill, compute) instead of a memory round trip (round 2: one
+        // chunk prefetched into registers, two barriers per chunk -- the 2-workgroup launches of SPyNet's coarse levels streamed
+        // 392 KB through one CU in 28 us).  Every wave issues exactly PPW pieces (1 KiB each) of every chunk -- the partial last
+        // chunk re-reads its last valid piece into the slot's unused tail -- so that "chunk c has landed" is
+        // s_waitcnt vmcnt(pieces this wave issued after it).  Raw s_barrier + explicit waits: __syncthreads() would wait for EVERY
+        // outstanding LDS-DMA (its fence cannot tell them from the stores it orders).  The first ring - 1 chunks are issued
+        // before the input tile is staged.
+        constexpr int PPW = GATHER ? 1 : CONV_CH * MT * WFR / NW;
+        static_assert(GATHER || (PPW * NW == CONV_CH * MT * WFR && PPW >= 1 && 2 * PPW <= 60), "pieces per wave and chunk");
+        constexpr int SLOT = CONV_CH * MT * WFR * 1024;
+        const int NS = p.ring;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned char* gw = reinterpret_cast<const unsigned char*>(wsrc) + lane * 16;
+        auto issue = [&](const int c, const int slot) {
+            const int np = min(CONV_CH, p.S - c * CONV_CH) * MT * WFR;                  // valid pieces of this chunk
+            const unsigned char* g = gw + (size_t)c * SLOT;
+            unsigned char* l = wl + slot * SLOT;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int pc = wv + j * NW;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + min(pc, np - 1) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(l + pc * 1024), 16, 0, 0);
+            }
+        };
+        int slot_w = 0;                                                // slot the next issued chunk goes to
+        if constexpr (!GATHER) {
+            const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
+            for (int c = 0; c < min(NS - 1, n_chunks); ++c) { issue(c, slot_w); slot_w = slot_w + 1 == NS ? 0 : slot_w + 1; }
+        }
         if constexpr (!GATHER) {                                   // stage the input tile (zero padded)
             const int iy0 = ty0 * p.stride - p.pad;
             const int ix0 = tx0 * p.stride - p.pad;
             const int row_chunks = p.LW * p.ncg;
             const float inv_rc = 1.0f / (float)row_chunks;
             const int total = p.LH * row_chunks;
-            for (int idx = tid; idx < total; idx += NT) {
-                const int r = (int)(((float)idx + 0.5f) * inv_rc);
-                const int i = idx - r * row_chunks;
-                const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
-                const int cg = i - c * p.ncg;
-                const int iy = iy0 + r;
-                const int ix = ix0 + c;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) {
-                    const size_t pix = (size_t)iy * p.w_in + ix;
-                    if (cg < p.ncg0)
-                        v = *reinterpret_cast<const uint4*>(p.src0 + pix * p.pixb0 + cg * 16);
-                    else
-                        v = *reinterpret_cast<const uint4*>(p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16);
+            // batches of SB chunks per thread: every load of a batch is in flight before the first LDS store (one chunk per
+            // iteration = one memory round trip per chunk: the 14 x 38-pixel, 64-channel tile of SPyNet's 7x7 convs took ten of
+            // them, most of the kernel's time on the coarse pyramid levels).  Loads are unconditional (clamped address), the
+            // zero padding is a mask.
+            constexpr int SB = 8;
+            for (int idx0 = tid; idx0 < total; idx0 += SB * NT) {
+                uint4 sv[SB];
+                int sd[SB];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int idx = min(idx0 + k * NT, total - 1);
+                    const int r = (int)(((float)idx + 0.5f) * inv_rc);
+                    const int i = idx - r * row_chunks;
+                    const int c = (int)(((float)i + 0.5f) * p.inv_ncg);
+                    const int cg = i - c * p.ncg;
+                    const int iy = iy0 + r;
+                    const int ix = ix0 + c;
+                    const bool ok = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+                    const size_t pix = (size_t)min(max(iy, 0), p.h_in - 1) * p.w_in + min(max(ix, 0), p.w_in - 1);
+                    const unsigned char* g = (cg < p.ncg0) ? p.src0 + pix * p.pixb0 + cg * 16 : p.src1 + pix * p.pixb1 + (cg - p.ncg0) * 16;
+                    uint4 v = *reinterpret_cast<const uint4*>(g);
+                    const unsigned keep = ok ? 0xffffffffu : 0u;
+                    v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                    sv[k] = v;
+                    sd[k] = ((r * p.LW + c) * p.ps + cg) * 16;
                 }
-                *reinterpret_cast<uint4*>(tile + ((size_t)(r * p.LW + c) * p.ps + cg) * 16) = v;
+#pragma unroll
+                for (int k = 0; k < SB; ++k)
+                    if (idx0 + k * NT < total) *reinterpret_cast<uint4*>(tile + sd[k]) = sv[k];
             }
         } else {
 #pragma unroll
@@ -502,42 +559,141 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
                 pbase[t] = (iy << 16) | ix;              // biased by 4096 so both halves stay non-negative
             }
         }
-        // Weight chunks: chunk c+1 is fetched into registers while chunk c feeds the MFMAs and parked afterwards.
-        constexpr int WPT = (CONV_CH * MT * WFR * 64) / NT;          // uint4 per thread per chunk (4 * MT * WFR with 4 waves)
-        const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
-        // named registers, not an array: hipcc keeps a prefetch *array* in scratch memory here (scratch_store right
-        // behind every load), which serialises the whole prefetch
-        static_assert(WPT <= 12, "prefetch register set");
-        uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
-#define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
-#define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * NT, n16n - 1)];
-#define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * NT < n16n) d[tid + k * NT] = w##k; }
-        {
-            const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
-            uint4* d = reinterpret_cast<uint4*>(wl);
-            for (int i = tid; i < n16; i += NT) d[i] = wsrc[i];      // chunk 0, issued together with the tile staging
-        }
-        zero_acc();
-        __syncthreads();
-        for (int c = 0; c < n_chunks; ++c) {
-            const int s0 = c * CONV_CH;
-            const int ns = min(CONV_CH, p.S - s0);
-            const bool has_next = (c + 1 < n_chunks);
-            // the prefetch is unconditional (the last iteration re-reads its own chunk and drops it) so that the
-            // prefetch registers have one definition per iteration: a conditional definition makes hipcc copy them
-            // right behind the loads, i.e. wait for every load before the MFMA loop
-            const int sn = has_next ? s0 + CONV_CH : s0;
-            const int n16n = min(CONV_CH, p.S - sn) * MT * WFR * 64;
-            {
-                const uint4* g = wsrc + (size_t)sn * MT * WFR * 64;
-                RV_W_ALL(RV_W_LOAD)
+        if constexpr (!GATHER) {
+            // While LDS-DMA is in flight every LDS read the COMPILER knows about gets an s_waitcnt vmcnt(0) in front of it (its
+            // waitcnt pass cannot tell which DMA a ds_read may alias), which would drain the ring at the first fragment read.  The
+            // reads of this loop are therefore inline asm, with the lgkmcnt waits written out: after the reads of step s + 1 are
+            // issued, lgkmcnt(NA + TILES) = "everything older has returned" = the fragments of step s (LDS returns in order); the
+            // empty asm ties make the MFMAs depend on the wait.
+            const unsigned lds_tab = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(tab);
+            const unsigned lds_wl = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wl;
+            const unsigned lds_tile = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tile;
+            unsigned pbaddr[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) pbaddr[t] = lds_tile + (unsigned)pbase[t];
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            auto ld128 = [](const unsigned addr) {
+                u32x4 v;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+                return make_uint4(v[0], v[1], v[2], v[3]);
+            };
+            auto tie = [](uint4& r) {                                 // one 128-bit operand: the four registers stay a tuple, no copies
+                u32x4 t = {r.x, r.y, r.z, r.w};
+                asm volatile("" : "+v"(t));
+                r = make_uint4(t[0], t[1], t[2], t[3]);
+            };
+            auto wait_set = [&](uint4 (&a)[NA], uint4 (&b)[TILES]) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NA + TILES) : "memory");
+#pragma unroll
+                for (int i = 0; i < NA; ++i) tie(a[i]);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) tie(b[t]);
+            };
+            static_assert(NA + TILES <= 15, "lgkmcnt range");
+            auto compute_chunk = [&](const unsigned wslot, const int s0, const int ns) {
+                // K-slot offsets of the chunk's steps -> registers (steps past the end repeat the last one; their MFMAs are skipped)
+                unsigned toff[CONV_CH];
+#pragma unroll
+                for (int j = 0; j < CONV_CH; ++j)
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(toff[j]) : "v"(lds_tab + (unsigned)(((s0 + min(j, ns - 1)) * 4 + q) * 4)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < CONV_CH; ++j) asm volatile("" : "+v"(toff[j]));
+                const unsigned wa = wslot + (unsigned)lane * 16;
+                auto load_set = [&](auto jc, uint4 (&a)[NA], uint4 (&b)[TILES]) {
+                    constexpr int j = decltype(jc)::value;              // step within the chunk (steps >= ns re-read step ns - 1 ...
+                    const unsigned wj = wa + (unsigned)min(j, ns - 1) * (NA * 1024);   // ... so that every read hits landed data)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        u32x4 v;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(wj), "n"(i * 1024));
+                        a[i] = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) b[t] = ld128(pbaddr[t] + toff[j]);
+                };
+                uint4 a0[NA], b0[TILES], a1[NA], b1[TILES];
+                load_set(std::integral_constant<int, 0>{}, a0, b0);
+#define RV_RING_PAIR(J)                                                                     \
+                load_set(std::integral_constant<int, (J) + 1>{}, a1, b1);                   \
+                wait_set(a0, b0);                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                          \
+                if ((J) < ns) mfma_step(a0, b0);                                            \
+                load_set(std::integral_constant<int, (J) + 2>{}, a0, b0);                   \
+                wait_set(a1, b1);                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                          \
+                if ((J) + 1 < ns) mfma_step(a1, b1);
+                RV_RING_PAIR(0) RV_RING_PAIR(2) RV_RING_PAIR(4)
+#undef RV_RING_PAIR
+                static_assert(CONV_CH == 8, "the ring loop is unrolled for 8 K-steps per chunk");
+                // last pair: NO read past the chunk's last step.  An asm read whose result is never used is a dead definition to
+                // the register allocator -- it reuses the registers at once, and the LDS data landing later overwrites whatever
+                // lives there by then (first version of this loop: corrupted the last step's B fragments of MT = 1 kernels).
+                load_set(std::integral_constant<int, 7>{}, a1, b1);
+                wait_set(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (6 < ns) mfma_step(a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < NA; ++i) tie(a1[i]);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) tie(b1[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (7 < ns) mfma_step(a1, b1);
+            };
+            const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
+            zero_acc();
+            int slot_r = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                const int after = min(NS - 2, n_chunks - 1 - c);       // chunks this wave has issued after chunk c
+                if (after <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS stores (table, tile staging)
+                __builtin_amdgcn_s_barrier();                          // chunk c landed for every wave; slot of chunk c - 1 is free
+                asm volatile("" ::: "memory");
+                if (c + NS - 1 < n_chunks) { issue(c + NS - 1, slot_w); slot_w = slot_w + 1 == NS ? 0 : slot_w + 1; }
+                compute_chunk(lds_wl + (unsigned)slot_r * SLOT, c * CONV_CH, min(CONV_CH, p.S - c * CONV_CH));
+                slot_r = slot_r + 1 == NS ? 0 : slot_r + 1;
             }
-            compute_steps(wl, s0, ns);
-            if (has_next) {
-                __syncthreads();                                   // everyone is done reading the chunk buffer
+        } else {
+            // Weight chunks: chunk c+1 is fetched into registers while chunk c feeds the MFMAs and parked afterwards.
+            constexpr int WPT = (CONV_CH * MT * WFR * 64) / NT;          // uint4 per thread per chunk (4 * MT * WFR with 4 waves)
+            const int n_chunks = (p.S + CONV_CH - 1) / CONV_CH;
+            // named registers, not an array: hipcc keeps a prefetch *array* in scratch memory here (scratch_store right
+            // behind every load), which serialises the whole prefetch
+            static_assert(WPT <= 12, "prefetch register set");
+            uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
+    #define RV_W_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11)
+    #define RV_W_LOAD(k) if constexpr (WPT > k) w##k = g[min(tid + k * NT, n16n - 1)];
+    #define RV_W_STORE(k) if constexpr (WPT > k) { if (tid + k * NT < n16n) d[tid + k * NT] = w##k; }
+            {
+                const int n16 = min(CONV_CH, p.S) * MT * WFR * 64;
                 uint4* d = reinterpret_cast<uint4*>(wl);
-                RV_W_ALL(RV_W_STORE)
-                __syncthreads();
+                for (int i = tid; i < n16; i += NT) d[i] = wsrc[i];      // chunk 0, issued together with the tile staging
+            }
+            zero_acc();
+            __syncthreads();
+            for (int c = 0; c < n_chunks; ++c) {
+                const int s0 = c * CONV_CH;
+                const int ns = min(CONV_CH, p.S - s0);
+                const bool has_next = (c + 1 < n_chunks);
+                // the prefetch is unconditional (the last iteration re-reads its own chunk and drops it) so that the
+                // prefetch registers have one definition per iteration: a conditional definition makes hipcc copy them
+                // right behind the loads, i.e. wait for every load before the MFMA loop
+                const int sn = has_next ? s0 + CONV_CH : s0;
+                const int n16n = min(CONV_CH, p.S - sn) * MT * WFR * 64;
+                {
+                    const uint4* g = wsrc + (size_t)sn * MT * WFR * 64;
+                    RV_W_ALL(RV_W_LOAD)
+                }
+                compute_steps(wl, s0, ns);
+                if (has_next) {
+                    __syncthreads();                                   // everyone is done reading the chunk buffer
+                    uint4* d = reinterpret_cast<uint4*>(wl);
+                    RV_W_ALL(RV_W_STORE)
+                    __syncthreads();
+                }
             }
         }
         epilogue(ty0, tx0, tid);
@@ -555,13 +711,13 @@ extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg);
 
 // RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
 // the XCD banding) and walk the tiles; the others launch one workgroup per tile.
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0>
 static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy table (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
@@ -574,7 +730,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         for (int i = 0; i < 4; ++i)
             if (occ_lds[dev][i] == lds && occ_val[dev][i] > 0) occ = occ_val[dev][i];
         if (occ == 0) {
-            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>, NW * 64, lds));
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP>, NW * 64, lds));
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
@@ -584,7 +740,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         if (gx > cap) gx = cap;
     }
     a.grid = gx;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -628,6 +784,13 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     a.mul = (const unsigned char*)d->mul; a.mul_c = d->mul_c;
     a.res = (const unsigned char*)d->res; a.res_c = d->res_c;
     a.out_mode = d->out_mode; a.out = d->out; a.out_c = d->out_c;
+    a.warp_flow = d->warp_flow; a.warp_h = d->warp_h; a.warp_w = d->warp_w;
+    if (d->warp_flow) {
+        RV_CHECK(d->warp_src == 0 || d->warp_src == 1, "conv: warp_src must be 0 or 1");
+        RV_CHECK(d->warp_src == 0 || d->src1, "conv: warp_src = 1 needs a second source");
+        RV_CHECK(d->warp_h > 1 && d->warp_w > 1 && d->h_in > 1 && d->w_in > 1, "conv: warp needs maps of at least 2 x 2 pixels");
+        RV_CHECK(!f32 && d->stride == 1 && d->ksize == 3, "conv: the fused warp is built for the 3x3 stride-1 fp16 convs");
+    }
     a.res_planar = d->res_planar; a.add_const = d->add_const;
     a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
 
@@ -679,23 +842,40 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         }
     }
     if (!resident) {
-        // chunked weights (one CONV_CH-step buffer): 8 x 32 pixels if the staged input fits, else 4 x 32, else gather mode
-        a.wl_bytes = (a.S <= CONV_CH ? a.S : CONV_CH) * wfr_kb;
-        auto lds_for = [&](int tl) { return (size_t)a.tab_bytes + (size_t)a.wl_bytes + tile_bytes(tl); };
+        // streamed weights: a ring of 2..4 LDS slots of CONV_CH K-steps each next to the staged input tile.  Large maps prefer a
+        // footprint that admits two workgroups per CU; 8 x 32 pixels if the staged input fits, else 4 x 32, else gather mode
+        // (one slot, register-prefetched, B fragments from global memory)
+        const size_t slot = (size_t)CONV_CH * wfr_kb;
+        const int n_chunks = (a.S + CONV_CH - 1) / CONV_CH;
+        auto ring_for = [&](int tl, size_t budget) {
+            const size_t fixed = (size_t)a.tab_bytes + tile_bytes(tl);
+            if (fixed + 2 * slot > budget) return 0;
+            int ns = (int)((budget - fixed) / slot);
+            if (ns > 4) ns = 4;
+            if (ns > n_chunks + 1) ns = n_chunks + 1 > 2 ? n_chunks + 1 : 2;
+            return ns;
+        };
+        static const int force_ring = getenv("REFVSR_CONV_RING") ? atoi(getenv("REFVSR_CONV_RING")) : 0;   // A/B knob: 2 | 3 | 4
+        const bool big = (long long)d->h_out * d->w_out > 64 * 1024;
+        int ns = 0;
         tiles = 4;
-        lds = lds_for(4);
-        if (lds > LDS_MAX) { tiles = 2; lds = lds_for(2); }
-        if (lds > LDS_MAX) {                           // strided predictor convs: gather B fragments from global memory
+        if (big) ns = ring_for(4, LDS_MAX / 2);
+        if (!ns && big) { tiles = 2; ns = ring_for(2, LDS_MAX / 2); }
+        if (!ns) { tiles = 4; ns = ring_for(4, LDS_MAX); }
+        if (!ns) { tiles = 2; ns = ring_for(2, LDS_MAX); }
+        if (ns) {
+            if (force_ring >= 2 && force_ring < ns) ns = force_ring;
+            a.ring = ns;
+            a.wl_bytes = (int)(ns * slot);
+            lds = (size_t)a.tab_bytes + (size_t)a.wl_bytes + tile_bytes(tiles);
+        } else {                                       // strided predictor convs: gather B fragments from global memory
             a.gather = 1;
+            a.ring = 1;
             tiles = 4;
             a.LH = a.LW = 0;
+            a.wl_bytes = (int)slot;
             lds = (size_t)a.tab_bytes + (size_t)a.wl_bytes;
             RV_CHECK(d->h_in < 60000 && d->w_in < 60000, "conv: frame too large for gather-mode coordinates");
-        }
-        // prefer 2 blocks/CU for mid-size tiles
-        if (!a.gather && tiles == 4 && lds > LDS_MAX / 2 && d->h_out * d->w_out > 64 * 1024) {
-            const size_t lds2 = lds_for(2);
-            if (lds2 <= LDS_MAX / 2) { tiles = 2; lds = lds2; } else { lds = lds_for(4); }
         }
         one_wg = !a.gather && lds > LDS_MAX / 2;
     }
@@ -732,6 +912,16 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         if (lean) return launch_conv<M, T, false, false, true, 1>(a, nz, lds, st);                        \
         return resident ? launch_conv<M, T, false, false, true>(a, nz, lds, st)                           \
                         : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
+    }
+    if (d->warp_flow) {                            // RefVSR.py:218,253 / 220,254,259: 8+24 -> 24 and 24+24 -> 24 (16 output rows x 2)
+        RV_CHECK(lean && MT == 2 && !w16, "conv: no fused-warp kernel for this shape (MT=%d tiles=%d lean=%d)", MT, tiles, (int)lean);
+#define RV_WARP_CASE(T, NW_)                                                                              \
+        return d->warp_src == 0 ? launch_conv<2, T, false, false, true, 1, NW_, 1>(a, nz, lds, st)        \
+                                : launch_conv<2, T, false, false, true, 1, NW_, 2>(a, nz, lds, st);
+        if (nw8) { RV_WARP_CASE(2, 8) }
+        if (tiles == 2) { RV_WARP_CASE(2, 4) }
+        RV_WARP_CASE(4, 4)
+#undef RV_WARP_CASE
     }
     if (w16) {
         if (MT == 3) return lean ? launch_conv<3, 2, false, false, true, 1, 16>(a, nz, lds, st) : launch_conv<3, 2, false, false, true, 0, 16>(a, nz, lds, st);

@@ -75,7 +75,13 @@ class Weights(object):
         chans = [(32, 8), (64, 32), (32, 64), (16, 32), (2, 16)]
         for lvl in range(6):
             for j, (co, ci) in enumerate(chans):
-                mf('FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j), [ci])
+                name = 'FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j)
+                mf(name, [ci])
+                if co > 16 and ci > 8:
+                    # the streamed 7x7 convs of the coarse pyramid levels (a handful of pixel tiles): 16 output channels per
+                    # workgroup, so that 2-4x as many CUs share the 200-400 KB weight stream (Engine.flow picks per level)
+                    w, b = g(name)
+                    self.conv[name + '/mt1'] = ops.ConvWeights(pack_conv(w, b, [ci], mt=1), device)
         fe = 'feature_match.feature_extract.'
         self.hd = bool(config.flag_HD_in)
         self.vgg7 = self.hd or config.scale != 4          # attention.py:31-35
@@ -163,6 +169,11 @@ class Engine(object):
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
         self.rb24 = not os.environ.get('REFVSR_NO_RB24')         # A/B knob: the generic lean kernel for C = 24 as well
+        # inter-frame warp fused into its consumer's tile staging (conv kernels with 16-row pairs: mid_channels = 24 / 32); the
+        # stand-alone warp kernel otherwise (C = 36 / 48 configs) and under the A/B knob
+        self.fuse_warp = self.C in (24, 32) and not os.environ.get('REFVSR_NO_FUSE_WARP')
+        # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
+        self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
         self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
@@ -321,9 +332,10 @@ class Engine(object):
         y = self._block_chain(x, pairs, 0.2)
         return ops.conv(self.cw(name + '.conv_tail'), y, res=x)
 
-    def resblocks(self, lr8, feat, name):
-        """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources."""
-        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1)
+    def resblocks(self, lr8, feat, name, flow=None):
+        """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources.  flow: the propagated
+        features are consumed as warp(feat, flow) (RefVSR.py:218,253,258), sampled inside the input conv's tile staging."""
+        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1, warp=None if flow is None else (1, flow))
         pairs = [(self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i)))
                  for i in range(self.nb)]
         return self._block_chain(x, pairs, 0.0)
@@ -360,8 +372,10 @@ class Engine(object):
         for lvl in range(6):
             x, fup = ops.spynet_level_input(pr[lvl], ps[lvl], flow)
             p = 'FlowNet.basic_module.%d.basic_module.' % lvl
+            small = x.shape[0] * x.shape[1] <= self.spynet_mt1_pixels
             for j in range(4):
-                x = ops.conv(self.cw(p + '%d.conv' % j), x, act=0.0)
+                cw = self.W.conv.get(p + '%d.conv/mt1' % j) if small else None
+                x = ops.conv(cw if cw is not None else self.cw(p + '%d.conv' % j), x, act=0.0)
             flow = ops.conv(self.cw(p + '4.conv'), x, planar_out=True, res_planar=fup)
         h_up, w_up = flow.shape[1:]
         out = ops.resize(flow, (h, w), ops.RS_BILINEAR, chan_mul=[float(w) / float(w_up), float(h) / float(h_up)])
@@ -481,8 +495,9 @@ class Engine(object):
         rgb2 = ops.block_gather_rgb(fr.ref, fr.idx, gh, gw, s2)                          # attention.py:152-154
         fr.aligned_up = self.aligned_conv(feats2, fr.lr, rgb2, 'aa2.align', s2)
 
-    def rap(self, fr, conf_prop, feat, feat_up):
-        """AA_AF_conf_prop (RefVSR.py:123-149)."""
+    def rap(self, fr, conf_prop, feat, feat_up, flow_up=None):
+        """AA_AF_conf_prop (RefVSR.py:123-149).  flow_up: the propagated 2x features are consumed as warp(feat_up, flow_up)
+        (RefVSR.py:220,254,259), sampled inside feat_fusion2_1's tile staging (their only consumer, :138-139)."""
         R = self.W.raw
         pair = torch.cat([conf_prop, fr.conf], 0)                                        # [2,h,w] (:130)
         a = ops.conv_direct(pair, *R['conf_fusion.0.0'], act=0.2, nhwc16_out=True)
@@ -491,7 +506,7 @@ class Engine(object):
         feat = ops.conv(self.cw('feat_fusion.1.0'), t, act=0.2, mul=alpha, res=feat)     # :131
         feat = self.res_list(feat, 'feat_decoder', 8)
         up1 = ops.conv(self.cw('upsample1.upsample_conv'), feat)                         # :138 (pixel shuffle fused)
-        feat_up = ops.conv(self.cw('feat_fusion2_1.0.0'), feat_up, up1, act=0.2)
+        feat_up = ops.conv(self.cw('feat_fusion2_1.0.0'), feat_up, up1, act=0.2, warp=None if flow_up is None else (0, flow_up))
         pair_up = ops.bicubic_scale(pair, 2, clamp01=True)                               # :140-141
         a = ops.conv_direct(pair_up, *R['conf_fusion2.0.0'], act=0.2, nhwc16_out=True)
         alpha2 = ops.conv(self.cw('conf_fusion2.1.0'), a, act=0.2)
@@ -666,13 +681,10 @@ class Engine(object):
                 for i in range(t - 1, ctr - 1, -1):
                     if fr[i].ready is not None:
                         M.wait_event(fr[i].ready)
+                    fl = None
                     if i < t - 1:
                         fl = self.flow(fr[i], fr[i + 1], share)          # cached by P above: waits on its event
-                        feat = ops.warp_nhwc16(feat, fl)
-                        conf = ops.warp_planar(conf, fl)
-                        feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
-                    feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
-                    feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+                    feat, feat_up, conf = self._prop_step(fr[i], 'backward_resblocks', feat, feat_up, conf, fl)
                 M.wait_event(ev_fw)
                 out = self.compute_up(feat_up, fw[1], conf, fw[2], fr[ctr].lr)
                 vis = None
@@ -699,6 +711,28 @@ class Engine(object):
             self._side = [torch.cuda.Stream(device=dev) for _ in range(2)]
         return self._side[k]
 
+    def _prop_step(self, f, branch, feat, feat_up, conf, fl, up_from_lr=False):
+        """One propagation step (RefVSR.py:216-230 backward, :251-277 forward): warp the carried maps with `fl` (None: first
+        step of a branch, nothing to warp), ResidualBlocksWithInputConv, AA_AF_conf_prop.  The two feature warps run inside
+        their consumers' tile staging (ops.conv warp=) unless self.fuse_warp is off; the 1-channel confidence map keeps its
+        own kernel.  up_from_lr: the 2x state is warp(warp(feat, fl), flow_up2(fl)) -- the reference's :254 quirk."""
+        if fl is None:
+            feat = self.resblocks(f.lr8, feat, branch)
+            return self.rap(f, conf, feat, feat_up)
+        fl2 = ops.flow_up2(fl)
+        conf = ops.warp_planar(conf, fl)
+        if up_from_lr:
+            feat = ops.warp_nhwc16(feat, fl)              # needed as a map: it is warped a second time onto the 2x grid
+            x = self.resblocks(f.lr8, feat, branch)
+            if self.fuse_warp:
+                return self.rap(f, conf, x, feat, flow_up=fl2)
+            return self.rap(f, conf, x, ops.warp_nhwc16(feat, fl2))
+        if self.fuse_warp:
+            x = self.resblocks(f.lr8, feat, branch, flow=fl)
+            return self.rap(f, conf, x, feat_up, flow_up=fl2)
+        x = self.resblocks(f.lr8, ops.warp_nhwc16(feat, fl), branch)
+        return self.rap(f, conf, x, ops.warp_nhwc16(feat_up, fl2))
+
     def _backward_branch(self, fr, flow, t, h, w):
         """Backward propagation branch (RefVSR.py:211-238): restarts from zeros in every window."""
         C, ctr, dev = self.C, t // 2, fr[0].lr.device
@@ -706,13 +740,8 @@ class Engine(object):
         feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
         conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
         for i in range(t - 1, ctr - 1, -1):
-            if i < t - 1:
-                fl = flow(i, i + 1)                       # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
-                feat = ops.warp_nhwc16(feat, fl)
-                conf = ops.warp_planar(conf, fl)
-                feat_up = ops.warp_nhwc16(feat_up, ops.flow_up2(fl))
-            feat = self.resblocks(fr[i].lr8, feat, 'backward_resblocks')
-            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+            fl = flow(i, i + 1) if i < t - 1 else None    # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
+            feat, feat_up, conf = self._prop_step(fr[i], 'backward_resblocks', feat, feat_up, conf, fl)
         return feat_up, conf
 
     def _forward_branch(self, fr, flow, t, h, w, is_first_frame):
@@ -727,17 +756,12 @@ class Engine(object):
             range_start = ctr
         for i in range(range_start, ctr + 1):
             if i > range_start:
-                fl = flow(i, i - 1)                       # forward_flows[:, i-1] = FlowNet(lrs[i], lrs[i-1])
-                feat = ops.warp_nhwc16(feat, fl)
-                feat_up = ops.warp_nhwc16(feat, ops.flow_up2(fl))      # :254 LR state resampled on the 2x grid
-                conf = ops.warp_planar(conf, fl)
-            elif not is_first_frame:
-                fl = self.fw_flow                                                   # :257-260
-                feat = ops.warp_nhwc16(self.fw_feat, fl)
-                feat_up = ops.warp_nhwc16(self.fw_feat_up, ops.flow_up2(fl))
-                conf = ops.warp_planar(self.fw_conf, fl)
-            feat = self.resblocks(fr[i].lr8, feat, 'forward_resblocks')
-            feat, feat_up, conf = self.rap(fr[i], conf, feat, feat_up)
+                # forward_flows[:, i-1] = FlowNet(lrs[i], lrs[i-1]); :253-255 warps the ALREADY WARPED LR state onto the 2x grid
+                feat, feat_up, conf = self._prop_step(fr[i], 'forward_resblocks', feat, None, conf, flow(i, i - 1), up_from_lr=True)
+            elif not is_first_frame:                                                # :257-260
+                feat, feat_up, conf = self._prop_step(fr[i], 'forward_resblocks', self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow)
+            else:
+                feat, feat_up, conf = self._prop_step(fr[i], 'forward_resblocks', feat, feat_up, conf, None)
             if i == ctr:                                                            # :279-283
                 self.fw_feat, self.fw_feat_up, self.fw_conf = feat, feat_up, conf
                 self.fw_flow = flow(ctr + 1, ctr)         # forward_flows[:, ctr]

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 5
+ABI_VERSION = 6
 RESBLOCK24_BLOB_BYTES = 43264
 
 
@@ -35,6 +35,7 @@ class RefvsrConv(C.Structure):
         ('res_planar', C.c_void_p),
         ('f32', C.c_int),
         ('add_const', C.c_float), ('clamp_lo', C.c_float), ('clamp_hi', C.c_float),
+        ('warp_flow', C.c_void_p), ('warp_src', C.c_int), ('warp_h', C.c_int), ('warp_w', C.c_int),
     ]
 
 

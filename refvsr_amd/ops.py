@@ -94,17 +94,27 @@ class ConvWeights(object):
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
-         planar_out=False, res_planar=None, add_const=0.0, clamp=None):
+         planar_out=False, res_planar=None, add_const=0.0, clamp=None, warp=None):
     """refvsr_conv_mfma.  Returns nhwc16 [ho,wo,cout] (or [2ho,2wo,cout/4] for pixel-shuffle weights),
-    or planar fp32 [cout,ho,wo] when planar_out.  For f32-packed weights all maps are fp32 HWC."""
+    or planar fp32 [cout,ho,wo] when planar_out.  For f32-packed weights all maps are fp32 HWC.
+    warp = (k, flow): source k (0 | 1) is consumed as warp_nhwc16(source_k, flow) -- sampled while the conv stages its input
+    tile, no intermediate map (bit-identical to the two launches); flow planar fp32 [2,h,w] defines the conv's input grid,
+    source k may have another size (RefVSR.py:254: the LR state on the 2x grid)."""
     f32 = cw.f32
     _nhwc(src0, f32)
-    h, w, c0 = src0.shape
-    c1 = 0
     if src1 is not None:
         _nhwc(src1, f32)
-        assert src1.shape[:2] == src0.shape[:2]
-        c1 = src1.shape[2]
+    c0 = src0.shape[2]
+    c1 = src1.shape[2] if src1 is not None else 0
+    if warp is not None:
+        wk, flow = warp
+        _planar(flow, 2)
+        h, w = flow.shape[1:]
+        other = src1 if wk == 0 else src0
+        assert wk in (0, 1) and (wk == 0 or src1 is not None) and (other is None or tuple(other.shape[:2]) == (h, w))
+    else:
+        h, w = src0.shape[:2]
+        assert src1 is None or src1.shape[:2] == src0.shape[:2]
     assert [c0] + ([c1] if src1 is not None else []) == list(cw.cpads), \
         'conv input channels %s do not match packed weights %s' % ([c0, c1], cw.cpads)
     k = cw.ksize
@@ -130,6 +140,11 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     else:
         d.res, d.res_c = None, 0
     d.res_planar, d.add_const, d.clamp_lo, d.clamp_hi = None, 0.0, 0.0, 0.0
+    if warp is not None:
+        wsrc = src0 if wk == 0 else src1
+        d.warp_flow, d.warp_src, d.warp_h, d.warp_w = flow.data_ptr(), wk, wsrc.shape[0], wsrc.shape[1]
+    else:
+        d.warp_flow, d.warp_src, d.warp_h, d.warp_w = None, 0, 0, 0
     if planar_out:
         out = torch.empty((cw.cout, ho, wo), dtype=torch.float32, device=src0.device)
         d.out_mode, d.out_c = OUT_PLANAR32, 0

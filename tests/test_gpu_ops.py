@@ -78,6 +78,14 @@ CONV_CASES = [
     (24, [16], 3, 1, 10, 12, False),
     (192, [48], 3, 1, 10, 34, True),
     (48, [48, 48], 3, 1, 12, 40, False),
+    # C = 48 at the sizes where the one-workgroup-per-CU variants are selected: 16-wave resident (270 x 480: 510
+    # tiles), > 2048 tiles (540 x 960), two-source
+    (48, [48], 3, 1, 270, 480, False),
+    (48, [48], 3, 1, 540, 960, False),
+    (48, [48, 48], 3, 1, 270, 480, False),
+    # streamed 7x7 convs at a size with many workgroups (LDS ring, two workgroups per CU)
+    (32, [64], 7, 1, 144, 240, False),
+    (64, [32], 7, 1, 72, 120, False),
 ]
 
 
@@ -105,6 +113,37 @@ def test_conv_mfma_vs_conv2d(dev, co, cins, ks, stride, h, w, shuffle):
     err = rel(got, want)
     report('conv_mfma co%d cin%s k%d s%d%s' % (co, cins, ks, stride, ' shuf' if shuffle else ''), rel=err)
     assert err < 1e-3          # fp16 output rounding (2^-11 relative) + fp32 accumulation order
+
+
+@pytest.mark.parametrize('co,ci,h,w,mt', [(64, 32, 9, 15, 1), (32, 64, 18, 30, 1), (32, 64, 36, 60, 2), (64, 32, 72, 120, 1), (2, 16, 9, 15, 1),
+                                          (16, 32, 20, 33, 1)])
+def test_conv_mfma_streamed_ring(dev, monkeypatch, co, ci, h, w, mt):
+    """The streamed (non-resident) 7x7 convs of SPyNet (SPyNet.py:142-202): weight chunks through the LDS-DMA ring with inline-asm
+    fragment reads.  16 output channels per workgroup (mt = 1, the packing of the coarse pyramid levels) and the default
+    packing give the same map bit for bit, and both match torch; planar fp32 output with residual for the 16 -> 2 flow head."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(co * 7 + ci + h)
+    wt = torch.randn(co, ci, 7, 7, generator=g) / (ci * 49) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    x = torch.randn(1, ci, h, w, generator=g)
+    xin = nhwc(x[0], dev)
+    xh = x.half().float()
+    cw_a = ops.ConvWeights(pack_conv(wt, b, [ci], mt=mt), dev)
+    cw_b = ops.ConvWeights(pack_conv(wt, b, [ci]), dev)
+    if co == 2:
+        res = torch.randn(2, h, w, generator=g)
+        got = ops.conv(cw_a, xin, planar_out=True, res_planar=res.to(dev)).cpu()
+        want = F.conv2d(xh, wt, b, padding=3)[0] + res
+        assert maxdiff(got, want) < 2e-3
+        return
+    a = ops.conv(cw_a, xin, act=0.0)
+    bb = ops.conv(cw_b, xin, act=0.0)
+    want = F.relu(F.conv2d(xh, wt, b, padding=3))[0]
+    e = rel(planar(a), want)
+    report('conv streamed co%d ci%d %dx%d mt%d' % (co, ci, h, w, mt), rel=e)
+    assert e < 1e-3
+    assert torch.equal(a, bb), 'mt = %d and default packing differ' % mt
 
 
 @pytest.mark.parametrize('cap', [8, 24])
@@ -409,6 +448,35 @@ def test_warp_vs_golden(dev):
     assert maxdiff(got, x) > 1e-2
 
 
+@pytest.mark.parametrize('cins,wk,h,w,src_hw', [([8, 24], 1, 45, 83, None), ([24, 24], 0, 54, 96, None), ([24, 24], 0, 54, 96, (27, 48)),
+                                                ([8, 24], 1, 270, 480, None), ([24, 24], 0, 540, 960, (270, 480)), ([8, 24], 1, 1080, 1920, None),
+                                                ([24, 24], 1, 16, 20, None)])
+def test_conv_fused_warp_is_bit_identical(dev, cins, wk, h, w, src_hw):
+    """warp fused into the consumer (RefvsrConv.warp_*: the propagated features are sampled while the conv stages its input tile,
+    models/utils.py:35-43 inside RefVSR.py:218,227-228 / 220,254,259-260) == refvsr_warp_nhwc16 followed by the plain conv, bit
+    for bit -- every kernel variant the engine can select (8 waves, 4 waves on 4 x 32 and on 8 x 32 tiles), both source slots,
+    a source map of another size than the grid (the LR state on the 2x grid, RefVSR.py:254), flows that leave the frame."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h + w + wk)
+    cin = sum(cins)
+    wt = torch.randn(24, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(24, generator=g) * 0.1
+    cw = ops.ConvWeights(pack_conv(wt, b, cins), dev)
+    sh, sw = src_hw or (h, w)
+    srcs = [nhwc(torch.randn(c, h, w, generator=g), dev) for c in cins]
+    srcs[wk] = nhwc(torch.randn(cins[wk], sh, sw, generator=g), dev)
+    flow = (torch.randn(2, h, w, generator=g) * 3.0)
+    flow[:, :2, :] += 40.0                                   # samples far outside the frame: zero padding
+    flow = flow.to(dev)
+    fused = ops.conv(cw, srcs[0], srcs[1], act=0.1, warp=(wk, flow))
+    plain = list(srcs)
+    plain[wk] = ops.warp_nhwc16(srcs[wk], flow)
+    two = ops.conv(cw, plain[0], plain[1], act=0.1)
+    assert fused.shape == two.shape and torch.equal(fused, two)
+    assert float(two.float().abs().max()) > 0.1
+
+
 def test_spynet_level_input(dev):
     from refvsr_amd import ops
     from oracle import refvsr_oracle as orc
@@ -580,7 +648,9 @@ def test_match_near_ties_flat_regions(dev, small_cfg, small_sd):
     # exact ties (identical patches): smallest index, like torch.max
     o_conf, o_idx = orc.feature_match(lr[None], ref[None], small_sd, False)
     flat = (o_conf.view(-1) > 1.0 - 1e-6)
-    report('match near-ties exact-tie columns', n=int(flat.sum()), mismatch=int((idx[flat] != o_idx[0][flat]).sum()))
+    mism = int((idx[flat] != o_idx[0][flat]).sum())
+    report('match near-ties exact-tie columns', n=int(flat.sum()), mismatch=mism)
+    assert int(flat.sum()) > 1000 and mism == 0      # exact ties pick the first index, every one of them (torch.max semantics)
 
 
 def test_feature_match_golden(dev, small_cfg, small_sd):
@@ -635,7 +705,7 @@ def test_spynet_flow_golden(dev, small_cfg, small_sd):
     a, b = g['a'][0].to(dev), g['b'][0].to(dev)
     fl = eng.flow(FrameCtx(a, a), FrameCtx(b, b)).cpu()
     report('spynet golden', abs=maxdiff(fl, g['flow'][0]), flow_mag=float(g['flow'].abs().max()))
-    assert maxdiff(fl, g['flow'][0]) < 3e-2           # pixels; fp16 conv stack, |flow| up to ~O(1-10)
+    assert maxdiff(fl, g['flow'][0]) < 4e-4           # pixels; measured 1.9e-4 (fp16 conv stack, hi + lo weights), bar = 2x
 
 
 def test_conv_stacks_golden(dev, small_cfg, small_sd):
@@ -646,10 +716,10 @@ def test_conv_stacks_golden(dev, small_cfg, small_sd):
     feat, img = g['feat'][0], g['img'][0]
     got = planar(eng.res_list(nhwc(feat, dev), 'feat_decoder2', 4))
     report('res_list golden', abs=maxdiff(got, g['res_list'][0]), mag=float(g['res_list'].abs().max()))
-    assert maxdiff(got, g['res_list'][0]) < 4e-3
+    assert maxdiff(got, g['res_list'][0]) < 1.3e-3     # measured 6.4e-4, bar = 2x
     got = planar(eng.resblocks(nhwc(img, dev, 8), nhwc(feat, dev), 'backward_resblocks'))
     report('resblocks golden', abs=maxdiff(got, g['resblocks'][0]), mag=float(g['resblocks'].abs().max()))
-    assert maxdiff(got, g['resblocks'][0]) < 1e-2     # 49 fp16 layers
+    assert maxdiff(got, g['resblocks'][0]) < 3.3e-3   # 49 fp16 layers; measured 1.6e-3, bar = 2x
     got = planar(ops.conv(eng.cw('upsample1.upsample_conv'), nhwc(feat, dev)))
     assert maxdiff(got, g['pixel_shuffle'][0]) < 3e-3
 
@@ -667,7 +737,7 @@ def test_compute_up_golden(dev, small_cfg, small_sd):
     got = eng.compute_up(nhwc(g['bw'][0], dev), nhwc(g['fw'][0], dev), g['conf_bw'][0].to(dev), g['conf_fw'][0].to(dev),
                          lr[0].to(dev)).cpu()
     report('compute_up', abs=maxdiff(got, want))
-    assert maxdiff(got, want) < 5e-3
+    assert maxdiff(got, want) < 1.1e-3               # measured 5.3e-4, bar = 2x
 
 
 # ------------------------------------------------------------------------------------------------
@@ -692,7 +762,7 @@ def test_dcn_modulated_deformable_conv(dev):
     got = planar(ops.conv(cd, ops.dcn_sample(nhwc(x[0], dev), om, 8)))
     # offsets reach several pixels here: their fp16-operand error (1e-3 px) times the map's gradient dominates
     report('dcn', rel=rel(got, want), off_mag=float(om[:144].abs().max()))
-    assert rel(got, want) < 1e-2
+    assert rel(got, want) < 2.3e-3                   # measured 1.1e-3, bar = 2x
     # zero offsets / zero mask logits: the op is 0.5 x the plain 3x3 convolution
     W0 = dict(W)
     W0['d.conv_offset.weight'] = torch.zeros(216, M, 3, 3)

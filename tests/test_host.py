@@ -224,6 +224,7 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
         _block_chain = engine.Engine._block_chain
         fuse_resblocks = True
         rb24 = False                             # the generic kernels (the 24-channel kernel is dispatched below)
+        chain_events = None
         chain_calls = False                      # per-block launches from Python
     e = E()
     for n in (1, 2, 5, 24):
