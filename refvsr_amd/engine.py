@@ -169,9 +169,12 @@ class Engine(object):
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not os.environ.get('REFVSR_NO_FUSE'))
         self.rb24 = not os.environ.get('REFVSR_NO_RB24')         # A/B knob: the generic lean kernel for C = 24 as well
-        # inter-frame warp fused into its consumer's tile staging (conv kernels with 16-row pairs: mid_channels = 24 / 32); the
-        # stand-alone warp kernel otherwise (C = 36 / 48 configs) and under the A/B knob
-        self.fuse_warp = self.C in (24, 32) and not os.environ.get('REFVSR_NO_FUSE_WARP')
+        # inter-frame warp fused into its consumer's tile staging (RefvsrConv.warp_*; conv kernels with 16-row pairs:
+        # mid_channels = 24 / 32).  Bit-identical to warp + conv (tests/test_gpu_ops.py), but OPT-IN: measured on MI355X it is
+        # slower (169.3 vs 176.4 frames/s, profiles/r03_fused_warp_ab.txt) -- the gather makes the tile staging a chain of
+        # dependent memory round trips (flow -> 4 taps per 16-byte group) that the register prefetch can no longer issue ahead
+        # of the K loop: 114 us for the fused 2x conv against 28 + 18 us for conv + stand-alone warp (3.0 TB/s gather kernel).
+        self.fuse_warp = self.C in (24, 32) and bool(getattr(config, 'fuse_warp', os.environ.get('REFVSR_FUSE_WARP')))
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
