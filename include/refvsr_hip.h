@@ -23,11 +23,12 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 6   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 7   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
-                                  6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging) */
+                                  6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging);
+                                  7: refvsr_conv24 (compile-time-specialised 24-output-channel 3x3 convs) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -127,6 +128,20 @@ int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* bl
 int refvsr_resblock24_kblock(int s, int q);
 /* Tuning knob: waves per workgroup of the 24-channel kernel, 8 (default) or 4.  Results do not depend on it. */
 int refvsr_set_resblock24_waves(int waves);
+/* 3x3 stride-1 pad-1 convolutions with 24 output channels on fp16 HWC maps, compile-time specialised like the block above
+ * (csrc/conv24.hip): the ResList tails (RefVSR_/common.py:80-82), feat_fusion / conf_fusion / fusion_UP convs (RefVSR.py:47-62,87),
+ * ref encoders, conv_hr and the input conv of ResidualBlocksWithInputConv (RefVSR.py:340-343) of the mid_channels = 24 family.
+ * out = post( act(conv(cat[src0, src1]) + bias) * mul + res ); (c0, c1) in {(24,0), (16,0), (8,24), (24,24)} = channel strides of
+ * the sources (src1 NULL when c1 = 0); out / mul / res: 24-channel maps [h][w][24] fp16 (mul, res optional).  blob: the conv's
+ * parameters, refvsr_conv24_blob_bytes(c0, c1) bytes, 16-byte aligned: [S K-steps x 3 fragments x 64 lanes x 8 halfs][32 bias
+ * floats]; fragment rows as in the resblock24 blob, lane (q, r) of K-step s holds K-block refvsr_conv24_kblock(ncg, s, q)
+ * (ty << 16 | tx << 8 | cg over the (c0 + c1) / 8 channel groups of the concatenated sources; -1 = zero block);
+ * refvsr_amd/packing.py:pack_conv24 builds it.  Same arithmetic as refvsr_conv_mfma up to fp32 summation order. */
+int refvsr_conv24_supported(int c0, int c1);
+int refvsr_conv24_blob_bytes(int c0, int c1);
+int refvsr_conv24_kblock(int ncg, int s, int q);
+int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
+                  const void* mul, const void* res, float post_slope, void* out, void* stream);
 /* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
  * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its
  * iter-th tile at buf[12 * workgroup + i] (uint64; [8], [9] = 100 MHz s_memrealtime at entry / exit, [10] = s_memtime at exit) -- tools/probe_resblock.py.  NULL switches it off (default). */

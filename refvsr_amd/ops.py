@@ -76,9 +76,12 @@ def _farr(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
 
 
+CONV24 = not os.environ.get('REFVSR_NO_CONV24')      # A/B knob: the generic conv kernel for the conv24 shapes as well
+
+
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'desc', 'odtype', 'raw')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'desc', 'odtype', 'raw', 'blob24')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
@@ -91,6 +94,12 @@ class ConvWeights(object):
         d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
         self.odtype = torch.float32 if self.f32 else torch.float16
         self.raw = pk.get('raw')      # (weight, bias) fp32 cpu tensors when the packer kept them (repacking for specialised kernels)
+        # 24-output-channel 3x3 convs of the supported input shapes also carry the blob of the specialised kernel (conv24.hip)
+        self.blob24 = None
+        if self.raw is not None and pk.get('src_channels') is not None and CONV24:
+            from .packing import conv24_ok, pack_conv24
+            if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32):
+                self.blob24 = pack_conv24(self.raw[0], self.raw[1], pk['src_channels']).to(device).contiguous()
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
@@ -120,6 +129,17 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     k = cw.ksize
     if pad is None:
         pad = k // 2
+    if (cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
+            0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == 24) and (res is None or res.shape[2] == 24)):
+        # compile-time-specialised kernel (24 output channels, 3x3): csrc/conv24.hip
+        for m_ in (mul, res):
+            if m_ is not None:
+                _nhwc(m_)
+                assert tuple(m_.shape[:2]) == (h, w)
+        out = torch.empty((h, w, 24), dtype=torch.float16, device=src0.device)
+        hip.check(hip.lib().refvsr_conv24(_ptr(src0), c0, _ptr(src1), c1, h, w, _ptr(cw.blob24), act, _ptr(mul), _ptr(res), post,
+                                          _ptr(out), _stream()), 'conv24')
+        return out
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1
     d = cw.desc

@@ -122,7 +122,8 @@ def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False):
     bias[:cout] = b[rows]
     return dict(wpack=wpack, bias=torch.from_numpy(bias), cout=cout, ksteps=S, mt=MT, ksize=ks,
                 cpads=[_padg(c, grp) for c in src_channels], shuffle=shuffle, f32=f32,
-                raw=(torch.from_numpy(w.copy()), torch.from_numpy(b.copy())))      # fp32 originals: repacking for specialised kernels
+                raw=(torch.from_numpy(w.copy()), torch.from_numpy(b.copy())),       # fp32 originals: repacking for specialised kernels
+                src_channels=list(src_channels))
 
 
 # ---- the 24-channel fused residual block (csrc/resblock24.hip) ---------------------------------------------------------
@@ -178,4 +179,80 @@ def pack_resblock24(w1, b1, w2, b2):
         out[o:o + 128] = bb.view(np.uint8)
         o += 128
     assert o == RB24_BLOB
+    return torch.from_numpy(out)
+
+
+# ---- 24-output-channel 3x3 convs (csrc/conv24.hip) -----------------------------------------------------------------------
+def c24_steps(ncg):
+    return {2: 5, 3: 7, 4: 9, 6: 14}[ncg]
+
+
+def c24_kblock(ncg, s, q):
+    """K-block (K-step s, quarter q) of the conv24 blob for ncg 16-byte channel groups of the concatenated (padded) sources
+    -> (ty, tx, cg) or None for a zero block; csrc/conv24.hip:c24_kblock is the same table (tests/test_host.py pins them).
+    A K-step takes four slots u = tx * (ncg | 1) + cg of the staged window whose LDS offsets are (immediate) + (one of <= 4
+    per-lane patterns), the blocks of quarters (0, 1) and of (2, 3) having slot offsets of equal parity."""
+    perm = (0, 2, 1, 3)
+    if ncg == 3:
+        if s < 6:
+            u = 4 * (s & 1) + perm[q]
+            return s >> 1, u // 3, u % 3
+        return None if q == 3 else (q, 2, 2)
+    if ncg == 4:
+        return s // 3, s % 3, perm[q]
+    if ncg == 2:
+        if s < 3:
+            u = (0, 4, 1, 3)[q]
+            return s, u // 3, u % 3
+        if s == 3:
+            return q & 1, 2, q >> 1
+        return None if q & 1 else (2, 2, q >> 1)
+    if ncg == 6:
+        if s < 9:
+            return s // 3, s % 3, perm[q]
+        if s < 12:
+            return s - 9, (0, 1, 0, 1)[q], (4, 5, 5, 4)[q]
+        if s == 12:
+            return q & 1, 2, 4 + (q >> 1)
+        return None if q & 1 else (2, 2, 4 + (q >> 1))
+    raise ValueError(ncg)
+
+
+def conv24_ok(w_shape, src_channels, shuffle=False, f32=False):
+    cout, cin, ks, _ = w_shape
+    pads = [_pad8(c) for c in src_channels]
+    return (cout == 24 and ks == 3 and not shuffle and not f32 and
+            (pads == [24] or pads == [16] or pads == [8, 24] or pads == [24, 24]))
+
+
+def pack_conv24(w, b, src_channels):
+    """uint8 blob of one conv for refvsr_conv24: fp16 [S][3][64 lanes][8] + 32 bias floats.  Lane l = (q = l >> 4, r = l & 15) of
+    K-step s holds the 8 (padded) input channels of K-block c24_kblock(ncg, s, q) for row r of fragment
+    f = 0: hi(W[r])   f = 1: lo(W[r])   f = 2: hi(W[16 + r]) if r < 8 else lo(W[8 + r])   (hi = fp16(w), lo = fp16(w - hi))."""
+    w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
+    b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
+    assert conv24_ok(w.shape, src_channels), (w.shape, src_channels)
+    Wk, _, ncg = kmatrix(w, src_channels)                       # [24, 9 * ncg * 8], K-block g = tap * ncg + cg
+    S = c24_steps(ncg)
+    hi = Wk.astype(np.float16)
+    lo = (Wk - hi.astype(np.float32)).astype(np.float16)
+    frag = np.zeros((S, 3, 4, 16, 8), np.float16)
+    for s_ in range(S):
+        for q in range(4):
+            kb = c24_kblock(ncg, s_, q)
+            if kb is None:
+                continue
+            ty, tx, cg = kb
+            g = (ty * 3 + tx) * ncg + cg
+            cols = slice(g * 8, g * 8 + 8)
+            frag[s_, 0, q] = hi[0:16, cols]
+            frag[s_, 1, q] = lo[0:16, cols]
+            frag[s_, 2, q, 0:8] = hi[16:24, cols]
+            frag[s_, 2, q, 8:16] = lo[16:24, cols]
+    out = np.zeros(S * 3 * 1024 + 128, np.uint8)
+    raw = frag.reshape(-1).view(np.uint8)
+    out[:raw.size] = raw
+    bb = np.zeros(32, np.float32)
+    bb[:24] = b
+    out[raw.size:] = bb.view(np.uint8)
     return torch.from_numpy(out)

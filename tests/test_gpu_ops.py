@@ -146,6 +146,49 @@ def test_conv_mfma_streamed_ring(dev, monkeypatch, co, ci, h, w, mt):
     assert torch.equal(a, bb), 'mt = %d and default packing differ' % mt
 
 
+@pytest.mark.parametrize('cins,h,w,act,post,use_mul,use_res', [
+    ([24], 19, 45, 0.2, 1.0, False, False), ([24], 270, 480, 1.0, 1.0, False, True), ([24], 61, 130, 0.2, 1.0, True, True),
+    ([24], 540, 960, 0.1, 1.0, False, False), ([16], 33, 70, 0.2, 1.0, False, False), ([16], 540, 960, 0.2, 1.0, False, False),
+    ([3, 24], 16, 32, 0.1, 1.0, False, False), ([3, 24], 270, 480, 0.1, 1.0, False, False), ([24, 24], 33, 70, 0.2, 1.0, False, False),
+    ([24, 24], 540, 960, 0.2, 1.0, False, False), ([24, 24], 7, 5, 1.0, 0.2, False, True), ([24], 8, 32, 0.0, 1.0, False, False),
+    ([24], 9, 33, 1.0, 1.0, True, False), ([24], 1080, 1920, 0.1, 1.0, False, False)])
+def test_conv24_specialised(dev, cins, h, w, act, post, use_mul, use_res):
+    """refvsr_conv24 (csrc/conv24.hip: compile-time K plans, 3-fragment hi + lo rows, bias in the accumulator) for every input
+    shape it covers, against torch fp32 on the same fp16 maps and against the runtime-generic refvsr_conv_mfma (same arithmetic
+    up to fp32 summation order): interior / border / partial tiles, maps smaller than a tile, all epilogue combinations."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h * 3 + w + len(cins))
+    cin = sum(cins)
+    wt = torch.randn(24, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(24, generator=g) * 0.1
+    x = torch.randn(1, cin, h, w, generator=g)
+    cw = ops.ConvWeights(pack_conv(wt, b, cins), dev)
+    assert cw.blob24 is not None
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(nhwc(x[0, o:o + c], dev))
+        o += c
+    mul = torch.rand(24, h, w, generator=g) if use_mul else None
+    res = torch.randn(24, h, w, generator=g) if use_res else None
+    kw = dict(act=act, post=post, mul=nhwc(mul, dev) if use_mul else None, res=nhwc(res, dev) if use_res else None)
+    got = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, **kw)
+    blob, cw.blob24 = cw.blob24, None                      # the same call through the generic kernel
+    gen = ops.conv(cw, srcs[0], srcs[1] if len(srcs) > 1 else None, **kw)
+    cw.blob24 = blob
+    want = F.leaky_relu(F.conv2d(x.half().float(), wt, b, padding=1), act)[0]
+    if use_mul:
+        want = want * mul.half().float()
+    if use_res:
+        want = want + res.half().float()
+    want = F.leaky_relu(want, post)
+    e, d = rel(planar(got), want), maxdiff(planar(got), planar(gen))
+    report('conv24 cin%s %dx%d act%.1f%s%s' % (cins, h, w, act, ' mul' if use_mul else '', ' res' if use_res else ''), rel=e, vs_generic=d)
+    assert got.shape == gen.shape == (h, w, 24)
+    assert e < 1e-3
+    assert d < 4e-3                                        # an fp16 ulp where the fp32 sums round differently
+
+
 @pytest.mark.parametrize('cap', [8, 24])
 def test_conv_mfma_persistent_tile_walk(dev, cap):
     """Single-chunk convs run on persistent workgroups that walk the pixel tiles (XCD-banded order).  Forcing a tiny

@@ -442,3 +442,62 @@ def test_resblock24_blob_and_address_model(relu):
             assert abs(v - float(o_ref[ch, oy, ox])) < 8e-3, (oy, ox, ch, v, float(o_ref[ch, oy, ox]))
             covered.add((oy, ox, ch))
     assert len(covered) == (13 * 32 + 5 * 8) * 24                    # tiles (0,0), (1,0) whole, (1,1): 5 rows x 8 columns
+
+
+@pytest.mark.parametrize('srcs', [[24], [16], [3, 24], [24, 24]])
+def test_conv24_blob_reproduces_conv(srcs):
+    """packing.pack_conv24: the K-block table equals the library's (csrc/conv24.hip:c24_kblock, whose plan -- every block once,
+    one immediate per step and pattern, equal slot parity inside a ds_read_b128 lane group -- is proven by a static_assert at
+    compile time), and the blob's fragments contracted with the staged window at the plan's slot offsets give the convolution
+    (hi + lo rows, half-wave fold of the third fragment) at every pixel of a frame with borders."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import c24_kblock, c24_steps, pack_conv24, _pad8
+    lib = hip.lib()
+    pads = [_pad8(c) for c in srcs]
+    ncg = sum(pads) // 8
+    S = c24_steps(ncg)
+    assert lib.refvsr_conv24_supported(pads[0], pads[1] if len(pads) > 1 else 0) == 1
+    assert lib.refvsr_conv24_blob_bytes(pads[0], pads[1] if len(pads) > 1 else 0) == S * 3 * 1024 + 128
+    for s in range(S):
+        for q in range(4):
+            kb, v = c24_kblock(ncg, s, q), lib.refvsr_conv24_kblock(ncg, s, q)
+            assert v == (-1 if kb is None else (kb[0] << 16 | kb[1] << 8 | kb[2])), (ncg, s, q)
+    assert lib.refvsr_conv24_kblock(ncg, S, 0) == -2 and lib.refvsr_conv24_supported(48, 0) == 0
+    g = torch.Generator().manual_seed(ncg)
+    cin = sum(srcs)
+    w = torch.randn(24, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(24, generator=g) * 0.1
+    blob = pack_conv24(w, b, srcs).numpy()
+    frag = blob[:S * 3 * 1024].view(np.float16).astype(np.float32).reshape(S, 3, 4, 16, 8)     # [s][f][q][row][8]
+    bias = blob[S * 3 * 1024:].view(np.float32)
+    h_, w_ = 5, 7
+    x = torch.randn(cin, h_, w_, generator=g).half().float()
+    # staged window memory: padded channel groups per pixel, zero border
+    xp = np.zeros((h_ + 2, w_ + 2, ncg, 8), np.float32)
+    o = 0
+    cgo = 0
+    for c, pc in zip(srcs, pads):
+        blk = np.zeros((h_, w_, pc), np.float32)
+        blk[:, :, :c] = x[o:o + c].permute(1, 2, 0).numpy()
+        xp[1:-1, 1:-1, cgo:cgo + pc // 8] = blk.reshape(h_, w_, pc // 8, 8)
+        o += c
+        cgo += pc // 8
+    want = F.conv2d(x[None], w, b, padding=1)[0].numpy()
+    got = np.zeros((24, h_, w_), np.float32)
+    for oy in range(h_):
+        for ox in range(w_):
+            acc0 = bias[0:16].copy()                                 # rows = channels 0..15
+            acc1 = np.concatenate([bias[16:24], np.zeros(8, np.float32)])    # rows 0-7: hi of 16..23 (+ bias), rows 8-15: lo
+            for s in range(S):
+                for q in range(4):
+                    kb = c24_kblock(ncg, s, q)
+                    if kb is None:
+                        assert not frag[s, :, q].any()               # zero block: zero weights, whatever it reads
+                        continue
+                    ty, tx, cg = kb
+                    bvec = xp[oy + ty, ox + tx, cg]
+                    acc0 += frag[s, 0, q] @ bvec + frag[s, 1, q] @ bvec
+                    acc1 += frag[s, 2, q] @ bvec
+            got[0:16, oy, ox] = acc0
+            got[16:24, oy, ox] = acc1[0:8] + acc1[8:16]
+    assert np.abs(got - want).max() < 2e-5
