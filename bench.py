@@ -190,7 +190,8 @@ def wavefront_model(per_frame, nfr, reset_branch):
         out['predicted_speedup'][str(n)] = {
             'hybrid_reset_aligned_partition': round(shard.predicted_speedup(nfr, n, hyb, reset_branch, ta, tb1, tb2, 0.3)[0], 3),
             'balanced_partition_handoff_at_every_boundary': round(shard.predicted_speedup(nfr, n, bal, reset_branch, ta, tb1, tb2, 0.3)[0], 3),
-            'no_reset_balanced (reset_branch=None, configs[4] regime)': round(shard.predicted_speedup(nfr, n, bal, None, ta, tb1, tb2, 0.3)[0], 3)}
+            'no_reset_balanced (reset_branch=None, configs[4] regime)': round(shard.predicted_speedup(nfr, n, bal, None, ta, tb1, tb2, 0.3)[0], 3),
+            'no_reset_growing_shards (shard.partition_chain)': round(shard.predicted_speedup(nfr, n, shard.partition_chain(nfr, n, tb1 / ta if ta > 0 else 0.165), None, ta, tb1, tb2, 0.3)[0], 3)}
     return out
 
 
@@ -252,7 +253,7 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     # reset-aligned shards need no hand-off; the short tail is re-balanced over the last two ranks so that ONE boundary still
     # lies inside a restart unit and the RCCL hand-off is exercised and timed (shard.partition_hybrid); reset_branch = None
     # (configs[4]) falls back to the balanced partition with a hand-off at every boundary
-    parts = shard.partition_hybrid(nfr, world, cfg.reset_branch) if cfg.reset_branch else shard.partition(nfr, world)
+    parts = shard.partition_hybrid(nfr, world, cfg.reset_branch) if cfg.reset_branch else shard.partition_chain(nfr, world)
     start, end = parts[rank]
     lo, hi = max(start - t // 2, 0), min(end + t // 2, nfr)
     lr, rf, _ = make_clip(hi - lo, h, w, seed=0, start=lo)          # this rank's frames (+ input halo), resident in HBM

@@ -159,6 +159,33 @@ def partition_hybrid(nframes, world, reset_branch):
     return parts
 
 
+def partition_chain(nframes, world, ratio=0.165):
+    """Partition for a clip WITHOUT forward-branch restarts (reset_branch = None, BASELINE configs[4]): every boundary needs
+    the hand-off, so the B1 steps of all frames form one serial chain over the ranks.  A rank can start its chain when its own
+    phase A is done AND the state has arrived; equal shards make rank r wait for r whole shards of B1 (4.1 x at 8 ranks with
+    the measured phase times).  Shards growing by (1 + ratio) per rank (ratio = t_B1 / t_A, 0.165 measured for RefVSR_small
+    at 270p: profiles/r03_bench.json `wavefront_model`) let the chain arrive exactly when phase A ends: n_0 = x,
+    n_r = x (1 + ratio)^r.  64 frames over 8 ranks: 4 5 6 7 8 10 11 13 -> 4.8 x predicted (equal shards: 4.1 x)."""
+    w = [1.0] + [(1.0 + ratio) ** r for r in range(1, world)]
+    tot = sum(w)
+    ideal = [nframes * v / tot for v in w]
+    n = [max(1, int(v)) if nframes >= world else 0 for v in ideal]
+    if nframes < world:
+        return partition(nframes, world)
+    # largest remainders first, keeping the sizes non-decreasing
+    while sum(n) < nframes:
+        r = max(range(world), key=lambda i: ideal[i] - n[i])
+        n[r] += 1
+    while sum(n) > nframes:
+        r = max(range(world), key=lambda i: n[i] - ideal[i])
+        n[r] -= 1
+    out, s0 = [], 0
+    for v in n:
+        out.append((s0, s0 + v))
+        s0 += v
+    return out
+
+
 def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
                   timings=None):
     """Two-phase run of this rank's share (contiguous ranges, any boundary; default: the balanced partition).

@@ -53,6 +53,7 @@ class _PackedConv(object):
         d.wpack, d.bias = wpack.data_ptr(), bias.data_ptr()
         d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
         self.odtype = torch.float32 if self.f32 else torch.float16
+        self.raw = self.blob24 = None          # the generic kernel: the specialised ones are their own ops (conv24, resblock24_chain)
 
 
 def conv_meta(cw):
@@ -97,6 +98,31 @@ def register():
 
     @resblock.register_fake
     def _(w1, b1, w2, b2, ksteps, x, act, post):
+        return torch.empty_like(x)
+
+    @op('conv24')
+    def conv24(blob: torch.Tensor, src0: torch.Tensor, src1: Optional[torch.Tensor], mul: Optional[torch.Tensor],
+               res: Optional[torch.Tensor], act: float, post: float) -> torch.Tensor:
+        h, w, c0 = src0.shape
+        out = torch.empty((h, w, 24), dtype=torch.float16, device=src0.device)
+        hip.check(hip.lib().refvsr_conv24(ops._ptr(src0), c0, ops._ptr(src1), 0 if src1 is None else src1.shape[2], h, w, ops._ptr(blob), act,
+                                          ops._ptr(mul), ops._ptr(res), post, ops._ptr(out), ops._stream()), 'conv24')
+        return out
+
+    @conv24.register_fake
+    def _(blob, src0, src1, mul, res, act, post):
+        return src0.new_empty((src0.shape[0], src0.shape[1], 24), dtype=torch.float16)
+
+    @op('resblock24_chain')
+    def resblock24_chain(blobs: torch.Tensor, x: torch.Tensor, act: float) -> torch.Tensor:
+        class _Ch(object):
+            pass
+        ch = _Ch()
+        ch.n, ch.blobs, ch.stride = blobs.shape[0], blobs, blobs.shape[1]
+        return ops.resblock24_chain(ch, x, act)
+
+    @resblock24_chain.register_fake
+    def _(blobs, x, act):
         return torch.empty_like(x)
 
     @op('match_argmax')
@@ -187,7 +213,7 @@ def register():
         return x.new_empty((c, x.shape[0], x.shape[1]), dtype=torch.float32)
 
 
-OP_NAMES = ('conv_mfma', 'resblock', 'match_argmax', 'warp', 'warp_planar', 'spynet_level_input', 'block_gather',
+OP_NAMES = ('conv_mfma', 'conv24', 'resblock', 'resblock24_chain', 'match_argmax', 'warp', 'warp_planar', 'spynet_level_input', 'block_gather',
             'block_gather_rgb', 'aligned_sample', 'resize', 'pack_nhwc16', 'unpack_nhwc16')
 
 register()

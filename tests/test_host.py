@@ -209,6 +209,28 @@ def test_partition():
     assert not shard.needs_handoff(18, 9) and shard.needs_handoff(20, 9)
 
 
+def test_wavefront_partitions_and_makespan_model():
+    """shard.partition_hybrid / partition_chain / predicted_speedup: the schedules bench.py uses for BASELINE configs[3] / [4]."""
+    parts = shard.partition_hybrid(64, 8, 9)
+    assert parts == [(0, 9), (9, 18), (18, 27), (27, 36), (36, 45), (45, 54), (54, 59), (59, 64)]
+    assert sum(shard.needs_handoff(a, 9) for a, _ in parts) == 1
+    assert shard.partition_hybrid(18, 2, 9) == [(0, 9), (9, 18)]                      # nothing to re-balance
+    ch = shard.partition_chain(64, 8, 0.165)
+    assert [b - a for a, b in ch] == [4, 5, 6, 7, 8, 10, 11, 13] and ch[0][0] == 0 and ch[-1][1] == 64
+    assert all(b0 == a1 for (_, b0), (a1, _) in zip(ch, ch[1:]))
+    assert shard.partition_chain(3, 8) == shard.partition(3, 8)
+    ta, tb1, tb2 = 5.77, 0.946, 0.552                                                 # ms per frame, profiles/r03_bench.json
+    s_h, _ = shard.predicted_speedup(64, 8, parts, 9, ta, tb1, tb2, 0.3)
+    s_b, _ = shard.predicted_speedup(64, 8, shard.partition(64, 8), 9, ta, tb1, tb2, 0.3)
+    s_n, _ = shard.predicted_speedup(64, 8, shard.partition(64, 8), None, ta, tb1, tb2, 0.3)
+    s_c, _ = shard.predicted_speedup(64, 8, ch, None, ta, tb1, tb2, 0.3)
+    assert abs(s_h - 64 / 9.0) < 0.02                    # exchange-free shards of <= 9 frames: 7.1 x
+    assert 4.0 < s_b < 4.3 and abs(s_b - s_n) < 1e-9     # a hand-off at every boundary: the B1 chain of all 64 frames
+    assert s_c > 4.7 and s_c > s_n + 0.6                 # growing shards: the chain arrives when phase A ends (4.76 x)
+    one, _ = shard.predicted_speedup(64, 1, [(0, 64)], 9, ta, tb1, tb2)
+    assert abs(one - 1.0) < 1e-12
+
+
 def test_block_chain_applies_blocks_in_order(monkeypatch):
     """Engine._block_chain: one fused launch per block (or two conv launches when fusing is off), in order."""
     from refvsr_amd import engine, ops

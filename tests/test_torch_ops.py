@@ -25,6 +25,9 @@ def test_fake_tensor_shape_inference():
         w = torch.empty(8, device=dev)
         assert torch.ops.refvsr.warp(x, fl).shape == (40, 60, 24)                                    # LR input / 2x flow form
         assert torch.ops.refvsr.resblock(w, w, w, w, 7, x, 0.0, 1.0).shape == x.shape
+        assert torch.ops.refvsr.resblock24_chain(torch.empty((3, 43264), dtype=torch.uint8, device=dev), x, 0.0).shape == x.shape
+        y = torch.ops.refvsr.conv24(w, torch.empty((20, 30, 8), dtype=torch.float16, device=dev), x, None, None, 0.1, 1.0)
+        assert y.shape == (20, 30, 24) and y.dtype == torch.float16
         y = torch.ops.refvsr.conv_mfma(w, w, [96, 3, 1, 0, 7, 3, 24, 0], x, None, None, None, None, 1, 1.0, 1.0, False, 0.0, 0.0, 0.0)
         assert y.shape == (40, 60, 24) and y.dtype == torch.float16                                   # pixel-shuffle weights
         y = torch.ops.refvsr.conv_mfma(w, w, [3, 3, 0, 0, 7, 1, 24, 0], x, None, None, None, None, 1, 1.0, 1.0, True, 0.0, 0.0, 1.0)
@@ -60,8 +63,15 @@ def test_torch_library_ops_match_direct_calls():
     mk = lambda co, cins, **kw: ops.ConvWeights(pack_conv(torch.randn(co, sum(cins), 3, 3, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, cins, **kw), dev)
     c1, c2, cs, cp = mk(C, [C]), mk(C, [C]), mk(4 * C, [C], shuffle=True), mk(3, [C])
     R = torch.ops.refvsr
+    # the specialised kernels are their own ops; conv_mfma is the generic kernel (direct call with the conv24 blob set aside)
+    assert c1.blob24 is not None
+    assert torch.equal(R.conv24(c1.blob24, x, None, None, x, 0.2, 1.0), ops.conv(c1, x, act=0.2, res=x))
+    ch = ops.Resblock24Chain([(c1, c2), (c2, c1)], dev)
+    assert torch.equal(R.resblock24_chain(ch.blobs, x, 0.0), ops.resblock24_chain(ch, x, 0.0))
+    blob, c1.blob24 = c1.blob24, None
     assert torch.equal(R.conv_mfma(c1.wpack, c1.bias, t.conv_meta(c1), x, None, None, x, None, 1, 0.2, 1.0, False, 0.0, 0.0, 0.0),
                        ops.conv(c1, x, act=0.2, res=x))
+    c1.blob24 = blob
     assert torch.equal(R.conv_mfma(cs.wpack, cs.bias, t.conv_meta(cs), x, None, None, None, None, 1, 1.0, 1.0, False, 0.0, 0.0, 0.0), ops.conv(cs, x))
     base = torch.rand(3, h, w, generator=g).to(dev)
     assert torch.equal(R.conv_mfma(cp.wpack, cp.bias, t.conv_meta(cp), x, None, None, None, base, 1, 1.0, 1.0, True, 0.0, 0.0, 1.0),
@@ -83,3 +93,5 @@ def test_torch_library_ops_match_direct_calls():
     torch.library.opcheck(R.warp, (x, fl), test_utils=('test_schema', 'test_faketensor'))
     torch.library.opcheck(R.resblock, (c1.wpack, c1.bias, c2.wpack, c2.bias, c1.ksteps, x, 0.0, 1.0), test_utils=('test_schema', 'test_faketensor'))
     torch.library.opcheck(R.match_argmax, (lr_f, ref_f), test_utils=('test_schema', 'test_faketensor'))
+    torch.library.opcheck(R.conv24, (c1.blob24, x, None, None, x, 0.2, 1.0), test_utils=('test_schema', 'test_faketensor'))
+    torch.library.opcheck(R.resblock24_chain, (ch.blobs, x, 0.0), test_utils=('test_schema', 'test_faketensor'))
