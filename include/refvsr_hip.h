@@ -28,7 +28,7 @@ extern "C" {
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
                                   6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging);
-                                  7: refvsr_conv24 (compile-time-specialised 24-output-channel 3x3 convs) */
+                                  7: refvsr_conv24 / refvsr_conv48 (compile-time-specialised 3x3 convs) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -141,6 +141,15 @@ int refvsr_conv24_supported(int c0, int c1);
 int refvsr_conv24_blob_bytes(int c0, int c1);
 int refvsr_conv24_kblock(int ncg, int s, int q);
 int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
+                  const void* mul, const void* res, float post_slope, void* out, void* stream);
+/* The same for 48 output channels (mid_channels = 48: configs/config_RefVSR_{L1,MFID,MFID_8K}.py -- the two convs of every
+ * ResidualBlockNoBN, sr_backbone_utils.py:42-97, and conf_fusion*.1): (c0, c1) in {(48,0), (16,0)}; out / mul / res are
+ * 48-channel maps; blob: [S x 6 fragments x 64 lanes x 8 halfs][64 bias floats], fragments [hi | lo] of output channels 0-15,
+ * 16-31, 32-47, K-blocks by refvsr_conv24_kblock(ncg, s, q).  48 -> 48 keeps its 84 KB weight set resident next to a
+ * 16 x 32-pixel tile walked by sixteen waves (one workgroup per CU). */
+int refvsr_conv48_supported(int c0, int c1);
+int refvsr_conv48_blob_bytes(int c0, int c1);
+int refvsr_conv48(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
                   const void* mul, const void* res, float post_slope, void* out, void* stream);
 /* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
  * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its

@@ -12,6 +12,11 @@
 // out = post( act(conv + bias) * mul + res ), the epilogue of refvsr_conv_mfma's fp16 HWC mode.  The generic kernel stays
 // for every other shape (strides, 5x5 / 7x7, pixel shuffle, planar outputs, other channel counts).
 //
+// COUT = 48 (the mid_channels = 48 family, configs/config_RefVSR_{L1,MFID,MFID_8K}.py: 30 ResidualBlockNoBN per branch, two
+// convs each): six fragments per K-step ([hi | lo] of output channels 0-15, 16-31, 32-47; no fold), 48 -> 48 with the 84 KB
+// weight set resident next to a 16 x 32-pixel tile (18 x 34 staged pixels, 68 KB) walked by SIXTEEN waves -- one workgroup per
+// CU, four waves per SIMD, 255 tiles for the 270 x 480 map of the 256-CU chip -- and 16 -> 48 on the 8 x 32 tile.
+//
 // LDS: [fragments: S K-steps x 3 x 1 KiB][bias: 32 floats][x tile: 10 x 34 pixels x PS slots of 16 bytes, PS = NCG | 1 (odd
 // pixel stride: bank-conflict-free B reads with the pixel permutation of common.h)].  K plans (c24_kblock): the K-blocks of
 // one window row are the slots u = tx * PS + cg; a K-step takes four of them whose offsets are (step immediate) + (one of
@@ -26,7 +31,7 @@
 #include "common.h"
 
 namespace {
-constexpr int C24_TH = 8, C24_TW = 32, C24_XH = 10, C24_XW = 34, C24_NPX = C24_XH * C24_XW;   // 340 staged pixels
+constexpr int C24_TW = 32, C24_XW = 34;                       // tile width; staged row = 34 pixels (tile height: template)
 
 __host__ __device__ constexpr int c24_steps(int ncg) { return ncg == 2 ? 5 : ncg == 3 ? 7 : ncg == 4 ? 9 : ncg == 6 ? 14 : 0; }
 
@@ -119,16 +124,22 @@ __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l
     return __uint_as_float(x0) + __uint_as_float(x1);
 }
 
-template <int NCG0, int NCG1, int NWV>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 2, NWV / 2))) void conv24_kernel(C24Args p) {
+// COUT = 24 | 48 output channels; TH = 8 | 16 tile rows; NWV waves walk the TH x 32 tile, T = 2 TH / NWV pixel groups per wave;
+// WPS = waves per SIMD the kernel is built for (register budget).
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void conv24_kernel(C24Args p) {
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
     constexpr int S = c24_steps(NCG), NPAT = c24_npat(NCG);
-    constexpr int WB = S * 3 * 1024, BIAS = WB, XT = WB + 128;
-    constexpr int NT = NWV * 64, T = 16 / NWV;
+    constexpr int NF = COUT == 24 ? 3 : 6;                          // fragments per K-step
+    constexpr int NM = COUT == 24 ? 2 : 3;                          // accumulator tiles per pixel group
+    constexpr int BIASB = COUT == 24 ? 128 : 256;
+    constexpr int WB = S * NF * 1024, BIAS = WB, XT = WB + BIASB;
+    constexpr int NT = NWV * 64, T = 2 * TH / NWV;
+    constexpr int C24_TH = TH, C24_XH = TH + 2, C24_NPX = C24_XH * C24_XW;
     constexpr int NCH = C24_NPX * NCG, KCH = (NCH + NT - 1) / NT;
     constexpr int PIXB0 = NCG0 * 16, PIXB1 = NCG1 * 16;
-    constexpr int OPX = 48;                                         // bytes per pixel of the 24-channel out / mul / res maps
-    static_assert(S > 0 && T >= 1, "unsupported shape");
+    constexpr int OPX = COUT * 2;                                   // bytes per pixel of the out / mul / res maps
+    static_assert((COUT == 24 || COUT == 48) && S > 0 && T >= 1 && T * NWV == 2 * TH, "unsupported shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.out), "s"(p.blob), "s"(p.mul), "s"(p.res), "s"(p.h), "s"(p.w), "s"(p.tiles_x),
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024),
                                                  (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
         }
-        if (wave == NPC % NWV && lane < 8)
+        if (wave == NPC % NWV && lane < BIASB / 16)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + NPC * 1024),
                                              (__attribute__((address_space(3))) void*)(smem + NPC * 1024), 16, 0, 0);
     }
@@ -240,8 +251,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
         const int ty0 = tyi * C24_TH, tx0 = (tl - tyi * p.tiles_x) * C24_TW;
         const bool interior = ty0 >= 1 && ty0 + C24_TH + 1 <= p.h && tx0 >= 1 && tx0 + C24_TW + 1 <= p.w;
         const long long oorg = ((long long)ty0 * p.w + tx0) * OPX;
-        // epilogue operands of this tile, in flight during the K loop
-        f16x4 m0[T], m1[T], r0[T], r1[T];
+        // epilogue operands of this tile, in flight during the K loop.  Accumulator tile m of a pixel group holds channels
+        // 16 m + 4 q .. (COUT = 24: tile 1 = channels 16 + 4 q for q < 2, see resblock24.hip)
+        f16x4 mv[NM][T], rv[NM][T];
         bool okt[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -252,58 +264,85 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
                 okt[t] = ty0 + oy0 + (t >> 1) < p.h && tx0 + (t & 1) * 16 + lpe < p.w;
             }
             const unsigned eo = (unsigned)((t >> 1) * rowb_o) + oo + (t & 1) * 16 * OPX;
-            m0[t] = m1[t] = r0[t] = r1[t] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-            if (p.mul && okt[t]) {
-                m0[t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo);
-                if (q < 2) m1[t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32);
-            }
-            if (p.res && okt[t]) {
-                r0[t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo);
-                if (q < 2) r1[t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                mv[m][t] = rv[m][t] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                const bool lane_ok = okt[t] && (COUT == 48 || m == 0 || q < 2);
+                if constexpr (COUT == 24) {                          // (COUT = 48: fetched in the epilogue -- register budget)
+                    if (p.mul && lane_ok) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
+                    if (p.res && lane_ok) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
+                }
             }
         }
         if (has_next) x_fetch(tl + 1);                               // next tile: in flight during the K loop
 
-        // ---------------- K loop: acc = bias + conv(x) on the 8 x 32 tile ---------------------------------------------------
-        f32x4 a0[T], a1[T];
-        {
-            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(smem + BIAS + q * 16);          // channels 4q ..
-            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(smem + BIAS + 64 + q * 16);     // channels 16 + 4q .. (24..31: zeros)
+        // ---------------- K loop: acc = bias + conv(x) on the TH x 32 tile ---------------------------------------------------
+        f32x4 acc[NM][T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) { a0[t] = bv0; a1[t] = bv1; }
+        for (int m = 0; m < NM; ++m) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS + m * 64 + q * 16);   // channels 16 m + 4 q .. (pads: zeros)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[m][t] = bv;
         }
         {
-            uint4 fa[2][3], fb[2][T];
-            auto load = [&](auto sc, uint4 (&af)[3], uint4 (&bf)[T]) {
+            uint4 fa[2][NF], fb[2][T];
+            auto load = [&](auto sc, uint4 (&af)[NF], uint4 (&bf)[T]) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int pp = c24_pat(NCG, s);
-                constexpr int imm = c24_off(NCG, s, 0) - c24_off(NCG, c24_pat_step(NCG, pp), 0) + c24_off(NCG, c24_pat_step(NCG, pp), 0);
+                constexpr int imm = c24_off(NCG, s, 0);
 #pragma unroll
-                for (int f = 0; f < 3; ++f) af[f] = *reinterpret_cast<const uint4*>(smem + (s * 3 + f) * 1024 + la);
+                for (int f = 0; f < NF; ++f) af[f] = *reinterpret_cast<const uint4*>(smem + (s * NF + f) * 1024 + la);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     if constexpr (pp == 0) bf[t] = *reinterpret_cast<const uint4*>(smem + pb[t] + imm);
                     else bf[t] = *reinterpret_cast<const uint4*>(smem + pb[t] + pd[pp] + imm);
                 }
             };
-            auto mfma = [&](const uint4 (&af)[3], const uint4 (&bf)[T]) {
-                const f16x8 a_hi = *reinterpret_cast<const f16x8*>(&af[0]);
-                const f16x8 a_lo = *reinterpret_cast<const f16x8*>(&af[1]);
-                const f16x8 a_mx = *reinterpret_cast<const f16x8*>(&af[2]);
+            auto mfma = [&](const uint4 (&af)[NF], const uint4 (&bf)[T]) {
+                if constexpr (COUT == 24) {                          // [hi 0-15] [lo 0-15] [hi 16-23 | lo 16-23]
+                    const f16x8 a_hi = *reinterpret_cast<const f16x8*>(&af[0]);
+                    const f16x8 a_lo = *reinterpret_cast<const f16x8*>(&af[1]);
+                    const f16x8 a_mx = *reinterpret_cast<const f16x8*>(&af[2]);
 #pragma unroll
-                for (int t = 0; t < T; ++t) a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, *reinterpret_cast<const f16x8*>(&bf[t]), a0[t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, *reinterpret_cast<const f16x8*>(&bf[t]), acc[0][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < T; ++t) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_mx, *reinterpret_cast<const f16x8*>(&bf[t]), a1[t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_mx, *reinterpret_cast<const f16x8*>(&bf[t]), acc[1][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < T; ++t) a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, *reinterpret_cast<const f16x8*>(&bf[t]), a0[t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, *reinterpret_cast<const f16x8*>(&bf[t]), acc[0][t], 0, 0, 0);
+                } else {                                             // [hi | lo] of channels 0-15, 16-31, 32-47: all hi, then all lo
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const f16x8 av = *reinterpret_cast<const f16x8*>(&af[2 * m + h]);
+#pragma unroll
+                            for (int t = 0; t < T; ++t)
+                                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, *reinterpret_cast<const f16x8*>(&bf[t]), acc[m][t], 0, 0, 0);
+                        }
+                }
             };
-            load(std::integral_constant<int, 0>{}, fa[0], fb[0]);
-            c24_static_for([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s + 1 < S) load(std::integral_constant<int, s + 1>{}, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma(fa[s & 1], fb[s & 1]);
-            }, std::make_integer_sequence<int, S>{});
+            if constexpr (COUT == 24) {
+                // two fragment sets: the reads of step s + 1 are issued above the MFMAs of step s
+                load(std::integral_constant<int, 0>{}, fa[0], fb[0]);
+                c24_static_for([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s + 1 < S) load(std::integral_constant<int, s + 1>{}, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma(fa[s & 1], fb[s & 1]);
+                }, std::make_integer_sequence<int, S>{});
+            } else {
+                // ONE fragment set (six weight fragments: a second set does not fit 128 VGPRs): the reads of step s + 1 are issued
+                // right behind the 6 T MFMAs of step s -- those have latched their operands by then and occupy the matrix pipe for
+                // 96 T cycles, longer than the reads take
+                load(std::integral_constant<int, 0>{}, fa[0], fb[0]);
+                c24_static_for([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma(fa[0], fb[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (s + 1 < S) load(std::integral_constant<int, s + 1>{}, fa[0], fb[0]);
+                }, std::make_integer_sequence<int, S>{});
+            }
         }
         if (has_next) {
             __syncthreads();                                         // every wave is done reading the x tile
@@ -314,30 +353,35 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
             unsigned char* ob = p.out + oorg;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                f32x4 y0 = a0[t];
-                f32x4 y1 = {c24_fold1(a1[t][0]), c24_fold1(a1[t][1]), c24_fold1(a1[t][2]), c24_fold1(a1[t][3])};
-                if (p.act_slope != 1.0f) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { y0[i] = fmaxf(y0[i], y0[i] * p.act_slope); y1[i] = fmaxf(y1[i], y1[i] * p.act_slope); }
-                }
-                if (p.mul) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { y0[i] *= (float)m0[t][i]; y1[i] *= (float)m1[t][i]; }
-                }
-                if (p.res) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { y0[i] += (float)r0[t][i]; y1[i] += (float)r1[t][i]; }
-                }
-                if (p.post_slope != 1.0f) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { y0[i] = fmaxf(y0[i], y0[i] * p.post_slope); y1[i] = fmaxf(y1[i], y1[i] * p.post_slope); }
-                }
-                const f16x4 o0 = {(f16)y0[0], (f16)y0[1], (f16)y0[2], (f16)y0[3]};
-                const f16x4 o1 = {(f16)y1[0], (f16)y1[1], (f16)y1[2], (f16)y1[3]};
                 unsigned char* d = ob + (unsigned)((t >> 1) * rowb_o) + oo + (t & 1) * 16 * OPX;
-                if (okt[t]) {
-                    *reinterpret_cast<f16x4*>(d) = o0;
-                    if (q < 2) *reinterpret_cast<f16x4*>(d + 32) = o1;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    f32x4 y = acc[m][t];
+                    if constexpr (COUT == 24) {
+                        if (m == 1) y = (f32x4){c24_fold1(y[0]), c24_fold1(y[1]), c24_fold1(y[2]), c24_fold1(y[3])};
+                    } else {
+                        const unsigned eo = (unsigned)((t >> 1) * rowb_o) + oo + (t & 1) * 16 * OPX;
+                        if (p.mul && okt[t]) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
+                        if (p.res && okt[t]) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
+                    }
+                    if (p.act_slope != 1.0f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], y[i] * p.act_slope);
+                    }
+                    if (p.mul) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] *= (float)mv[m][t][i];
+                    }
+                    if (p.res) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] += (float)rv[m][t][i];
+                    }
+                    if (p.post_slope != 1.0f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], y[i] * p.post_slope);
+                    }
+                    const f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                    if (okt[t] && (COUT == 48 || m == 0 || q < 2)) *reinterpret_cast<f16x4*>(d + 32 * m) = o;
                 }
             }
         }
@@ -345,24 +389,28 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
     }
 }
 
-template <int NCG0, int NCG1>
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS>
 static int launch_c24(C24Args& a, hipStream_t st) {
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
-    constexpr int LDS = c24_steps(NCG) * 3 * 1024 + 128 + C24_NPX * PS * 16;
+    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : 6) * 1024 + (COUT == 24 ? 128 : 256) + (TH + 2) * C24_XW * PS * 16;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<NCG0, NCG1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<NCG0, NCG1, 8>, 512, LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS>, NWV * 64, LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
+    a.tiles_x = rv_cdiv(a.w, C24_TW);
+    a.n_tiles = a.tiles_x * rv_cdiv(a.h, TH);
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((conv24_kernel<NCG0, NCG1, 8>), dim3(a.grid), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS>), dim3(a.grid), dim3(NWV * 64), LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -370,10 +418,15 @@ static int launch_c24(C24Args& a, hipStream_t st) {
 extern "C" int refvsr_conv24_supported(int c0, int c1) {
     return (c0 == 24 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 8 && c1 == 24) || (c0 == 24 && c1 == 24);
 }
+extern "C" int refvsr_conv48_supported(int c0, int c1) { return (c0 == 48 && c1 == 0) || (c0 == 16 && c1 == 0); }
 
 extern "C" int refvsr_conv24_blob_bytes(int c0, int c1) {
     if (!refvsr_conv24_supported(c0, c1)) return -1;
     return c24_steps((c0 + c1) / 8) * 3 * 1024 + 128;
+}
+extern "C" int refvsr_conv48_blob_bytes(int c0, int c1) {
+    if (!refvsr_conv48_supported(c0, c1)) return -1;
+    return c24_steps((c0 + c1) / 8) * 6 * 1024 + 256;
 }
 
 extern "C" int refvsr_conv24_kblock(int ncg, int s, int q) {
@@ -381,26 +434,40 @@ extern "C" int refvsr_conv24_kblock(int ncg, int s, int q) {
     return c24_kblock(ncg, s, q);
 }
 
-extern "C" int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
-                             const void* mul, const void* res, float post_slope, void* out, void* stream) {
-    RV_CHECK(src0 && out && blob && h > 0 && w > 0, "conv24: bad args");
-    RV_CHECK(refvsr_conv24_supported(c0, c1), "conv24: %d + %d input channels not supported", c0, c1);
-    RV_CHECK((c1 == 0) == (src1 == nullptr), "conv24: src1 / c1 mismatch");
-    RV_CHECK(((uintptr_t)blob & 15) == 0, "conv24: blob must be 16-byte aligned");
-    RV_CHECK(act_slope >= 0.f && act_slope <= 1.f && post_slope >= 0.f && post_slope <= 1.f, "conv24: activation slopes must lie in [0, 1]");
-    RV_CHECK(src0 != out && src1 != out, "conv24: in-place operation is not supported");
-    RV_CHECK((long long)h * w * 48 < (1ll << 31), "conv24: map too large for 32-bit offsets");
+static int c24_fill(C24Args& a, const char* who, int cout, const void* src0, const void* src1, int c1, int h, int w, const void* blob,
+                    float act_slope, const void* mul, const void* res, float post_slope, void* out) {
+    RV_CHECK(src0 && out && blob && h > 0 && w > 0, "%s: bad args", who);
+    RV_CHECK((c1 == 0) == (src1 == nullptr), "%s: src1 / c1 mismatch", who);
+    RV_CHECK(((uintptr_t)blob & 15) == 0, "%s: blob must be 16-byte aligned", who);
+    RV_CHECK(act_slope >= 0.f && act_slope <= 1.f && post_slope >= 0.f && post_slope <= 1.f, "%s: activation slopes must lie in [0, 1]", who);
+    RV_CHECK(src0 != out && src1 != out, "%s: in-place operation is not supported", who);
+    RV_CHECK((long long)h * w * cout * 2 < (1ll << 31), "%s: map too large for 32-bit offsets", who);
     RV_CHECK(refvsr_init() == 0, "init failed");
-    C24Args a;
     memset(&a, 0, sizeof(a));
     a.src0 = (const unsigned char*)src0; a.src1 = (const unsigned char*)src1; a.out = (unsigned char*)out;
     a.blob = (const unsigned char*)blob; a.mul = (const unsigned char*)mul; a.res = (const unsigned char*)res;
     a.h = h; a.w = w; a.act_slope = act_slope; a.post_slope = post_slope;
-    a.tiles_x = rv_cdiv(w, C24_TW);
-    a.n_tiles = a.tiles_x * rv_cdiv(h, C24_TH);
+    return 0;
+}
+
+extern "C" int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
+                             const void* mul, const void* res, float post_slope, void* out, void* stream) {
+    RV_CHECK(refvsr_conv24_supported(c0, c1), "conv24: %d + %d input channels not supported", c0, c1);
+    C24Args a;
+    if (c24_fill(a, "conv24", 24, src0, src1, c1, h, w, blob, act_slope, mul, res, post_slope, out)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    if (c0 == 24 && c1 == 0) return launch_c24<3, 0>(a, st);
-    if (c0 == 16 && c1 == 0) return launch_c24<2, 0>(a, st);
-    if (c0 == 8 && c1 == 24) return launch_c24<1, 3>(a, st);
-    return launch_c24<3, 3>(a, st);
+    if (c0 == 24 && c1 == 0) return launch_c24<24, 3, 0, 8, 8, 4>(a, st);
+    if (c0 == 16 && c1 == 0) return launch_c24<24, 2, 0, 8, 8, 4>(a, st);
+    if (c0 == 8 && c1 == 24) return launch_c24<24, 1, 3, 8, 8, 4>(a, st);
+    return launch_c24<24, 3, 3, 8, 8, 4>(a, st);
+}
+
+extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
+                             const void* mul, const void* res, float post_slope, void* out, void* stream) {
+    RV_CHECK(refvsr_conv48_supported(c0, c1), "conv48: %d + %d input channels not supported", c0, c1);
+    C24Args a;
+    if (c24_fill(a, "conv48", 48, src0, src1, c1, h, w, blob, act_slope, mul, res, post_slope, out)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (c0 == 48) return launch_c24<48, 6, 0, 16, 16, 4>(a, st);     // 84 KB of weights + 18 x 34-pixel tile: one workgroup per CU
+    return launch_c24<48, 2, 0, 8, 8, 4>(a, st);
 }

@@ -94,7 +94,8 @@ class ConvWeights(object):
         d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
         self.odtype = torch.float32 if self.f32 else torch.float16
         self.raw = pk.get('raw')      # (weight, bias) fp32 cpu tensors when the packer kept them (repacking for specialised kernels)
-        # 24-output-channel 3x3 convs of the supported input shapes also carry the blob of the specialised kernel (conv24.hip)
+        # 3x3 convs with 24 / 48 output channels of the supported input shapes also carry the blob of the specialised kernel
+        # (conv24.hip; the attribute keeps its first name)
         self.blob24 = None
         if self.raw is not None and pk.get('src_channels') is not None and CONV24:
             from .packing import conv24_ok, pack_conv24
@@ -129,16 +130,18 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     k = cw.ksize
     if pad is None:
         pad = k // 2
+    co_ = cw.cout
     if (cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
-            0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == 24) and (res is None or res.shape[2] == 24)):
-        # compile-time-specialised kernel (24 output channels, 3x3): csrc/conv24.hip
+            0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_)):
+        # compile-time-specialised kernel (24 | 48 output channels, 3x3): csrc/conv24.hip
         for m_ in (mul, res):
             if m_ is not None:
                 _nhwc(m_)
                 assert tuple(m_.shape[:2]) == (h, w)
-        out = torch.empty((h, w, 24), dtype=torch.float16, device=src0.device)
-        hip.check(hip.lib().refvsr_conv24(_ptr(src0), c0, _ptr(src1), c1, h, w, _ptr(cw.blob24), act, _ptr(mul), _ptr(res), post,
-                                          _ptr(out), _stream()), 'conv24')
+        out = torch.empty((h, w, co_), dtype=torch.float16, device=src0.device)
+        fn = hip.lib().refvsr_conv24 if co_ == 24 else hip.lib().refvsr_conv48
+        hip.check(fn(_ptr(src0), c0, _ptr(src1), c1, h, w, _ptr(cw.blob24), act, _ptr(mul), _ptr(res), post, _ptr(out), _stream()),
+                  'conv24' if co_ == 24 else 'conv48')
         return out
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1

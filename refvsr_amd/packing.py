@@ -219,24 +219,34 @@ def c24_kblock(ncg, s, q):
 
 
 def conv24_ok(w_shape, src_channels, shuffle=False, f32=False):
+    """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 or 48 output channels, the listed inputs."""
     cout, cin, ks, _ = w_shape
     pads = [_pad8(c) for c in src_channels]
-    return (cout == 24 and ks == 3 and not shuffle and not f32 and
-            (pads == [24] or pads == [16] or pads == [8, 24] or pads == [24, 24]))
+    if ks != 3 or shuffle or f32:
+        return False
+    if cout == 24:
+        return pads in ([24], [16], [8, 24], [24, 24])
+    if cout == 48:
+        return pads in ([48], [16])
+    return False
 
 
 def pack_conv24(w, b, src_channels):
-    """uint8 blob of one conv for refvsr_conv24: fp16 [S][3][64 lanes][8] + 32 bias floats.  Lane l = (q = l >> 4, r = l & 15) of
-    K-step s holds the 8 (padded) input channels of K-block c24_kblock(ncg, s, q) for row r of fragment
-    f = 0: hi(W[r])   f = 1: lo(W[r])   f = 2: hi(W[16 + r]) if r < 8 else lo(W[8 + r])   (hi = fp16(w), lo = fp16(w - hi))."""
+    """uint8 blob of one conv for refvsr_conv24 / refvsr_conv48: fp16 [S][NF][64 lanes][8] + bias floats (32 | 64).  Lane
+    l = (q = l >> 4, r = l & 15) of K-step s holds the 8 (padded) input channels of K-block c24_kblock(ncg, s, q) for row r of
+    fragment f (hi = fp16(w), lo = fp16(w - hi)):
+      24 outputs (NF = 3): f = 0: hi(W[r])   f = 1: lo(W[r])   f = 2: hi(W[16 + r]) if r < 8 else lo(W[8 + r])
+      48 outputs (NF = 6): f = 2 m: hi(W[16 m + r])   f = 2 m + 1: lo(W[16 m + r])"""
     w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
     b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
     assert conv24_ok(w.shape, src_channels), (w.shape, src_channels)
-    Wk, _, ncg = kmatrix(w, src_channels)                       # [24, 9 * ncg * 8], K-block g = tap * ncg + cg
+    cout = w.shape[0]
+    Wk, _, ncg = kmatrix(w, src_channels)                       # [cout, 9 * ncg * 8], K-block g = tap * ncg + cg
     S = c24_steps(ncg)
+    nf = 3 if cout == 24 else 6
     hi = Wk.astype(np.float16)
     lo = (Wk - hi.astype(np.float32)).astype(np.float16)
-    frag = np.zeros((S, 3, 4, 16, 8), np.float16)
+    frag = np.zeros((S, nf, 4, 16, 8), np.float16)
     for s_ in range(S):
         for q in range(4):
             kb = c24_kblock(ncg, s_, q)
@@ -245,14 +255,20 @@ def pack_conv24(w, b, src_channels):
             ty, tx, cg = kb
             g = (ty * 3 + tx) * ncg + cg
             cols = slice(g * 8, g * 8 + 8)
-            frag[s_, 0, q] = hi[0:16, cols]
-            frag[s_, 1, q] = lo[0:16, cols]
-            frag[s_, 2, q, 0:8] = hi[16:24, cols]
-            frag[s_, 2, q, 8:16] = lo[16:24, cols]
-    out = np.zeros(S * 3 * 1024 + 128, np.uint8)
+            if cout == 24:
+                frag[s_, 0, q] = hi[0:16, cols]
+                frag[s_, 1, q] = lo[0:16, cols]
+                frag[s_, 2, q, 0:8] = hi[16:24, cols]
+                frag[s_, 2, q, 8:16] = lo[16:24, cols]
+            else:
+                for m in range(3):
+                    frag[s_, 2 * m, q] = hi[16 * m:16 * m + 16, cols]
+                    frag[s_, 2 * m + 1, q] = lo[16 * m:16 * m + 16, cols]
+    nb = 32 if cout == 24 else 64
+    out = np.zeros(S * nf * 1024 + nb * 4, np.uint8)
     raw = frag.reshape(-1).view(np.uint8)
     out[:raw.size] = raw
-    bb = np.zeros(32, np.float32)
-    bb[:24] = b
+    bb = np.zeros(nb, np.float32)
+    bb[:cout] = b
     out[raw.size:] = bb.view(np.uint8)
     return torch.from_numpy(out)

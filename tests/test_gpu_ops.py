@@ -189,6 +189,39 @@ def test_conv24_specialised(dev, cins, h, w, act, post, use_mul, use_res):
     assert d < 4e-3                                        # an fp16 ulp where the fp32 sums round differently
 
 
+@pytest.mark.parametrize('cins,h,w,act,use_res', [([48], 19, 45, 0.0, False), ([48], 270, 480, 1.0, True), ([48], 61, 130, 0.2, True),
+                                                   ([48], 540, 960, 0.0, False), ([48], 16, 32, 1.0, True), ([48], 17, 33, 0.0, False),
+                                                   ([16], 33, 70, 0.2, False), ([16], 270, 480, 0.2, False), ([48], 7, 5, 1.0, True)])
+def test_conv48_specialised(dev, cins, h, w, act, use_res):
+    """refvsr_conv48 (csrc/conv24.hip, COUT = 48: six fragments per K-step, 16 x 32 tiles on sixteen waves for 48 -> 48; the two
+    convs of every residual block of the mid_channels = 48 models) against torch fp32 on the same fp16 maps and against the
+    generic kernel: interior / border / partial tiles (16-row tiles: 270 = 16 x 16 + 14), maps smaller than a tile."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h * 5 + w)
+    cin = sum(cins)
+    wt = torch.randn(48, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(48, generator=g) * 0.1
+    x = torch.randn(1, cin, h, w, generator=g)
+    cw = ops.ConvWeights(pack_conv(wt, b, cins), dev)
+    assert cw.blob24 is not None and cw.cout == 48
+    xin = nhwc(x[0], dev)
+    res = torch.randn(48, h, w, generator=g) if use_res else None
+    kw = dict(act=act, res=nhwc(res, dev) if use_res else None)
+    got = ops.conv(cw, xin, **kw)
+    blob, cw.blob24 = cw.blob24, None
+    gen = ops.conv(cw, xin, **kw)
+    cw.blob24 = blob
+    want = F.leaky_relu(F.conv2d(x.half().float(), wt, b, padding=1), act)[0]
+    if use_res:
+        want = want + res.half().float()
+    e, d = rel(planar(got), want), maxdiff(planar(got), planar(gen))
+    report('conv48 cin%s %dx%d act%.1f%s' % (cins, h, w, act, ' res' if use_res else ''), rel=e, vs_generic=d)
+    assert got.shape == gen.shape == (h, w, 48)
+    assert e < 1e-3
+    assert d < 4e-3
+
+
 @pytest.mark.parametrize('cap', [8, 24])
 def test_conv_mfma_persistent_tile_walk(dev, cap):
     """Single-chunk convs run on persistent workgroups that walk the pixel tiles (XCD-banded order).  Forcing a tiny

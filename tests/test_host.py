@@ -466,8 +466,8 @@ def test_resblock24_blob_and_address_model(relu):
     assert len(covered) == (13 * 32 + 5 * 8) * 24                    # tiles (0,0), (1,0) whole, (1,1): 5 rows x 8 columns
 
 
-@pytest.mark.parametrize('srcs', [[24], [16], [3, 24], [24, 24]])
-def test_conv24_blob_reproduces_conv(srcs):
+@pytest.mark.parametrize('srcs,cout', [([24], 24), ([16], 24), ([3, 24], 24), ([24, 24], 24), ([48], 48), ([16], 48)])
+def test_conv24_blob_reproduces_conv(srcs, cout):
     """packing.pack_conv24: the K-block table equals the library's (csrc/conv24.hip:c24_kblock, whose plan -- every block once,
     one immediate per step and pattern, equal slot parity inside a ds_read_b128 lane group -- is proven by a static_assert at
     compile time), and the blob's fragments contracted with the staged window at the plan's slot offsets give the convolution
@@ -478,20 +478,22 @@ def test_conv24_blob_reproduces_conv(srcs):
     pads = [_pad8(c) for c in srcs]
     ncg = sum(pads) // 8
     S = c24_steps(ncg)
-    assert lib.refvsr_conv24_supported(pads[0], pads[1] if len(pads) > 1 else 0) == 1
-    assert lib.refvsr_conv24_blob_bytes(pads[0], pads[1] if len(pads) > 1 else 0) == S * 3 * 1024 + 128
+    nf, nb = (3, 32) if cout == 24 else (6, 64)
+    sup, nbytes = (lib.refvsr_conv24_supported, lib.refvsr_conv24_blob_bytes) if cout == 24 else (lib.refvsr_conv48_supported, lib.refvsr_conv48_blob_bytes)
+    assert sup(pads[0], pads[1] if len(pads) > 1 else 0) == 1
+    assert nbytes(pads[0], pads[1] if len(pads) > 1 else 0) == S * nf * 1024 + nb * 4
     for s in range(S):
         for q in range(4):
             kb, v = c24_kblock(ncg, s, q), lib.refvsr_conv24_kblock(ncg, s, q)
             assert v == (-1 if kb is None else (kb[0] << 16 | kb[1] << 8 | kb[2])), (ncg, s, q)
-    assert lib.refvsr_conv24_kblock(ncg, S, 0) == -2 and lib.refvsr_conv24_supported(48, 0) == 0
+    assert lib.refvsr_conv24_kblock(ncg, S, 0) == -2 and lib.refvsr_conv24_supported(48, 0) == 0 and lib.refvsr_conv48_supported(24, 24) == 0
     g = torch.Generator().manual_seed(ncg)
     cin = sum(srcs)
-    w = torch.randn(24, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
-    b = torch.randn(24, generator=g) * 0.1
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
     blob = pack_conv24(w, b, srcs).numpy()
-    frag = blob[:S * 3 * 1024].view(np.float16).astype(np.float32).reshape(S, 3, 4, 16, 8)     # [s][f][q][row][8]
-    bias = blob[S * 3 * 1024:].view(np.float32)
+    frag = blob[:S * nf * 1024].view(np.float16).astype(np.float32).reshape(S, nf, 4, 16, 8)   # [s][f][q][row][8]
+    bias = blob[S * nf * 1024:].view(np.float32)
     h_, w_ = 5, 7
     x = torch.randn(cin, h_, w_, generator=g).half().float()
     # staged window memory: padded channel groups per pixel, zero border
@@ -505,11 +507,12 @@ def test_conv24_blob_reproduces_conv(srcs):
         o += c
         cgo += pc // 8
     want = F.conv2d(x[None], w, b, padding=1)[0].numpy()
-    got = np.zeros((24, h_, w_), np.float32)
+    got = np.zeros((cout, h_, w_), np.float32)
     for oy in range(h_):
         for ox in range(w_):
-            acc0 = bias[0:16].copy()                                 # rows = channels 0..15
-            acc1 = np.concatenate([bias[16:24], np.zeros(8, np.float32)])    # rows 0-7: hi of 16..23 (+ bias), rows 8-15: lo
+            acc = [bias[16 * m:16 * m + 16].copy() for m in range(nb // 16)]       # rows = channels 16 m .. (pads: zeros)
+            if cout == 24:
+                acc[1][8:] = 0.0                                     # rows 8-15 of the third fragment collect lo sums only
             for s in range(S):
                 for q in range(4):
                     kb = c24_kblock(ncg, s, q)
@@ -518,8 +521,16 @@ def test_conv24_blob_reproduces_conv(srcs):
                         continue
                     ty, tx, cg = kb
                     bvec = xp[oy + ty, ox + tx, cg]
-                    acc0 += frag[s, 0, q] @ bvec + frag[s, 1, q] @ bvec
-                    acc1 += frag[s, 2, q] @ bvec
-            got[0:16, oy, ox] = acc0
-            got[16:24, oy, ox] = acc1[0:8] + acc1[8:16]
+                    if cout == 24:
+                        acc[0] += frag[s, 0, q] @ bvec + frag[s, 1, q] @ bvec
+                        acc[1] += frag[s, 2, q] @ bvec
+                    else:
+                        for m in range(3):
+                            acc[m] += frag[s, 2 * m, q] @ bvec + frag[s, 2 * m + 1, q] @ bvec
+            if cout == 24:
+                got[0:16, oy, ox] = acc[0]
+                got[16:24, oy, ox] = acc[1][0:8] + acc[1][8:16]
+            else:
+                for m in range(3):
+                    got[16 * m:16 * m + 16, oy, ox] = acc[m]
     assert np.abs(got - want).max() < 2e-5
