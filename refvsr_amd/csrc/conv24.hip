@@ -29,6 +29,7 @@
 #include <utility>
 
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int C24_TW = 32, C24_XW = 34;                       // tile width; staged row = 34 pixels (tile height: template)
@@ -468,6 +469,9 @@ extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1,
     C24Args a;
     if (c24_fill(a, "conv48", 48, src0, src1, c1, h, w, blob, act_slope, mul, res, post_slope, out)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    if (c0 == 48) return launch_c24<48, 6, 0, 16, 16, 4>(a, st);     // 84 KB of weights + 18 x 34-pixel tile: one workgroup per CU
+    // 84 KB of weights + 18 x 34-pixel tile: one workgroup per CU.  Sixteen waves with two pixel groups each (default), or eight
+    // waves with four (A/B knob REFVSR_CONV48_WAVES=8: 37 % fewer LDS fragment reads, half the waves per SIMD)
+    static const bool w8 = getenv("REFVSR_CONV48_WAVES") && atoi(getenv("REFVSR_CONV48_WAVES")) == 8;
+    if (c0 == 48) return w8 ? launch_c24<48, 6, 0, 8, 16, 2>(a, st) : launch_c24<48, 6, 0, 16, 16, 4>(a, st);
     return launch_c24<48, 2, 0, 8, 8, 4>(a, st);
 }

@@ -132,7 +132,8 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         pad = k // 2
     co_ = cw.cout
     if (cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
-            0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_)):
+            0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_) and
+            h * w * max(co_, c0, c1) * 2 < 2 ** 31):         # (32-bit element offsets in the specialised kernels: 8K HR maps go generic)
         # compile-time-specialised kernel (24 | 48 output channels, 3x3): csrc/conv24.hip
         for m_ in (mul, res):
             if m_ is not None:
