@@ -236,6 +236,10 @@ class OracleNetworkIR(orc.OracleNetwork):
             self.frame_itr_num = 0
         self.frame_itr_num += 1
         outs = collections.OrderedDict()
+        if is_log:                                                           # :229-230
+            outs['vis'] = collections.OrderedDict()
+            if self.cfg.save_sample:                                         # :367-384 (conf / index maps of frame t//2)
+                outs['vis'].update(self.sample_vis(lrs[:, ctr], refs[:, ctr], index_maps[ctr], conf_maps[ctr], conf_bw, conf))
         outs['result'] = out.clamp(0, 1)
         if trace is not None:
             trace.update(keyframe_idx=self.keyframe_idx.copy(), refill=refill, is_first_frame=is_first_frame)

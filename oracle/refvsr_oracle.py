@@ -661,23 +661,7 @@ class OracleNetwork(object):
             if fl_fw is not None:
                 vis['FW_LR_prev_warp'] = warp(lrs[:, ctr - 1], fl_fw)
             if self.cfg.save_sample:                                         # :301-316
-                lr_c, ref_c, idx_c = lrs[:, ctr], refs[:, ctr], index_maps[ctr]
-                lr_down = bicubic_scale(lr_c, 0.5, clamp=True)
-                ref_down = bicubic_scale(ref_c, 0.5, clamp=True)
-                s1, s2 = self.ks // 2, self.ks
-                o1 = (lr_down.shape[-2] * 2, lr_down.shape[-1] * 2)
-                o2 = (lr_c.shape[-2] * 2, lr_c.shape[-1] * 2)
-                fm1 = block_gather(ref_down, idx_c, s1, o1)
-                vis['FW_aa1_fm_ref_aligned'] = fm1
-                if s1 > 1:                                                   # aa1.align exists (HD configs)
-                    vis['FW_aa1_ref_aligned'] = aligned_conv(fm1, lr_down, block_gather(ref_c, idx_c, s1, o1), W, 'Network.aa1.align', s1)
-                fm2 = block_gather(ref_c, idx_c, s2, o2)
-                vis['FW_aa2_fm_ref_aligned'] = fm2
-                vis['FW_aa2_ref_aligned'] = aligned_conv(fm2, lr_c, fm2, W, 'Network.aa2.align', s2)
-                vis['conf_map_norm'] = norm_res_vis(conf_maps[ctr])
-                vis['conf_map_prop_backward_norm'] = norm_res_vis(conf_bw)
-                vis['conf_map_prop_forward_norm'] = norm_res_vis(conf)
-                vis['conf_map_prop_norm'] = norm_res_vis(torch.maximum(conf_bw, conf))
+                vis.update(self.sample_vis(lrs[:, ctr], refs[:, ctr], index_maps[ctr], conf_maps[ctr], conf_bw, conf))
             outs['vis'] = vis
         if is_log and self.cfg.save_sample:                                  # :318-322
             ev = collections.OrderedDict()
@@ -687,6 +671,28 @@ class OracleNetwork(object):
             ev['conf_map_prop_forward'] = conf
             outs['eval_vis'] = ev
         return outs
+
+    def sample_vis(self, lr_c, ref_c, idx_c, conf_c, conf_bw, conf_fw):
+        """The save_sample block of the debugging samples (RefVSR.py:301-316; the same code in RefVSR_IR.py:368-384)."""
+        W = self.W
+        vis = collections.OrderedDict()
+        lr_down = bicubic_scale(lr_c, 0.5, clamp=True)
+        ref_down = bicubic_scale(ref_c, 0.5, clamp=True)
+        s1, s2 = self.ks // 2, self.ks
+        o1 = (lr_down.shape[-2] * 2, lr_down.shape[-1] * 2)
+        o2 = (lr_c.shape[-2] * 2, lr_c.shape[-1] * 2)
+        fm1 = block_gather(ref_down, idx_c, s1, o1)
+        vis['FW_aa1_fm_ref_aligned'] = fm1
+        if s1 > 1:                                                           # aa1.align exists (HD configs)
+            vis['FW_aa1_ref_aligned'] = aligned_conv(fm1, lr_down, block_gather(ref_c, idx_c, s1, o1), W, 'Network.aa1.align', s1)
+        fm2 = block_gather(ref_c, idx_c, s2, o2)
+        vis['FW_aa2_fm_ref_aligned'] = fm2
+        vis['FW_aa2_ref_aligned'] = aligned_conv(fm2, lr_c, fm2, W, 'Network.aa2.align', s2)
+        vis['conf_map_norm'] = norm_res_vis(conf_c)
+        vis['conf_map_prop_backward_norm'] = norm_res_vis(conf_bw)
+        vis['conf_map_prop_forward_norm'] = norm_res_vis(conf_fw)
+        vis['conf_map_prop_norm'] = norm_res_vis(torch.maximum(conf_bw, conf_fw))
+        return vis
 
     def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, trace=None):
         """Network.forward (RefVSR.py:151-325), inference semantics (is_train=False); = phase_a + phase_b (the split

@@ -878,6 +878,33 @@ class Engine(object):
             after_state()
         return self.phase_b2(pa, want_vis)
 
+    def _sample_vis(self, f, conf_bw, conf_fw):
+        """The save_sample block of the `vis` samples (RefVSR.py:301-316; identical in RefVSR_IR.py:367-384) for centre frame f."""
+        vis = collections.OrderedDict()
+        h, w = f.lr.shape[1:]
+        hm, wm = (h // (self.cfg.scale // 2), w // (self.cfg.scale // 2)) if self.hd else (h, w)
+        gh, gw = (hm // 2, wm // 2) if self.vgg7 else (hm, wm)
+        s1, s2 = self.ks // 2, self.ks
+        lr_down = ops.bicubic_scale(f.lr, 0.5, clamp01=True)
+        ref_down = ops.bicubic_scale(f.ref, 0.5, clamp01=True)
+        vis['FW_aa1_fm_ref_aligned'] = ops.block_gather_rgb(ref_down, f.idx, gh, gw, s1, planar=True)
+        if s1 > 1:
+            fm8 = ops.block_gather_rgb(ref_down, f.idx, gh, gw, s1)
+            rgb8 = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s1)
+            vis['FW_aa1_ref_aligned'] = ops.unpack_nhwc16(self.aligned_conv(fm8, lr_down, rgb8, 'aa1.align', s1), 3)
+        vis['FW_aa2_fm_ref_aligned'] = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s2, planar=True)
+        rgb8 = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s2)
+        vis['FW_aa2_ref_aligned'] = ops.unpack_nhwc16(self.aligned_conv(rgb8, f.lr, rgb8, 'aa2.align', s2), 3)
+
+        def norm(x):
+            x = x - x.min()
+            return x / x.max()
+        vis['conf_map_norm'] = norm(f.conf)
+        vis['conf_map_prop_backward_norm'] = norm(conf_bw)
+        vis['conf_map_prop_forward_norm'] = norm(conf_fw)
+        vis['conf_map_prop_norm'] = norm(ops.max2(conf_bw, conf_fw))
+        return vis
+
     def _debug_vis(self, fr, t, is_first_frame, range_start, fw_flow_in, flow, conf_bw, conf_fw, save_sample):
         """The `vis` debugging samples of Network.forward (RefVSR.py:219-221,262-263,301-316), is_log only; planar fp32
         [C,H,W] maps.  (The min/max normalisation of the four confidence maps, models/utils.py:23-32, uses torch
@@ -890,29 +917,7 @@ class Engine(object):
         if fl is not None:
             vis['FW_LR_prev_warp'] = ops.warp_planar(fr[ctr - 1].lr, fl)
         if save_sample:
-            f = fr[ctr]
-            h, w = f.lr.shape[1:]
-            hm, wm = (h // (self.cfg.scale // 2), w // (self.cfg.scale // 2)) if self.hd else (h, w)
-            gh, gw = (hm // 2, wm // 2) if self.vgg7 else (hm, wm)
-            s1, s2 = self.ks // 2, self.ks
-            lr_down = ops.bicubic_scale(f.lr, 0.5, clamp01=True)
-            ref_down = ops.bicubic_scale(f.ref, 0.5, clamp01=True)
-            vis['FW_aa1_fm_ref_aligned'] = ops.block_gather_rgb(ref_down, f.idx, gh, gw, s1, planar=True)
-            if s1 > 1:
-                fm8 = ops.block_gather_rgb(ref_down, f.idx, gh, gw, s1)
-                rgb8 = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s1)
-                vis['FW_aa1_ref_aligned'] = ops.unpack_nhwc16(self.aligned_conv(fm8, lr_down, rgb8, 'aa1.align', s1), 3)
-            vis['FW_aa2_fm_ref_aligned'] = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s2, planar=True)
-            rgb8 = ops.block_gather_rgb(f.ref, f.idx, gh, gw, s2)
-            vis['FW_aa2_ref_aligned'] = ops.unpack_nhwc16(self.aligned_conv(rgb8, f.lr, rgb8, 'aa2.align', s2), 3)
-
-            def norm(x):
-                x = x - x.min()
-                return x / x.max()
-            vis['conf_map_norm'] = norm(f.conf)
-            vis['conf_map_prop_backward_norm'] = norm(conf_bw)
-            vis['conf_map_prop_forward_norm'] = norm(conf_fw)
-            vis['conf_map_prop_norm'] = norm(ops.max2(conf_bw, conf_fw))
+            vis.update(self._sample_vis(fr[ctr], conf_bw, conf_fw))
         return vis
 
     def _forward_seq(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False):

@@ -7,8 +7,8 @@ the per-frame window cache) with refvsr_amd/engine.py; adds the EDVR extractor (
 per frame like the matching) and the different propagation order: backward branch over ALL t frames, forward branch
 restarted at frame 0 of every window from the carried state, key-frame refill -- including the reference's quirks (the
 forward branch warps its 2x map and confidence with the flow variable left over from the backward loop, :335-337).
-Feature maps have C = 36 channels (channel stride 40, zero padding).  Sequential on the caller's stream; no reference
-counterpart of the `vis` samples is produced (is_log returns an empty dict)."""
+Feature maps have C = 36 channels (channel stride 40, zero padding).  Sequential on the caller's stream.
+"""
 import collections
 
 import numpy as np
@@ -171,11 +171,11 @@ class EngineIR(Engine):
     @torch.no_grad()
     def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False):
         with torch.cuda.device(lrs.device), ops.on_stream(torch.cuda.current_stream()):
-            out = self._forward_ir(lrs, refs, is_first_frame, frame_ids)
-        vis = collections.OrderedDict() if want_vis else None
-        return out, ((vis, collections.OrderedDict()) if want_log else vis)
+            out, dbg = self._forward_ir(lrs, refs, is_first_frame, frame_ids, bool(want_log and want_vis))
+        # RefVSR_IR returns no 'eval_vis' (RefVSR_IR.py:366-386); `vis` holds the save_sample block only (:374-384)
+        return out, ((None, dbg) if want_log else None)
 
-    def _forward_ir(self, lrs, refs, is_first_frame, frame_ids):
+    def _forward_ir(self, lrs, refs, is_first_frame, frame_ids, sample=False):
         t, h, w = self._check_window(lrs, refs)
         if h < 64 or w < 64 or t < 5:
             raise RuntimeError('RefVSR_IR needs frames of at least 64x64 and a window of at least 5 frames (RefVSR_IR.py:244-246,203)')
@@ -247,4 +247,5 @@ class EngineIR(Engine):
         if is_first_frame:
             self.frame_itr_num = 0
         self.frame_itr_num += 1
-        return out
+        dbg = self._sample_vis(fr[ctr], conf_bw, conf) if sample else collections.OrderedDict()
+        return out, dbg

@@ -155,7 +155,7 @@ class Network(nn.Module):
         if is_log:                                             # RefVSR.py:162-164,219-221,262-263,301-316
             outs['vis'] = collections.OrderedDict((k, torch.stack([d[k] for d in dbg_all], 0)) for k in dbg_all[0])
         outs['result'] = results[0].unsqueeze(0) if n == 1 else torch.stack(results, 0)     # (n == 1: a view, no 25 MB copy)
-        if want_vis:
+        if want_vis and vis_all[0] is not None:                # (RefVSR_IR has no 'eval_vis')
             ev = collections.OrderedDict()
             for k in vis_all[0]:
                 ev[k] = torch.stack([v[k] for v in vis_all], 0)

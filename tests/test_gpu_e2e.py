@@ -105,13 +105,26 @@ def test_refvsr_ir_stream_against_reference_fixture(dev):
     from refvsr_amd.synth import window_indices
     g = load_golden('e2e_IR_64x64_t5_reset2')
     t, rb = int(g['t']), int(g['reset_branch'])
-    net, cfg, sd = make_net('config_RefVSR_IR_MFID', t, dev, reset=rb, save_sample=False)
+    net, cfg, sd = make_net('config_RefVSR_IR_MFID', t, dev, reset=rb, save_sample=True)
     assert cfg.network == 'RefVSR_IR' and cfg.mid_channels == 36 and type(net.Network).__name__ == 'Network'
     lr, rf = g['lr'], g['ref']
     nframes = lr.shape[1]
     for f in range(nframes):
         w = window_indices(f, nframes, t)
-        res = net(lr[:, w].to(dev), rf[:, w].to(dev), f == 0)['result'].cpu()
+        outs = net(lr[:, w].to(dev), rf[:, w].to(dev), f == 0, is_log=True)
+        res = outs['result'].cpu()
+        # the `vis` samples (RefVSR_IR.py:229-230,367-384): the reference's keys (no 'eval_vis' in this model), values for the
+        # calls whose samples the fixture stores
+        assert 'eval_vis' not in outs and list(outs.keys())[0] == 'vis'
+        vkeys = sorted(k[4:-2] for k in g if k.startswith('vis_') and k.endswith('_%d' % f))
+        if vkeys:
+            assert sorted(outs['vis'].keys()) == vkeys, (sorted(outs['vis'].keys()), vkeys)
+            ev = {k: maxdiff(outs['vis'][k].cpu(), g['vis_%s_%d' % (k, f)]) for k in vkeys}
+            report('e2e IR_64x64 f%d vis' % f, **ev)
+            for k, e in ev.items():
+                assert e < (1e-6 if k == 'FW_aa2_fm_ref_aligned' else 5e-3), (k, e)      # a pure gather of the frame: exact
+        else:
+            assert len(outs['vis']) == 7
         want = g['result_%d' % f]
         eng = net.Network.engine(0)
         st = eng.export_state()

@@ -143,12 +143,18 @@ def test_refvsr_ir_stream():
     t = int(g['t'])
     cfg.frame_num = t
     cfg.reset_branch = int(g['reset_branch'])
+    cfg.save_sample = True
     o = iro.OracleNetworkIR(cfg, make_state_dict(cfg, 1234))
     lr, rf = g['lr'], g['ref']
     for f in range(2):                      # first-frame + steady call (the other two repeat them after the reset)
         w = window_indices(f, lr.shape[1], t)
-        outs = o.forward(lr[:, w], rf[:, w], f == 0)
+        outs = o.forward(lr[:, w], rf[:, w], f == 0, is_log=True)
         assert maxdiff(outs['result'], g['result_%d' % f]) < TOL
         assert o.frame_itr_num == int(g['itr_%d' % f]) and list(o.keyframe_idx) == g['keyframes_%d' % f].tolist()
+        # the `vis` samples (RefVSR_IR.py:367-384): same keys in the same order, values
+        vkeys = [k[4:-2] for k in g if k.startswith('vis_') and k.endswith('_%d' % f)]
+        assert sorted(outs['vis'].keys()) == sorted(vkeys) and len(vkeys) == 7
+        for k in vkeys:
+            assert maxdiff(outs['vis'][k], g['vis_%s_%d' % (k, f)]) < 1e-4, (f, k)
         assert maxdiff(o.forward_feat_prop_prev, g['state_feat_%d' % f].float()) < 2e-3      # stored as fp16
         assert maxdiff(o.forward_flow_prev, g['state_flow_%d' % f]) < TOL

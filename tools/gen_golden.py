@@ -288,8 +288,13 @@ def gen_e2e_ir(tag, name, t, h, w, nframes, reset_override='keep'):
     with torch.no_grad():
         for f, win in enumerate(windows(nframes, t)):
             x, r = lr[:, win], rf[:, win]
-            outs = net(x, r, f == 0, is_log=False, is_train=False)
-            oo = o.forward(x, r, f == 0)
+            outs = net(x, r, f == 0, is_log=True, is_train=False)          # is_log: the `vis` samples (RefVSR_IR.py:367-384)
+            oo = o.forward(x, r, f == 0, is_log=True)
+            assert list(outs['vis'].keys()) == list(oo['vis'].keys()), (list(outs['vis'].keys()), list(oo['vis'].keys()))
+            if f < 2:                                                       # (the later calls repeat the first two after the reset)
+                for k, v in outs['vis'].items():
+                    arrs['vis_%s_%d' % (k, f)] = v
+            print('  vis: ' + ' '.join('%s=%.2e' % (k, md(v, oo['vis'][k])) for k, v in outs['vis'].items()))
             N = net.Network
             d = dict(result=md(outs['result'], oo['result']), feat=md(N.forward_feat_prop_prev, o.forward_feat_prop_prev),
                      feat_up=md(N.forward_feat_prop_UP_prev, o.forward_feat_prop_UP_prev),
