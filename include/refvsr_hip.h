@@ -23,12 +23,13 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 7   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 8   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
                                   6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging);
-                                  7: refvsr_conv24 / refvsr_conv48 (compile-time-specialised 3x3 convs) */
+                                  7: refvsr_conv24 / refvsr_conv48 (compile-time-specialised 3x3 convs);
+                                  8: RefvsrConv.f32 = 2 (plain fp16 weights in the streamed convs) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -66,7 +67,11 @@ typedef struct RefvsrConv {
     const float* res_planar;           /* PLANAR32: optional planar fp32 residual [cout][h][w]        */
     int f32;                           /* 0: nhwc16 maps, fp16 hi+lo weights on 16x16x32 f16 MFMA;
                                           1: the same maps in fp32 ("nhwc32", channel stride % 4 == 0), fp32 weights,
-                                             exact fp32 products on v_mfma_f32_16x16x4_f32 (src/mul/res/out all fp32) */
+                                             exact fp32 products on v_mfma_f32_16x16x4_f32 (src/mul/res/out all fp32);
+                                          2 (ABI 8): like 0 with plain fp16 weights (no lo term; wpack [nz][S][MT][1][64][8]):
+                                             half the weight stream and half the MFMAs -- streamed convs only (more than 16
+                                             K-steps, stride 1, mt_per_block <= 2); used for SPyNet's 7x7 convs, whose
+                                             contribution to the end-to-end error budget is measured in DESIGN.md section 2 */
     float add_const;                   /* PLANAR32: constant added after the residual                 */
     float clamp_lo, clamp_hi;          /* PLANAR32: clamp when clamp_lo < clamp_hi                    */
     /* Fused inter-frame warp (ABI 6): when warp_flow != NULL, source `warp_src` (0 = src0, 1 = src1) is NOT read directly:

@@ -82,13 +82,14 @@ struct ConvArgs {
 // or 8 waves on the same 8 x 32 tile (two pixel groups per wave).
 // WARP (resident fp16 kernels): 0 = plain sources; 1 | 2 = source 0 | 1 is warp(source, p.warp_flow), evaluated while the tile is
 // staged (models/utils.py:35-43; the arithmetic of resample.hip:warp_nhwc16_kernel, so warp + conv == this kernel bit for bit).
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0, bool HI1 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
     static_assert(WARP == 0 || (RESIDENT && !F32), "the fused warp lives in the resident fp16 kernels' tile staging");
     constexpr int NT = NW * 64;                      // threads per workgroup
     static_assert(!(GATHER && RESIDENT), "gather mode streams its weights");
     static_assert(EPI == 0 || (RESIDENT && !F32), "the lean epilogue is built for the resident fp16 kernels");
-    constexpr int WFR = F32 ? 1 : 2;                 // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo
+    static_assert(!HI1 || (!F32 && !RESIDENT && !GATHER), "single-fp16 weights are built for the streamed fp16 kernels");
+    constexpr int WFR = (F32 || HI1) ? 1 : 2;        // 1 KiB weight fragments per (kstep, mtile): fp32 | fp16 hi+lo | fp16 hi only (HI1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tab = reinterpret_cast<int*>(smem);
     unsigned char* wl = smem + p.tab_bytes;
@@ -194,13 +195,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
             }
         } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)                            // all hi products, then all lo: no back-to-back
+            for (int h = 0; h < WFR; ++h)                          // all hi products, then all lo: no back-to-back
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {                  // MFMAs on one accumulator
                     const f16x8 bv = *reinterpret_cast<const f16x8*>(&b[t]);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        const f16x8 av = *reinterpret_cast<const f16x8*>(&a[m * 2 + h]);
+                        const f16x8 av = *reinterpret_cast<const f16x8*>(&a[m * WFR + h]);
                         acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][t], 0, 0, 0);
                     }
                 }
@@ -711,13 +712,13 @@ extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg);
 
 // RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
 // the XCD banding) and walk the tiles; the others launch one workgroup per tile.
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0, bool HI1 = false>
 static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy table (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
@@ -730,7 +731,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         for (int i = 0; i < 4; ++i)
             if (occ_lds[dev][i] == lds && occ_val[dev][i] > 0) occ = occ_val[dev][i];
         if (occ == 0) {
-            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP>, NW * 64, lds));
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>, NW * 64, lds));
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
@@ -740,14 +741,16 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         if (gx > cap) gx = cap;
     }
     a.grid = gx;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     RV_CHECK(d != nullptr, "conv: null descriptor");
-    const bool f32 = d->f32 != 0;
+    const bool f32 = d->f32 == 1;
+    const bool hi1 = d->f32 == 2;                      // fp16 weights without the lo term (streamed kernels only)
+    RV_CHECK(d->f32 >= 0 && d->f32 <= 2, "conv: weight mode (f32) must be 0, 1 or 2");
     const int cgrp = f32 ? 4 : 8;                      // channels per 16-byte group
     const int esz = f32 ? 4 : 2;
     RV_CHECK(d->src0 && d->c0 > 0 && d->c0 % cgrp == 0, "conv: src0/c0 invalid (c0=%d)", d->c0);
@@ -798,7 +801,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     const int n_mt = (d->cout + 15) / 16;
     const int nz = (n_mt + MT - 1) / MT;
     a.tab_bytes = ((a.S * 4 * 4 + 15) / 16) * 16;
-    const int wfr_kb = MT * (f32 ? 1 : 2) * 1024;      // bytes of weight fragments per K-step
+    const int wfr_kb = MT * ((f32 || hi1) ? 1 : 2) * 1024;   // bytes of weight fragments per K-step
     static const bool no_resident = getenv("REFVSR_CONV_NO_PERSIST") != nullptr;   // A/B knob, read once
     const size_t LDS_MAX = 160 * 1024;
 
@@ -815,7 +818,7 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     bool resident = false, one_wg = false;             // one_wg: LDS admits a single workgroup per CU
     bool w16 = false;                                  // 16 x 32 tile, 16 waves
     static const int res_max = getenv("REFVSR_CONV_RES_MAX") ? atoi(getenv("REFVSR_CONV_RES_MAX")) : CONV_RES_MAX;   // A/B knob
-    if (!no_resident && a.S <= res_max && a.S <= CONV_RES_MAX) {
+    if (!no_resident && !hi1 && a.S <= res_max && a.S <= CONV_RES_MAX) {
         int best_wg = 0;
         static const int force_tiles = getenv("REFVSR_CONV_TILES") ? atoi(getenv("REFVSR_CONV_TILES")) : 0;   // A/B knob: 2 | 4
         for (int tl = 4; tl >= 2; tl -= 2) {
@@ -893,10 +896,20 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     a.n_xy = a.tiles_x * rv_cdiv(d->h_out, tiles * 2);
     hipStream_t st = (hipStream_t)stream;
     if (a.gather) {                                // only the fp16 strided predictors need it
-        RV_CHECK(!f32, "conv: gather mode is built for the fp16 path only");
+        RV_CHECK(!f32 && !hi1, "conv: gather mode is built for the fp16 hi+lo path only");
         if (MT == 1) return launch_conv<1, 4, false, true, false>(a, nz, lds, st);
         if (MT == 2) return launch_conv<2, 4, false, true, false>(a, nz, lds, st);
         return launch_conv<3, 4, false, true, false>(a, nz, lds, st);
+    }
+    if (hi1) {                                     // SPyNet's streamed 7x7 convs (Engine.flow): half the weight stream, half the MFMAs
+        RV_CHECK(!a.gather && !d->warp_flow && MT <= 2, "conv: single-fp16 weights are built for the streamed stride-1 convs (MT=%d)", MT);
+        const bool nw8h = tiles == 4 && !no_nw8 && (one_wg || n_tiles8 <= 2048);
+        if (nw8h) return MT == 1 ? launch_conv<1, 2, false, false, false, 0, 8, 0, true>(a, nz, lds, st)
+                                 : launch_conv<2, 2, false, false, false, 0, 8, 0, true>(a, nz, lds, st);
+        if (tiles == 4) return MT == 1 ? launch_conv<1, 4, false, false, false, 0, 4, 0, true>(a, nz, lds, st)
+                                       : launch_conv<2, 4, false, false, false, 0, 4, 0, true>(a, nz, lds, st);
+        return MT == 1 ? launch_conv<1, 2, false, false, false, 0, 4, 0, true>(a, nz, lds, st)
+                       : launch_conv<2, 2, false, false, false, 0, 4, 0, true>(a, nz, lds, st);
     }
     // lean epilogue: fp16 HWC output, slopes in [0, 1], maps addressable with 32-bit element offsets, tile coordinates in
     // the packed chunk descriptor's range

@@ -73,15 +73,19 @@ class Weights(object):
             self.conv[name] = ops.ConvWeights(pack_conv(w, b, srcs, f32=True), device)
 
         chans = [(32, 8), (64, 32), (32, 64), (16, 32), (2, 16)]
+        # SPyNet's streamed 7x7 convs (every conv but the first of a level) on plain fp16 weights: half the weight stream and
+        # half the MFMAs of the kernels that are bound by both.  Their share of the end-to-end error budget is measured
+        # (tools/lo_term_study.py); config.spynet_hi_lo = True / REFVSR_SPYNET_HILO=1 restores hi + lo.
+        hi_only = not (bool(getattr(config, 'spynet_hi_lo', False)) or os.environ.get('REFVSR_SPYNET_HILO', '0') == '1')
         for lvl in range(6):
             for j, (co, ci) in enumerate(chans):
                 name = 'FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j)
-                mf(name, [ci])
+                w, b = g(name)
+                self.conv[name] = ops.ConvWeights(pack_conv(w, b, [ci], hi_only=hi_only and j > 0), device)
                 if co > 16 and ci > 8:
                     # the streamed 7x7 convs of the coarse pyramid levels (a handful of pixel tiles): 16 output channels per
                     # workgroup, so that 2-4x as many CUs share the 200-400 KB weight stream (Engine.flow picks per level)
-                    w, b = g(name)
-                    self.conv[name + '/mt1'] = ops.ConvWeights(pack_conv(w, b, [ci], mt=1), device)
+                    self.conv[name + '/mt1'] = ops.ConvWeights(pack_conv(w, b, [ci], mt=1, hi_only=hi_only), device)
         fe = 'feature_match.feature_extract.'
         self.hd = bool(config.flag_HD_in)
         self.vgg7 = self.hd or config.scale != 4          # attention.py:31-35

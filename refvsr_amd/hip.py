@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 7
+ABI_VERSION = 8
 RESBLOCK24_BLOB_BYTES = 43264
 
 

@@ -81,23 +81,25 @@ CONV24 = not os.environ.get('REFVSR_NO_CONV24')      # A/B knob: the generic con
 
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'desc', 'odtype', 'raw', 'blob24')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'hi_only', 'desc', 'odtype', 'raw', 'blob24')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
         self.bias = pk['bias'].to(device).contiguous()
         self.cout, self.ksteps, self.mt, self.ksize = pk['cout'], pk['ksteps'], pk['mt'], pk['ksize']
         self.cpads, self.shuffle, self.f32 = pk['cpads'], pk['shuffle'], bool(pk.get('f32', False))
+        self.hi_only = bool(pk.get('hi_only', False))      # plain fp16 weights (descriptor weight mode 2)
         # launch descriptor with the per-weight fields filled once (the C side copies it at every call)
         d = self.desc = hip.RefvsrConv()
         d.wpack, d.bias = self.wpack.data_ptr(), self.bias.data_ptr()
-        d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
+        d.cout, d.mt_per_block, d.ksteps, d.ksize = self.cout, self.mt, self.ksteps, self.ksize
+        d.f32 = 2 if self.hi_only else int(self.f32)
         self.odtype = torch.float32 if self.f32 else torch.float16
         self.raw = pk.get('raw')      # (weight, bias) fp32 cpu tensors when the packer kept them (repacking for specialised kernels)
         # 3x3 convs with 24 / 48 output channels of the supported input shapes also carry the blob of the specialised kernel
         # (conv24.hip; the attribute keeps its first name)
         self.blob24 = None
-        if self.raw is not None and pk.get('src_channels') is not None and CONV24:
+        if self.raw is not None and pk.get('src_channels') is not None and CONV24 and not self.hi_only:
             from .packing import conv24_ok, pack_conv24
             if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32):
                 self.blob24 = pack_conv24(self.raw[0], self.raw[1], pk['src_channels']).to(device).contiguous()

@@ -90,9 +90,10 @@ def kmatrix(w, src_channels, shuffle=False, grp=8):
     return Wk, rows, ncg
 
 
-def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False):
-    """Returns dict(wpack, bias fp32 [nz*MT*16], cout, ksteps, mt, ksize, cpads, shuffle, f32).
-    wpack: fp16 [nz,S,MT,2,64,8] (hi, lo) or fp32 [nz,S,MT,64,4]."""
+def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False, hi_only=False):
+    """Returns dict(wpack, bias fp32 [nz*MT*16], cout, ksteps, mt, ksize, cpads, shuffle, f32, hi_only).
+    wpack: fp16 [nz,S,MT,2,64,8] (hi, lo), fp16 [nz,S,MT,1,64,8] (hi_only: plain fp16 weights, descriptor mode 2: the streamed
+    kernels only -- SPyNet's 7x7 convs) or fp32 [nz,S,MT,64,4]."""
     w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
     b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
     cout, cin, ks, _ = w.shape
@@ -112,8 +113,12 @@ def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False):
     # [nz, MT, lr, S, q, grp] -> [nz, S, MT, q, lr, grp]
     frag = full.reshape(nz, MT, 16, S, 4, grp).transpose(0, 3, 1, 4, 2, 5).reshape(nz, S, MT, 64, grp)
     frag = torch.from_numpy(np.ascontiguousarray(frag))
+    assert not (f32 and hi_only)
     if f32:
         wpack = frag
+    elif hi_only:
+        assert S > 16 and MT <= 2 and not shuffle, 'hi_only weights are for the streamed convs (more than 16 K-steps, MT <= 2)'
+        wpack = frag.to(torch.float16).unsqueeze(3).contiguous()           # [nz,S,MT,1,64,8]
     else:
         hi = frag.to(torch.float16)
         lo = (frag - hi.float()).to(torch.float16)
@@ -121,7 +126,7 @@ def pack_conv(w, b, src_channels, shuffle=False, mt=None, f32=False):
     bias = np.zeros(R, np.float32)
     bias[:cout] = b[rows]
     return dict(wpack=wpack, bias=torch.from_numpy(bias), cout=cout, ksteps=S, mt=MT, ksize=ks,
-                cpads=[_padg(c, grp) for c in src_channels], shuffle=shuffle, f32=f32,
+                cpads=[_padg(c, grp) for c in src_channels], shuffle=shuffle, f32=f32, hi_only=hi_only,
                 raw=(torch.from_numpy(w.copy()), torch.from_numpy(b.copy())),       # fp32 originals: repacking for specialised kernels
                 src_channels=list(src_channels))
 

@@ -78,11 +78,12 @@ def test_stream_against_reference_fixture(dev, tag, name):
                conf=e_conf, flow=e_flow)
         assert net.Network.frame_itr_num == int(g['itr_%d' % f])
         assert res.shape == want.shape and float(res.min()) >= 0.0 and float(res.max()) <= 1.0
-        # tolerances = 2x the worst value measured on MI355X over the six streams (profiles/r01_final3_gpu_parity_report.txt:
-        # result 5.6e-3 / 63.1 dB, feat 1.2e-2, feat_up 1.0e-2, conf 1.2e-4, flow 2.3e-4): fp16 HWC feature maps through
-        # ~100 layers and a recurrent state
+        # tolerances = 2x the worst value measured on MI355X over the streams (profiles/r01_final3_gpu_parity_report.txt:
+        # result 5.6e-3 / 63.1 dB, feat 1.2e-2, feat_up 1.0e-2, conf 1.2e-4): fp16 HWC feature maps through ~100 layers and a
+        # recurrent state; with plain fp16 weights in SPyNet's streamed convs (round 3) flow 6.3e-4 px (3.7e-4 with hi + lo) and
+        # -- the carried confidence map is sampled with that flow -- conf 1.9e-4
         assert e_res < 1.2e-2 and psnr(res, want) > 60.0
-        assert e_feat < 2.5e-2 and e_up < 2.1e-2 and e_conf < 2.5e-4 and e_flow < 5e-4
+        assert e_feat < 2.5e-2 and e_up < 2.1e-2 and e_conf < 4e-4 and e_flow < 1.3e-3
         for k, v in outs['eval_vis'].items():
             assert maxdiff(v.cpu(), g['ev_%s_%d' % (k, f)]) < 1e-3, k
         # the `vis` debugging samples (RefVSR.py:219-221,262-263,301-316): same keys as the reference, values for the streams

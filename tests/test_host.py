@@ -147,6 +147,23 @@ def test_weight_packing_reproduces_conv(co, cins, ks, stride, shuffle, f32):
     assert np.abs(got - ref).max() < 2e-5          # hi+lo fp16 weights carry ~22 bits; f32 mode is exact
 
 
+def test_weight_packing_hi_only():
+    """Weight mode 2 (RefvsrConv.f32 = 2, SPyNet's streamed 7x7 convs): ONE fp16 fragment per (K-step, m-tile), equal to the hi
+    fragment of the hi + lo packing; only for streamed shapes (more than 16 K-steps)."""
+    rs = np.random.RandomState(1)
+    w = (rs.randn(64, 32, 7, 7) * 0.05).astype(np.float32)
+    b = rs.randn(64).astype(np.float32)
+    full = pack_conv(w, b, [32])
+    for mt in (None, 1):
+        hi = pack_conv(w, b, [32], mt=mt, hi_only=True)
+        ref = pack_conv(w, b, [32], mt=mt)
+        assert hi['hi_only'] and not hi['f32'] and hi['wpack'].dtype == torch.float16
+        assert hi['wpack'].shape == ref['wpack'].shape[:3] + (1, 64, 8) and hi['ksteps'] == full['ksteps'] == 49
+        assert torch.equal(hi['wpack'][:, :, :, 0], ref['wpack'][:, :, :, 0]) and torch.equal(hi['bias'], ref['bias'])
+    with pytest.raises(AssertionError):
+        pack_conv((rs.randn(24, 24, 3, 3) * 0.1).astype(np.float32), b[:24], [24], hi_only=True)     # resident shape: 7 K-steps
+
+
 def test_model_shell_state_dict_contract(small_cfg, small_sd):
     from refvsr_amd import SRNet
     net = SRNet(small_cfg)
