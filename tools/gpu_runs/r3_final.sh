@@ -33,8 +33,25 @@ for pass in 1 2; do
   python tools/pmc_summary.py gpurun_out/pmc_rb$pass resblock > gpurun_out/r03_pmc_sq_resblock_pass$pass.txt
   rm -rf gpurun_out/pmc_rb$pass
 done
-echo "== bench (default) ==" | tee -a $L
+echo "== bench (default), shader clock / package power sampled once a second next to it ==" | tee -a $L
+( while true; do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Graphics Package" | tr '\n' ' '; echo; sleep 1; done > gpurun_out/r03_clocks_during_bench.txt ) &
+SMI=$!
 timeout 900 python bench.py 2>&1 | tail -1 > gpurun_out/r03_bench.json
+kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
+python - <<'PY' | tee -a $L
+import re
+rows = []
+for l in open('gpurun_out/r03_clocks_during_bench.txt'):
+    m, p = re.search(r'\((\d+)Mhz\)', l), re.search(r'Power \(W\): ([0-9.]+)', l)
+    if m and p:
+        rows.append((int(m.group(1)), float(p.group(1))))
+busy = [r for r in rows if r[1] > 350]
+if busy:
+    c = sorted(r[0] for r in busy); w = sorted(r[1] for r in busy)
+    print('clock samples under load: %d of %d; sclk min/median/max %d/%d/%d MHz; power median/max %.0f/%.0f W' % (len(busy), len(rows), c[0], c[len(c) // 2], c[-1], w[len(w) // 2], w[-1]))
+else:
+    print('no loaded clock samples (%d rows)' % len(rows))
+PY
 python -c "import json; d=json.load(open('gpurun_out/r03_bench.json')); print('value', d['value'], 'dropin', d['dropin_surface']['value'], 'roofline', {k: d['roofline'][k] for k in ('kernel','achieved','frac','mean_launch_ms','traffic')}, 'match', d['roofline_match_top2']['frac'], 'cpu', d['cpu_baseline'], 'wf', d.get('wavefront_model', {}).get('predicted_speedup'))" | cut -c1-1200 | tee -a $L
 fmt='import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],2),"fps", round(d["ms_per_step"],3),"ms; dropin", d["dropin_surface"] and round(d["dropin_surface"]["value"],2))'
 echo "== bench --no-pipeline (frame ids, one call at a time) ==" | tee -a $L
@@ -55,6 +72,9 @@ rm -rf gpurun_out/prof
 echo "== MFID (configs[2]) ==" | tee -a $L
 timeout 400 python bench.py --config config_RefVSR_MFID --steps 20 --warmup 3 --no-cpu-baseline --no-kernels --no-wavefront 2>&1 | tail -1 > gpurun_out/r03_bench_MFID.json
 python -c "$fmt" < gpurun_out/r03_bench_MFID.json | tee -a $L
+echo "== RefVSR_IR_MFID (C = 36, EDVR refill; sequential engine) ==" | tee -a $L
+timeout 400 python bench.py --config config_RefVSR_IR_MFID --steps 10 --warmup 2 --no-cpu-baseline --no-kernels --no-wavefront --no-dropin 2>&1 | tail -1 > gpurun_out/r03_bench_IR_MFID.json
+python -c "import json; d=json.load(open('gpurun_out/r03_bench_IR_MFID.json')); print('IR_MFID', round(d['value'],2), 'fps', round(d['ms_per_step'],2), 'ms')" 2>&1 | tail -1 | tee -a $L
 echo "== MFID_8K 1080p (configs[4]) ==" | tee -a $L
 timeout 600 python bench.py --config config_RefVSR_MFID_8K --size 1080x1920 --frames 5 --steps 6 --warmup 2 --no-cpu-baseline --no-kernels --no-dropin --no-wavefront 2>&1 | tail -1 > gpurun_out/r03_bench_MFID_8K_1080p.json
 python -c "import json; d=json.load(open('gpurun_out/r03_bench_MFID_8K_1080p.json')); print('8K', round(d['value'],2), 'fps', round(d['ms_per_step'],1), 'ms')" | tee -a $L
@@ -64,3 +84,6 @@ python -c "import json; d=json.load(open('gpurun_out/r03_bench_n2_gloo_one_gpu.j
 echo "== resblock24 probe + micro-benchmark ==" | tee -a $L
 timeout 300 python tools/probe_resblock24.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_probe_resblock24.txt
 timeout 300 python tools/bench_resblock.py 2>&1 | grep resblock | tee gpurun_out/r03_resblock_microbench.txt | grep -v "4 waves" | tee -a $L
+timeout 200 python tools/bench_spynet.py 2>&1 | grep "spynet flow" | tee gpurun_out/r03_spynet_microbench.txt | tee -a $L
+REFVSR_SPYNET_HILO=1 timeout 200 python tools/bench_spynet.py 2>&1 | grep "spynet flow" | tee -a gpurun_out/r03_spynet_microbench.txt | tee -a $L
+timeout 120 python tools/bench_match.py 2>&1 | grep match_top2 | tee gpurun_out/r03_match_microbench.txt | tee -a $L
