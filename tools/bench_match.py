@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """match_top2 at the BASELINE size (270x480 VGG features): time per launch, % of the dense fp16 MFMA peak and checksums of
-the outputs (run once per schedule: REFVSR_MATCH_TOP2=4 selects the round-2 kernel; the checksums must agree)."""
+the outputs (checksums: to compare schedule variants across processes)."""
 import os
 import sys
 
@@ -32,6 +32,6 @@ for _ in range(5):
 us = min(ts)
 flops = 2.0 * n * n * 144
 print('match_top2 %s (%s): %.1f us (min of 5x5; all: %s)  %.1f TFLOP/s = %.1f %% of 2.5 PF  | idx checksum %d  val checksum %.6f'
-      % (sys.argv[1] if len(sys.argv) > 1 else '270x480', 'v4' if os.environ.get('REFVSR_MATCH_TOP2', '') == '4' else 'v6', us,
+      % (sys.argv[1] if len(sys.argv) > 1 else '270x480', 'match_top2_kernel_v4', us,
          ' '.join('%.0f' % t for t in ts), flops / us / 1e6, flops / us / 1e6 / 25.0,
          int(idx.long().sum()), float(val.double().sum())))
