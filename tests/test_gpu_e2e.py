@@ -205,6 +205,42 @@ def test_long_recurrence_against_live_oracle(dev):
         report('recurrence %s worst of %d frames' % (variant or 'random', nfr), res=worst_e, psnr_vs_oracle=float(low_p), dPSNR_vs_gt=float(worst_d))
 
 
+def test_mfid_midsize_against_live_oracle(dev):
+    """BASELINE configs[2] model (config_RefVSR_MFID: C = 48, 30 blocks) at 64x96 -> 256x384, t = 5, against the live oracle:
+    the C = 48 launch shapes of a non-toy map (conv48 with its 16-wave 16 x 64-pixel tiles, two-source 96 -> 48 input convs,
+    the 48 -> 192 pixel-shuffle conv) under the north-star PSNR bar, and with the specialised kernels switched off
+    (generic conv_mfma path) to the same bar."""
+    from oracle import refvsr_oracle as orc
+    from refvsr_amd import ops
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, gt = make_clip(3, 64, 96, seed=11)
+    net, cfg, sd = make_net('config_RefVSR_MFID', 5, dev, save_sample=False)
+    assert cfg.mid_channels == 48 and cfg.num_blocks == 30
+    o = orc.OracleNetwork(cfg, sd)
+    outs = []
+    for f in range(3):
+        w = window_indices(f, 3, 5)
+        a = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+        want = o.forward(lr[w][None], rf[w][None], f == 0)['result']
+        d_psnr = abs(psnr(a, gt[f][None]) - psnr(want, gt[f][None]))
+        report('e2e MFID 64x96 f%d' % f, res=maxdiff(a, want), psnr_vs_oracle=float(psnr(a, want)), dPSNR_vs_gt=float(d_psnr))
+        assert a.shape == (1, 3, 256, 384) and maxdiff(a, want) < 2e-2 and psnr(a, want) > 55.0 and d_psnr < 1e-3
+        outs.append((a, want))
+    if ops.CONV24:                                       # the same stream on the generic kernels
+        old = ops.CONV24
+        ops.CONV24 = False
+        try:
+            net2, _, _ = make_net('config_RefVSR_MFID', 5, dev, save_sample=False)
+            for f in range(3):
+                w = window_indices(f, 3, 5)
+                b = net2(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+                d_psnr = abs(psnr(b, gt[f][None]) - psnr(outs[f][1], gt[f][None]))
+                report('e2e MFID 64x96 generic f%d' % f, res=maxdiff(b, outs[f][1]), vs_specialised=maxdiff(b, outs[f][0]), dPSNR_vs_gt=float(d_psnr))
+                assert maxdiff(b, outs[f][1]) < 2e-2 and d_psnr < 1e-3
+        finally:
+            ops.CONV24 = old
+
+
 def test_hd_midsize_against_live_oracle(dev):
     """flag_HD_in path (RefVSR_small_MFID_8K geometry) at 128x192 -> 512x768: exercises the stride-4/8 gather-mode
     predictor convs, aa1 alignment and the VGG conv2_1 + max-pool matching branch at a non-toy size."""
@@ -517,6 +553,35 @@ def test_full_size_against_reference_fixture(dev, variant):
         else:
             assert p > 25.0                                    # the operating point is a plausible SR result
             assert e_crop < 4e-3 and p_crop > 70.0
+
+
+def test_full_size_mfid_against_reference_fixture(dev):
+    """BASELINE configs[2] (config_RefVSR_MFID, C = 48, 30 blocks) at the headline size 270x480 -> 1080x1920, t = 5: first-frame
+    and steady-state call vs the REFERENCE (tools/gen_golden.py --full-mfid): PSNR scalar under the north-star bar, strided
+    sub-sample and two full-resolution crops.  The launch shapes of this test are the ones the RefVSR_MFID bench line runs."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'e2e_full_F_270x480_t5.npz')
+    if not os.path.exists(path):
+        pytest.skip('full-size MFID fixture not generated')
+    from refvsr_amd.synth import make_clip, window_indices
+    g = load_golden('e2e_full_F_270x480_t5')
+    nfr = int(g['nframes'])
+    lr, rf, gt = make_clip(nfr, 270, 480, seed=0)
+    assert abs(float(lr.double().sum()) - float(g['lr_checksum'])) < 1e-6 * abs(float(g['lr_checksum']))
+    net, cfg, sd = make_net('config_RefVSR_MFID', 5, dev, save_sample=False)
+    st = int(g['stride'])
+    crops = g['crops'].tolist()
+    for f in range(nfr):
+        w = window_indices(f, nfr, 5)
+        res = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+        p = psnr(res, gt[f][None])
+        d_psnr = abs(p - float(g['psnr_%d' % f]))
+        e_crop = max(maxdiff(res[0, :, y0:y0 + 128, x0:x0 + 128], g['crop%d_%d' % (ci, f)]) for ci, (y0, x0) in enumerate(crops))
+        p_crop = min(psnr(res[0, :, y0:y0 + 128, x0:x0 + 128], g['crop%d_%d' % (ci, f)]) for ci, (y0, x0) in enumerate(crops))
+        e_sub = maxdiff(res[0, :, ::st, ::st], g['sub_%d' % f])
+        report('full-size MFID vs reference f%d' % f, sub_err=e_sub, crop_err=e_crop, crop_psnr_vs_ref=float(p_crop), psnr=float(p),
+               ref_psnr=float(g['psnr_%d' % f]), dPSNR=float(d_psnr))
+        assert d_psnr < 1e-3                                   # the north-star bar, against the reference itself
+        assert e_sub < 2.4e-2 and e_crop < 7e-3 and p_crop > 60.0   # measured sub 1.14e-2, crop 3.3e-3 / 64.7 dB, |dPSNR| 3.5e-5: bars = 2x
 
 
 # ------------------------------------------------------------------------------------------------

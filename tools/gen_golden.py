@@ -363,7 +363,38 @@ def gen_full(nframes=2, stride=8):
     save('e2e_full_S_270x480_t5', **arrs)
 
 
+def gen_full_mfid(nframes=2, stride=8):
+    """Full BASELINE size (270x480 -> 1080x1920, t=5) for BASELINE configs[2]'s model (config_RefVSR_MFID: C = 48, 30 blocks),
+    random weights: PSNR scalars, the strided sub-sample and the two 128x128 full-resolution crops per frame (the matching does
+    not depend on the model width: its index / confidence maps are pinned by the S fixture).  ~8 min per frame on 8 cores."""
+    from refvsr_amd.synth import make_clip, window_indices
+    import time
+    lr, rf, gt = make_clip(nframes, 270, 480, seed=0)
+    crops = [(300, 500), (700, 1400)]
+    arrs = dict(nframes=np.int64(nframes), stride=np.int64(stride), crops=np.asarray(crops, np.int64),
+                lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
+    print('== full-size F (config_RefVSR_MFID) 270x480 t=5, %d frames, random weights ==' % nframes)
+    net, cfg, mine, sd = ref_net('config_RefVSR_MFID', 5, save_sample=False)
+    with torch.no_grad():
+        for f in range(nframes):
+            w = window_indices(f, nframes, 5)
+            t0 = time.time()
+            res = net(lr[w][None], rf[w][None], f == 0, is_log=False, is_train=False)['result']
+            p = float(10 * torch.log10(1 / torch.mean((res - gt[f][None]) ** 2)))
+            print('  frame %d: %.1f s, PSNR vs GT %.6f dB' % (f, time.time() - t0, p), flush=True)
+            arrs['psnr_%d' % f] = np.float64(p)
+            for ci, (y0, x0) in enumerate(crops):
+                arrs['crop%d_%d' % (ci, f)] = res[0, :, y0:y0 + 128, x0:x0 + 128].clone()
+            arrs['sub_%d' % f] = res[0, :, ::stride, ::stride].clone()
+    save('e2e_full_F_270x480_t5', **arrs)
+
+
 def main():
+    if '--full-mfid' in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        gen_full_mfid()
+        return
     if '--spec' in sys.argv:
         gen_spec()
         return
