@@ -131,7 +131,9 @@ int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* bl
                             void* scratch0, void* scratch1, void* out, void* stream);
 /* (ty << 16 | tx << 8 | cg) of K-block (K-step s = 0..6, quarter q = 0..3) of the blob's K order, -1 for the zero block. */
 int refvsr_resblock24_kblock(int s, int q);
-/* Tuning knob: waves per workgroup of the 24-channel kernel, 8 (default) or 4.  Results do not depend on it. */
+/* Tuning knob: workgroup shape of the 24-channel kernel.  0 (default): by map size -- 8 waves on 8 x 32-pixel tiles, or 16
+ * waves on 16 x 32 tiles (one workgroup per CU) when the map has at least four 8 x 32 tiles per CU; 4 | 8 | 16 force a
+ * shape.  Results do not depend on it (bit-identical). */
 int refvsr_set_resblock24_waves(int waves);
 /* 3x3 stride-1 pad-1 convolutions with 24 output channels on fp16 HWC maps, compile-time specialised like the block above
  * (csrc/conv24.hip): the ResList tails (RefVSR_/common.py:80-82), feat_fusion / conf_fusion / fusion_UP convs (RefVSR.py:47-62,87),

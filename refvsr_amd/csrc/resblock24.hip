@@ -35,22 +35,19 @@
 #include "common.h"
 
 namespace {
-constexpr int RB_TH = 8, RB_TW = 32;
-constexpr int RB_XH = RB_TH + 4, RB_XW = RB_TW + 4;       // x tile: 12 x 36 pixels
-constexpr int RB_IH = RB_TH + 2, RB_IW = RB_TW + 2;       // intermediate: 10 x 34
-constexpr int RB_NI = RB_IH * RB_IW;                      // 340 intermediate pixels
-constexpr int RB_G1 = (RB_NI + 15) / 16;                  // 22 sixteen-pixel groups of phase 1
+constexpr int RB_TW = 32;                                 // tile width; the tile height TH is a template parameter (8 | 16)
+constexpr int RB_XW = RB_TW + 4;                          // x tile: (TH + 4) x 36 pixels
+constexpr int RB_IW = RB_TW + 2;                          // intermediate: (TH + 2) x 34
 constexpr int RB_PXB = 48;                                // bytes per pixel (24 halfs)
 constexpr int RB_ROWB = RB_XW * RB_PXB;                   // 1728 bytes per tile row
-constexpr int RB_XBYTES = RB_XH * RB_ROWB;                // 20736
-constexpr int RB_XCH = RB_XBYTES / 16;                    // 1296 sixteen-byte chunks
 constexpr int RB_RCH = RB_ROWB / 16;                      // 108 chunks per tile row
+constexpr int rb_xbytes(int th) { return (th + 4) * RB_ROWB; }         // 20736 (TH = 8) | 34560 (TH = 16)
 constexpr int RB_S = 7, RB_NF = 3;
 constexpr int RB_WB = RB_S * RB_NF * 1024;                // 21504 bytes of fragments per conv
 constexpr int RB_BIAS = 2 * RB_WB;                        // 43008
 constexpr int RB_BLOB = RB_BIAS + 256;                    // 43264
 constexpr int RB_XT = RB_BLOB;                            // LDS offset of the x tile
-constexpr int RB_LDS = RB_XT + RB_XBYTES;                 // 64000 -> two workgroups per CU
+constexpr int rb_lds(int th) { return RB_XT + rb_xbytes(th); }         // 64000 -> two workgroups per CU | 77824 -> one
 static_assert(RB_BLOB == REFVSR_RESBLOCK24_BLOB_BYTES, "blob size is part of the C-ABI");
 }  // namespace
 
@@ -152,8 +149,13 @@ __device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
 
 // NWV = waves per workgroup (8: three + two pixel groups per wave, <= 128 VGPRs, four waves per SIMD with the two workgroups
 // of a CU; 4: six + four groups per wave, twice the weight-fragment reuse, two waves per SIMD).
-template <bool RELU, int NWV, bool PROBE = false>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 2, NWV / 2))) void resblock24_kernel(RB24Args p) {
+template <bool RELU, int NWV, bool PROBE = false, int TH = 8>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 4 ? 2 : 4, NWV == 4 ? 2 : 4))) void resblock24_kernel(RB24Args p) {
+    static_assert((TH == 8 && (NWV == 4 || NWV == 8)) || (TH == 16 && NWV == 16), "tile height / waves");
+    constexpr int RB_TH = TH, RB_XH = TH + 4, RB_IH = TH + 2;    // TH = 8: x tile 12 x 36, intermediate 10 x 34 (22 sixteen-pixel groups)
+    constexpr int RB_NI = RB_IH * RB_IW;                         // TH = 16: 20 x 36, 18 x 34 (39 groups), 16 waves, ONE workgroup per CU
+    constexpr int RB_G1 = (RB_NI + 15) / 16;                     //   (the large maps, see refvsr_resblock24_chain)
+    constexpr int RB_XBYTES = rb_xbytes(TH), RB_XCH = RB_XBYTES / 16;
     // PROBE: stamps 0 entry, 1 prologue loads issued, 2 first barrier passed; of tile `probe_iter`: 3 conv1 K loop done, 4 fold +
     // barrier A, 5 t written (+ next tile's loads issued), 6 barrier B, 7 conv2 K loop done, 8 barrier C + next tile parked,
     // 9 stores issued, 10 barrier D; 11 exit ([8]/[10] = previous stamp when there is no next tile)
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
     constexpr int NT = NWV * 64;
     constexpr int T1 = (RB_G1 + NWV - 1) / NWV;                  // phase-1 groups of a "full" wave (3 | 6)
     constexpr int T1REM = RB_G1 % NWV;                           // waves below this index are full, the others have T1 - 1
-    constexpr int T2 = 16 / NWV;                                 // phase-2 groups per wave (2 | 4)
+    constexpr int T2 = 2 * TH / NWV;                             // phase-2 groups per wave (2 | 4)
     constexpr int KCH = (RB_XCH + NT - 1) / NT;                  // x-tile chunks per thread (3 | 6)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -379,30 +381,33 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
 extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
 extern int g_rb_probe_iter;
 
-static int g_rb24_waves = 8;                 // A/B knob (refvsr_set_resblock24_waves): 4 or 8 waves per workgroup
+static int g_rb24_waves = 0;                 // A/B knob (refvsr_set_resblock24_waves): 0 = by map size; 4 | 8: 8 x 32 tiles; 16: 16 x 32
 extern "C" int refvsr_set_resblock24_waves(int waves) {
-    if (waves != 4 && waves != 8) return 1;
+    if (waves != 0 && waves != 4 && waves != 8 && waves != 16) return 1;
     g_rb24_waves = waves;
     return 0;
 }
 
-template <bool RELU, int NWV, bool PROBE = false>
+template <bool RELU, int NWV, bool PROBE = false, int TH = 8>
 static int launch_rb24(RB24Args& a, hipStream_t st) {
+    constexpr int RB_LDS = rb_lds(TH);
+    a.tiles_x = rv_cdiv(a.w, RB_TW);
+    a.n_tiles = a.tiles_x * rv_cdiv(a.h, TH);
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE, TH>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE>, NWV * 64, RB_LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE, TH>, NWV * 64, RB_LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
+    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -425,8 +430,6 @@ extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, con
     RB24Args a;
     memset(&a, 0, sizeof(a));
     a.h = h; a.w = w; a.act_slope = act_slope;
-    a.tiles_x = rv_cdiv(w, RB_TW);
-    a.n_tiles = a.tiles_x * rv_cdiv(h, RB_TH);
     hipStream_t st = (hipStream_t)stream;
     const unsigned char* cur = (const unsigned char*)src;
     for (int i = 0; i < n; ++i) {
@@ -434,9 +437,16 @@ extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, con
         a.src = cur; a.out = dst; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
         int rc;
         a.probe = g_rb_probe; a.probe_iter = g_rb_probe_iter;
-        if (g_rb_probe && act_slope == 0.f && g_rb24_waves == 8) rc = launch_rb24<true, 8, true>(a, st);   // tools/probe_resblock.py
-        else if (act_slope == 0.f) rc = g_rb24_waves == 8 ? launch_rb24<true, 8>(a, st) : launch_rb24<true, 4>(a, st);
-        else rc = g_rb24_waves == 8 ? launch_rb24<false, 8>(a, st) : launch_rb24<false, 4>(a, st);
+        // 16 x 32 tiles on sixteen waves (one workgroup per CU: half the weight fill per CU, 10 % less halo work in conv1, 17 % less
+        // tile staging) pay on maps of many tiles per workgroup -- 540 x 960: 27.3 -> 26.3 us, 1080 x 1920: 100.1 -> 95.9 us; at
+        // 270 x 480 (one tile per workgroup either way) the two shapes are equal (9.3 vs 9.4 us: the fill is latency, not bandwidth,
+        // and sixteen waves wait longer at the barriers), below that the 8 x 32 tiles fill more CUs (135 x 240: 6.2 vs 8.2 us)
+        const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8);
+        const int waves = g_rb24_waves ? g_rb24_waves : (nt8 >= 4 * rv_num_cus() ? 16 : 8);
+        if (g_rb_probe && act_slope == 0.f && waves == 8) rc = launch_rb24<true, 8, true>(a, st);          // tools/probe_resblock24.py
+        else if (g_rb_probe && act_slope == 0.f && waves == 16) rc = launch_rb24<true, 16, true, 16>(a, st);
+        else if (act_slope == 0.f) rc = waves == 16 ? launch_rb24<true, 16, false, 16>(a, st) : waves == 8 ? launch_rb24<true, 8>(a, st) : launch_rb24<true, 4>(a, st);
+        else rc = waves == 16 ? launch_rb24<false, 16, false, 16>(a, st) : waves == 8 ? launch_rb24<false, 8>(a, st) : launch_rb24<false, 4>(a, st);
         if (rc) return rc;
         cur = dst;
     }

@@ -399,8 +399,9 @@ def test_resblock_chain_call(dev, n):
                                      (540, 960, 0.2, 2), (8, 32, 0.0, 1), (9, 33, 0.2, 1)])
 def test_resblock24_chain(dev, h, w, act, n):
     """refvsr_resblock24_chain (compile-time-specialised 24-channel kernel, weights as one blob per block) vs torch fp32 on
-    the same fp16-rounded maps, vs the runtime-generic lean kernel (same arithmetic up to fp32 summation order), with both
-    workgroup shapes (bit-identical), interior and border tiles, maps smaller than one tile."""
+    the same fp16-rounded maps, vs the runtime-generic lean kernel (same arithmetic up to fp32 summation order), with all three
+    workgroup shapes (8 x 32 tiles on 4 / 8 waves, 16 x 32 tiles on 16 waves: bit-identical), interior and border tiles, maps
+    smaller than one tile."""
     from refvsr_amd import ops
     from refvsr_amd.packing import pack_conv
     C = 24
@@ -419,10 +420,11 @@ def test_resblock24_chain(dev, h, w, act, n):
     got = ops.resblock24_chain(ops.Resblock24Chain(pairs, dev), xin, act)      # blobs repacked from the kept raw weights
     got_raw = ops.resblock24_chain(ops.Resblock24Chain(raw, dev), xin, act)
     assert torch.equal(got, got_raw) and torch.equal(xin, x0)
-    lib.refvsr_set_resblock24_waves(4)
-    four = ops.resblock24_chain(ops.Resblock24Chain(raw, dev), xin, act)
-    lib.refvsr_set_resblock24_waves(8)
-    assert torch.equal(got, four), '4-wave and 8-wave workgroups differ'
+    for waves in (4, 16, 0):                    # 8 x 32 tiles on 4 waves, 16 x 32 tiles on 16 waves, the size-dependent default
+        lib.refvsr_set_resblock24_waves(waves)
+        other = ops.resblock24_chain(ops.Resblock24Chain(raw, dev), xin, act)
+        lib.refvsr_set_resblock24_waves(0)
+        assert torch.equal(got, other), 'workgroup shape %d differs from 8 waves' % waves
     want, lean = x.half().float(), xin
     for ((w1, b1), (w2, b2)), (c1, c2) in zip(raw, pairs):
         t = F.leaky_relu(F.conv2d(want[None], w1, b1, padding=1), act).half().float()

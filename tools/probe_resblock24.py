@@ -25,6 +25,8 @@ def main():
     ws = [torch.randn(Cc, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5 * 0.5 for _ in range(2)]
     ch = ops.Resblock24Chain([((ws[0], torch.zeros(Cc)), (ws[1], torch.zeros(Cc)))], dev)
     probe = torch.zeros(512 * 12, dtype=torch.int64, device=dev)
+    if os.environ.get('PROBE_WAVES'):                      # 8: 8 x 32 tiles; 16: 16 x 32 tiles on sixteen waves; default: by map size
+        hip.lib().refvsr_set_resblock24_waves(int(os.environ['PROBE_WAVES']))
     for name, h, w, it in (('LR', 270, 480, 0), ('LR/2', 135, 240, 0), ('2x first tile', 540, 960, 0), ('2x 2nd tile', 540, 960, 1),
                            ('2x 4th tile', 540, 960, 3)):
         x = ops.pack_nhwc16(torch.randn(Cc, h, w, generator=g).to(dev))
