@@ -44,13 +44,18 @@ def main():
             y = ops.resblock24_chain(ch, y, 0.0)
             e1.record()
             torch.cuda.synchronize()
-            p = probe.view(512, 12).cpu()
-            p = p[(p[:, 0] > 0) & (p[:, 9] > 0)].double()
-            reps.append((e0.elapsed_time(e1) * 1e3, p))
+            pa = probe.view(512, 12).cpu()
+            keep = (pa[:, 0] > 0) & (pa[:, 9] > 0)
+            p = pa[keep].double()
+            # s_memtime counters are per XCD (workgroup i runs on XCD i % 8): skews only within one XCD
+            xcd = torch.arange(512)[keep] % 8
+            skew = max(float(p[xcd == x][:, 0].max() - p[xcd == x][:, 0].min()) for x in range(8) if bool((xcd == x).any()))
+            span = max(float(p[xcd == x][:, 11].max() - p[xcd == x][:, 0].min()) for x in range(8) if bool((xcd == x).any()))
+            reps.append((e0.elapsed_time(e1) * 1e3, p, skew, span))
         hip.lib().refvsr_set_probe(None, 0)
-        ev_us, p = reps[-1]
-        print('== %s (%dx%d, tile iteration %d): %d workgroups stamped, event time %.1f us; entry skew %.0f cycles, first entry -> last exit %.0f cycles'
-              % (name, h, w, it, p.shape[0], ev_us, float(p[:, 0].max() - p[:, 0].min()), float(p[:, 11].max() - p[:, 0].min())))
+        ev_us, p, skew, span = reps[-1]
+        print('== %s (%dx%d, tile iteration %d): %d workgroups stamped, event time %.1f us; per XCD (worst of 8): entry skew %.0f cycles, first entry -> last exit %.0f cycles'
+              % (name, h, w, it, p.shape[0], ev_us, skew, span))
         d = p[:, 1:11] - p[:, 0:10]
         for i, s in enumerate(STAGES):
             if it > 0 and i < 3:
