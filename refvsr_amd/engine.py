@@ -602,6 +602,8 @@ class Engine(object):
             # 254-workgroup matching kernel is not queued behind the persistent conv workgroups of the other streams
             hi = -1 if os.environ.get('REFVSR_STREAM_PRIORITY', '0') == '1' else 0
             self._pipe = [torch.cuda.Stream(device=dev) for _ in range(3)] + [torch.cuda.Stream(device=dev, priority=hi)]
+            if os.environ.get('REFVSR_PIPE_ONE_M', '0') == '1':      # A/B knob: one M stream (consecutive calls' backward branches serialise)
+                self._pipe[1] = self._pipe[0]
             self._pipe_calls = 0
         return self._pipe
 

@@ -37,6 +37,20 @@ def main():
     for k, v in ksum.most_common(16):
         print('  %-48s %6.3f ms  %6.1f launches/frame  avg %7.1f us' % (k, v / 1e6 / nfr, kcnt[k] / float(nfr), v / kcnt[k] / 1e3))
     print('per HIP queue, ms per frame: ' + ', '.join('q%d %.3f' % (q, v / 1e6 / nfr) for q, v in sorted(qs.items())))
+    # which logical stream is which queue: the three kernels with the most time per queue, and the Stream_Id column when present
+    qk = collections.defaultdict(collections.Counter)
+    qstream = collections.defaultdict(set)
+    sid = 'Stream_Id' if rows and 'Stream_Id' in rows[0] else None
+    for r in rows:
+        s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if t0 <= s_ < t1:
+            q = int(r['Queue_Id'])
+            qk[q][r['Kernel_Name'].split('(')[0].replace('void ', '')[-40:]] += e_ - s_
+            if sid:
+                qstream[q].add(r[sid])
+    for q in sorted(qk):
+        print('  q%d%s: ' % (q, (' streams ' + ','.join(sorted(qstream[q]))) if sid else '') +
+              '; '.join('%s %.2f ms' % (k, v / 1e6 / nfr) for k, v in qk[q].most_common(4)))
 
 
 if __name__ == '__main__':
