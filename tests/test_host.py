@@ -164,6 +164,27 @@ def test_weight_packing_hi_only():
         pack_conv((rs.randn(24, 24, 3, 3) * 0.1).astype(np.float32), b[:24], [24], hi_only=True)     # resident shape: 7 K-steps
 
 
+def test_engine_weight_modes(small_cfg, small_sd):
+    """Which convs carry which weight representation (refvsr_amd/engine.py:Weights): SPyNet's streamed 7x7 convs (every conv of
+    a level but the first, and their mt = 1 variants) plain fp16 (descriptor mode 2), everything else fp16 hi + lo, the VGG
+    head of the matching exact fp32; config.spynet_hi_lo restores hi + lo in SPyNet."""
+    import copy
+    from refvsr_amd.engine import Weights
+    W = Weights(small_cfg, small_sd, torch.device('cpu'))
+    modes = collections.Counter()
+    for name, cw in W.conv.items():
+        spy = name.startswith('FlowNet.') and '.basic_module.0.conv' not in name.split('FlowNet.basic_module.')[1][1:]
+        assert cw.hi_only == spy, name
+        assert cw.desc.f32 == (2 if spy else (1 if cw.f32 else 0)), name
+        assert cw.wpack.shape[3] == (1 if spy else 2) or cw.f32, name
+        modes[cw.desc.f32] += 1
+    assert modes[2] == 6 * 4 + 6 * 2 and modes[1] == 3 and modes[0] > 100          # 6 levels x (4 convs + 2 mt = 1 variants)
+    cfg2 = copy.deepcopy(small_cfg)
+    cfg2.spynet_hi_lo = True
+    W2 = Weights(cfg2, small_sd, torch.device('cpu'))
+    assert not any(cw.hi_only for cw in W2.conv.values())
+
+
 def test_model_shell_state_dict_contract(small_cfg, small_sd):
     from refvsr_amd import SRNet
     net = SRNet(small_cfg)
