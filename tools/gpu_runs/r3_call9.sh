@@ -1,5 +1,6 @@
 #!/bin/bash
 # match_top2 v6 (fragment reads one tile ahead) vs v4: parity tests, micro-benchmark, bench A/B; RefVSR_IR vis test
+# (historical: the v6 kernel and its REFVSR_MATCH_TOP2 knob were removed after this run -- slower, profiles/r03_match_top2_v6_ab.txt)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 L=gpurun_out/r3_call9.log
