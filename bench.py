@@ -19,8 +19,15 @@ What the JSON line carries beside the contract fields:
                         the reference's call surface (what the build's own eval harness, refvsr_amd/evalrun.py, uses)
   dropin_surface     -- the same K steps through the UNMODIFIED reference call surface (`net(x, ref, is_first_frame)`,
                         frames recognised by content, no pipelining): what run.py / eval.py get with the 3-line plug-in
-  roofline           -- the dominant kernel (fused matching GEMM + arg-max, MFMA-bound): algorithmic FLOPs per launch /
-                        mean launch duration from HIP events recorded around every launch inside the timed region
+  roofline           -- the TIME-dominant kernel (the fused 24-channel ResBlock, ~30 % of the device time in 156 launches per
+                        frame, MFMA-bound): useful FLOPs per LR launch / mean launch duration from HIP events recorded around
+                        every run of blocks in a second, single-stream pass over the same frames (inside the pipelined region the
+                        launches of other streams sit between the events); configurations whose blocks do not run on that
+                        kernel (C = 48 / 36) report the matching kernel here
+  roofline_match_top2 -- the fused matching GEMM + arg-max (one launch per frame, ~16 % of the device time): algorithmic FLOPs per
+                        launch / mean duration from HIP events around every launch inside the timed region
+  wavefront_model    -- (N = 1) phase A / B1 / B2 times of one restart unit of BASELINE configs[3], host-synchronised per phase,
+                        and the makespan model's predicted speed-up at 2 / 4 / 8 ranks per partition (refvsr_amd/shard.py)
   kernels            -- device time per launch (HIP events around back-to-back launches queued behind a long kernel, so
                         the host launch rate does not enter) of the time-dominant conv kernels (MFMA and HBM fractions)
                         and of the HBM-bound warp / gather / sampler / resize kernels (GB/s of algorithmic bytes against
