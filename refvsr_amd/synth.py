@@ -8,10 +8,11 @@ import numpy as np
 import torch
 
 
-def make_clip(nframes, h, w, seed=0, scale=4, start=0):
+def make_clip(nframes, h, w, seed=0, scale=4, start=0, want_gt=True):
     """Returns (lr [T,3,h,w], ref [T,3,h,w], gt [T,3,scale*h,scale*w]) float32 in [0,1] (CPU).
     Frame k of the returned clip is global frame `start + k` of an endless clip, so shards of one
-    long clip can be generated independently."""
+    long clip can be generated independently.  want_gt=False: gt is None (the HR clip is 16x the LR clip: 25 MB per
+    270x480 frame -- callers that only need inputs must not keep it)."""
     rs = np.random.RandomState(seed)
     H, W = h * scale, w * scale
     ncomp = 10
@@ -42,9 +43,10 @@ def make_clip(nframes, h, w, seed=0, scale=4, start=0):
         q = lambda a: np.round(a * 255.0) / 255.0
         lrs.append(q(lr))
         refs.append(q(ref))
-        gts.append(q(gt))
+        if want_gt:
+            gts.append(q(gt))
     to = lambda a: torch.from_numpy(np.stack(a).astype(np.float32))
-    return to(lrs), to(refs), to(gts)
+    return to(lrs), to(refs), (to(gts) if want_gt else None)
 
 
 def window_indices(f, nframes, t):
