@@ -139,6 +139,25 @@ def test_refvsr_ir_stream_against_reference_fixture(dev):
         assert e_res < 2e-2 and psnr(res, want) > 55.0 and e_feat < 3e-2 and e_conf < 1e-3 and e_flow < 1e-3
 
 
+def test_refvsr_ir_padded_size_against_live_oracle(dev):
+    """RefVSR_IR at 66x70 (neither side a multiple of 4): the EDVR extractor's reflect padding to 68x72 and the crop of its
+    features (RefVSR_IR.py:171-217) -- the path the 270x480 bench line of this model runs -- against the live oracle:
+    first-frame and steady call, key-frame bookkeeping, the north-star PSNR bar."""
+    from oracle import refvsr_ir_oracle as iro
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, gt = make_clip(2, 66, 70, seed=13)
+    net, cfg, sd = make_net('config_RefVSR_IR_MFID', 5, dev, save_sample=False)
+    o = iro.OracleNetworkIR(cfg, sd)
+    for f in range(2):
+        w = window_indices(f, 2, 5)
+        a = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+        want = o.forward(lr[w][None], rf[w][None], f == 0)['result']
+        d_psnr = abs(psnr(a, gt[f][None]) - psnr(want, gt[f][None]))
+        report('e2e IR 66x70 f%d' % f, res=maxdiff(a, want), psnr_vs_oracle=float(psnr(a, want)), dPSNR_vs_gt=float(d_psnr))
+        assert [int(k) for k in net.Network.engine(0).keyframe_idx] == [int(k) for k in o.keyframe_idx]
+        assert a.shape == (1, 3, 264, 280) and maxdiff(a, want) < 2e-2 and psnr(a, want) > 55.0 and d_psnr < 1e-3
+
+
 def test_midsize_against_live_oracle_and_cache_equivalence(dev):
     """64x96, t=5: 4 frames against the oracle; the cross-window cache must not change a single bit."""
     from oracle import refvsr_oracle as orc
