@@ -260,6 +260,27 @@ def test_mfid_midsize_against_live_oracle(dev):
             ops.CONV24 = old
 
 
+def test_x2_midsize_against_live_oracle(dev):
+    """x2 SR (config.scale = 2: matching on VGG19[0:7] features at half resolution with matching_ksize 4, aa1 + aa2 alignment,
+    one pixel-shuffle stage -- RefVSR.py:60-66,104-119) at 64x96 -> 128x192, t = 5, against the live oracle; the fixture of
+    this mode (S2_16x24_t3) is toy-sized."""
+    import torch.nn.functional as F
+    from oracle import refvsr_oracle as orc
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, gt4 = make_clip(3, 64, 96, seed=21)
+    gt = F.avg_pool2d(gt4, 2)                          # the x2 ground truth of the same scene
+    net, cfg, sd = make_net('config_RefVSR_small_L1', 5, dev, save_sample=False, scale=2)
+    assert cfg.scale == 2 and cfg.matching_ksize == 4
+    o = orc.OracleNetwork(cfg, sd)
+    for f in range(3):
+        w = window_indices(f, 3, 5)
+        a = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'].cpu()
+        want = o.forward(lr[w][None], rf[w][None], f == 0)['result']
+        d_psnr = abs(psnr(a, gt[f][None]) - psnr(want, gt[f][None]))
+        report('e2e x2 64x96 f%d' % f, res=maxdiff(a, want), psnr_vs_oracle=float(psnr(a, want)), dPSNR_vs_gt=float(d_psnr))
+        assert a.shape == (1, 3, 128, 192) and maxdiff(a, want) < 2e-2 and psnr(a, want) > 55.0 and d_psnr < 1e-3
+
+
 def test_hd_midsize_against_live_oracle(dev):
     """flag_HD_in path (RefVSR_small_MFID_8K geometry) at 128x192 -> 512x768: exercises the stride-4/8 gather-mode
     predictor convs, aa1 alignment and the VGG conv2_1 + max-pool matching branch at a non-toy size."""
