@@ -47,18 +47,12 @@ def main():
             pa = probe.view(512, 12).cpu()
             keep = (pa[:, 0] > 0) & (pa[:, 9] > 0)
             p = pa[keep].double()
-            # s_memtime counters are not common to the chip (per XCD / clock domain): workgroups are clustered by counter value
-            # (gaps above 1e6 cycles separate domains) and the skews are taken inside a cluster
-            order = torch.argsort(p[:, 0])
-            e_sorted = p[order, 0]
-            cuts = [0] + [int(i) + 1 for i in torch.nonzero(e_sorted[1:] - e_sorted[:-1] > 1e6).flatten()] + [p.shape[0]]
-            skew = max(float(e_sorted[b - 1] - e_sorted[a]) for a, b in zip(cuts[:-1], cuts[1:]))
-            span = max(float(p[order[a:b], 11].max() - e_sorted[a]) for a, b in zip(cuts[:-1], cuts[1:]))
-            reps.append((e0.elapsed_time(e1) * 1e3, p, skew, span, len(cuts) - 1))
+            # (s_memtime counters are not common to the chip -- per XCD / clock domain -- so only differences inside one
+            #  workgroup are meaningful: no entry skew / first-entry-to-last-exit figures)
+            reps.append((e0.elapsed_time(e1) * 1e3, p))
         hip.lib().refvsr_set_probe(None, 0)
-        ev_us, p, skew, span, ndom = reps[-1]
-        print('== %s (%dx%d, tile iteration %d): %d workgroups stamped, event time %.1f us; per clock domain (worst of %d): entry skew %.0f cycles, first entry -> last exit %.0f cycles'
-              % (name, h, w, it, p.shape[0], ev_us, ndom, skew, span))
+        ev_us, p = reps[-1]
+        print('== %s (%dx%d, tile iteration %d): %d workgroups stamped, event time %.1f us' % (name, h, w, it, p.shape[0], ev_us))
         d = p[:, 1:11] - p[:, 0:10]
         for i, s in enumerate(STAGES):
             if it > 0 and i < 3:
