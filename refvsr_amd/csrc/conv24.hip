@@ -17,6 +17,12 @@
 // weight set resident next to a 16 x 32-pixel tile (18 x 34 staged pixels, 68 KB) walked by SIXTEEN waves -- one workgroup per
 // CU, four waves per SIMD, 255 tiles for the 270 x 480 map of the 256-CU chip -- and 16 -> 48 on the 8 x 32 tile.
 //
+// SHUF = 24 | 48 (PixelShufflePack.upsample_conv + F.pixel_shuffle, mmedit upsample.py:36-51; RefVSR.py:89-90,138): the
+// C -> 4 C conv as groups of 48 output rows on the COUT = 48 kernel, blockIdx.y = group z, rows ordered sub-pixel-major so that
+// a lane's four accumulator rows are four consecutive channels of ONE sub-pixel: C = 24: group z = output row parity dy, rows
+// [dx = 0: channels 0-23][dx = 1: channels 0-23]; C = 48: group z = sub-pixel 2 dy + dx, rows = channels 0-47.  The epilogue
+// stores straight into the [2h][2w][C] map (bias only: no activation / multiplier / residual on this layer).
+//
 // LDS: [fragments: S K-steps x 3 x 1 KiB][bias: 32 floats][x tile: 10 x 34 pixels x PS slots of 16 bytes, PS = NCG | 1 (odd
 // pixel stride: bank-conflict-free B reads with the pixel permutation of common.h)].  K plans (c24_kblock): the K-blocks of
 // one window row are the slots u = tx * PS + cg; a K-step takes four of them whose offsets are (step immediate) + (one of
@@ -127,8 +133,9 @@ __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l
 
 // COUT = 24 | 48 output channels; TH = 8 | 16 tile rows; NWV waves walk the TH x 32 tile, T = 2 TH / NWV pixel groups per wave;
 // WPS = waves per SIMD the kernel is built for (register budget).
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS>
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void conv24_kernel(C24Args p) {
+    static_assert(SHUF == 0 || (COUT == 48 && (SHUF == 24 || SHUF == 48) && NCG0 * 8 == SHUF && NCG1 == 0), "pixel-shuffle variant");
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
     constexpr int S = c24_steps(NCG), NPAT = c24_npat(NCG);
     constexpr int NF = COUT == 24 ? 3 : 6;                          // fragments per K-step
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     // ---- weights + bias: global -> LDS (1 KiB per wave instruction), issued first
     {
         constexpr int NPC = WB / 1024;                               // full pieces; the 128-byte bias tail: 8 lanes
-        const unsigned char* g = p.blob + lane * 16;
+        const unsigned char* g = p.blob + (SHUF ? (int)blockIdx.y * (WB + BIASB) : 0) + lane * 16;       // SHUF: one blob per row group
 #pragma unroll
         for (int j = 0; j < (NPC + NWV - 1) / NWV; ++j) {
             const int c = wave + j * NWV;
@@ -349,6 +356,28 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             __syncthreads();                                         // every wave is done reading the x tile
             x_park();
         }
+        if constexpr (SHUF != 0) {
+            // ---------------- pixel-shuffle epilogue: rows 16 m + 4 q .. of group z -> channels ch0 .. of sub-pixel (dy, dx) -------
+            const int z = (int)blockIdx.y;
+            const unsigned w2 = 2u * (unsigned)p.w;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                int lpe = lp;
+                if (!interior) asm volatile("" : "+v"(lpe));
+                const unsigned oy = (unsigned)(ty0 + oy0 + (t >> 1)), ox = (unsigned)(tx0 + (t & 1) * 16 + lpe);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int r0 = 16 * m + 4 * q;
+                    const int dx = SHUF == 24 ? (r0 >= 24 ? 1 : 0) : (z & 1);
+                    const int dy = SHUF == 24 ? z : (z >> 1);
+                    const int ch0 = SHUF == 24 ? r0 - 24 * dx : r0;
+                    const f32x4 y = acc[m][t];
+                    const f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+                    if (okt[t])
+                        *reinterpret_cast<f16x4*>(p.out + ((2u * oy + dy) * w2 + 2u * ox + dx) * (unsigned)(SHUF * 2) + ch0 * 2) = o;
+                }
+            }
+        } else
         // ---------------- epilogue: out = post(act(acc) * mul + res) ----------------------------------------------------------
         {
             unsigned char* ob = p.out + oorg;
@@ -390,8 +419,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     }
 }
 
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS>
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0>
 static int launch_c24(C24Args& a, hipStream_t st) {
+    constexpr int NZ = SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;          // row groups of the pixel-shuffle variant (blockIdx.y)
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
     constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : 6) * 1024 + (COUT == 24 ? 128 : 256) + (TH + 2) * C24_XW * PS * 16;
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -399,19 +429,19 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS>, NWV * 64, LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF>, NWV * 64, LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
     a.tiles_x = rv_cdiv(a.w, C24_TW);
     a.n_tiles = a.tiles_x * rv_cdiv(a.h, TH);
-    int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
+    int cap = (rv_num_cus() * occ_dev[dev] / NZ) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS>), dim3(a.grid), dim3(NWV * 64), LDS, st, a);
+    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -428,6 +458,12 @@ extern "C" int refvsr_conv24_blob_bytes(int c0, int c1) {
 extern "C" int refvsr_conv48_blob_bytes(int c0, int c1) {
     if (!refvsr_conv48_supported(c0, c1)) return -1;
     return c24_steps((c0 + c1) / 8) * 6 * 1024 + 256;
+}
+
+extern "C" int refvsr_conv_shuffle2_supported(int c) { return c == 24 || c == 48; }
+extern "C" int refvsr_conv_shuffle2_blob_bytes(int c) {
+    if (!refvsr_conv_shuffle2_supported(c)) return -1;
+    return (c == 24 ? 2 : 4) * (c24_steps(c / 8) * 6 * 1024 + 256);
 }
 
 extern "C" int refvsr_conv24_kblock(int ncg, int s, int q) {
@@ -474,4 +510,15 @@ extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1,
     static const bool w8 = getenv("REFVSR_CONV48_WAVES") && atoi(getenv("REFVSR_CONV48_WAVES")) == 8;
     if (c0 == 48) return w8 ? launch_c24<48, 6, 0, 8, 16, 2>(a, st) : launch_c24<48, 6, 0, 16, 16, 4>(a, st);
     return launch_c24<48, 2, 0, 8, 8, 4>(a, st);
+}
+
+// C -> 4 C 3x3 conv + F.pixel_shuffle(2) on fp16 HWC maps: src [h][w][C] -> out [2h][2w][C], bias only.  blobs: the 2 (C = 24) or
+// 4 (C = 48) row-group blobs of refvsr_amd/packing.py:pack_conv_shuffle2, back to back.
+extern "C" int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs, void* out, void* stream) {
+    RV_CHECK(refvsr_conv_shuffle2_supported(c), "conv_shuffle2: %d channels not supported", c);
+    C24Args a;
+    if (c24_fill(a, "conv_shuffle2", 4 * c, src, nullptr, 0, h, w, blobs, 1.0f, nullptr, nullptr, 1.0f, out)) return 1;   // (4 c: the 2h x 2w x c output map)
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 24) return launch_c24<48, 3, 0, 8, 8, 4, 24>(a, st);
+    return launch_c24<48, 6, 0, 16, 16, 4, 48>(a, st);
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 8
+ABI_VERSION = 9
 RESBLOCK24_BLOB_BYTES = 43264
 
 
@@ -65,6 +65,9 @@ SIGNATURES = {
     'refvsr_conv48_supported': [_I, _I],         # returns 0 / 1
     'refvsr_conv48_blob_bytes': [_I, _I],        # returns the size
     'refvsr_conv48': [_P, _I, _P, _I, _I, _I, _P, _F, _P, _P, _F, _P, _P],
+    'refvsr_conv_shuffle2_supported': [_I],      # returns 0 / 1
+    'refvsr_conv_shuffle2_blob_bytes': [_I],     # returns the size
+    'refvsr_conv_shuffle2': [_P, _I, _I, _I, _P, _P, _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     'refvsr_pack_nhwc16': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_pack_nhwc32': [_P, _I, _I, _I, _P, _I, _P],

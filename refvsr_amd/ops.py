@@ -100,9 +100,11 @@ class ConvWeights(object):
         # (conv24.hip; the attribute keeps its first name)
         self.blob24 = None
         if self.raw is not None and pk.get('src_channels') is not None and CONV24 and not self.hi_only:
-            from .packing import conv24_ok, pack_conv24
+            from .packing import conv24_ok, conv_shuffle2_ok, pack_conv24, pack_conv_shuffle2
             if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32):
                 self.blob24 = pack_conv24(self.raw[0], self.raw[1], pk['src_channels']).to(device).contiguous()
+            elif self.shuffle and conv_shuffle2_ok(tuple(self.raw[0].shape), pk['src_channels'], self.f32) and not os.environ.get('REFVSR_NO_CONV_SHUFFLE2'):
+                self.blob24 = pack_conv_shuffle2(self.raw[0], self.raw[1]).to(device).contiguous()     # refvsr_conv_shuffle2
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
@@ -133,7 +135,13 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     if pad is None:
         pad = k // 2
     co_ = cw.cout
-    if (cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
+    if (cw.shuffle and cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
+            src1 is None and mul is None and res is None and act == 1.0 and post == 1.0 and h * w * co_ * 2 < 2 ** 31):
+        # C -> 4 C conv + pixel shuffle on the compile-time-specialised kernel (csrc/conv24.hip, SHUF variant)
+        out = torch.empty((2 * h, 2 * w, c0), dtype=torch.float16, device=src0.device)
+        hip.check(hip.lib().refvsr_conv_shuffle2(_ptr(src0), c0, h, w, _ptr(cw.blob24), _ptr(out), _stream()), 'conv_shuffle2')
+        return out
+    if (cw.blob24 is not None and not cw.shuffle and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
             0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_) and
             h * w * max(co_, c0, c1) * 2 < 2 ** 31):         # (32-bit element offsets in the specialised kernels: 8K HR maps go generic)
         # compile-time-specialised kernel (24 | 48 output channels, 3x3): csrc/conv24.hip

@@ -232,8 +232,14 @@ def conv24_ok(w_shape, src_channels, shuffle=False, f32=False):
     if cout == 24:
         return pads in ([24], [16], [8, 24], [24, 24])
     if cout == 48:
-        return pads in ([48], [16])
+        return pads in ([48], [16], [24])       # ([24]: the row groups of the pixel-shuffle conv, pack_conv_shuffle2)
     return False
+
+
+def conv_shuffle2_ok(w_shape, src_channels, f32=False):
+    """C -> 4 C 3x3 pixel-shuffle convs served by refvsr_conv_shuffle2 (csrc/conv24.hip): C = 24 | 48."""
+    cout, cin, ks, _ = w_shape
+    return ks == 3 and not f32 and list(src_channels) in ([24], [48]) and cin == src_channels[0] and cout == 4 * cin
 
 
 def pack_conv24(w, b, src_channels):
@@ -277,3 +283,20 @@ def pack_conv24(w, b, src_channels):
     bb[:cout] = b
     out[raw.size:] = bb.view(np.uint8)
     return torch.from_numpy(out)
+
+
+def pack_conv_shuffle2(w, b):
+    """uint8 blobs of the C -> 4 C pixel-shuffle conv for refvsr_conv_shuffle2 (C = 24 | 48): 2 | 4 conv48-style blobs of 48 output
+    rows, back to back.  F.pixel_shuffle(2) puts conv channel 4 c + 2 dy + dx at channel c of sub-pixel (dy, dx); the kernel wants
+    a lane's four consecutive accumulator rows to be four consecutive channels of one sub-pixel:
+      C = 24: blob z = dy, row R -> sub-pixel dx = R // 24, channel R % 24;   C = 48: blob z = 2 dy + dx, row R = channel R."""
+    w = w.detach().cpu().float() if isinstance(w, torch.Tensor) else torch.from_numpy(np.asarray(w, np.float32))
+    b = b.detach().cpu().float() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b, np.float32))
+    c = w.shape[1]
+    assert conv_shuffle2_ok(tuple(w.shape), [c]), tuple(w.shape)
+    blobs = []
+    for z in range(2 if c == 24 else 4):
+        R = np.arange(48)
+        rows = 4 * (R % 24) + 2 * z + R // 24 if c == 24 else 4 * R + z
+        blobs.append(pack_conv24(w[rows], b[rows], [c]))
+    return torch.cat(blobs)

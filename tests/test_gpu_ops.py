@@ -200,6 +200,31 @@ def test_conv24_specialised(dev, cins, h, w, act, post, use_mul, use_res):
     assert d < 4e-3                                        # an fp16 ulp where the fp32 sums round differently
 
 
+
+@pytest.mark.parametrize('c,h,w', [(24, 16, 32), (24, 45, 83), (24, 270, 480), (24, 7, 5), (48, 33, 70), (48, 270, 480), (24, 540, 960)])
+def test_conv_shuffle2_specialised(dev, c, h, w):
+    """refvsr_conv_shuffle2 (PixelShufflePack: C -> 4 C 3x3 conv + F.pixel_shuffle(2), mmedit upsample.py:36-51) on the
+    compile-time-specialised kernel vs torch on the same fp16-rounded map and vs the generic kernel's SHUFFLE2 output mode
+    (same arithmetic up to fp32 summation order): interior and border tiles, maps smaller than a tile, both channel counts."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(c + h + w)
+    wt = torch.randn(4 * c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    b = torch.randn(4 * c, generator=g) * 0.1
+    x = torch.randn(c, h, w, generator=g)
+    xin = nhwc(x, dev)
+    cw = ops.ConvWeights(pack_conv(wt, b, [c], shuffle=True), dev)
+    assert cw.blob24 is not None and cw.shuffle
+    got = ops.conv(cw, xin)
+    assert got.shape == (2 * h, 2 * w, c)
+    blob, cw.blob24 = cw.blob24, None
+    generic = ops.conv(cw, xin)
+    cw.blob24 = blob
+    want = F.pixel_shuffle(F.conv2d(x.half().float()[None], wt, b, padding=1), 2)[0]
+    e, eg = rel(planar(got), want), rel(planar(got), planar(generic).float())
+    report('conv_shuffle2 c%d %dx%d' % (c, h, w), rel=e, vs_generic=eg)
+    assert e < 1e-3 and eg < 1e-3
+
 @pytest.mark.parametrize('cins,h,w,act,use_res', [([48], 19, 45, 0.0, False), ([48], 270, 480, 1.0, True), ([48], 61, 130, 0.2, True),
                                                    ([48], 540, 960, 0.0, False), ([48], 16, 32, 1.0, True), ([48], 17, 33, 0.0, False),
                                                    ([16], 33, 70, 0.2, False), ([16], 270, 480, 0.2, False), ([48], 7, 5, 1.0, True)])

@@ -164,6 +164,35 @@ def test_weight_packing_hi_only():
         pack_conv((rs.randn(24, 24, 3, 3) * 0.1).astype(np.float32), b[:24], [24], hi_only=True)     # resident shape: 7 K-steps
 
 
+@pytest.mark.parametrize('c', [24, 48])
+def test_conv_shuffle2_row_groups(c):
+    """packing.pack_conv_shuffle2 (refvsr_conv_shuffle2): the row groups of the C -> 4 C conv, each packed like a 48-output conv,
+    scattered by the kernel's rule (C = 24: blob z = dy, row R -> dx = R // 24, channel R % 24; C = 48: blob z = 2 dy + dx, row R =
+    channel R) give F.pixel_shuffle(conv, 2); blob sizes as the library reports them."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import pack_conv24, pack_conv_shuffle2
+    g = torch.Generator().manual_seed(c)
+    w = torch.randn(4 * c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    b = torch.randn(4 * c, generator=g) * 0.1
+    x = torch.randn(1, c, 6, 7, generator=g)
+    want = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)[0]
+    blobs = pack_conv_shuffle2(w, b)
+    nz = 2 if c == 24 else 4
+    assert hip.lib().refvsr_conv_shuffle2_supported(c) == 1 and hip.lib().refvsr_conv_shuffle2_supported(36) == 0
+    assert blobs.numel() == hip.lib().refvsr_conv_shuffle2_blob_bytes(c) and blobs.numel() % nz == 0
+    got = torch.zeros_like(want)
+    per = blobs.numel() // nz
+    for z in range(nz):
+        R = np.arange(48)
+        rows = 4 * (R % 24) + 2 * z + R // 24 if c == 24 else 4 * R + z
+        assert torch.equal(blobs[z * per:(z + 1) * per], pack_conv24(w[rows], b[rows], [c]))
+        y = F.conv2d(x, w[rows], b[rows], padding=1)[0]                      # what the kernel's accumulators of group z hold
+        for r in range(48):
+            dy, dx, ch = (z, r // 24, r % 24) if c == 24 else (z >> 1, z & 1, r)
+            got[ch, dy::2, dx::2] = y[r]
+    assert torch.equal(got, want)
+
+
 def test_engine_weight_modes(small_cfg, small_sd):
     """Which convs carry which weight representation (refvsr_amd/engine.py:Weights): SPyNet's streamed 7x7 convs (every conv of
     a level but the first, and their mt = 1 variants) plain fp16 (descriptor mode 2), everything else fp16 hi + lo, the VGG
