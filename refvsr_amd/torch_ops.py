@@ -53,7 +53,7 @@ class _PackedConv(object):
         d.wpack, d.bias = wpack.data_ptr(), bias.data_ptr()
         d.cout, d.mt_per_block, d.ksteps, d.ksize, d.f32 = self.cout, self.mt, self.ksteps, self.ksize, int(self.f32)
         self.odtype = torch.float32 if self.f32 else torch.float16
-        self.raw = self.blob24 = None          # the generic kernel: the specialised ones are their own ops (conv24, resblock24_chain)
+        self.raw = self.blob24 = None          # the generic kernel: the specialised ones are their own ops (conv24, conv_shuffle2, resblock24_chain)
 
 
 def conv_meta(cw):
@@ -112,6 +112,17 @@ def register():
     @conv24.register_fake
     def _(blob, src0, src1, mul, res, act, post):
         return src0.new_empty((src0.shape[0], src0.shape[1], 24), dtype=torch.float16)
+
+    @op('conv_shuffle2')
+    def conv_shuffle2(blobs: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+        h, w, c = src.shape
+        out = torch.empty((2 * h, 2 * w, c), dtype=torch.float16, device=src.device)
+        hip.check(hip.lib().refvsr_conv_shuffle2(ops._ptr(src), c, h, w, ops._ptr(blobs), ops._ptr(out), ops._stream()), 'conv_shuffle2')
+        return out
+
+    @conv_shuffle2.register_fake
+    def _(blobs, src):
+        return src.new_empty((2 * src.shape[0], 2 * src.shape[1], src.shape[2]), dtype=torch.float16)
 
     @op('resblock24_chain')
     def resblock24_chain(blobs: torch.Tensor, x: torch.Tensor, act: float) -> torch.Tensor:
