@@ -170,7 +170,7 @@ def kernel_rooflines(cfg, eng, h, w, dev):
     add('conv_mfma HR %d->%d 3x3 (conv_hr)' % (C, C), lambda: ops.conv(cw, x_hr, act=0.1), 2.0 * 9 * C * C * 16 * h * w,
         2.0 * 16 * h * w * C * 2, 'mfma', 'conv HR')
     cwu = eng.cw('upsample2.upsample_conv')
-    add('conv_mfma 2x %d->%d 3x3 + pixel shuffle (upsample2)' % (C, 4 * C), lambda: ops.conv(cwu, x_2x, act=0.1), 2.0 * 9 * C * 4 * C * 4 * h * w,
+    add('conv 2x %d->%d 3x3 + pixel shuffle (upsample2)' % (C, 4 * C), lambda: ops.conv(cwu, x_2x, act=0.1), 2.0 * 9 * C * 4 * C * 4 * h * w,
         (4 * h * w * C + 16 * h * w * C) * 2.0, 'mfma', 'conv shuffle 2x')
     wb = lambda px: (2.0 * C * 2 + 8) * px
     add('warp_nhwc16 LR', lambda: ops.warp_nhwc16(x_lr, flow), 0.0, wb(h * w), 'hbm', 'warp LR')

@@ -160,15 +160,15 @@ int refvsr_conv48_blob_bytes(int c0, int c1);
 int refvsr_conv48(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
                   const void* mul, const void* res, float post_slope, void* out, void* stream);
 /* PixelShufflePack (mmedit upsample.py:36-51; RefVSR.py:89-90 upsample1 / upsample2, used at :114,116,138): the C -> 4 C 3x3 conv
- * and F.pixel_shuffle(2) in one launch of the same kernel family, C = 24 | 48: src [h][w][C] fp16 HWC -> out [2h][2w][C], bias
- * only.  blobs: refvsr_conv_shuffle2_blob_bytes(C) bytes = 2 (C = 24) or 4 (C = 48) conv48-style blobs of 48 output rows each,
+ * and F.pixel_shuffle(2) in one launch of the same kernel family, C = 24 | 48: src [h][w][C] fp16 HWC -> out [2h][2w][C], bias +
+ * optional leaky activation (act_slope in [0, 1], 1 = none: it commutes with the shuffle, RefVSR.py:116).  blobs: refvsr_conv_shuffle2_blob_bytes(C) bytes = 2 (C = 24) or 4 (C = 48) conv48-style blobs of 48 output rows each,
  * back to back, rows ordered sub-pixel-major: C = 24: blob z = output row parity dy, rows [dx = 0: channels 0-23][dx = 1: 0-23]
  * (row R of blob z = weight row 4 (R % 24) + 2 z + R / 24 of the reference conv); C = 48: blob z = sub-pixel 2 dy + dx, row R =
  * weight row 4 R + z (refvsr_amd/packing.py:pack_conv_shuffle2).  Same arithmetic as refvsr_conv_mfma's SHUFFLE2 output mode
  * up to fp32 summation order. */
 int refvsr_conv_shuffle2_supported(int c);
 int refvsr_conv_shuffle2_blob_bytes(int c);
-int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs, void* out, void* stream);
+int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs, float act_slope, void* out, void* stream);
 /* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
  * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its
  * iter-th tile at buf[12 * workgroup + i] (uint64; [8], [9] = 100 MHz s_memrealtime at entry / exit, [10] = s_memtime at exit) -- tools/probe_resblock.py.  NULL switches it off (default). */

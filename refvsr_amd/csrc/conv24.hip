@@ -21,7 +21,7 @@
 // C -> 4 C conv as groups of 48 output rows on the COUT = 48 kernel, blockIdx.y = group z, rows ordered sub-pixel-major so that
 // a lane's four accumulator rows are four consecutive channels of ONE sub-pixel: C = 24: group z = output row parity dy, rows
 // [dx = 0: channels 0-23][dx = 1: channels 0-23]; C = 48: group z = sub-pixel 2 dy + dx, rows = channels 0-47.  The epilogue
-// stores straight into the [2h][2w][C] map (bias only: no activation / multiplier / residual on this layer).
+// stores straight into the [2h][2w][C] map (bias + optional leaky activation; no multiplier / residual on this layer).
 //
 // LDS: [fragments: S K-steps x 3 x 1 KiB][bias: 32 floats][x tile: 10 x 34 pixels x PS slots of 16 bytes, PS = NCG | 1 (odd
 // pixel stride: bank-conflict-free B reads with the pixel permutation of common.h)].  K plans (c24_kblock): the K-blocks of
@@ -371,7 +371,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                     const int dx = SHUF == 24 ? (r0 >= 24 ? 1 : 0) : (z & 1);
                     const int dy = SHUF == 24 ? z : (z >> 1);
                     const int ch0 = SHUF == 24 ? r0 - 24 * dx : r0;
-                    const f32x4 y = acc[m][t];
+                    f32x4 y = acc[m][t];
+                    if (p.act_slope != 1.0f) {                       // (the activation commutes with the shuffle: RefVSR.py:116)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], y[i] * p.act_slope);
+                    }
                     const f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
                     if (okt[t])
                         *reinterpret_cast<f16x4*>(p.out + ((2u * oy + dy) * w2 + 2u * ox + dx) * (unsigned)(SHUF * 2) + ch0 * 2) = o;
@@ -512,12 +516,12 @@ extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1,
     return launch_c24<48, 2, 0, 8, 8, 4>(a, st);
 }
 
-// C -> 4 C 3x3 conv + F.pixel_shuffle(2) on fp16 HWC maps: src [h][w][C] -> out [2h][2w][C], bias only.  blobs: the 2 (C = 24) or
+// act(C -> 4 C 3x3 conv + bias) through F.pixel_shuffle(2) on fp16 HWC maps: src [h][w][C] -> out [2h][2w][C].  blobs: the 2 (C = 24) or
 // 4 (C = 48) row-group blobs of refvsr_amd/packing.py:pack_conv_shuffle2, back to back.
-extern "C" int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs, void* out, void* stream) {
+extern "C" int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs, float act_slope, void* out, void* stream) {
     RV_CHECK(refvsr_conv_shuffle2_supported(c), "conv_shuffle2: %d channels not supported", c);
     C24Args a;
-    if (c24_fill(a, "conv_shuffle2", 4 * c, src, nullptr, 0, h, w, blobs, 1.0f, nullptr, nullptr, 1.0f, out)) return 1;   // (4 c: the 2h x 2w x c output map)
+    if (c24_fill(a, "conv_shuffle2", 4 * c, src, nullptr, 0, h, w, blobs, act_slope, nullptr, nullptr, 1.0f, out)) return 1;   // (4 c: the 2h x 2w x c output map)
     hipStream_t st = (hipStream_t)stream;
     if (c == 24) return launch_c24<48, 3, 0, 8, 8, 4, 24>(a, st);
     return launch_c24<48, 6, 0, 16, 16, 4, 48>(a, st);

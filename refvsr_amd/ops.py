@@ -136,10 +136,10 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         pad = k // 2
     co_ = cw.cout
     if (cw.shuffle and cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
-            src1 is None and mul is None and res is None and act == 1.0 and post == 1.0 and h * w * co_ * 2 < 2 ** 31):
+            src1 is None and mul is None and res is None and 0.0 <= act <= 1.0 and post == 1.0 and h * w * co_ * 2 < 2 ** 31):
         # C -> 4 C conv + pixel shuffle on the compile-time-specialised kernel (csrc/conv24.hip, SHUF variant)
         out = torch.empty((2 * h, 2 * w, c0), dtype=torch.float16, device=src0.device)
-        hip.check(hip.lib().refvsr_conv_shuffle2(_ptr(src0), c0, h, w, _ptr(cw.blob24), _ptr(out), _stream()), 'conv_shuffle2')
+        hip.check(hip.lib().refvsr_conv_shuffle2(_ptr(src0), c0, h, w, _ptr(cw.blob24), act, _ptr(out), _stream()), 'conv_shuffle2')
         return out
     if (cw.blob24 is not None and not cw.shuffle and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
             0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_) and

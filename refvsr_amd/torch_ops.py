@@ -114,14 +114,14 @@ def register():
         return src0.new_empty((src0.shape[0], src0.shape[1], 24), dtype=torch.float16)
 
     @op('conv_shuffle2')
-    def conv_shuffle2(blobs: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    def conv_shuffle2(blobs: torch.Tensor, src: torch.Tensor, act: float) -> torch.Tensor:
         h, w, c = src.shape
         out = torch.empty((2 * h, 2 * w, c), dtype=torch.float16, device=src.device)
-        hip.check(hip.lib().refvsr_conv_shuffle2(ops._ptr(src), c, h, w, ops._ptr(blobs), ops._ptr(out), ops._stream()), 'conv_shuffle2')
+        hip.check(hip.lib().refvsr_conv_shuffle2(ops._ptr(src), c, h, w, ops._ptr(blobs), act, ops._ptr(out), ops._stream()), 'conv_shuffle2')
         return out
 
     @conv_shuffle2.register_fake
-    def _(blobs, src):
+    def _(blobs, src, act):
         return src.new_empty((2 * src.shape[0], 2 * src.shape[1], src.shape[2]), dtype=torch.float16)
 
     @op('resblock24_chain')

@@ -28,7 +28,7 @@ def test_fake_tensor_shape_inference():
         assert torch.ops.refvsr.resblock24_chain(torch.empty((3, 43264), dtype=torch.uint8, device=dev), x, 0.0).shape == x.shape
         y = torch.ops.refvsr.conv24(w, torch.empty((20, 30, 8), dtype=torch.float16, device=dev), x, None, None, 0.1, 1.0)
         assert y.shape == (20, 30, 24) and y.dtype == torch.float16
-        assert torch.ops.refvsr.conv_shuffle2(torch.empty(86528, dtype=torch.uint8, device=dev), x).shape == (40, 60, 24)
+        assert torch.ops.refvsr.conv_shuffle2(torch.empty(86528, dtype=torch.uint8, device=dev), x, 0.1).shape == (40, 60, 24)
         y = torch.ops.refvsr.conv_mfma(w, w, [96, 3, 1, 0, 7, 3, 24, 0], x, None, None, None, None, 1, 1.0, 1.0, False, 0.0, 0.0, 0.0)
         assert y.shape == (40, 60, 24) and y.dtype == torch.float16                                   # pixel-shuffle weights
         y = torch.ops.refvsr.conv_mfma(w, w, [3, 3, 0, 0, 7, 1, 24, 0], x, None, None, None, None, 1, 1.0, 1.0, True, 0.0, 0.0, 1.0)
@@ -73,7 +73,7 @@ def test_torch_library_ops_match_direct_calls():
     assert torch.equal(R.conv_mfma(c1.wpack, c1.bias, t.conv_meta(c1), x, None, None, x, None, 1, 0.2, 1.0, False, 0.0, 0.0, 0.0),
                        ops.conv(c1, x, act=0.2, res=x))
     c1.blob24 = blob
-    assert cs.blob24 is not None and torch.equal(R.conv_shuffle2(cs.blob24, x), ops.conv(cs, x))      # the specialised pixel-shuffle conv
+    assert cs.blob24 is not None and torch.equal(R.conv_shuffle2(cs.blob24, x, 0.1), ops.conv(cs, x, act=0.1))      # the specialised pixel-shuffle conv
     blob, cs.blob24 = cs.blob24, None
     assert torch.equal(R.conv_mfma(cs.wpack, cs.bias, t.conv_meta(cs), x, None, None, None, None, 1, 1.0, 1.0, False, 0.0, 0.0, 0.0), ops.conv(cs, x))
     cs.blob24 = blob
@@ -99,4 +99,4 @@ def test_torch_library_ops_match_direct_calls():
     torch.library.opcheck(R.match_argmax, (lr_f, ref_f), test_utils=('test_schema', 'test_faketensor'))
     torch.library.opcheck(R.conv24, (c1.blob24, x, None, None, x, 0.2, 1.0), test_utils=('test_schema', 'test_faketensor'))
     torch.library.opcheck(R.resblock24_chain, (ch.blobs, x, 0.0), test_utils=('test_schema', 'test_faketensor'))
-    torch.library.opcheck(R.conv_shuffle2, (cs.blob24, x), test_utils=('test_schema', 'test_faketensor'))
+    torch.library.opcheck(R.conv_shuffle2, (cs.blob24, x, 0.1), test_utils=('test_schema', 'test_faketensor'))
