@@ -30,7 +30,7 @@ extern "C" {
                                   6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging);
                                   7: refvsr_conv24 / refvsr_conv48 (compile-time-specialised 3x3 convs);
                                   8: RefvsrConv.f32 = 2 (plain fp16 weights in the streamed convs);
-                                  9: refvsr_conv_shuffle2 (compile-time-specialised C -> 4 C conv + pixel shuffle) */
+                                  9: refvsr_conv_shuffle2 (compile-time-specialised C -> 4 C conv + pixel shuffle), refvsr_conv32 */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -155,6 +155,13 @@ int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int
  * 48-channel maps; blob: [S x 6 fragments x 64 lanes x 8 halfs][64 bias floats], fragments [hi | lo] of output channels 0-15,
  * 16-31, 32-47, K-blocks by refvsr_conv24_kblock(ncg, s, q).  48 -> 48 keeps its 84 KB weight set resident next to a
  * 16 x 32-pixel tile walked by sixteen waves (one workgroup per CU). */
+/* The same for 32 output channels (AlignedConv2d, RefVSR_/alignment.py:18-24,53-100: the RGB stem and the 32 -> 32 convs of its
+ * ResBlocks, at the 2x / HD resolutions): (c0, c1) in {(32,0), (8,0)}; blob: [S x 4 fragments x 64 lanes x 8 halfs][32 bias floats],
+ * fragments [hi | lo] of output channels 0-15, 16-31. */
+int refvsr_conv32_supported(int c0, int c1);
+int refvsr_conv32_blob_bytes(int c0, int c1);
+int refvsr_conv32(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
+                  const void* mul, const void* res, float post_slope, void* out, void* stream);
 int refvsr_conv48_supported(int c0, int c1);
 int refvsr_conv48_blob_bytes(int c0, int c1);
 int refvsr_conv48(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,

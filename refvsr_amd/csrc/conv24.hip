@@ -12,6 +12,9 @@
 // out = post( act(conv + bias) * mul + res ), the epilogue of refvsr_conv_mfma's fp16 HWC mode.  The generic kernel stays
 // for every other shape (strides, 5x5 / 7x7, pixel shuffle, planar outputs, other channel counts).
 //
+// COUT = 32 (AlignedConv2d's 32-channel convs, RefVSR_/alignment.py:18-24): four fragments per K-step ([hi | lo] of output channels
+// 0-15, 16-31), inputs 32 (NCG 4) and 8 (NCG 1: the RGB stem; K plan: the three taps of a window row + a zero block per step).
+//
 // COUT = 48 (the mid_channels = 48 family, configs/config_RefVSR_{L1,MFID,MFID_8K}.py: 30 ResidualBlockNoBN per branch, two
 // convs each): six fragments per K-step ([hi | lo] of output channels 0-15, 16-31, 32-47; no fold), 48 -> 48 with the 84 KB
 // weight set resident next to a 16 x 32-pixel tile (18 x 34 staged pixels, 68 KB) walked by SIXTEEN waves -- one workgroup per
@@ -40,13 +43,16 @@
 namespace {
 constexpr int C24_TW = 32, C24_XW = 34;                       // tile width; staged row = 34 pixels (tile height: template)
 
-__host__ __device__ constexpr int c24_steps(int ncg) { return ncg == 2 ? 5 : ncg == 3 ? 7 : ncg == 4 ? 9 : ncg == 6 ? 14 : 0; }
+__host__ __device__ constexpr int c24_steps(int ncg) { return ncg == 1 ? 3 : ncg == 2 ? 5 : ncg == 3 ? 7 : ncg == 4 ? 9 : ncg == 6 ? 14 : 0; }
 
 // K-block (K-step s, quarter q) -> ty << 16 | tx << 8 | cg, or -1 for a zero block
 __host__ __device__ constexpr int c24_kblock(int ncg, int s, int q) {
     const int perm[4] = {0, 2, 1, 3};
     int ty = 0, tx = 0, cg = 0;
-    if (ncg == 3) {
+    if (ncg == 1) {
+        if (q == 3) return -1;
+        ty = s; tx = perm[q]; cg = 0;                                  // taps tx = 0, 2, 1 of row s (+ a zero block)
+    } else if (ncg == 3) {
         if (s < 6) { const int u = 4 * (s & 1) + perm[q]; ty = s >> 1; tx = u / 3; cg = u % 3; }
         else { if (q == 3) return -1; ty = q; tx = 2; cg = 2; }
     } else if (ncg == 4) {
@@ -75,12 +81,12 @@ __host__ __device__ constexpr int c24_off(int ncg, int s, int q) {
 }
 // pattern of a K-step: steps of one pattern differ only by an immediate
 __host__ __device__ constexpr int c24_pat(int ncg, int s) {
-    return ncg == 3 ? (s < 6 ? 0 : 1) : ncg == 4 ? 0 : ncg == 2 ? (s < 3 ? 0 : s - 2) : (s < 9 ? 0 : s < 12 ? 1 : s - 10);
+    return ncg == 1 ? 0 : ncg == 3 ? (s < 6 ? 0 : 1) : ncg == 4 ? 0 : ncg == 2 ? (s < 3 ? 0 : s - 2) : (s < 9 ? 0 : s < 12 ? 1 : s - 10);
 }
-__host__ __device__ constexpr int c24_npat(int ncg) { return ncg == 3 ? 2 : ncg == 4 ? 1 : ncg == 2 ? 3 : 4; }
+__host__ __device__ constexpr int c24_npat(int ncg) { return ncg == 1 ? 1 : ncg == 3 ? 2 : ncg == 4 ? 1 : ncg == 2 ? 3 : 4; }
 // first K-step of a pattern
 __host__ __device__ constexpr int c24_pat_step(int ncg, int p) {
-    return ncg == 3 ? (p ? 6 : 0) : ncg == 4 ? 0 : ncg == 2 ? (p ? p + 2 : 0) : (p == 0 ? 0 : p == 1 ? 9 : p + 10);
+    return ncg == 1 ? 0 : ncg == 3 ? (p ? 6 : 0) : ncg == 4 ? 0 : ncg == 2 ? (p ? p + 2 : 0) : (p == 0 ? 0 : p == 1 ? 9 : p + 10);
 }
 
 // compile-time proof of the plans: every K-block of the 3 x 3 x ncg window exactly once, K-steps of one pattern differ by an
@@ -111,7 +117,7 @@ __host__ __device__ constexpr bool c24_plan_ok(int ncg) {
         if (c24_pat(ncg, c24_pat_step(ncg, p)) != p) return false;
     return true;
 }
-static_assert(c24_plan_ok(2) && c24_plan_ok(3) && c24_plan_ok(4) && c24_plan_ok(6), "conv24 K plan");
+static_assert(c24_plan_ok(1) && c24_plan_ok(2) && c24_plan_ok(3) && c24_plan_ok(4) && c24_plan_ok(6), "conv24 K plan");
 
 template <class F, int... I>
 __device__ __forceinline__ void c24_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -138,16 +144,16 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     static_assert(SHUF == 0 || (COUT == 48 && (SHUF == 24 || SHUF == 48) && NCG0 * 8 == SHUF && NCG1 == 0), "pixel-shuffle variant");
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
     constexpr int S = c24_steps(NCG), NPAT = c24_npat(NCG);
-    constexpr int NF = COUT == 24 ? 3 : 6;                          // fragments per K-step
-    constexpr int NM = COUT == 24 ? 2 : 3;                          // accumulator tiles per pixel group
-    constexpr int BIASB = COUT == 24 ? 128 : 256;
+    constexpr int NF = COUT == 24 ? 3 : COUT / 8;                   // fragments per K-step (COUT = 32 | 48: [hi | lo] per 16 channels)
+    constexpr int NM = COUT == 24 ? 2 : COUT / 16;                  // accumulator tiles per pixel group
+    constexpr int BIASB = COUT == 48 ? 256 : 128;
     constexpr int WB = S * NF * 1024, BIAS = WB, XT = WB + BIASB;
     constexpr int NT = NWV * 64, T = 2 * TH / NWV;
     constexpr int C24_TH = TH, C24_XH = TH + 2, C24_NPX = C24_XH * C24_XW;
     constexpr int NCH = C24_NPX * NCG, KCH = (NCH + NT - 1) / NT;
     constexpr int PIXB0 = NCG0 * 16, PIXB1 = NCG1 * 16;
     constexpr int OPX = COUT * 2;                                   // bytes per pixel of the out / mul / res maps
-    static_assert((COUT == 24 || COUT == 48) && S > 0 && T >= 1 && T * NWV == 2 * TH, "unsupported shape");
+    static_assert((COUT == 24 || COUT == 32 || COUT == 48) && S > 0 && T >= 1 && T * NWV == 2 * TH, "unsupported shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.out), "s"(p.blob), "s"(p.mul), "s"(p.res), "s"(p.h), "s"(p.w), "s"(p.tiles_x),
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 mv[m][t] = rv[m][t] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                const bool lane_ok = okt[t] && (COUT == 48 || m == 0 || q < 2);
+                const bool lane_ok = okt[t] && (COUT != 24 || m == 0 || q < 2);
                 if constexpr (COUT == 24) {                          // (COUT = 48: fetched in the epilogue -- register budget)
                     if (p.mul && lane_ok) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
                     if (p.res && lane_ok) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                         }
                 }
             };
-            if constexpr (COUT == 24) {
+            if constexpr (NF <= 4) {
                 // two fragment sets: the reads of step s + 1 are issued above the MFMAs of step s
                 load(std::integral_constant<int, 0>{}, fa[0], fb[0]);
                 c24_static_for([&](auto sc) {
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                         for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], y[i] * p.post_slope);
                     }
                     const f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-                    if (okt[t] && (COUT == 48 || m == 0 || q < 2)) *reinterpret_cast<f16x4*>(d + 32 * m) = o;
+                    if (okt[t] && (COUT != 24 || m == 0 || q < 2)) *reinterpret_cast<f16x4*>(d + 32 * m) = o;
                 }
             }
         }
@@ -427,7 +433,7 @@ template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0>
 static int launch_c24(C24Args& a, hipStream_t st) {
     constexpr int NZ = SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;          // row groups of the pixel-shuffle variant (blockIdx.y)
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
-    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : 6) * 1024 + (COUT == 24 ? 128 : 256) + (TH + 2) * C24_XW * PS * 16;
+    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : COUT / 8) * 1024 + (COUT == 48 ? 256 : 128) + (TH + 2) * C24_XW * PS * 16;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
@@ -454,10 +460,15 @@ extern "C" int refvsr_conv24_supported(int c0, int c1) {
     return (c0 == 24 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 8 && c1 == 24) || (c0 == 24 && c1 == 24);
 }
 extern "C" int refvsr_conv48_supported(int c0, int c1) { return (c0 == 48 && c1 == 0) || (c0 == 16 && c1 == 0); }
+extern "C" int refvsr_conv32_supported(int c0, int c1) { return (c0 == 32 && c1 == 0) || (c0 == 8 && c1 == 0); }
 
 extern "C" int refvsr_conv24_blob_bytes(int c0, int c1) {
     if (!refvsr_conv24_supported(c0, c1)) return -1;
     return c24_steps((c0 + c1) / 8) * 3 * 1024 + 128;
+}
+extern "C" int refvsr_conv32_blob_bytes(int c0, int c1) {
+    if (!refvsr_conv32_supported(c0, c1)) return -1;
+    return c24_steps((c0 + c1) / 8) * 4 * 1024 + 128;
 }
 extern "C" int refvsr_conv48_blob_bytes(int c0, int c1) {
     if (!refvsr_conv48_supported(c0, c1)) return -1;
@@ -501,6 +512,17 @@ extern "C" int refvsr_conv24(const void* src0, int c0, const void* src1, int c1,
     if (c0 == 16 && c1 == 0) return launch_c24<24, 2, 0, 8, 8, 4>(a, st);
     if (c0 == 8 && c1 == 24) return launch_c24<24, 1, 3, 8, 8, 4>(a, st);
     return launch_c24<24, 3, 3, 8, 8, 4>(a, st);
+}
+
+// 32 output channels (AlignedConv2d, RefVSR_/alignment.py:18-24,53-100: the 3 -> 32 stem and the 32 -> 32 convs of its ResBlocks)
+extern "C" int refvsr_conv32(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
+                             const void* mul, const void* res, float post_slope, void* out, void* stream) {
+    RV_CHECK(refvsr_conv32_supported(c0, c1), "conv32: %d + %d input channels not supported", c0, c1);
+    C24Args a;
+    if (c24_fill(a, "conv32", 32, src0, src1, c1, h, w, blob, act_slope, mul, res, post_slope, out)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (c0 == 32) return launch_c24<32, 4, 0, 8, 8, 4>(a, st);
+    return launch_c24<32, 1, 0, 8, 8, 4>(a, st);
 }
 
 extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,

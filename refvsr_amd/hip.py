@@ -62,6 +62,9 @@ SIGNATURES = {
     'refvsr_conv24_blob_bytes': [_I, _I],        # returns the size
     'refvsr_conv24_kblock': [_I, _I, _I],        # returns the packed K-block
     'refvsr_conv24': [_P, _I, _P, _I, _I, _I, _P, _F, _P, _P, _F, _P, _P],
+    'refvsr_conv32_supported': [_I, _I],         # returns 0 / 1
+    'refvsr_conv32_blob_bytes': [_I, _I],        # returns the size
+    'refvsr_conv32': [_P, _I, _P, _I, _I, _I, _P, _F, _P, _P, _F, _P, _P],
     'refvsr_conv48_supported': [_I, _I],         # returns 0 / 1
     'refvsr_conv48_blob_bytes': [_I, _I],        # returns the size
     'refvsr_conv48': [_P, _I, _P, _I, _I, _I, _P, _F, _P, _P, _F, _P, _P],

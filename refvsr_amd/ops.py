@@ -101,7 +101,7 @@ class ConvWeights(object):
         self.blob24 = None
         if self.raw is not None and pk.get('src_channels') is not None and CONV24 and not self.hi_only:
             from .packing import conv24_ok, conv_shuffle2_ok, pack_conv24, pack_conv_shuffle2
-            if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32):
+            if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32) and not (self.cout == 32 and os.environ.get('REFVSR_NO_CONV32')):
                 self.blob24 = pack_conv24(self.raw[0], self.raw[1], pk['src_channels']).to(device).contiguous()
             elif self.shuffle and conv_shuffle2_ok(tuple(self.raw[0].shape), pk['src_channels'], self.f32) and not os.environ.get('REFVSR_NO_CONV_SHUFFLE2'):
                 self.blob24 = pack_conv_shuffle2(self.raw[0], self.raw[1]).to(device).contiguous()     # refvsr_conv_shuffle2
@@ -144,15 +144,14 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     if (cw.blob24 is not None and not cw.shuffle and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
             0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_) and
             h * w * max(co_, c0, c1) * 2 < 2 ** 31):         # (32-bit element offsets in the specialised kernels: 8K HR maps go generic)
-        # compile-time-specialised kernel (24 | 48 output channels, 3x3): csrc/conv24.hip
+        # compile-time-specialised kernel (24 | 32 | 48 output channels, 3x3): csrc/conv24.hip
         for m_ in (mul, res):
             if m_ is not None:
                 _nhwc(m_)
                 assert tuple(m_.shape[:2]) == (h, w)
         out = torch.empty((h, w, co_), dtype=torch.float16, device=src0.device)
-        fn = hip.lib().refvsr_conv24 if co_ == 24 else hip.lib().refvsr_conv48
-        hip.check(fn(_ptr(src0), c0, _ptr(src1), c1, h, w, _ptr(cw.blob24), act, _ptr(mul), _ptr(res), post, _ptr(out), _stream()),
-                  'conv24' if co_ == 24 else 'conv48')
+        fn = {24: hip.lib().refvsr_conv24, 32: hip.lib().refvsr_conv32, 48: hip.lib().refvsr_conv48}[co_]
+        hip.check(fn(_ptr(src0), c0, _ptr(src1), c1, h, w, _ptr(cw.blob24), act, _ptr(mul), _ptr(res), post, _ptr(out), _stream()), 'conv%d' % co_)
         return out
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1

@@ -189,7 +189,7 @@ def pack_resblock24(w1, b1, w2, b2):
 
 # ---- 24-output-channel 3x3 convs (csrc/conv24.hip) -----------------------------------------------------------------------
 def c24_steps(ncg):
-    return {2: 5, 3: 7, 4: 9, 6: 14}[ncg]
+    return {1: 3, 2: 5, 3: 7, 4: 9, 6: 14}[ncg]
 
 
 def c24_kblock(ncg, s, q):
@@ -198,6 +198,8 @@ def c24_kblock(ncg, s, q):
     A K-step takes four slots u = tx * (ncg | 1) + cg of the staged window whose LDS offsets are (immediate) + (one of <= 4
     per-lane patterns), the blocks of quarters (0, 1) and of (2, 3) having slot offsets of equal parity."""
     perm = (0, 2, 1, 3)
+    if ncg == 1:
+        return None if q == 3 else (s, perm[q], 0)
     if ncg == 3:
         if s < 6:
             u = 4 * (s & 1) + perm[q]
@@ -224,13 +226,15 @@ def c24_kblock(ncg, s, q):
 
 
 def conv24_ok(w_shape, src_channels, shuffle=False, f32=False):
-    """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 or 48 output channels, the listed inputs."""
+    """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 / 32 / 48 output channels, the listed inputs."""
     cout, cin, ks, _ = w_shape
     pads = [_pad8(c) for c in src_channels]
     if ks != 3 or shuffle or f32:
         return False
     if cout == 24:
         return pads in ([24], [16], [8, 24], [24, 24])
+    if cout == 32:
+        return pads in ([32], [8])              # AlignedConv2d: the 32 -> 32 convs and the RGB stem
     if cout == 48:
         return pads in ([48], [16], [24])       # ([24]: the row groups of the pixel-shuffle conv, pack_conv_shuffle2)
     return False
@@ -247,14 +251,14 @@ def pack_conv24(w, b, src_channels):
     l = (q = l >> 4, r = l & 15) of K-step s holds the 8 (padded) input channels of K-block c24_kblock(ncg, s, q) for row r of
     fragment f (hi = fp16(w), lo = fp16(w - hi)):
       24 outputs (NF = 3): f = 0: hi(W[r])   f = 1: lo(W[r])   f = 2: hi(W[16 + r]) if r < 8 else lo(W[8 + r])
-      48 outputs (NF = 6): f = 2 m: hi(W[16 m + r])   f = 2 m + 1: lo(W[16 m + r])"""
+      32 | 48 outputs (NF = 4 | 6): f = 2 m: hi(W[16 m + r])   f = 2 m + 1: lo(W[16 m + r])"""
     w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
     b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
     assert conv24_ok(w.shape, src_channels), (w.shape, src_channels)
     cout = w.shape[0]
     Wk, _, ncg = kmatrix(w, src_channels)                       # [cout, 9 * ncg * 8], K-block g = tap * ncg + cg
     S = c24_steps(ncg)
-    nf = 3 if cout == 24 else 6
+    nf = 3 if cout == 24 else cout // 8
     hi = Wk.astype(np.float16)
     lo = (Wk - hi.astype(np.float32)).astype(np.float16)
     frag = np.zeros((S, nf, 4, 16, 8), np.float16)
@@ -272,10 +276,10 @@ def pack_conv24(w, b, src_channels):
                 frag[s_, 2, q, 0:8] = hi[16:24, cols]
                 frag[s_, 2, q, 8:16] = lo[16:24, cols]
             else:
-                for m in range(3):
+                for m in range(cout // 16):
                     frag[s_, 2 * m, q] = hi[16 * m:16 * m + 16, cols]
                     frag[s_, 2 * m + 1, q] = lo[16 * m:16 * m + 16, cols]
-    nb = 32 if cout == 24 else 64
+    nb = 64 if cout == 48 else 32
     out = np.zeros(S * nf * 1024 + nb * 4, np.uint8)
     raw = frag.reshape(-1).view(np.uint8)
     out[:raw.size] = raw

@@ -226,6 +226,40 @@ def test_conv_shuffle2_specialised(dev, c, h, w):
     report('conv_shuffle2 c%d %dx%d' % (c, h, w), rel=e, vs_generic=eg)
     assert e < 1e-3 and eg < 1e-3
 
+@pytest.mark.parametrize('cins,h,w,act,post,use_res', [([32], 19, 45, 0.2, 1.0, False), ([32], 540, 960, 1.0, 0.2, True), ([32], 61, 130, 0.2, 1.0, False),
+                                                        ([3], 540, 960, 0.2, 1.0, False), ([3], 33, 70, 0.2, 1.0, False), ([32], 7, 5, 1.0, 0.2, True),
+                                                        ([32], 270, 480, 1.0, 0.2, True)])
+def test_conv32_specialised(dev, cins, h, w, act, post, use_res):
+    """refvsr_conv32 (csrc/conv24.hip, COUT = 32: AlignedConv2d's RGB stem and the convs of its 32-channel ResBlocks,
+    RefVSR_/alignment.py:18-24 -- conv, LeakyReLU / conv, + x, LeakyReLU) against torch fp32 on the same fp16 maps and against the
+    generic kernel: both input shapes (32 channels; 3 -> 8-padded RGB with the one-group K plan), interior / border tiles."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h * 7 + w + cins[0])
+    cin = sum(cins)
+    wt = torch.randn(32, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(32, generator=g) * 0.1
+    x = torch.randn(1, cin, h, w, generator=g)
+    cw = ops.ConvWeights(pack_conv(wt, b, cins), dev)
+    assert cw.blob24 is not None and cw.cout == 32
+    xin = nhwc(x[0], dev, 8) if cin == 3 else nhwc(x[0], dev)
+    res = torch.randn(32, h, w, generator=g) if use_res else None
+    kw = dict(act=act, post=post, res=nhwc(res, dev) if use_res else None)
+    got = ops.conv(cw, xin, **kw)
+    blob, cw.blob24 = cw.blob24, None
+    gen = ops.conv(cw, xin, **kw)
+    cw.blob24 = blob
+    want = F.leaky_relu(F.conv2d(x.half().float(), wt, b, padding=1), act)[0]
+    if use_res:
+        want = want + res.half().float()
+    want = F.leaky_relu(want, post)
+    e, d = rel(planar(got), want), maxdiff(planar(got), planar(gen))
+    report('conv32 cin%s %dx%d act%.1f post%.1f%s' % (cins, h, w, act, post, ' res' if use_res else ''), rel=e, vs_generic=d)
+    assert got.shape == gen.shape == (h, w, 32)
+    assert e < 1e-3
+    assert d < 4e-3
+
+
 @pytest.mark.parametrize('cins,h,w,act,use_res', [([48], 19, 45, 0.0, False), ([48], 270, 480, 1.0, True), ([48], 61, 130, 0.2, True),
                                                    ([48], 540, 960, 0.0, False), ([48], 16, 32, 1.0, True), ([48], 17, 33, 0.0, False),
                                                    ([16], 33, 70, 0.2, False), ([16], 270, 480, 0.2, False), ([48], 7, 5, 1.0, True)])

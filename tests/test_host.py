@@ -533,7 +533,7 @@ def test_resblock24_blob_and_address_model(relu):
     assert len(covered) == (13 * 32 + 5 * 8) * 24                    # tiles (0,0), (1,0) whole, (1,1): 5 rows x 8 columns
 
 
-@pytest.mark.parametrize('srcs,cout', [([24], 24), ([16], 24), ([3, 24], 24), ([24, 24], 24), ([48], 48), ([16], 48)])
+@pytest.mark.parametrize('srcs,cout', [([24], 24), ([16], 24), ([3, 24], 24), ([24, 24], 24), ([48], 48), ([16], 48), ([32], 32), ([3], 32)])
 def test_conv24_blob_reproduces_conv(srcs, cout):
     """packing.pack_conv24: the K-block table equals the library's (csrc/conv24.hip:c24_kblock, whose plan -- every block once,
     one immediate per step and pattern, equal slot parity inside a ds_read_b128 lane group -- is proven by a static_assert at
@@ -545,15 +545,16 @@ def test_conv24_blob_reproduces_conv(srcs, cout):
     pads = [_pad8(c) for c in srcs]
     ncg = sum(pads) // 8
     S = c24_steps(ncg)
-    nf, nb = (3, 32) if cout == 24 else (6, 64)
-    sup, nbytes = (lib.refvsr_conv24_supported, lib.refvsr_conv24_blob_bytes) if cout == 24 else (lib.refvsr_conv48_supported, lib.refvsr_conv48_blob_bytes)
+    nf, nb = {24: (3, 32), 32: (4, 32), 48: (6, 64)}[cout]
+    sup, nbytes = {24: (lib.refvsr_conv24_supported, lib.refvsr_conv24_blob_bytes), 32: (lib.refvsr_conv32_supported, lib.refvsr_conv32_blob_bytes),
+                   48: (lib.refvsr_conv48_supported, lib.refvsr_conv48_blob_bytes)}[cout]
     assert sup(pads[0], pads[1] if len(pads) > 1 else 0) == 1
     assert nbytes(pads[0], pads[1] if len(pads) > 1 else 0) == S * nf * 1024 + nb * 4
     for s in range(S):
         for q in range(4):
             kb, v = c24_kblock(ncg, s, q), lib.refvsr_conv24_kblock(ncg, s, q)
             assert v == (-1 if kb is None else (kb[0] << 16 | kb[1] << 8 | kb[2])), (ncg, s, q)
-    assert lib.refvsr_conv24_kblock(ncg, S, 0) == -2 and lib.refvsr_conv24_supported(48, 0) == 0 and lib.refvsr_conv48_supported(24, 24) == 0
+    assert lib.refvsr_conv24_kblock(ncg, S, 0) == -2 and lib.refvsr_conv24_supported(48, 0) == 0 and lib.refvsr_conv48_supported(24, 24) == 0 and lib.refvsr_conv32_supported(24, 0) == 0
     g = torch.Generator().manual_seed(ncg)
     cin = sum(srcs)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
@@ -592,12 +593,12 @@ def test_conv24_blob_reproduces_conv(srcs, cout):
                         acc[0] += frag[s, 0, q] @ bvec + frag[s, 1, q] @ bvec
                         acc[1] += frag[s, 2, q] @ bvec
                     else:
-                        for m in range(3):
+                        for m in range(cout // 16):
                             acc[m] += frag[s, 2 * m, q] @ bvec + frag[s, 2 * m + 1, q] @ bvec
             if cout == 24:
                 got[0:16, oy, ox] = acc[0]
                 got[16:24, oy, ox] = acc[1][0:8] + acc[1][8:16]
             else:
-                for m in range(3):
+                for m in range(cout // 16):
                     got[16 * m:16 * m + 16, oy, ox] = acc[m]
     assert np.abs(got - want).max() < 2e-5
