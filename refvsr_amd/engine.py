@@ -601,9 +601,13 @@ class Engine(object):
             # P (per-frame preparation: SPyNet pyramid, matching, reference encoders) may run at high priority so that the
             # 254-workgroup matching kernel is not queued behind the persistent conv workgroups of the other streams
             hi = -1 if os.environ.get('REFVSR_STREAM_PRIORITY', '0') == '1' else 0
-            self._pipe = [torch.cuda.Stream(device=dev) for _ in range(3)] + [torch.cuda.Stream(device=dev, priority=hi)]
-            if os.environ.get('REFVSR_PIPE_ONE_M', '0') == '1':      # A/B knob: one M stream (consecutive calls' backward branches serialise)
-                self._pipe[1] = self._pipe[0]
+            # ONE M stream by default: alternating two of them (REFVSR_PIPE_TWO_M=1) gains nothing measurable and puts four
+            # concurrently active streams in front of the runtime's four hardware queues -- in 3 of 8 processes each got its own
+            # queue and the rate dropped from 187 to 150-155 frames/s (profiles/r03_one_vs_two_m_streams.txt: eight interleaved runs
+            # each, one M: 187.0-188.2 every time; the matching workgroups and three other kernels displace each other CU by CU)
+            m = torch.cuda.Stream(device=dev)
+            m2 = torch.cuda.Stream(device=dev) if os.environ.get('REFVSR_PIPE_TWO_M', '0') == '1' else m
+            self._pipe = [m, m2, torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=hi)]
             self._pipe_calls = 0
         return self._pipe
 
@@ -618,8 +622,8 @@ class Engine(object):
         ctr, C, dev = t // 2, self.C, lrs.device
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
-        # the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch
-        # carries state), so calls alternate between two M streams and overlap
+        # the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch carries
+        # state): with REFVSR_PIPE_TWO_M=1 calls alternate between two M streams; by default M0 is M1 (see _pipe_streams)
         M, Mo = (M0, M1) if (self._pipe_calls & 1) == 0 else (M1, M0)
         self._pipe_calls += 1
         while len(self._inflight) >= 2:
