@@ -601,12 +601,17 @@ class Engine(object):
             # P (per-frame preparation: SPyNet pyramid, matching, reference encoders) may run at high priority so that the
             # 254-workgroup matching kernel is not queued behind the persistent conv workgroups of the other streams
             hi = -1 if os.environ.get('REFVSR_STREAM_PRIORITY', '0') == '1' else 0
-            # ONE M stream by default: alternating two of them (REFVSR_PIPE_TWO_M=1) gains nothing measurable and puts four
-            # concurrently active streams in front of the runtime's four hardware queues -- in 3 of 8 processes each got its own
-            # queue and the rate dropped from 187 to 150-155 frames/s (profiles/r03_one_vs_two_m_streams.txt: eight interleaved runs
-            # each, one M: 187.0-188.2 every time; the matching workgroups and three other kernels displace each other CU by CU)
+            # M streams.  mid_channels = 24 (RefVSR_small): ONE -- alternating two gains nothing measurable there and puts four
+            # concurrently active streams in front of the runtime's four hardware queues: in 3 of 8 processes each got its own queue
+            # and the rate dropped from 187 to 150-155 frames/s (profiles/r03_one_vs_two_m_streams.txt: eight interleaved runs each,
+            # one M: 187.0-188.2 every time; the matching workgroups and three other kernels displace each other CU by CU).
+            # Wider models (C = 48 / 36: one 16-wave workgroup per CU and launch): TWO alternating streams, +4.5 % on RefVSR_MFID
+            # (79.5 vs 76.1 frames/s, four interleaved runs each, no slow mode seen in any MFID run of the round).
+            # REFVSR_PIPE_TWO_M=1 | 0 overrides.
+            two = os.environ.get('REFVSR_PIPE_TWO_M')
+            two = (self.C != 24) if two is None else two == '1'
             m = torch.cuda.Stream(device=dev)
-            m2 = torch.cuda.Stream(device=dev) if os.environ.get('REFVSR_PIPE_TWO_M', '0') == '1' else m
+            m2 = torch.cuda.Stream(device=dev) if two else m
             self._pipe = [m, m2, torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=hi)]
             self._pipe_calls = 0
         return self._pipe
@@ -623,7 +628,7 @@ class Engine(object):
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
         # the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch carries
-        # state): with REFVSR_PIPE_TWO_M=1 calls alternate between two M streams; by default M0 is M1 (see _pipe_streams)
+        # state): calls may alternate between two M streams; for mid_channels = 24 M0 is M1 by default (see _pipe_streams)
         M, Mo = (M0, M1) if (self._pipe_calls & 1) == 0 else (M1, M0)
         self._pipe_calls += 1
         while len(self._inflight) >= 2:
