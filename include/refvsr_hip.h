@@ -23,14 +23,16 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 9   /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 10  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
                                   6: RefvsrConv.warp_* (inter-frame warp fused into the conv's tile staging);
                                   7: refvsr_conv24 / refvsr_conv48 (compile-time-specialised 3x3 convs);
                                   8: RefvsrConv.f32 = 2 (plain fp16 weights in the streamed convs);
-                                  9: refvsr_conv_shuffle2 (compile-time-specialised C -> 4 C conv + pixel shuffle), refvsr_conv32 */
+                                  9: refvsr_conv_shuffle2 (compile-time-specialised C -> 4 C conv + pixel shuffle), refvsr_conv32;
+                                  10: RefvsrConv.batch (one launch over several images that share the weights),
+                                      refvsr_spynet_level_input_batch, refvsr_conf_alpha, refvsr_warp_nhwc16's flow_scale */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -83,6 +85,12 @@ typedef struct RefvsrConv {
      * Supported by the resident 3x3 kernels with fp16 HWC output (the two call sites: ResidualBlocksWithInputConv's input conv,
      * RefVSR.py:218,227-228 / 253,258-259, and feat_fusion2_1, :220,254,259-260 via :138-139); other shapes are refused. */
     const float* warp_flow; int warp_src; int warp_h, warp_w;
+    /* Batch (ABI 10): batch > 1 runs the same conv over `batch` images in ONE launch (blockIdx.y = image); image b reads
+     * src0 + b * bs_src0 (src1 + b * bs_src1) and writes out + b * bs_out, res_planar + b * bs_res_planar (byte strides).
+     * mul / res / warp_flow must be NULL then.  batch = 0 or 1: a single image (strides ignored).  Used for the two SPyNet
+     * flows a frame needs (SPyNet.py:49-104 is called per pair by the reference; same weights, same shapes): the coarse
+     * pyramid levels are launches of 2-36 workgroups, two images per launch fill twice the CUs for the same latency. */
+    int batch; size_t bs_src0, bs_src1, bs_out, bs_res_planar;
 } RefvsrConv;
 
 int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
@@ -236,6 +244,11 @@ int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flo
  * planar fp32 [2][h][w].  ref/supp: planar fp32 [3][h][w]; flow_prev: planar [2][h/2][w/2]. */
 int refvsr_spynet_level_input(const float* ref, const float* supp, const float* flow_prev, int h, int w,
                               void* out8, float* flow_up, void* stream);
+/* The same for `batch` (1..4) independent (ref, supp) pairs of one pyramid level in one launch: ref / supp are host arrays of
+ * `batch` device pointers; flow_prev [batch][2][h/2][w/2] (or NULL), out8 [batch][h][w][8], flow_up [batch][2][h][w] are
+ * contiguous batches.  Image b == refvsr_spynet_level_input of pair b, bit for bit. */
+int refvsr_spynet_level_input_batch(const float* const* ref, const float* const* supp, int batch, const float* flow_prev,
+                                    int h, int w, void* out8, float* flow_up, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Reference matching  (FeatureMatching.forward, RefVSR_/attention.py:72-91)

@@ -69,6 +69,8 @@ struct ConvArgs {
     int ring;                        // streamed kernels: LDS ring slots of CONV_CH K-steps each (2..4)
     const float* warp_flow;          // WARP kernels: flow on the conv's input grid; the warped source has warp_h x warp_w pixels
     int warp_h, warp_w;
+    int batch;                       // images per launch (blockIdx.y); byte strides between the images of each map
+    unsigned long long bs_src0, bs_src1, bs_out, bs_res_planar;
 };
 
 // EPI = 0: general epilogue (every output mode, fp16 / fp32 maps).  EPI = 1: the fp16 HWC store with optional alpha
@@ -101,6 +103,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
                  "s"(p.ncg0), "s"(p.ncg), "s"(p.ps), "s"(p.pixb0), "s"(p.pixb1), "s"(p.h_in), "s"(p.w_in), "s"(p.h_out),
                  "s"(p.w_out), "s"(p.ks), "s"(p.stride), "s"(p.pad), "s"(p.LH), "s"(p.LW), "s"(p.G), "s"(p.S), "s"(p.inv_ncg),
                  "s"(p.cout), "s"(p.tab_bytes), "s"(p.wl_bytes), "s"(p.tiles_x), "s"(p.n_xy), "s"(p.grid));
+    if (p.batch > 1) {                               // image blockIdx.y of the batch (uniform: scalar pointer arithmetic)
+        const unsigned long long bi = blockIdx.y;
+        p.src0 += bi * p.bs_src0;
+        if (p.src1) p.src1 += bi * p.bs_src1;
+        p.out = reinterpret_cast<unsigned char*>(p.out) + bi * p.bs_out;
+        if (p.res_planar) p.res_planar = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.res_planar) + bi * p.bs_res_planar);
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -735,13 +744,13 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
-        int cap = (rv_num_cus() * occ / nz) & ~7;
+        int cap = (rv_num_cus() * occ / (nz * (a.batch > 1 ? a.batch : 1))) & ~7;
         if (cap < 8) cap = 8;
         if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;
     }
     a.grid = gx;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>), dim3(gx, 1, nz), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>), dim3(gx, a.batch > 1 ? a.batch : 1, nz), dim3(NW * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -796,6 +805,14 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     }
     a.res_planar = d->res_planar; a.add_const = d->add_const;
     a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
+    RV_CHECK(d->batch >= 0 && d->batch <= 65535, "conv: batch out of range (%d)", d->batch);
+    a.batch = d->batch > 1 ? d->batch : 1;
+    if (a.batch > 1) {
+        RV_CHECK(!d->mul && !d->res && !d->warp_flow, "conv: batch > 1 takes no mul / res / warp operands");
+        RV_CHECK(d->bs_src0 % 16 == 0 && d->bs_src1 % 16 == 0 && d->bs_out % 8 == 0 && d->bs_res_planar % 4 == 0, "conv: batch strides must keep the maps aligned");
+        RV_CHECK(d->bs_src0 > 0 && d->bs_out > 0 && (!d->src1 || d->bs_src1 > 0) && (!d->res_planar || d->bs_res_planar > 0), "conv: batch strides missing");
+        a.bs_src0 = d->bs_src0; a.bs_src1 = d->bs_src1; a.bs_out = d->bs_out; a.bs_res_planar = d->bs_res_planar;
+    }
 
     const int MT = d->mt_per_block;
     const int n_mt = (d->cout + 15) / 16;

@@ -330,12 +330,24 @@ extern "C" int refvsr_warp_planar(const float* x, int c, int hin, int win, const
 // ------------------------------------------------------------------------------------------------
 // SPyNet level input: x2 align_corners flow upsample (*2) + border-clamped flow_warp + concat
 // ------------------------------------------------------------------------------------------------
-__global__ void spynet_level_input_kernel(const float* __restrict__ ref, const float* __restrict__ supp,
-                                          const float* __restrict__ flow_prev, int h, int w,
-                                          f16* __restrict__ out8, float* __restrict__ flow_up) {
+struct SpyLevelArgs {                   // up to 4 independent (ref, supp) pairs of one pyramid level per launch (blockIdx.z)
+    const float* ref[4]; const float* supp[4];
+    const float* flow_prev;             // [batch][2][h/2][w/2] or NULL
+    f16* out8; float* flow_up;          // [batch][h][w][8], [batch][2][h][w]
+    int h, w;
+};
+
+__global__ void spynet_level_input_kernel(SpyLevelArgs a) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
+    const int h = a.h, w = a.w;
     if (x >= w) return;
+    const int bi = blockIdx.z;
+    const float* __restrict__ ref = bi == 0 ? a.ref[0] : bi == 1 ? a.ref[1] : bi == 2 ? a.ref[2] : a.ref[3];
+    const float* __restrict__ supp = bi == 0 ? a.supp[0] : bi == 1 ? a.supp[1] : bi == 2 ? a.supp[2] : a.supp[3];
+    const float* __restrict__ flow_prev = a.flow_prev ? a.flow_prev + (size_t)bi * 2 * (h / 2) * (w / 2) : nullptr;
+    f16* __restrict__ out8 = a.out8 + (size_t)bi * h * w * 8;
+    float* __restrict__ flow_up = a.flow_up + (size_t)bi * 2 * h * w;
     const size_t plane = (size_t)h * w;
     const size_t pix = (size_t)y * w + x;
     float u = 0.0f, v = 0.0f;
@@ -380,12 +392,24 @@ __global__ void spynet_level_input_kernel(const float* __restrict__ ref, const f
     *reinterpret_cast<f16x8*>(out8 + pix * 8) = o;
 }
 
-extern "C" int refvsr_spynet_level_input(const float* ref, const float* supp, const float* flow_prev, int h, int w,
-                                         void* out8, float* flow_up, void* stream) {
-    RV_CHECK(ref && supp && out8 && flow_up && h > 0 && w > 0, "spynet_level_input: bad args");
+extern "C" int refvsr_spynet_level_input_batch(const float* const* ref, const float* const* supp, int batch, const float* flow_prev,
+                                               int h, int w, void* out8, float* flow_up, void* stream) {
+    RV_CHECK(ref && supp && out8 && flow_up && h > 0 && w > 0 && batch >= 1 && batch <= 4, "spynet_level_input: bad args");
     RV_CHECK(flow_prev == nullptr || (h % 2 == 0 && w % 2 == 0), "spynet_level_input: odd level size");
-    hipLaunchKernelGGL(spynet_level_input_kernel, dim3(rv_cdiv(w, 128), h), dim3(128), 0, (hipStream_t)stream,
-                       ref, supp, flow_prev, h, w, (f16*)out8, flow_up);
+    SpyLevelArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(ref[b] && supp[b], "spynet_level_input: null frame pointer (pair %d)", b);
+        a.ref[b] = ref[b]; a.supp[b] = supp[b];
+    }
+    a.flow_prev = flow_prev; a.out8 = (f16*)out8; a.flow_up = flow_up; a.h = h; a.w = w;
+    hipLaunchKernelGGL(spynet_level_input_kernel, dim3(rv_cdiv(w, 128), h, batch), dim3(128), 0, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int refvsr_spynet_level_input(const float* ref, const float* supp, const float* flow_prev, int h, int w,
+                                         void* out8, float* flow_up, void* stream) {
+    RV_CHECK(ref && supp, "spynet_level_input: bad args");
+    return refvsr_spynet_level_input_batch(&ref, &supp, 1, flow_prev, h, w, out8, flow_up, stream);
 }

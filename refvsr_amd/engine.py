@@ -22,10 +22,17 @@ import os
 import torch
 
 from . import ops
+from .knobs import env_flag
 from .packing import pack_conv
 from .weights import VGG_MEAN, VGG_STD
 
 _uid = itertools.count()
+
+
+def _timed_event(stream):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(stream)
+    return e
 
 
 class FrameCtx(object):
@@ -76,7 +83,7 @@ class Weights(object):
         # SPyNet's streamed 7x7 convs (every conv but the first of a level) on plain fp16 weights: half the weight stream and
         # half the MFMAs of the kernels that are bound by both.  Their share of the end-to-end error budget is measured
         # (tools/lo_term_study.py); config.spynet_hi_lo = True / REFVSR_SPYNET_HILO=1 restores hi + lo.
-        hi_only = not (bool(getattr(config, 'spynet_hi_lo', False)) or os.environ.get('REFVSR_SPYNET_HILO', '0') == '1')
+        hi_only = not (bool(getattr(config, 'spynet_hi_lo', False)) or env_flag('REFVSR_SPYNET_HILO'))
         for lvl in range(6):
             for j, (co, ci) in enumerate(chans):
                 name = 'FlowNet.basic_module.%d.basic_module.%d.conv' % (lvl, j)
@@ -169,27 +176,29 @@ class Engine(object):
         self.cache = bool(getattr(config, 'cache_windows', True))
         self.match_row_splits = 1
         self.match_margin = float(getattr(config, 'match_exact_margin', ops.MATCH_EXACT_MARGIN))
-        self.chain_calls = bool(getattr(config, 'chain_calls', os.environ.get('REFVSR_NO_CHAIN_CALLS') is None))
+        self.chain_calls = bool(getattr(config, 'chain_calls', not env_flag('REFVSR_NO_CHAIN_CALLS')))
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
-                               and not os.environ.get('REFVSR_NO_FUSE'))
-        self.rb24 = not os.environ.get('REFVSR_NO_RB24')         # A/B knob: the generic lean kernel for C = 24 as well
+                               and not env_flag('REFVSR_NO_FUSE'))
+        self.rb24 = not env_flag('REFVSR_NO_RB24')               # A/B knob: the generic lean kernel for C = 24 as well
         # inter-frame warp fused into its consumer's tile staging (RefvsrConv.warp_*; conv kernels with 16-row pairs:
         # mid_channels = 24 / 32).  Bit-identical to warp + conv (tests/test_gpu_ops.py), but OPT-IN: measured on MI355X it is
         # slower (169.3 vs 176.4 frames/s, profiles/r03_fused_warp_ab.txt) -- the gather makes the tile staging a chain of
         # dependent memory round trips (flow -> 4 taps per 16-byte group) that the register prefetch can no longer issue ahead
         # of the K loop: 114 us for the fused 2x conv against 28 + 18 us for conv + stand-alone warp (3.0 TB/s gather kernel).
-        self.fuse_warp = self.C in (24, 32) and bool(getattr(config, 'fuse_warp', os.environ.get('REFVSR_FUSE_WARP')))
+        self.fuse_warp = self.C in (24, 32) and bool(getattr(config, 'fuse_warp', env_flag('REFVSR_FUSE_WARP')))
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
-        self.overlap = bool(getattr(config, 'overlap_streams', True)) and not os.environ.get('REFVSR_NO_OVERLAP')
+        self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3
+        self.overlap = bool(getattr(config, 'overlap_streams', True)) and not env_flag('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
-        self.overlap_prepare = bool(os.environ.get('REFVSR_OVERLAP_PREPARE'))
+        self.overlap_prepare = env_flag('REFVSR_OVERLAP_PREPARE')
         self._side = None
         # pipelined mode (opt-in, see forward()): internal streams M (backward branch + upsampler), F (forward branch),
         # P (per-frame preparation + flows); the caller's stream only receives the result
         self.pipelined = bool(getattr(config, 'pipelined', False))
         self._pipe = None
         self._inflight = collections.deque()
+        self.stream_events = None      # bench.py: list collecting per-call section events of the pipelined mode's streams
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
         self.chain_events = None       # bench.py: list collecting (start, end, blocks, h, w) of the fused-ResBlock runs
         self.reset_state()
@@ -207,10 +216,13 @@ class Engine(object):
         self.id_cache = {}
 
     def set_pipelined(self, on=True):
-        """Opt in to cross-call pipelining.  Contract: forward() is then given `frame_ids` (one hashable id per window
-        frame; equal ids <=> equal (lr, ref) content within a stream) and the input tensors are already materialised
-        when forward() is called (e.g. a pre-loaded clip) -- the engine's internal streams do not wait for work that
-        is still pending on the caller's stream.  Results are bit-identical to the default mode."""
+        """Opt in to cross-call pipelining: forward() is then given `frame_ids` (one hashable id per window frame; equal ids
+        <=> equal (lr, ref) content within a stream) and spreads consecutive calls over the engine's internal streams.
+        Inputs: forward(..., input_ready=) says when lrs / refs are final -- None (default): the internal streams wait for the
+        caller's stream as it stands at the call (always safe; since that stream also waits for the previous result, calls then
+        overlap only internally); 'materialised': the caller asserts the tensors are final (pre-loaded clip; what bench.py's
+        headline does); an event / stream: the producer's, e.g. a copy stream (shard.EngineExecutor).  Results are bit-identical
+        to the default mode in every case."""
         self.pipelined = bool(on)
 
     def export_state(self):
@@ -394,6 +406,53 @@ class Engine(object):
                 out.record_stream(st)
         self.flow_cache[key] = (out, ev)
         return out
+
+    def flows(self, pairs, share=None):
+        """FlowNet for several ordered frame pairs [(ref frame, supp frame), ...].  The pairs that are not cached yet are
+        computed TOGETHER, one launch per layer over all of them (RefvsrConv.batch; the reference calls SPyNet once per pair,
+        SPyNet.py:49-104, RefVSR.py:182-191): same weights, same shapes, and the coarse pyramid levels are launches of 2-36
+        workgroups -- two flows per launch cost about what one does.  Results equal flow() pair by pair, bit for bit."""
+        todo = []
+        for a, b in pairs:
+            if (a.uid, b.uid) not in self.flow_cache and all((a.uid, b.uid) != (x.uid, y.uid) for x, y in todo):
+                todo.append((a, b))
+        if len(todo) >= 2 and self.spynet_batch:
+            for i0 in range(0, len(todo), 4):
+                chunk = todo[i0:i0 + 4]
+                if len(chunk) >= 2:
+                    self._flow_batch(chunk, share)
+        return [self.flow(a, b, share) for a, b in pairs]
+
+    def _flow_batch(self, todo, share):
+        cur = torch.cuda.current_stream()
+        for a, b in todo:
+            for f in (a, b):
+                if f.ready is not None:
+                    cur.wait_event(f.ready)
+        pr = [self.pyramid(a) for a, _ in todo]
+        ps = [self.pyramid(b) for _, b in todo]
+        B = len(todo)
+        h, w = todo[0][0].lr.shape[1:]
+        flow = None
+        for lvl in range(6):
+            x, fup = ops.spynet_level_input_batch([p_[lvl] for p_ in pr], [p_[lvl] for p_ in ps], flow)
+            p = 'FlowNet.basic_module.%d.basic_module.' % lvl
+            small = x.shape[1] * x.shape[2] <= self.spynet_mt1_pixels
+            for j in range(4):
+                cw = self.W.conv.get(p + '%d.conv/mt1' % j) if small else None
+                x = ops.conv(cw if cw is not None else self.cw(p + '%d.conv' % j), x, act=0.0, batch=B)
+            flow = ops.conv(self.cw(p + '4.conv'), x, planar_out=True, res_planar=fup, batch=B)
+        h_up, w_up = flow.shape[2:]
+        out = ops.resize(flow.view(2 * B, h_up, w_up), (h, w), ops.RS_BILINEAR,
+                         chan_mul=[float(w) / float(w_up), float(h) / float(h_up)] * B).view(B, 2, h, w)
+        ev = None
+        if share:
+            ev = torch.cuda.Event()
+            ev.record()
+            for st in share:
+                out.record_stream(st)
+        for i, (a, b) in enumerate(todo):
+            self.flow_cache[(a.uid, b.uid)] = (out[i], ev)
 
     def feature_match(self, fr):
         """FeatureMatching.forward (RefVSR_/attention.py:58-100), fused GEMM+argmax."""
@@ -597,27 +656,39 @@ class Engine(object):
 
     # ------------------------------------------------------------------ pipelined forward (opt-in)
     def _pipe_streams(self, dev):
+        """Internal streams of the pipelined mode: (M0, M1, F, P).
+
+        Layout (REFVSR_PIPE_LAYOUT / config.pipe_layout), round 4:
+          'pf_m' (default)  TWO internal streams: P carries the per-frame preparation AND the forward-branch step (F is P),
+                            M the backward branch + upsampler.  With the caller's stream (which only receives the result) that
+                            is three streams for the runtime's four hardware queues: which streams share a queue is no longer
+                            decided per process.  Round 3 ran P, F and M as three streams (+ the caller's): on boxes where every
+                            stream got its own hardware queue THREE kernels ran concurrently -- the 254-workgroup / 152 KB-LDS
+                            matching kernel and two conv chains displacing each other CU by CU -- and the rate fell from 187-196 to
+                            141-155 frames/s (BENCH_r03: 140.9; profiles/r03_one_vs_two_m_streams.txt).  The fast mode of round 3 was
+                            the one in which F and P happened to share a hardware queue, i.e. exactly this layout.
+          'pfm'             round 3: P, F, M on three streams (kept for the A/B and the slow-mode reproduction)
+          'p_fm'            F on M's stream (one conv chain at a time; measured slower: the backward branch + forward step + upsampler
+                            in series are longer than a frame)
+        Wider models (C = 48 / 36) additionally alternate two M streams (REFVSR_PIPE_TWO_M=1 | 0 overrides)."""
         if self._pipe is None or self._pipe[0].device != dev:
-            # P (per-frame preparation: SPyNet pyramid, matching, reference encoders) may run at high priority so that the
-            # 254-workgroup matching kernel is not queued behind the persistent conv workgroups of the other streams
-            hi = -1 if os.environ.get('REFVSR_STREAM_PRIORITY', '0') == '1' else 0
-            # M streams.  mid_channels = 24 (RefVSR_small): ONE -- alternating two gains nothing measurable there and puts four
-            # concurrently active streams in front of the runtime's four hardware queues: in 3 of 8 processes each got its own queue
-            # and the rate dropped from 187 to 150-155 frames/s (profiles/r03_one_vs_two_m_streams.txt: eight interleaved runs each,
-            # one M: 187.0-188.2 every time; the matching workgroups and three other kernels displace each other CU by CU).
-            # Wider models (C = 48 / 36: one 16-wave workgroup per CU and launch): TWO alternating streams, +4.5 % on RefVSR_MFID
-            # (79.5 vs 76.1 frames/s, four interleaved runs each, no slow mode seen in any MFID run of the round).
-            # REFVSR_PIPE_TWO_M=1 | 0 overrides.
+            hi = -1 if env_flag('REFVSR_STREAM_PRIORITY') else 0
+            layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or 'pf_m')
+            if layout not in ('pf_m', 'pfm', 'p_fm'):
+                raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm, got %r' % layout)
             two = os.environ.get('REFVSR_PIPE_TWO_M')
-            two = (self.C != 24) if two is None else two == '1'
+            two = (self.C != 24) if two in (None, '') else env_flag('REFVSR_PIPE_TWO_M')
             m = torch.cuda.Stream(device=dev)
             m2 = torch.cuda.Stream(device=dev) if two else m
-            self._pipe = [m, m2, torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=hi)]
+            p_ = torch.cuda.Stream(device=dev, priority=hi)
+            f_ = p_ if layout == 'pf_m' else (m if layout == 'p_fm' else torch.cuda.Stream(device=dev))
+            self._pipe = [m, m2, f_, p_]
+            self.pipe_layout = layout
             self._pipe_calls = 0
         return self._pipe
 
     @torch.no_grad()
-    def _forward_pipelined(self, lrs, refs, is_first_frame, want_vis, frame_ids):
+    def _forward_pipelined(self, lrs, refs, is_first_frame, want_vis, frame_ids, input_ready=None):
         """Same computation as _forward_seq, spread over three internal streams so that consecutive calls overlap:
         P prepares the window's new frame and its flows while M is still walking the previous call's backward branch
         and F its forward-branch step.  Dependencies are carried by HIP events (per-frame `ready`, per-flow, per-call
@@ -635,9 +706,31 @@ class Engine(object):
             self._inflight.popleft().synchronize()
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
             is_first_frame = True
+        streams = []
         for st in (M0, M1, F_, P):
+            if all(st is not s_ for s_ in streams):
+                streams.append(st)
+        # inputs: the internal streams read lrs / refs.  input_ready = 'materialised' (the caller asserts the tensors are final,
+        # e.g. a pre-loaded clip): no wait.  An event / stream: the internal streams wait for it (a producer on a copy stream keeps
+        # the calls pipelined).  None: wait for the caller's stream as it stands -- always safe, but the caller's stream also
+        # carries the wait for the previous call's result, so consecutive calls then overlap only inside a call.
+        if input_ready is None:
+            input_ready = torch.cuda.Event()
+            input_ready.record(caller)
+        if not isinstance(input_ready, str):
+            for st in streams:
+                if isinstance(input_ready, torch.cuda.Stream):
+                    st.wait_stream(input_ready)
+                else:
+                    st.wait_event(input_ready)
+        elif input_ready != 'materialised':
+            raise ValueError("input_ready must be None, 'materialised', a torch.cuda.Event or a torch.cuda.Stream")
+        for st in streams:
             lrs.record_stream(st)
             refs.record_stream(st)
+        sev = self.stream_events                     # bench.py: per-call (start, end) HIP events of the P / F / M sections
+        mark = (lambda st: None) if sev is None else _timed_event
+        tev = {}
         if is_first_frame or self.fw_feat is None or bool(self.cfg.EVAL.is_gradio):
             # restart of the forward branch: run the reference order on M, after everything in flight
             for st in (P, F_, Mo):
@@ -652,6 +745,7 @@ class Engine(object):
             share = (M0, M1, F_, P)
             # ---- P: everything that is a function of single frames / frame pairs
             with ops.on_stream(P):
+                tev['P0'] = mark(P)
                 n_ctx = next(_uid)
                 fr = self._frames(lrs, refs, frame_ids)            # new frames are cloned here, on P
                 for f in fr:
@@ -676,9 +770,13 @@ class Engine(object):
                             for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
                                 for st in share:
                                     x.record_stream(st)
+                # the window's new flows in one batched SPyNet pass: the backward flows and the forward flow of this call
+                self.flows([(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])], share)
                 bw_flows = {i: self.flow(fr[i], fr[i + 1], share) for i in range(ctr, t - 1)}
+                tev['P1'] = mark(P)
             # ---- F: forward-branch step (state of the previous call, cached frames)
             with ops.on_stream(F_):
+                tev['F0'] = mark(F_)
                 for f in (fr[ctr], fr[ctr + 1]):
                     if f.ready is not None:
                         F_.wait_event(f.ready)
@@ -689,10 +787,12 @@ class Engine(object):
                 for x in fw:
                     x.record_stream(M0)
                     x.record_stream(M1)
-                ev_fw = torch.cuda.Event()
+                ev_fw = torch.cuda.Event(enable_timing=sev is not None)
                 ev_fw.record()
+                tev['F1'] = ev_fw
             # ---- M: backward branch + upsampler
             with ops.on_stream(M):
+                tev['M0'] = mark(M)
                 feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
                 feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
                 conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
@@ -714,8 +814,11 @@ class Engine(object):
                     vis['conf_map_prop_forward'] = fw[2]
             del bw_flows
             self.frame_itr_num += 1
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=sev is not None)
         done.record(M)
+        if sev is not None and tev:
+            tev['M1'] = done
+            sev.append(tev)
         caller.wait_event(done)
         out.record_stream(caller)
         if vis:
@@ -787,7 +890,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False):
+    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False, input_ready=None):
         """lrs, refs: cuda float32 [t,3,h,w].  Returns (result planar [3,4h,4w], vis dict or None).
         frame_ids (optional): one hashable id per window frame -> the window cache is keyed by id instead of by
         content comparison; together with set_pipelined(True) it enables cross-call stream pipelining."""
@@ -796,10 +899,20 @@ class Engine(object):
             # of a running clip keeps the cache -- same clip, same ids)
             self.id_cache, self.flow_cache = {}, {}
         with torch.cuda.device(lrs.device):          # launches go to the tensors' device, whatever the current device is
-            if self.pipelined and frame_ids is not None and self.cache and self.overlap and not want_log:
-                return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids)
-            with ops.on_stream(torch.cuda.current_stream()):
+            if self.takes_pipelined_path(frame_ids, want_log):
+                return self._forward_pipelined(lrs, refs, is_first_frame, want_vis, frame_ids, input_ready)
+            cur = torch.cuda.current_stream()
+            if isinstance(input_ready, torch.cuda.Stream):
+                cur.wait_stream(input_ready)
+            elif isinstance(input_ready, torch.cuda.Event):
+                cur.wait_event(input_ready)
+            with ops.on_stream(cur):
                 return self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids, want_log)
+
+    def takes_pipelined_path(self, frame_ids, want_log=False):
+        """True when forward() with these arguments runs on the internal streams (the only path that reads the inputs off the
+        caller's stream order)."""
+        return bool(self.pipelined and frame_ids is not None and self.cache and self.overlap and not want_log)
 
     # ------------------------------------------------------------------ two-phase forward (multi-GPU wavefront)
     def _check_window(self, lrs, refs):
@@ -824,6 +937,9 @@ class Engine(object):
             zero_flow = torch.zeros((2, h, w), dtype=torch.float32, device=dev) if bool(self.cfg.EVAL.is_gradio) else None
             fr = self._frames(lrs, refs, frame_ids)
             flow = (lambda a, b: zero_flow) if zero_flow is not None else (lambda a, b: self.flow(fr[a], fr[b]))
+            if zero_flow is None:
+                self.flows([(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])] +
+                           ([(fr[i], fr[i - 1]) for i in range(1, ctr + 1)] if first_hint else []))
             for i in range(0 if first_hint else ctr, t):
                 self.prepare_frame(fr[i])
             bw_up, conf_bw = self._backward_branch(fr, flow, t, h, w)
@@ -962,6 +1078,12 @@ class Engine(object):
         share = (main, self._side_stream(dev)) if overlap else None
         flow = (lambda a, b: zero_flow) if gradio else (lambda a, b: self.flow(fr[a], fr[b], share))   # :183-191
         fw_flow_in = self.fw_flow
+        if not gradio and t > 1:
+            # every flow this call consumes, in one batched SPyNet pass before the streams fork (cached pairs cost nothing)
+            need = [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
+            if is_first_frame:
+                need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]
+            self.flows(need, share)
         if overlap:
             for i in range(ctr, t):
                 self.pyramid(fr[i])                        # shared by both streams: build on main before the fork

@@ -169,8 +169,12 @@ class EngineIR(Engine):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False):
+    def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False, input_ready=None):
         with torch.cuda.device(lrs.device), ops.on_stream(torch.cuda.current_stream()):
+            if isinstance(input_ready, torch.cuda.Stream):
+                torch.cuda.current_stream().wait_stream(input_ready)
+            elif isinstance(input_ready, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(input_ready)
             out, dbg = self._forward_ir(lrs, refs, is_first_frame, frame_ids, bool(want_log and want_vis))
         # RefVSR_IR returns no 'eval_vis' (RefVSR_IR.py:366-386); `vis` holds the save_sample block only (:374-384)
         return out, ((None, dbg) if want_log else None)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 9
+ABI_VERSION = 10
 RESBLOCK24_BLOB_BYTES = 43264
 
 
@@ -36,6 +36,7 @@ class RefvsrConv(C.Structure):
         ('f32', C.c_int),
         ('add_const', C.c_float), ('clamp_lo', C.c_float), ('clamp_hi', C.c_float),
         ('warp_flow', C.c_void_p), ('warp_src', C.c_int), ('warp_h', C.c_int), ('warp_w', C.c_int),
+        ('batch', C.c_int), ('bs_src0', C.c_size_t), ('bs_src1', C.c_size_t), ('bs_out', C.c_size_t), ('bs_res_planar', C.c_size_t),
     ]
 
 
@@ -83,6 +84,7 @@ SIGNATURES = {
     'refvsr_warp_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_warp_planar': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_spynet_level_input': [_P, _P, _P, _I, _I, _P, _P, _P],
+    'refvsr_spynet_level_input_batch': [_P, _P, _I, _P, _I, _I, _P, _P, _P],
     'refvsr_match_patches': [_P, _I, _I, _P, _P, _P, _P],
     'refvsr_match_top2': [_P, _I, _P, _I, _I, _P, _P, _P],
     'refvsr_match_refine': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P],

@@ -119,9 +119,10 @@ class Network(nn.Module):
             self._engines.append(self._engine_cls(self.config, W))
         return self._engines
 
-    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, frame_ids=None):
+    def forward(self, lrs, refs, is_first_frame, is_log=False, is_train=False, frame_ids=None, input_ready=None):
         """Same contract as RefVSR.py:151: lrs, refs [n,t,3,h,w] in [0,1]; returns OrderedDict with
-        'result' [n,3,4h,4w] (+ 'eval_vis' when is_log and config.save_sample)."""
+        'result' [n,3,4h,4w] (+ 'eval_vis' when is_log and config.save_sample).
+        frame_ids / input_ready: extensions (window cache keyed by ids; when the inputs are final -- Engine.set_pipelined)."""
         if is_train:
             raise NotImplementedError('refvsr_amd implements the inference path only (is_train=False)')
         hip.lib()                                              # fail loudly if the extension is missing
@@ -130,14 +131,15 @@ class Network(nn.Module):
                                % lrs.device)
         n = lrs.shape[0]
         self.ensure_engines(n, lrs.device)
-        if frame_ids is not None and any(e.pipelined for e in self._engines[:n]):
-            # pipelined mode: the engine's internal streams read the inputs without waiting for the caller's stream (waiting
-            # would serialise consecutive calls, Engine.set_pipelined) -- a dtype / layout conversion here would be exactly such
-            # pending work, so it is refused instead of raced against
+        if input_ready is not None and any(e.takes_pipelined_path(frame_ids, bool(is_log)) for e in self._engines[:n]):
+            # the engine's internal streams will read the inputs when `input_ready` says so, not in the caller's stream order: a
+            # dtype / layout conversion here would be pending work on the caller's stream that nothing waits for -- refused
+            # instead of raced against.  (input_ready=None waits for the caller's stream, conversions included; calls that take
+            # the sequential path -- is_log, cache or overlap off -- run in the caller's stream order anyway.)
             for t_ in (lrs, refs):
                 if t_.dtype != torch.float32 or not t_.is_contiguous():
-                    raise RuntimeError('pipelined mode needs materialised contiguous float32 inputs (got %s, contiguous=%s): convert '
-                                       'and synchronise before the call, or call set_pipelined(False)' % (t_.dtype, t_.is_contiguous()))
+                    raise RuntimeError('pipelined mode with input_ready= needs contiguous float32 inputs (got %s, contiguous=%s): '
+                                       'convert before the producer signals, or pass input_ready=None' % (t_.dtype, t_.is_contiguous()))
         lrs = lrs.float().contiguous()
         refs = refs.float().contiguous()
         want_vis = bool(is_log and self.config.save_sample)
@@ -145,7 +147,8 @@ class Network(nn.Module):
         dbg_all = []
         for b in range(n):
             out, vis = self._engines[b].forward(lrs[b], refs[b], bool(is_first_frame), want_vis,
-                                                None if frame_ids is None else [(b, f) for f in frame_ids], want_log=bool(is_log))
+                                                None if frame_ids is None else [(b, f) for f in frame_ids], want_log=bool(is_log),
+                                                input_ready=input_ready)
             if is_log:
                 vis, dbg = vis
                 dbg_all.append(dbg)
@@ -237,6 +240,7 @@ class SRNet(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         return super().load_state_dict(strip_module_prefix(state_dict), strict=strict)
 
-    def forward(self, x, ref, is_first_frame=True, is_log=False, is_train=False, frame_ids=None):
-        """frame_ids (optional extension, not in the reference): one id per window frame, see Engine.forward."""
-        return self.Network.forward(x, ref, is_first_frame, is_log=is_log, is_train=is_train, frame_ids=frame_ids)
+    def forward(self, x, ref, is_first_frame=True, is_log=False, is_train=False, frame_ids=None, input_ready=None):
+        """frame_ids, input_ready (optional extensions, not in the reference): one id per window frame / when the inputs are
+        final -- see Engine.forward and Engine.set_pipelined."""
+        return self.Network.forward(x, ref, is_first_frame, is_log=is_log, is_train=is_train, frame_ids=frame_ids, input_ready=input_ready)

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import hip
+from .knobs import env_flag
 from .hip import (OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32, RS_BICUBIC, RS_BILINEAR,  # noqa: F401
                   RS_BILINEAR_AC, RS_NEAREST)
 
@@ -76,7 +77,7 @@ def _farr(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
 
 
-CONV24 = not os.environ.get('REFVSR_NO_CONV24')      # A/B knob: the generic conv kernel for the conv24 shapes as well
+CONV24 = not env_flag('REFVSR_NO_CONV24')      # A/B knob: the generic conv kernel for the conv24 shapes as well
 
 
 class ConvWeights(object):
@@ -101,19 +102,24 @@ class ConvWeights(object):
         self.blob24 = None
         if self.raw is not None and pk.get('src_channels') is not None and CONV24 and not self.hi_only:
             from .packing import conv24_ok, conv_shuffle2_ok, pack_conv24, pack_conv_shuffle2
-            if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32) and not (self.cout == 32 and os.environ.get('REFVSR_NO_CONV32')):
+            if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32) and not (self.cout == 32 and env_flag('REFVSR_NO_CONV32')):
                 self.blob24 = pack_conv24(self.raw[0], self.raw[1], pk['src_channels']).to(device).contiguous()
-            elif self.shuffle and conv_shuffle2_ok(tuple(self.raw[0].shape), pk['src_channels'], self.f32) and not os.environ.get('REFVSR_NO_CONV_SHUFFLE2'):
+            elif self.shuffle and conv_shuffle2_ok(tuple(self.raw[0].shape), pk['src_channels'], self.f32) and not env_flag('REFVSR_NO_CONV_SHUFFLE2'):
                 self.blob24 = pack_conv_shuffle2(self.raw[0], self.raw[1]).to(device).contiguous()     # refvsr_conv_shuffle2
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
-         planar_out=False, res_planar=None, add_const=0.0, clamp=None, warp=None):
+         planar_out=False, res_planar=None, add_const=0.0, clamp=None, warp=None, batch=None):
     """refvsr_conv_mfma.  Returns nhwc16 [ho,wo,cout] (or [2ho,2wo,cout/4] for pixel-shuffle weights),
     or planar fp32 [cout,ho,wo] when planar_out.  For f32-packed weights all maps are fp32 HWC.
     warp = (k, flow): source k (0 | 1) is consumed as warp_nhwc16(source_k, flow) -- sampled while the conv stages its input
     tile, no intermediate map (bit-identical to the two launches); flow planar fp32 [2,h,w] defines the conv's input grid,
-    source k may have another size (RefVSR.py:254: the LR state on the 2x grid)."""
+    source k may have another size (RefVSR.py:254: the LR state on the 2x grid).
+    batch = B: src0 is a contiguous batch [B,h,w,c] (res_planar [B,cout,h,w]) of images sharing the weights: ONE launch
+    (RefvsrConv.batch), output [B,...]; image b == conv of image b alone, bit for bit."""
+    if batch is not None:
+        return _conv_batch(cw, src0, int(batch), stride, pad, act, post, planar_out, res_planar, add_const, clamp,
+                           src1, mul, res, warp)
     f32 = cw.f32
     _nhwc(src0, f32)
     if src1 is not None:
@@ -198,6 +204,54 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         d.out_mode, d.out_c = OUT_NHWC16, co
     d.out = out.data_ptr()
     hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
+    return out
+
+
+def _conv_batch(cw, src0, B, stride, pad, act, post, planar_out, res_planar, add_const, clamp, src1, mul, res, warp):
+    assert src1 is None and mul is None and res is None and warp is None and not cw.shuffle, 'batched conv: single source, no mul / res / warp'
+    assert src0.dim() == 4 and src0.shape[0] == B and src0.is_contiguous() and B >= 1
+    f32 = cw.f32
+    _nhwc(src0[0], f32)
+    h, w, c0 = src0.shape[1:]
+    assert [c0] == list(cw.cpads), 'conv input channels %s do not match packed weights %s' % ([c0], cw.cpads)
+    k = cw.ksize
+    if pad is None:
+        pad = k // 2
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    d = cw.desc
+    d.src0, d.c0, d.src1, d.c1 = src0.data_ptr(), c0, None, 0
+    d.h_in, d.w_in, d.h_out, d.w_out = h, w, ho, wo
+    d.stride, d.pad = stride, pad
+    d.act_slope, d.post_slope = act, post
+    d.mul, d.mul_c, d.res, d.res_c = None, 0, None, 0
+    d.res_planar, d.add_const, d.clamp_lo, d.clamp_hi = None, 0.0, 0.0, 0.0
+    d.warp_flow, d.warp_src, d.warp_h, d.warp_w = None, 0, 0, 0
+    esz = 4 if f32 else 2
+    d.bs_res_planar = 0
+    if planar_out:
+        out = torch.empty((B, cw.cout, ho, wo), dtype=torch.float32, device=src0.device)
+        d.out_mode, d.out_c = OUT_PLANAR32, 0
+        if res_planar is not None:
+            assert res_planar.is_cuda and res_planar.dtype == torch.float32 and res_planar.is_contiguous() and \
+                tuple(res_planar.shape) == (B, cw.cout, ho, wo)
+            d.res_planar = res_planar.data_ptr()
+            d.bs_res_planar = cw.cout * ho * wo * 4
+        d.add_const = add_const
+        if clamp is not None:
+            d.clamp_lo, d.clamp_hi = clamp
+        d.bs_out = cw.cout * ho * wo * 4
+    else:
+        co = _round_up(cw.cout, 4 if f32 else 8)
+        out = torch.empty((B, ho, wo, co), dtype=cw.odtype, device=src0.device)
+        d.out_mode, d.out_c = OUT_NHWC16, co
+        d.bs_out = ho * wo * co * esz
+    d.out = out.data_ptr()
+    d.batch, d.bs_src0, d.bs_src1 = B, h * w * c0 * esz, 0
+    try:
+        hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
+    finally:
+        d.batch = 0                                  # the descriptor is shared with the single-image calls
     return out
 
 
@@ -464,6 +518,26 @@ def spynet_level_input(ref, supp, flow_prev):
     fup = torch.empty((2, h, w), dtype=torch.float32, device=ref.device)
     hip.check(hip.lib().refvsr_spynet_level_input(_ptr(ref), _ptr(supp), _ptr(flow_prev), h, w, _ptr(out8), _ptr(fup),
                                                   _stream()), 'spynet_level_input')
+    return out8, fup
+
+
+def spynet_level_input_batch(refs, supps, flow_prev):
+    """refvsr_spynet_level_input_batch: B independent (ref, supp) pairs of one pyramid level in one launch.  refs / supps:
+    lists of B planar fp32 [3,h,w] tensors; flow_prev [B,2,h/2,w/2] or None.  Returns (x [B,h,w,8] fp16, flow_up [B,2,h,w])."""
+    B = len(refs)
+    assert 1 <= B <= 4 and len(supps) == B
+    for t_ in list(refs) + list(supps):
+        _planar(t_, 3)
+    h, w = refs[0].shape[1:]
+    if flow_prev is not None:
+        assert flow_prev.is_cuda and flow_prev.dtype == torch.float32 and flow_prev.is_contiguous() and \
+            tuple(flow_prev.shape) == (B, 2, h // 2, w // 2)
+    out8 = torch.empty((B, h, w, 8), dtype=torch.float16, device=refs[0].device)
+    fup = torch.empty((B, 2, h, w), dtype=torch.float32, device=refs[0].device)
+    pr = (C.c_void_p * B)(*[t_.data_ptr() for t_ in refs])
+    ps = (C.c_void_p * B)(*[t_.data_ptr() for t_ in supps])
+    hip.check(hip.lib().refvsr_spynet_level_input_batch(pr, ps, B, _ptr(flow_prev), h, w, _ptr(out8), _ptr(fup), _stream()),
+              'spynet_level_input_batch')
     return out8, fup
 
 

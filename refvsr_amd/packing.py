@@ -225,8 +225,11 @@ def c24_kblock(ncg, s, q):
     raise ValueError(ncg)
 
 
-def conv24_ok(w_shape, src_channels, shuffle=False, f32=False):
-    """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 / 32 / 48 output channels, the listed inputs."""
+def conv24_ok(w_shape, src_channels, shuffle=False, f32=False, shuffle_group=False):
+    """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 / 32 / 48 output channels, the listed inputs --
+    the same lists as the library's refvsr_conv{24,32,48}_supported (pinned against each other in tests/test_capi.py).
+    shuffle_group=True (internal, pack_conv_shuffle2 only): the 24 -> 48 row groups of the pixel-shuffle conv, which
+    refvsr_conv48 itself does NOT serve (a plain 24 -> 48 conv goes to the generic kernel)."""
     cout, cin, ks, _ = w_shape
     pads = [_pad8(c) for c in src_channels]
     if ks != 3 or shuffle or f32:
@@ -236,7 +239,7 @@ def conv24_ok(w_shape, src_channels, shuffle=False, f32=False):
     if cout == 32:
         return pads in ([32], [8])              # AlignedConv2d: the 32 -> 32 convs and the RGB stem
     if cout == 48:
-        return pads in ([48], [16], [24])       # ([24]: the row groups of the pixel-shuffle conv, pack_conv_shuffle2)
+        return pads in ([48], [16]) or (shuffle_group and pads == [24])
     return False
 
 
@@ -246,7 +249,7 @@ def conv_shuffle2_ok(w_shape, src_channels, f32=False):
     return ks == 3 and not f32 and list(src_channels) in ([24], [48]) and cin == src_channels[0] and cout == 4 * cin
 
 
-def pack_conv24(w, b, src_channels):
+def pack_conv24(w, b, src_channels, shuffle_group=False):
     """uint8 blob of one conv for refvsr_conv24 / refvsr_conv48: fp16 [S][NF][64 lanes][8] + bias floats (32 | 64).  Lane
     l = (q = l >> 4, r = l & 15) of K-step s holds the 8 (padded) input channels of K-block c24_kblock(ncg, s, q) for row r of
     fragment f (hi = fp16(w), lo = fp16(w - hi)):
@@ -254,7 +257,7 @@ def pack_conv24(w, b, src_channels):
       32 | 48 outputs (NF = 4 | 6): f = 2 m: hi(W[16 m + r])   f = 2 m + 1: lo(W[16 m + r])"""
     w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
     b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
-    assert conv24_ok(w.shape, src_channels), (w.shape, src_channels)
+    assert conv24_ok(w.shape, src_channels, shuffle_group=shuffle_group), (w.shape, src_channels)
     cout = w.shape[0]
     Wk, _, ncg = kmatrix(w, src_channels)                       # [cout, 9 * ncg * 8], K-block g = tap * ncg + cg
     S = c24_steps(ncg)
@@ -302,5 +305,5 @@ def pack_conv_shuffle2(w, b):
     for z in range(2 if c == 24 else 4):
         R = np.arange(48)
         rows = 4 * (R % 24) + 2 * z + R // 24 if c == 24 else 4 * R + z
-        blobs.append(pack_conv24(w[rows], b[rows], [c]))
+        blobs.append(pack_conv24(w[rows], b[rows], [c], shuffle_group=True))
     return torch.cat(blobs)

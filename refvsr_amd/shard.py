@@ -166,19 +166,22 @@ def partition_chain(nframes, world, ratio=0.165):
     the measured phase times).  Shards growing by (1 + ratio) per rank (ratio = t_B1 / t_A, 0.165 measured for RefVSR_small
     at 270p: profiles/r03_bench.json `wavefront_model`) let the chain arrive exactly when phase A ends: n_0 = x,
     n_r = x (1 + ratio)^r.  64 frames over 8 ranks: 4 5 6 7 8 10 11 13 -> 4.8 x predicted (equal shards: 4.1 x)."""
-    w = [1.0] + [(1.0 + ratio) ** r for r in range(1, world)]
-    tot = sum(w)
-    ideal = [nframes * v / tot for v in w]
-    n = [max(1, int(v)) if nframes >= world else 0 for v in ideal]
     if nframes < world:
         return partition(nframes, world)
-    # largest remainders first, keeping the sizes non-decreasing
+    w = [(1.0 + ratio) ** r for r in range(world)]
+    tot = sum(w)
+    ideal = [nframes * v / tot for v in w]
+    n = [max(1, int(v)) for v in ideal]          # every rank owns at least one frame (nframes >= world)
+    # largest remainders first ...
     while sum(n) < nframes:
-        r = max(range(world), key=lambda i: ideal[i] - n[i])
+        r = max(range(world), key=lambda i: (ideal[i] - n[i], i))
         n[r] += 1
+    # ... and when the floor-to-one bump overshot: take from the largest shard (ties -> highest rank), never below 1
     while sum(n) > nframes:
-        r = max(range(world), key=lambda i: n[i] - ideal[i])
+        r = max(range(world), key=lambda i: (n[i], i))
+        assert n[r] > 1
         n[r] -= 1
+    n.sort()                                      # non-decreasing sizes along the chain
     out, s0 = [], 0
     for v in n:
         out.append((s0, s0 + v))
@@ -289,13 +292,15 @@ class EngineExecutor(object):
     indices (id-keyed window cache, no content compare), the hand-off uses the packed single-message state."""
     supports_after_state = True
 
-    def __init__(self, net, device, h, w, nframes, frame_num, keep_on_device=True):
+    def __init__(self, net, device, h, w, nframes, frame_num, keep_on_device=True, pipelined=True, inputs_materialised=False):
         self.net, self.dev, self.h, self.w, self.nframes, self.t = net, device, h, w, nframes, frame_num
         self.keep = keep_on_device
         self.eng = net.Network.ensure_engines(1, device)[0]
-        # the windows are copied to the device on the caller's stream right before each call: cross-call pipelining (whose
-        # internal streams do not wait for the caller's stream, Engine.set_pipelined) stays off here
-        self.eng.set_pipelined(False)
+        # cross-call pipelining of forward() (run_sharded): safe by default since round 4 -- the engine's internal streams wait for
+        # the caller's stream, on which the windows are copied right before each call (Engine.set_pipelined); a caller whose
+        # windows are resident and final before the run says so (inputs_materialised) and gets the full cross-call overlap
+        self.eng.set_pipelined(bool(pipelined))
+        self.input_ready = 'materialised' if inputs_materialised else None
 
     def _ids(self, f):
         return [min(max(f - self.t // 2 + k, 0), self.nframes - 1) for k in range(self.t)]
@@ -305,7 +310,8 @@ class EngineExecutor(object):
 
     def __call__(self, lrs, refs, first, f=None):
         ids = None if f is None else self._ids(f)
-        return self._out(self.net(lrs[None].to(self.dev), refs[None].to(self.dev), first, frame_ids=ids)['result'][0])
+        return self._out(self.net(lrs[None].to(self.dev), refs[None].to(self.dev), first, frame_ids=ids,
+                                  input_ready=self.input_ready if ids is not None else None)['result'][0])
 
     def phase_a(self, lrs, refs, f, hint):
         return self.net.Network.phase_a(lrs[None].to(self.dev), refs[None].to(self.dev), frame_ids=self._ids(f), first_hint=hint)

@@ -311,13 +311,39 @@ def test_pipelined_mode_is_bit_identical(dev):
     torch.cuda.synchronize()
     ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
     want = [ref_net(wl[f], wr[f], f == 0)['result'].clone() for f in range(nfr)]
-    for rep in range(3):
-        net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    # every stream layout (round 4 default 'pf_m': preparation + forward step on one stream, backward branch + upsampler on the
+    # other; 'pfm': round 3's three streams; 'p_fm') x every way of saying when the inputs are final
+    side = torch.cuda.Stream(device=dev)
+    for rep, (layout, ready) in enumerate([('pf_m', 'materialised'), ('pf_m', None), ('pfm', 'materialised'), ('p_fm', 'materialised'),
+                                           ('pf_m', 'event'), ('pf_m', 'stream')]):
+        net, cfg_, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+        cfg_.pipe_layout = layout
         net.Network.set_pipelined(True)
-        outs = [net(wl[f], wr[f], f == 0, frame_ids=wins[f])['result'] for f in range(nfr)]     # no sync in between
+        outs = []
+        for f in range(nfr):                                                                   # no sync in between
+            if ready in ('event', 'stream'):
+                # the producer runs on its own stream: the window is assembled there, right before the call
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    xl, xr = lr[wins[f]][None].contiguous(), rf[wins[f]][None].contiguous()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                outs.append(net(xl, xr, f == 0, frame_ids=wins[f], input_ready=ev if ready == 'event' else side)['result'])
+                xl.record_stream(torch.cuda.current_stream())
+                xr.record_stream(torch.cuda.current_stream())
+            else:
+                outs.append(net(wl[f], wr[f], f == 0, frame_ids=wins[f], input_ready=ready)['result'])
         torch.cuda.synchronize()
+        assert net.Network.engine(0).pipe_layout == layout
         for f in range(nfr):
-            assert torch.equal(outs[f], want[f]), 'pipelined frame %d differs (repeat %d)' % (f, rep)
+            assert torch.equal(outs[f], want[f]), 'pipelined frame %d differs (layout %s, input_ready %s)' % (f, layout, ready)
+    # conversions are refused when the caller vouches for the inputs (nothing would wait for the pending conversion kernel)
+    net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    net.Network.set_pipelined(True)
+    with pytest.raises(RuntimeError):
+        net(wl[0].double(), wr[0].double(), True, frame_ids=wins[0], input_ready='materialised')
+    # ... and accepted on the paths that run in the caller's stream order (input_ready=None; is_log)
+    assert torch.equal(net(wl[0].double(), wr[0].double(), True, frame_ids=wins[0])['result'], want[0])
     # ids without pipelining (cache keyed by id, default stream order)
     net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
     for f in range(nfr):
