@@ -260,46 +260,50 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
 
 def wavefront_model(per_frame, nfr, reset_branch):
     """serial_fraction and predicted strong-scaling speedups of shard.run_wavefront from measured per-frame phase times
-    (shard.predicted_speedup: makespan model, hand-off 0.3 ms = 33 MB over one xGMI link + latency)."""
+    (shard.simulate_wavefront: pre-emptive makespan model of the two-lane schedule; hand-off 0.3 ms = 33 MB over one xGMI link +
+    latency; cold = extra phase-A time of a block's first frame, measured or 0.85 x phase A)."""
     from refvsr_amd import shard
     ta, tb1, tb2 = per_frame['phase_a_ms'], per_frame['phase_b1_ms'], per_frame['phase_b2_ms']
+    cold = per_frame.get('phase_a_cold_extra_ms')
+    cold = 0.85 * ta if cold is None else cold
     tot = ta + tb1 + tb2
-    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'handoff_ms_assumed': 0.3, 'predicted_speedup': {}}
+    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'handoff_ms_assumed': 0.3, 'cold_block_start_ms': cold, 'predicted_speedup': {}}
+    sp = lambda n, parts, rb, il=True: round(shard.predicted_speedup(nfr, n, parts, rb, ta, tb1, tb2, 0.3, cold, il)[0], 3)
     for n in (2, 4, 8):
-        hyb = shard.partition_hybrid(nfr, n, reset_branch) if reset_branch else shard.partition(nfr, n)
         bal = shard.partition(nfr, n)
-        out['predicted_speedup'][str(n)] = {
-            'hybrid_reset_aligned_partition': round(shard.predicted_speedup(nfr, n, hyb, reset_branch, ta, tb1, tb2, 0.3)[0], 3),
-            'balanced_partition_handoff_at_every_boundary': round(shard.predicted_speedup(nfr, n, bal, reset_branch, ta, tb1, tb2, 0.3)[0], 3),
-            'no_reset_balanced (reset_branch=None, configs[4] regime)': round(shard.predicted_speedup(nfr, n, bal, None, ta, tb1, tb2, 0.3)[0], 3),
-            'no_reset_growing_shards (shard.partition_chain)': round(shard.predicted_speedup(nfr, n, shard.partition_chain(nfr, n, tb1 / ta if ta > 0 else 0.165), None, ta, tb1, tb2, 0.3)[0], 3)}
+        grow = shard.partition_chain(nfr, n, tb1 / ta if ta > 0 else 0.165)
+        ent = {}
+        if reset_branch:
+            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, 0.3, cold)
+            ent['with_restarts (reset_branch=%d)' % reset_branch] = {'chosen': nm, 'speedup': round(s_, 3),
+                                                                    'hybrid_reset_aligned': sp(n, shard.partition_hybrid(nfr, n, reset_branch), reset_branch),
+                                                                    'balanced_handoff_at_every_boundary': sp(n, bal, reset_branch)}
+        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, 0.3, cold)
+        ent['no_restarts (reset_branch=None, configs[4] regime)'] = {
+            'chosen': nm, 'speedup': round(s_, 3), 'balanced': sp(n, bal, None), 'growing_shards': sp(n, grow, None),
+            'block_cyclic_3': sp(n, shard.partition_cyclic(nfr, n, 3), None) if 3 * n < nfr else None,
+            'growing_shards_round3_order (B1 after ALL local phase A)': sp(n, grow, None, False)}
+        out['predicted_speedup'][str(n)] = ent
     return out
 
 
-def wavefront_model_single_gpu(args, dev, h, w):
-    """N = 1: the phases of BASELINE configs[3] (config_RefVSR_small_MFID, reset_branch 9) timed on this GPU over one restart
-    unit, and the speedups the makespan model predicts for 2 / 4 / 8 ranks -- no multi-GPU box needed for the prediction, the
-    driver's SCALE run measures the real thing."""
-    from refvsr_amd import SRNet, get_config, make_state_dict
+def measure_phases(net, cfg, dev, h, w, t=5):
+    """Per-frame phase times of one restart unit (or 9 frames) on this GPU, host-synchronised per phase; first repetition =
+    warm-up.  Also the extra phase-A time of a COLD window in the middle of a clip (a block start of the wavefront partitions)."""
     from refvsr_amd.synth import make_clip, window_indices
-    name = 'config_RefVSR_small_MFID'
-    cfg = get_config('bench', 'bench', name)
-    cfg.frame_num = t = 5
-    R = cfg.reset_branch
-    nfr = R + 1
-    net = SRNet(cfg).to(dev).eval()
-    net.load_state_dict(make_state_dict(cfg, 1234))
+    R = cfg.reset_branch or 9
+    nfr = R + 4
     lr, rf, _ = make_clip(nfr, h, w, seed=0, want_gt=False)
     lr, rf = lr.to(dev), rf.to(dev)
     N = net.Network
+    win = lambda f: (lr[torch.tensor(window_indices(f, nfr, t), device=dev)][None].contiguous(),
+                     rf[torch.tensor(window_indices(f, nfr, t), device=dev)][None].contiguous(), window_indices(f, nfr, t))
     acc = [0.0, 0.0, 0.0]
-    for rep in range(2):                                   # first repetition = warm-up
+    for rep in range(2):
         N.reset()
         acc = [0.0, 0.0, 0.0]
-        for f in range(nfr - 1):                           # frames 0 .. R-1: one restart unit (incl. its first-frame call)
-            wi = torch.tensor(window_indices(f, nfr, t), device=dev)
-            x, r = lr[wi][None].contiguous(), rf[wi][None].contiguous()
-            ids = window_indices(f, nfr, t)
+        for f in range(R):                                 # frames 0 .. R-1: one restart unit (incl. its first-frame call)
+            x, r, ids = win(f)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             hnd = N.phase_a(x, r, frame_ids=ids, first_hint=(f == 0))
@@ -312,17 +316,45 @@ def wavefront_model_single_gpu(args, dev, h, w):
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             acc = [acc[0] + t1 - t0, acc[1] + t2 - t1, acc[2] + t3 - t2]
-    per_frame = {'phase_a_ms': 1e3 * acc[0] / (nfr - 1), 'phase_b1_ms': 1e3 * acc[1] / (nfr - 1), 'phase_b2_ms': 1e3 * acc[2] / (nfr - 1)}
-    out = {'workload': '%s %dx%d, frame_num=5, reset_branch=%d: phases of one restart unit (9 frames, host-synchronised per phase) on one GPU; '
-                       'prediction for a 64-frame clip (BASELINE configs[3])' % (name, h, w, R),
+    per_frame = {'phase_a_ms': 1e3 * acc[0] / R, 'phase_b1_ms': 1e3 * acc[1] / R, 'phase_b2_ms': 1e3 * acc[2] / R}
+    cold = []
+    for rep in range(3):                                   # phase A of a mid-clip frame on an empty window cache
+        N.reset()
+        x, r, ids = win(R // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        N.phase_a(x, r, frame_ids=ids, first_hint=False)
+        torch.cuda.synchronize()
+        cold.append(1e3 * (time.perf_counter() - t0))
+    N.reset()
+    # (the first-frame call of the restart unit is in the phase-A mean: compare the cold window with the steady frames only)
+    per_frame['phase_a_cold_extra_ms'] = max(0.0, min(cold[1:]) - per_frame['phase_a_ms'])
+    return per_frame
+
+
+def wavefront_model_single_gpu(args, dev, h, w):
+    """N = 1: the phases of BASELINE configs[3] (config_RefVSR_small_MFID, reset_branch 9) timed on this GPU over one restart
+    unit, and the speedups the makespan model predicts for 2 / 4 / 8 ranks -- no multi-GPU box needed for the prediction, the
+    driver's SCALE run measures the real thing."""
+    from refvsr_amd import SRNet, get_config, make_state_dict
+    name = 'config_RefVSR_small_MFID'
+    cfg = get_config('bench', 'bench', name)
+    cfg.frame_num = 5
+    net = SRNet(cfg).to(dev).eval()
+    net.load_state_dict(make_state_dict(cfg, 1234))
+    per_frame = measure_phases(net, cfg, dev, h, w)
+    out = {'workload': '%s %dx%d, frame_num=5, reset_branch=%d: phases of one restart unit (9 frames, host-synchronised per phase) and of a cold '
+                       'mid-clip window on one GPU; prediction for a 64-frame clip (BASELINE configs[3]) under the two-lane schedule of '
+                       'shard.run_wavefront' % (name, h, w, cfg.reset_branch),
            'phase_ms_per_frame_measured': per_frame}
-    out.update(wavefront_model(per_frame, 64, R))
+    out.update(wavefront_model(per_frame, 64, cfg.reset_branch))
     return out
 
 
 def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     """BASELINE configs[3]: an args.clip-frame clip of config_RefVSR_small_MFID (reset_branch = 9), sharded by frame index
-    over the ranks with the forward-state hand-off (RCCL send/recv of one packed fp16 buffer per shard boundary)."""
+    over the ranks with the forward-state hand-off (RCCL send/recv of one packed fp16 buffer per block boundary that lies inside
+    a restart unit).  Every rank measures its phase times first; the mean decides the partition (shard.choose_partition)."""
     from refvsr_amd import SRNet, get_config, make_state_dict, shard
     from refvsr_amd.synth import make_clip, window_indices
     name = 'config_RefVSR_small_MFID'
@@ -331,46 +363,71 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     nfr = args.clip
     net = SRNet(cfg).to(dev).eval()
     net.load_state_dict(make_state_dict(cfg, 1234))
-    # reset-aligned shards need no hand-off; the short tail is re-balanced over the last two ranks so that ONE boundary still
-    # lies inside a restart unit and the RCCL hand-off is exercised and timed (shard.partition_hybrid); reset_branch = None
-    # (configs[4]) falls back to the balanced partition with a hand-off at every boundary
-    parts = shard.partition_hybrid(nfr, world, cfg.reset_branch) if cfg.reset_branch else shard.partition_chain(nfr, world)
-    start, end = parts[rank]
-    lo, hi = max(start - t // 2, 0), min(end + t // 2, nfr)
-    lr, rf, _ = make_clip(hi - lo, h, w, seed=0, start=lo, want_gt=False)          # this rank's frames (+ input halo), resident in HBM
-    lr, rf = lr.to(dev), rf.to(dev)
-    wins = {f: torch.tensor([i - lo for i in window_indices(f, nfr, t)], device=dev) for f in range(start, end)}
-    win = {f: (lr[wins[f]].contiguous(), rf[wins[f]].contiguous()) for f in range(start, end)}
-    ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
     comm_dev = dev if backend == 'nccl' else torch.device('cpu')
-    # warm-up: kernels, allocator and the point-to-point communicators (their first use costs seconds)
-    if end > start:
-        ex.phase_b(ex.phase_a(win[start][0], win[start][1], start, True), True)
+    pf = measure_phases(net, cfg, dev, h, w)
+    keys = ('phase_a_ms', 'phase_b1_ms', 'phase_b2_ms', 'phase_a_cold_extra_ms')
+    v = torch.tensor([pf[k] for k in keys], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    per_frame = {k: float(x) / world for k, x in zip(keys, v.cpu().tolist())}
+    blocks, predicted, pname = shard.choose_partition(nfr, world, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
+                                                      per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'])
+    if args.wavefront_partition:                           # A/B: force a partition family
+        fam = args.wavefront_partition
+        parts = {'balanced': shard.partition(nfr, world), 'growing': shard.partition_chain(nfr, world),
+                 'hybrid': shard.partition_hybrid(nfr, world, cfg.reset_branch or 9)}.get(fam)
+        if parts is None and fam.startswith('cyclic'):
+            parts = shard.partition_cyclic(nfr, world, int(fam[6:] or 3))
+        blocks, pname = shard.as_blocks(parts), fam
+        predicted = shard.predicted_speedup(nfr, world, blocks, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
+                                            per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'])[0]
+    mine = [(a, b) for a, b, r in blocks if r == rank]
+    need = sorted(set(i for a, b in mine for f in range(a, b) for i in window_indices(f, nfr, t)))
+    clip = {}
+    for i in need:                                         # this rank's frames (+ input halos), resident in HBM
+        if i not in clip:
+            l1, r1, _ = make_clip(1, h, w, seed=0, start=i, want_gt=False)
+            clip[i] = (l1[0].to(dev), r1[0].to(dev))
+    win = {f: (torch.stack([clip[i][0] for i in window_indices(f, nfr, t)], 0).contiguous(),
+               torch.stack([clip[i][1] for i in window_indices(f, nfr, t)], 0).contiguous()) for a, b in mine for f in range(a, b)}
+    ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
+    # warm-up: the point-to-point communicators (their first use costs seconds) and the hand-off time itself: the packed state of
+    # this model goes round the ring once, timed on every rank around recv
     net.Network.reset()
-    tok = torch.zeros(1, device=comm_dev)
-    if rank + 1 < world:
-        dist.send(tok, rank + 1)
-    if rank > 0:
-        dist.recv(tok, rank - 1)
+    nb = ex.state_nbytes()
+    buf = torch.zeros(nb, dtype=torch.uint8, device=comm_dev)
+    handoff_ms = []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        if world > 1:
+            if rank % 2 == 0:
+                dist.send(buf, (rank + 1) % world)
+                dist.recv(buf, (rank - 1) % world)
+            else:
+                dist.recv(buf, (rank - 1) % world)
+                dist.send(buf, (rank + 1) % world)
+        torch.cuda.synchronize()
+        handoff_ms.append(1e3 * (time.perf_counter() - t0) / 2.0)      # two messages in series per rank
+    hv = torch.tensor([min(handoff_ms[1:])], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(hv, op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     tim = {}
-    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=parts, timings=tim)
+    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=blocks, timings=tim)
     torch.cuda.synchronize()
     dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    # per-frame checksums of every rank -> rank 0, compared with rank 0's own sequential run of the whole clip
+    # per-frame checksums of every rank -> rank 0, compared with rank 0's own sequential run of the first frames
     sums = torch.zeros(nfr, 2, dtype=torch.float64, device=comm_dev)
     for f, r in res.items():
         rd = r.double()
         sums[f, 0], sums[f, 1] = rd.sum().to(comm_dev), (rd * rd).sum().to(comm_dev)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    # per-rank phase times (host clock after device synchronisation at the phase ends) -> rank 0
-    ph = torch.zeros(world, 4, dtype=torch.float64, device=comm_dev)
-    ph[rank] = torch.tensor([tim.get('phase_a', 0.0), tim.get('phase_b1', 0.0), tim.get('phase_b2', 0.0), float(end - start)], dtype=torch.float64)
-    dist.all_reduce(ph, op=dist.ReduceOp.SUM)
+    msgs = torch.tensor([float(tim.get('handoff_messages', 0)), float(tim.get('recv_wait', 0.0))], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(msgs, op=dist.ReduceOp.SUM)
     out = None
     if rank == 0:
         ncheck = min(nfr, args.clip_check)
@@ -384,20 +441,24 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
             r = net(lr0[wi][None], rf0[wi][None], f == 0)['result'][0].double()
             ok = ok and float(r.sum()) == float(sums[f, 0]) and float((r * r).sum()) == float(sums[f, 1])
         C = cfg.mid_channels
-        ph = ph.cpu()
-        nloc = ph[:, 3].clamp(min=1.0)
-        per_frame = {'phase_a_ms': float((ph[:, 0] / nloc).mean() * 1e3), 'phase_b1_ms': float((ph[:, 1] / nloc).mean() * 1e3),
-                     'phase_b2_ms': float((ph[:, 2] / nloc).mean() * 1e3)}
-        model = wavefront_model(per_frame, nfr, cfg.reset_branch)
-        out = {'partition': [list(p_) for p_ in parts], 'phase_ms_per_frame_measured': per_frame, 'model': model, 'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
+        seq_s = nfr * (per_frame['phase_a_ms'] + per_frame['phase_b1_ms'] + per_frame['phase_b2_ms']) * 1e-3
+        out = {'ranks_seen': dist.get_world_size(), 'backend': backend + (' (= RCCL)' if backend == 'nccl' else ''),
+               'gpus_visible': torch.cuda.device_count(),
+               'partition': {'name': pname, 'blocks': [list(b_) for b_ in blocks], 'predicted_speedup': round(float(predicted), 3)},
+               'phase_ms_per_frame_measured': per_frame, 'model': wavefront_model(per_frame, nfr, cfg.reset_branch),
+               'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
                            '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
                'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
-               'schedule': 'phase A (flows, matching, encoders, alignment, backward branch) of all local frames concurrently on all ranks; '
-                           'B1 (forward-branch steps) along the hand-off chain, state sent right after the last B1; B2 (BW/FW fusion + '
-                           'upsampler) of all local frames afterwards, off the chain',
-               'handoff': {'backend': backend, 'messages': sum(1 for r in range(1, world) if parts[r][1] > parts[r][0] and shard.needs_handoff(parts[r][0], cfg.reset_branch)),
-                           'bytes_per_message': 64 + h * w * (10 * C + 12), 'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
-                           'overlap': 'isend issued after the last forward-branch step, under the upsamplers'},
+               'speedup_over_one_rank_phase_sum': seq_s / float(el.item()),
+               'schedule': 'two lanes per rank (HIP streams): phase A (flows, matching, encoders, alignment, backward branch) of all local '
+                           'frames on lane 1; the B1 chain (forward-branch steps) on lane 2, B1(f) as soon as phase A of frame f is done and '
+                           'the state has arrived, state sent right after a block\'s last B1; B2 (BW/FW fusion + upsampler) afterwards on lane 1',
+               'handoff': {'messages': int(msgs[0].item()), 'bytes_per_message': 64 + h * w * (10 * C + 12),
+                           'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
+                           'ms_per_message_measured': float(hv.item()),
+                           'how': 'the packed state of this model sent round the ring of ranks (send / recv pairs), host clock around two '
+                                  'messages in series after device synchronisation, best of 2 after one warm-up, max over ranks',
+                           'host_seconds_blocked_in_recv_all_ranks': float(msgs[1].item())},
                'frames_checked_against_single_rank_run': ncheck, 'frames_equal': bool(ok)}
     dist.barrier()
     return out
@@ -422,7 +483,8 @@ def main():
     ap.add_argument('--no-wavefront', action='store_true', help='N > 1: skip the sharded-clip leg with the state hand-off')
     ap.add_argument('--clip', type=int, default=64, help='N > 1: frames of the sharded clip (BASELINE configs[3]: 64)')
     ap.add_argument('--clip-check', type=int, default=12, help='frames of the sharded clip re-run on one rank and compared')
-    ap.add_argument('--wavefront-timeout', type=float, default=180.0)
+    ap.add_argument('--wavefront-timeout', type=float, default=240.0)
+    ap.add_argument('--wavefront-partition', default=None, help='N > 1 A/B: balanced | growing | hybrid | cyclicK (default: shard.choose_partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--match-margin', type=float, default=None, help='A/B knob: margin of the exact-search flagging (0 = top-2 re-rank only)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
@@ -564,10 +626,16 @@ def main():
             if float(flag.item()) == 0.0:
                 break
     warm_s = time.perf_counter() - tw
+    # the collector must not stop the host inside a 100 ms timed pass: everything allocated so far (model, windows, warm pools)
+    # goes to the permanent generation, the young generations are collected between the passes
+    import gc
+    gc.collect()
+    gc.freeze()
     # ---- R timed repetitions, the two call modes interleaved (fast / reference surface / fast / ...): every sample is printed,
     # `value` is the MEDIAN of the fast mode's samples
     samples, samples_dropin, sums, ev = [], [], [], None
     for rep in range(max(1, args.repeats)):
+        gc.collect()
         el, e = timed_pass(use_ids, pipelined, True)
         samples.append(el)
         sums.append(stream_summary(e[2], el))

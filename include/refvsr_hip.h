@@ -144,6 +144,10 @@ int refvsr_resblock24_kblock(int s, int q);
  * waves on 16 x 32 tiles (one workgroup per CU) when the map has at least four 8 x 32 tiles per CU; 4 | 8 | 16 force a
  * shape.  Results do not depend on it (bit-identical). */
 int refvsr_set_resblock24_waves(int waves);
+/* Tuning knob: how the 24-channel kernel stores its output tile.  0: 8-byte stores (one per lane and pixel group); 1: 16-byte
+ * stores after a v_permlane16_swap exchange between neighbouring lane rows (half the store instructions); 2: the same as
+ * write-through (sc1) stores.  Results do not depend on it (bit-identical). */
+int refvsr_set_resblock24_store(int mode);
 /* 3x3 stride-1 pad-1 convolutions with 24 output channels on fp16 HWC maps, compile-time specialised like the block above
  * (csrc/conv24.hip): the ResList tails (RefVSR_/common.py:80-82), feat_fusion / conf_fusion / fusion_UP convs (RefVSR.py:47-62,87),
  * ref encoders, conv_hr and the input conv of ResidualBlocksWithInputConv (RefVSR.py:340-343) of the mid_channels = 24 family.
@@ -158,6 +162,16 @@ int refvsr_conv24_blob_bytes(int c0, int c1);
 int refvsr_conv24_kblock(int ncg, int s, int q);
 int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
                   const void* mul, const void* res, float post_slope, void* out, void* stream);
+/* The confidence fusions in ONE launch (ABI 10): conf_fusion / conf_fusion2 / conf_fusion_BWFW of RefVSR.py:47-52, called at
+ * :130, :141-142 and :107-109 as  conv_{16->C}(lrelu(conv_{2->16}(cat[conf_a, conf_b])))  on the LR grid (up = 1) and on
+ * clamp(F.interpolate(cat[conf_a, conf_b], scale_factor=2, mode='bicubic'), 0, 1) (up = 2).  conf_a / conf_b: planar fp32
+ * [h][w]; w0 / b0: the 2 -> 16 conv's fp32 weights [16][2][3][3] / bias [16] (device); blob: the 16 -> cout blob of refvsr_conv24 /
+ * refvsr_conv48 (cout = 24 | 48); alpha: fp16 HWC [up h][up w][cout]; conf_max (optional, up = 1 only): max(conf_a, conf_b)
+ * [h][w], the propagated confidence of RefVSR.py:147.  The 16-channel map, the concatenated and the up-sampled pair never
+ * exist in HBM; results are bit-identical to torch.cat + [refvsr_resize +] refvsr_conv_direct_f32 + refvsr_conv24/48
+ * [+ refvsr_max2] (tests/test_gpu_ops.py). */
+int refvsr_conf_alpha(const float* conf_a, const float* conf_b, int h, int w, int up, const float* w0, const float* b0,
+                      float slope0, const void* blob, int cout, float slope1, void* alpha, float* conf_max, void* stream);
 /* The same for 48 output channels (mid_channels = 48: configs/config_RefVSR_{L1,MFID,MFID_8K}.py -- the two convs of every
  * ResidualBlockNoBN, sr_backbone_utils.py:42-97, and conf_fusion*.1): (c0, c1) in {(48,0), (16,0)}; out / mul / res are
  * 48-channel maps; blob: [S x 6 fragments x 64 lanes x 8 halfs][64 bias floats], fragments [hi | lo] of output channels 0-15,
@@ -236,6 +250,12 @@ int refvsr_max2(const float* a, const float* b, float* out, size_t n, void* stre
  * (RefVSR.py:254).  flow: planar fp32 [2][hf][wf]. */
 int refvsr_warp_nhwc16(const void* x, int hin, int win, int cs, const float* flow, int hf, int wf,
                        void* out, void* stream);
+/* warp(x, F.interpolate(flow_lr, scale_factor=2, mode='bilinear', align_corners=True) * 2) in one launch (ABI 10): the 2x
+ * propagation state is warped by the up-sampled LR flow (RefVSR.py:220,254,259); the [2][2hl][2wl] flow map is evaluated per
+ * pixel instead of being written and read back.  flow_lr: planar fp32 [2][hl][wl]; out [2hl][2wl][cs].  Bit-identical to
+ * refvsr_resize(BILINEAR_AC, chan_mul 2) + refvsr_warp_nhwc16. */
+int refvsr_warp_nhwc16_up2(const void* x, int hin, int win, int cs, const float* flow_lr, int hl, int wl,
+                           void* out, void* stream);
 int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flow, int hf, int wf,
                        float* out, void* stream);
 /* One SPyNet pyramid level input (SPyNet.py:83-103): flow_up = 2*bilinear_x2(flow_prev, align_corners)

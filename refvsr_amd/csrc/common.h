@@ -97,10 +97,13 @@ __device__ __forceinline__ float rv_linspace_m1p1(int j, int n) {
 // Shared by the stand-alone warp kernels (resample.hip) and the conv kernels that warp a source while staging it.
 struct WarpCoord { int x0, y0; float w00, w01, w10, w11; bool v00, v01, v10, v11; };
 
+__device__ __forceinline__ WarpCoord warp_coord_uv(const float u, const float v, int hf, int wf, int hin, int win, int y, int x);
 __device__ __forceinline__ WarpCoord warp_coord(const float* flow, int hf, int wf, int hin, int win, int y, int x) {
     const size_t fp = (size_t)y * wf + x;
-    const float u = flow[fp];
-    const float v = flow[(size_t)hf * wf + fp];
+    return warp_coord_uv(flow[fp], flow[(size_t)hf * wf + fp], hf, wf, hin, win, y, x);
+}
+// (u, v): the flow at grid pixel (y, x)
+__device__ __forceinline__ WarpCoord warp_coord_uv(const float u, const float v, int hf, int wf, int hin, int win, int y, int x) {
     const float gx = rv_linspace_m1p1(x, wf) + u / (((float)win - 1.0f) / 2.0f);
     const float gy = rv_linspace_m1p1(y, hf) + v / (((float)hin - 1.0f) / 2.0f);
     const float xs = ((gx + 1.0f) * (float)win - 1.0f) / 2.0f;
@@ -137,6 +140,71 @@ __device__ __forceinline__ uint4 warp_group16(const unsigned char* x, int pixb, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) o.h[k] = (f16)acc[k];
     return o.u;
+}
+
+// align_corners=True bilinear taps of output index o (n_in -> n_out samples): shared by resample.hip's resize_kernel and by the
+// kernels that evaluate the up-sampled map in place.  Contraction is switched OFF here: under hipcc's default -ffp-contract=fast
+// `x - (float)i0` may or may not fuse with the product that made x, depending on the code around the inlined copy -- two
+// kernels restating the same taps then differ by an ulp (found on the GPU: refvsr_warp_nhwc16_up2 vs resize + warp).
+__device__ __forceinline__ void rv_bilinear_ac_src(int o, int n_in, int n_out, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
+    const float sc = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
+    const float x = (float)o * sc;
+    i0 = min((int)x, n_in - 1);
+    i1 = min(i0 + 1, n_in - 1);
+    l1 = x - (float)i0;
+}
+// F.interpolate(s, scale_factor=2, mode='bilinear', align_corners=True) of a planar fp32 map [h][w] at output pixel (oy, ox)
+// of the [2h][2w] grid: the taps and FMA chains of resample.hip's resize_kernel<BILINEAR_AC> (flow_up2 of the engine)
+__device__ __forceinline__ float rv_bilinear_ac2_at(const float* __restrict__ s, int h, int w, int oy, int ox) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    rv_bilinear_ac_src(oy, h, 2 * h, y0, y1, ly);
+    rv_bilinear_ac_src(ox, w, 2 * w, x0, x1, lx);
+    const float wy0 = 1.0f - ly, wx0 = 1.0f - lx;
+    const float r0 = fmaf(lx, s[(size_t)y0 * w + x1], fmaf(wx0, s[(size_t)y0 * w + x0], 0.0f));
+    const float r1 = fmaf(lx, s[(size_t)y1 * w + x1], fmaf(wx0, s[(size_t)y1 * w + x0], 0.0f));
+    return fmaf(ly, r1, fmaf(wy0, r0, 0.0f));
+}
+
+// ---- bicubic F.interpolate taps (ATen upsample_bicubic2d, A = -0.75, align_corners=False): shared by resample.hip's
+// resize_kernel and the kernels that evaluate the up-sampled map on the fly (conv24.hip: CONF variant)
+__device__ __forceinline__ void rv_cubic_taps(float t, float* wgt) {
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    wgt[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    wgt[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    wgt[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    wgt[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+// source indices (clamped) and weights of output index o; scale = source step per output sample
+__device__ __forceinline__ void rv_cubic_src(int o, int n_in, float scale, int* idx, float* wgt) {
+    const float x = ((float)o + 0.5f) * scale - 0.5f;
+    const float fl = floorf(x);
+    const int ix = (int)fl;
+    rv_cubic_taps(x - fl, wgt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[k] = min(max(ix - 1 + k, 0), n_in - 1);
+}
+// one bicubic sample of a planar fp32 map [h][w] at output pixel (oy, ox): the FMA chains of resize_kernel<BICUBIC>
+__device__ __forceinline__ float rv_bicubic_at(const float* __restrict__ s, int h, int w, int oy, int ox, float sy, float sx) {
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    rv_cubic_src(oy, h, sy, iy, wy);
+    rv_cubic_src(ox, w, sx, ix, wx);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r = 0.0f;
+        const float* row = s + (size_t)iy[j] * w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r = fmaf(wx[i], row[ix[i]], r);
+        acc = fmaf(wy[j], r, acc);
+    }
+    return acc;
 }
 
 // ---- K-block order of the MFMA convolutions (shared with refvsr_amd/packing.py:kslot) --------------------------

@@ -128,6 +128,12 @@ struct C24Args {
     const unsigned char* blob; const unsigned char* mul; const unsigned char* res;
     int h, w, tiles_x, n_tiles, grid;
     float act_slope, post_slope;
+    // CONF variants (refvsr_conf_alpha): the 16-channel input map is not read, it is COMPUTED while the tile is staged
+    const float* conf_a; const float* conf_b;    // the two planar fp32 confidence maps [ch][cw]
+    const float* cw0; const float* cb0;          // first conv of the pair: fp32 weights [16][2][3][3], bias [16]
+    float* conf_max;                             // optional by-product max(conf_a, conf_b) [ch][cw] (CONF = 1)
+    int ch, cw;                                  // size of the confidence maps (CONF = 2: half the conv's grid)
+    float slope0;
 };
 
 __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l] + a[l ^ 32] (see resblock24.hip:rb_fold1)
@@ -139,9 +145,15 @@ __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l
 
 // COUT = 24 | 48 output channels; TH = 8 | 16 tile rows; NWV waves walk the TH x 32 tile, T = 2 TH / NWV pixel groups per wave;
 // WPS = waves per SIMD the kernel is built for (register budget).
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0>
+// CONF = 1 | 2 (16 -> COUT convs of the confidence fusions, RefVSR.py:47-52,130,141-142,107-109): the kernel's 16-channel
+// input  a = lrelu(conv3x3_{2->16}(cat[conf_a, conf_b]))  -- for CONF = 2 of the pair up-sampled x2 (bicubic, clamped to [0, 1]) --
+// is evaluated per staged pixel from the two fp32 confidence maps instead of being read: torch.cat, [F.interpolate,] the
+// 2 -> 16 conv (refvsr_conv_direct_f32's fp32 FMA order, fp16 rounding) and for CONF = 1 the torch.max of the two maps
+// (RefVSR.py:147) leave the launch list; results are bit-identical to the separate launches.
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void conv24_kernel(C24Args p) {
     static_assert(SHUF == 0 || (COUT == 48 && (SHUF == 24 || SHUF == 48) && NCG0 * 8 == SHUF && NCG1 == 0), "pixel-shuffle variant");
+    static_assert(CONF == 0 || (NCG0 == 2 && NCG1 == 0 && SHUF == 0), "confidence variant: 16-channel single source");
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
     constexpr int S = c24_steps(NCG), NPAT = c24_npat(NCG);
     constexpr int NF = COUT == 24 ? 3 : COUT / 8;                   // fragments per K-step (COUT = 32 | 48: [hi | lo] per 16 channels)
@@ -230,9 +242,85 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
         for (int k = 0; k < KCH; ++k)
             if (k * NT + NT <= NCH || tid + k * NT < NCH) *reinterpret_cast<uint4*>(smem + xl[k]) = xv[k];
     };
+    // ---- CONF: LDS behind the x tile: [pair tile: 2 x (TH + 4) x 36 floats][first conv: 18 taps x 16 outputs][its bias: 16]
+    constexpr int PTH = TH + 4, PTW = C24_XW + 2;
+    constexpr int PT = XT + C24_NPX * PXB, CW0 = PT + 2 * PTH * PTW * 4, CB0 = CW0 + 18 * 16 * 4;
+    if constexpr (CONF != 0) {
+        float* wl0 = reinterpret_cast<float*>(smem + CW0);            // [tap = ci * 9 + ky * 3 + kx][co]: 64-byte rows, co fastest
+        for (int i = tid; i < 18 * 16; i += NT) {
+            const int co = i & 15, tap = i >> 4;
+            wl0[i] = p.cw0[(co * 2 + tap / 9) * 9 + tap % 9];
+        }
+        if (tid < 16) reinterpret_cast<float*>(smem + CB0)[tid] = p.cb0[tid];
+    }
+    // the whole x tile of tile t, computed: stage 1 = the (TH + 4) x 36 window of the pair (zero outside the frame = the first
+    // conv's padding; CONF = 2: clamp01(bicubic x2) of the half-size maps), stage 2 = lrelu(conv 2 -> 16) per staged pixel
+    // (zero outside the frame = the second conv's padding).  Called by all threads; contains one barrier.
+    auto conf_stage = [&](const int t) {
+        const int tyi = t / p.tiles_x;
+        const int ty0 = tyi * C24_TH, tx0 = (t - tyi * p.tiles_x) * C24_TW;
+        float* pt = reinterpret_cast<float*>(smem + PT);
+        for (int i = tid; i < 2 * PTH * PTW; i += NT) {
+            const int c = i / (PTH * PTW), rem = i - c * (PTH * PTW);
+            const int r = rem / PTW, cc = rem - r * PTW;
+            const int y = ty0 - 2 + r, x = tx0 - 2 + cc;
+            float v = 0.0f;
+            if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w) {
+                const float* src = c ? p.conf_b : p.conf_a;
+                if constexpr (CONF == 1) v = src[(size_t)y * p.cw + x];
+                else v = fminf(fmaxf(rv_bicubic_at(src, p.ch, p.cw, y, x, 0.5f, 0.5f), 0.0f), 1.0f);
+            }
+            pt[i] = v;
+        }
+        __syncthreads();
+        const float* wl0 = reinterpret_cast<const float*>(smem + CW0);
+        const float* bl0 = reinterpret_cast<const float*>(smem + CB0);
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            const int i = tid + k * NT;
+            if (i < NCH) {
+                const int px = i >> 1, cg = i & 1;
+                const int r = px / C24_XW, c = px - r * C24_XW;
+                const int iy = ty0 - 1 + r, ix = tx0 - 1 + c;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w) {
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {             // conv_direct.hip's order: ci, ky, kx; acc = fma(x, w, acc)
+                                const float xv = pt[ci * (PTH * PTW) + (r + ky) * PTW + (c + kx)];
+                                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl0 + (ci * 9 + ky * 3 + kx) * 16 + cg * 8);
+                                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl0 + (ci * 9 + ky * 3 + kx) * 16 + cg * 8 + 4);
+                                acc[0] = fmaf(xv, w0[0], acc[0]); acc[1] = fmaf(xv, w0[1], acc[1]);
+                                acc[2] = fmaf(xv, w0[2], acc[2]); acc[3] = fmaf(xv, w0[3], acc[3]);
+                                acc[4] = fmaf(xv, w1[0], acc[4]); acc[5] = fmaf(xv, w1[1], acc[5]);
+                                acc[6] = fmaf(xv, w1[2], acc[6]); acc[7] = fmaf(xv, w1[3], acc[7]);
+                            }
+                    union { f16x8 h; uint4 u; } o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o.h[j] = (f16)rv_lrelu(acc[j] + bl0[cg * 8 + j], p.slope0);
+                    v = o.u;
+                }
+                *reinterpret_cast<uint4*>(smem + XT + px * PXB + cg * 16) = v;
+            }
+        }
+        if constexpr (CONF == 1) {
+            if (p.conf_max) {                                          // RefVSR.py:147 for the pixels this tile owns
+                for (int i = tid; i < C24_TH * C24_TW; i += NT) {
+                    const int r = i / C24_TW, c = i - r * C24_TW;
+                    const int y = ty0 + r, x = tx0 + c;
+                    if (y < p.h && x < p.w)
+                        p.conf_max[(size_t)y * p.w + x] = fmaxf(pt[(r + 2) * PTW + c + 2], pt[PTH * PTW + (r + 2) * PTW + c + 2]);
+                }
+            }
+        }
+    };
     int tl, k_hi;
     rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
-    if (tl < k_hi) x_fetch(tl);
+    if constexpr (CONF == 0) { if (tl < k_hi) x_fetch(tl); }
     __builtin_amdgcn_sched_barrier(0);                               // weights and first tile in flight before the rest of the set-up
 
     // ---- per-lane constants
@@ -256,11 +344,15 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     const int rowb_o = p.w * OPX;
     const unsigned oo = (unsigned)(oy0 * rowb_o + lp * OPX + q * 8);  // this lane's channels 4q.. of group 0, relative to the tile origin
 
-    if (tl < k_hi) x_park();
-    __syncthreads();                                                 // weights, bias, first tile
+    if constexpr (CONF == 0) { if (tl < k_hi) x_park(); }
+    __syncthreads();                                                 // weights, bias, first tile (CONF: first-conv weights)
 
     for (; tl < k_hi; ++tl) {
         const bool has_next = tl + 1 < k_hi;
+        if constexpr (CONF != 0) {                                   // the tile is computed, not prefetched: staged at the top
+            conf_stage(tl);
+            __syncthreads();
+        }
         const int tyi = tl / p.tiles_x;
         const int ty0 = tyi * C24_TH, tx0 = (tl - tyi * p.tiles_x) * C24_TW;
         const bool interior = ty0 >= 1 && ty0 + C24_TH + 1 <= p.h && tx0 >= 1 && tx0 + C24_TW + 1 <= p.w;
@@ -288,7 +380,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                 }
             }
         }
-        if (has_next) x_fetch(tl + 1);                               // next tile: in flight during the K loop
+        if constexpr (CONF == 0) { if (has_next) x_fetch(tl + 1); }  // next tile: in flight during the K loop
 
         // ---------------- K loop: acc = bias + conv(x) on the TH x 32 tile ---------------------------------------------------
         f32x4 acc[NM][T];
@@ -360,7 +452,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
         }
         if (has_next) {
             __syncthreads();                                         // every wave is done reading the x tile
-            x_park();
+            if constexpr (CONF == 0) x_park();
         }
         if constexpr (SHUF != 0) {
             // ---------------- pixel-shuffle epilogue: rows 16 m + 4 q .. of group z -> channels ch0 .. of sub-pixel (dy, dx) -------
@@ -425,24 +517,25 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                 }
             }
         }
-        if (has_next) __syncthreads();                               // next x tile visible
+        if constexpr (CONF == 0) { if (has_next) __syncthreads(); }  // next x tile visible
     }
 }
 
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0>
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0>
 static int launch_c24(C24Args& a, hipStream_t st) {
     constexpr int NZ = SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;          // row groups of the pixel-shuffle variant (blockIdx.y)
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
-    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : COUT / 8) * 1024 + (COUT == 48 ? 256 : 128) + (TH + 2) * C24_XW * PS * 16;
+    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : COUT / 8) * 1024 + (COUT == 48 ? 256 : 128) + (TH + 2) * C24_XW * PS * 16 +
+                        (CONF ? 2 * (TH + 4) * (C24_XW + 2) * 4 + 18 * 16 * 4 + 64 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF>, NWV * 64, LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF>, NWV * 64, LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
@@ -451,7 +544,7 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     int cap = (rv_num_cus() * occ_dev[dev] / NZ) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
+    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -547,4 +640,28 @@ extern "C" int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const 
     hipStream_t st = (hipStream_t)stream;
     if (c == 24) return launch_c24<48, 3, 0, 8, 8, 4, 24>(a, st);
     return launch_c24<48, 6, 0, 16, 16, 4, 48>(a, st);
+}
+
+// The confidence fusions of AA_AF_conf_prop / compute_up in ONE launch (RefVSR.py:47-52 conf_fusion / conf_fusion2 /
+// conf_fusion_BWFW, called at :130, :141-142, :107-109):
+//   alpha = lrelu_{slope1}( conv3x3_{16 -> cout}( lrelu_{slope0}( conv3x3_{2 -> 16}( P ) ) ) ),
+//   P = cat[conf_a, conf_b]  (up = 1)   |   clamp01( F.interpolate(cat[conf_a, conf_b], x2, bicubic) )  (up = 2),
+// both convs zero padded.  conf_a / conf_b: planar fp32 [h][w]; w0 / b0: fp32 [16][2][3][3] / [16] (device); blob: the 16 -> cout
+// blob of refvsr_conv24 / refvsr_conv48 (cout = 24 | 48); alpha: fp16 HWC [up h][up w][cout]; conf_max (optional, up = 1):
+// max(conf_a, conf_b) [h][w] (RefVSR.py:147).  Bit-identical to torch.cat + [refvsr_resize +] refvsr_conv_direct_f32 +
+// refvsr_conv24 / 48 [+ refvsr_max2].
+extern "C" int refvsr_conf_alpha(const float* conf_a, const float* conf_b, int h, int w, int up, const float* w0, const float* b0,
+                                 float slope0, const void* blob, int cout, float slope1, void* alpha, float* conf_max, void* stream) {
+    RV_CHECK(conf_a && conf_b && w0 && b0 && alpha, "conf_alpha: null argument");
+    RV_CHECK(up == 1 || up == 2, "conf_alpha: up must be 1 or 2");
+    RV_CHECK(cout == 24 || cout == 48, "conf_alpha: %d output channels not supported (24 | 48)", cout);
+    RV_CHECK(conf_max == nullptr || up == 1, "conf_alpha: the max by-product exists at up = 1 only");
+    RV_CHECK(slope0 >= 0.f && slope0 <= 1.f, "conf_alpha: activation slopes must lie in [0, 1]");
+    C24Args a;
+    if (c24_fill(a, "conf_alpha", cout, conf_a, nullptr, 0, up * h, up * w, blob, slope1, nullptr, nullptr, 1.0f, alpha)) return 1;
+    a.src0 = nullptr;
+    a.conf_a = conf_a; a.conf_b = conf_b; a.cw0 = w0; a.cb0 = b0; a.conf_max = conf_max; a.ch = h; a.cw = w; a.slope0 = slope0;
+    hipStream_t st = (hipStream_t)stream;
+    if (cout == 24) return up == 1 ? launch_c24<24, 2, 0, 8, 8, 4, 0, 1>(a, st) : launch_c24<24, 2, 0, 8, 8, 4, 0, 2>(a, st);
+    return up == 1 ? launch_c24<48, 2, 0, 8, 8, 4, 0, 1>(a, st) : launch_c24<48, 2, 0, 8, 8, 4, 0, 2>(a, st);
 }

@@ -86,27 +86,10 @@ struct ResizeArgs {
     int clamp01, out_nhwc16, out_c;
 };
 
-__device__ __forceinline__ void cubic_taps(float t, float* wgt) {
-    const float A = -0.75f;
-    float x = t + 1.0f;
-    wgt[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
-    x = t;
-    wgt[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
-    x = 1.0f - t;
-    wgt[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
-    x = 2.0f - t;
-    wgt[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
-}
-
 // 1-D source taps for output index o: up to 4 (index, weight) pairs.
 __device__ __forceinline__ int src_taps(int mode, int o, int n_in, int n_out, float scale, int* idx, float* wgt) {
     if (mode == REFVSR_RS_BICUBIC) {
-        const float x = ((float)o + 0.5f) * scale - 0.5f;
-        const float fl = floorf(x);
-        const int ix = (int)fl;
-        cubic_taps(x - fl, wgt);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) idx[k] = min(max(ix - 1 + k, 0), n_in - 1);
+        rv_cubic_src(o, n_in, scale, idx, wgt);      // common.h (shared with the confidence-fusion kernel of conv24.hip)
         return 4;
     }
     if (mode == REFVSR_RS_NEAREST) {
@@ -114,13 +97,13 @@ __device__ __forceinline__ int src_taps(int mode, int o, int n_in, int n_out, fl
         wgt[0] = 1.0f;
         return 1;
     }
-    float x;
-    if (mode == REFVSR_RS_BILINEAR) {
-        x = fmaxf(((float)o + 0.5f) * scale - 0.5f, 0.0f);
-    } else {  // align_corners=True
-        const float sc = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
-        x = (float)o * sc;
+    if (mode == REFVSR_RS_BILINEAR_AC) {         // align_corners=True: common.h (shared with refvsr_warp_nhwc16_up2)
+        float l1;
+        rv_bilinear_ac_src(o, n_in, n_out, idx[0], idx[1], l1);
+        wgt[0] = 1.0f - l1; wgt[1] = l1;
+        return 2;
     }
+    const float x = fmaxf(((float)o + 0.5f) * scale - 0.5f, 0.0f);
     const int i0 = min((int)x, n_in - 1);
     const int i1 = min(i0 + 1, n_in - 1);
     const float l1 = x - (float)i0;
@@ -150,12 +133,12 @@ __global__ __launch_bounds__(256) void resize_kernel(ResizeArgs a) {
             const float* s = a.src + ch * plane;
             float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                float r = 0.0f;
+            for (int j = 0; j < NT; ++j) {               // explicit FMA chains: the same arithmetic wherever this sum is restated
+                float r = 0.0f;                          // (rv_bicubic_at, common.h)
                 const float* row = s + (size_t)iy[j] * a.w;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) r += wx[i] * row[ix[i]];
-                acc += wy[j] * r;
+                for (int i = 0; i < NT; ++i) r = fmaf(wx[i], row[ix[i]], r);
+                acc = fmaf(wy[j], r, acc);
             }
             if (a.has_norm) acc = (acc - a.mean[ch & 3]) / a.stdv[ch & 3];
             if (a.has_mul) acc *= a.mul[ch & 3];
@@ -297,6 +280,36 @@ extern "C" int refvsr_warp_nhwc16(const void* x, int hin, int win, int cs, const
     const int ng = cs / 8;
     hipLaunchKernelGGL(warp_nhwc16_kernel, dim3(rv_cdiv(wf * ng, 256), hf), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)x, hin, win, cs, flow, hf, wf, (f16*)out);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// warp(x, flow_up2(flow_lr)) without the 2x flow map: the flow of grid pixel (y, px) is F.interpolate(flow_lr, x2, bilinear,
+// align_corners=True) * 2 evaluated in place (RefVSR.py:220,254,259: the 2x state is warped by the up-sampled LR flow) --
+// the arithmetic of refvsr_resize(BILINEAR_AC, chan_mul = 2) followed by refvsr_warp_nhwc16, bit for bit
+__global__ void warp_nhwc16_up2_kernel(const f16* __restrict__ x, int hin, int win, int cs, const float* __restrict__ flow_lr,
+                                       int hl, int wl, f16* __restrict__ out) {
+    const int ng = cs / 8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int hf = 2 * hl, wf = 2 * wl;
+    if (i >= wf * ng) return;
+    const int px = i / ng;
+    const int g = i - px * ng;
+    float u = rv_bilinear_ac2_at(flow_lr, hl, wl, y, px) * 2.0f;
+    float v = rv_bilinear_ac2_at(flow_lr + (size_t)hl * wl, hl, wl, y, px) * 2.0f;
+    asm volatile("" : "+v"(u), "+v"(v));             // the values a flow map would hold: nothing downstream may fuse with their making
+    const WarpCoord c = warp_coord_uv(u, v, hf, wf, hin, win, y, px);
+    *reinterpret_cast<uint4*>(out + ((size_t)y * wf + px) * cs + g * 8) =
+        warp_group16(reinterpret_cast<const unsigned char*>(x), cs * 2, hin, win, c, g * 16);
+}
+
+extern "C" int refvsr_warp_nhwc16_up2(const void* x, int hin, int win, int cs, const float* flow_lr, int hl, int wl,
+                                      void* out, void* stream) {
+    RV_CHECK(x && flow_lr && out && hin > 1 && win > 1 && hl > 0 && wl > 0 && cs % 8 == 0, "warp_nhwc16_up2: bad args");
+    const int ng = cs / 8;
+    hipLaunchKernelGGL(warp_nhwc16_up2_kernel, dim3(rv_cdiv(2 * wl * ng, 256), 2 * hl), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, hin, win, cs, flow_lr, hl, wl, (f16*)out);
     RV_LAUNCH_CHECK();
     return 0;
 }

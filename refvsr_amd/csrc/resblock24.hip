@@ -34,6 +34,11 @@
 
 #include "common.h"
 
+#ifndef REFVSR_RB24_STORE_DEFAULT
+#define REFVSR_RB24_STORE_DEFAULT 0
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 constexpr int RB_TW = 32;                                 // tile width; the tile height TH is a template parameter (8 | 16)
 constexpr int RB_XW = RB_TW + 4;                          // x tile: (TH + 4) x 36 pixels
@@ -149,7 +154,13 @@ __device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
 
 // NWV = waves per workgroup (8: three + two pixel groups per wave, <= 128 VGPRs, four waves per SIMD with the two workgroups
 // of a CU; 4: six + four groups per wave, twice the weight-fragment reuse, two waves per SIMD).
-template <bool RELU, int NWV, bool PROBE = false, int TH = 8>
+// STORE: how the output tile leaves the workgroup.  0 (round 3): 8-byte stores, lane (q, pixel) writes its own four channels.
+// 1: 16-byte stores -- the lanes q and q ^ 1 exchange halves with v_permlane16_swap so that a lane holds EIGHT consecutive
+// channels of one pixel (of the wave's left 16-pixel group for even q, of the right one for odd q): half the store instructions
+// (the store phase is issue bound: 8 waves x 6 stores of 8 bytes per tile).  2: the same as write-through stores (sc1): the tile is
+// on its way to memory while the workgroup is still running instead of being written back by the end-of-kernel release (every
+// workgroup of an LR launch ends at about the same time; the next launch reads the map through the fabric anyway).
+template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 4 ? 2 : 4, NWV == 4 ? 2 : 4))) void resblock24_kernel(RB24Args p) {
     static_assert((TH == 8 && (NWV == 4 || NWV == 8)) || (TH == 16 && NWV == 16), "tile height / waves");
     constexpr int RB_TH = TH, RB_XH = TH + 4, RB_IH = TH + 2;    // TH = 8: x tile 12 x 36, intermediate 10 x 34 (22 sixteen-pixel groups)
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
             x_park();
         }
         if (stamp) RB_STAMP(8);
-        {
+        if constexpr (STORE == 0) {
             unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -369,6 +380,40 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
                     if (q < 2) *reinterpret_cast<uint2*>(d + 32) = v1;
                 }
             }
+        } else {
+            static_assert(T2 % 2 == 0, "the two pixel groups of an output row live in one wave");
+            unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
+            const int gsel = q & 1;                                  // this lane stores a pixel of the left (0) | right (1) group
+#pragma unroll
+            for (int tp = 0; tp < T2 / 2; ++tp) {
+                const uint2 a0 = rb_pack(c0[2 * tp]), b0 = rb_pack(c0[2 * tp + 1]);
+                const uint2 a1 = rb_pack(rb_fold_halves(c1[2 * tp])), b1 = rb_pack(rb_fold_halves(c1[2 * tp + 1]));
+                // odd 16-lane rows of the left group's registers <-> even rows of the right group's: lane (q, pixel) ends up with
+                // channels 8 (q >> 1) .. + 8 of its pixel in group q & 1 (and, for q < 2, channels 16-23 from the folded tile)
+                const auto sx = __builtin_amdgcn_permlane16_swap(a0.x, b0.x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(a0.y, b0.y, false, false);
+                const auto tx = __builtin_amdgcn_permlane16_swap(a1.x, b1.x, false, false);
+                const auto ty_ = __builtin_amdgcn_permlane16_swap(a1.y, b1.y, false, false);
+                const unsigned sx0 = sx[0], sx1 = sx[1], sy0 = sy[0], sy1 = sy[1], tx0_ = tx[0], tx1 = tx[1], ty0_ = ty_[0], ty1 = ty_[1];
+                const u32x4 lo = {sx0, sy0, sx1, sy1};               // channels 8 (q >> 1) .. + 8
+                const u32x4 hi = {tx0_, ty0_, tx1, ty1};              // q < 2: channels 16 .. 23
+                bool ok = true;
+                if (!interior) {
+                    int lpe = lp;
+                    asm volatile("" : "+v"(lpe));
+                    ok = ty0 + oy0 + tp < p.h && tx0 + gsel * 16 + lpe < p.w;
+                }
+                unsigned char* d = ob + (unsigned)(tp * rowb_g) + (unsigned)(oy0 * rowb_g + (gsel * 16 + lp) * RB_PXB);
+                if (ok) {
+                    if constexpr (STORE == 2) {
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d + (q >> 1) * 16), "v"(lo) : "memory");
+                        if (q < 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d + 32), "v"(hi) : "memory");
+                    } else {
+                        *reinterpret_cast<u32x4*>(d + (q >> 1) * 16) = lo;
+                        if (q < 2) *reinterpret_cast<u32x4*>(d + 32) = hi;
+                    }
+                }
+            }
         }
         if (stamp) RB_STAMP(9);
         if (has_next) __syncthreads();                           // D: next x tile visible
@@ -381,6 +426,12 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
 extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
 extern int g_rb_probe_iter;
 
+static int g_rb24_store = REFVSR_RB24_STORE_DEFAULT;   // A/B knob (refvsr_set_resblock24_store): 0 | 1 | 2, see the kernel's STORE parameter
+extern "C" int refvsr_set_resblock24_store(int mode) {
+    if (mode < 0 || mode > 2) return 1;
+    g_rb24_store = mode;
+    return 0;
+}
 static int g_rb24_waves = 0;                 // A/B knob (refvsr_set_resblock24_waves): 0 = by map size; 4 | 8: 8 x 32 tiles; 16: 16 x 32
 extern "C" int refvsr_set_resblock24_waves(int waves) {
     if (waves != 0 && waves != 4 && waves != 8 && waves != 16) return 1;
@@ -388,7 +439,7 @@ extern "C" int refvsr_set_resblock24_waves(int waves) {
     return 0;
 }
 
-template <bool RELU, int NWV, bool PROBE = false, int TH = 8>
+template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0>
 static int launch_rb24(RB24Args& a, hipStream_t st) {
     constexpr int RB_LDS = rb_lds(TH);
     a.tiles_x = rv_cdiv(a.w, RB_TW);
@@ -397,17 +448,17 @@ static int launch_rb24(RB24Args& a, hipStream_t st) {
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE, TH>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE, TH, STORE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE, TH>, NWV * 64, RB_LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE, TH, STORE>, NWV * 64, RB_LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
+    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH, STORE>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -445,8 +496,14 @@ extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, con
         const int waves = g_rb24_waves ? g_rb24_waves : (nt8 >= 4 * rv_num_cus() ? 16 : 8);
         if (g_rb_probe && act_slope == 0.f && waves == 8) rc = launch_rb24<true, 8, true>(a, st);          // tools/probe_resblock24.py
         else if (g_rb_probe && act_slope == 0.f && waves == 16) rc = launch_rb24<true, 16, true, 16>(a, st);
-        else if (act_slope == 0.f) rc = waves == 16 ? launch_rb24<true, 16, false, 16>(a, st) : waves == 8 ? launch_rb24<true, 8>(a, st) : launch_rb24<true, 4>(a, st);
-        else rc = waves == 16 ? launch_rb24<false, 16, false, 16>(a, st) : waves == 8 ? launch_rb24<false, 8>(a, st) : launch_rb24<false, 4>(a, st);
+        else if (waves == 4) rc = act_slope == 0.f ? launch_rb24<true, 4>(a, st) : launch_rb24<false, 4>(a, st);
+#define RB24_PICK(R_)                                                                                                              \
+        (waves == 16 ? (g_rb24_store == 2 ? launch_rb24<R_, 16, false, 16, 2>(a, st) : g_rb24_store == 1 ? launch_rb24<R_, 16, false, 16, 1>(a, st) \
+                                                                                                        : launch_rb24<R_, 16, false, 16, 0>(a, st))  \
+                     : (g_rb24_store == 2 ? launch_rb24<R_, 8, false, 8, 2>(a, st) : g_rb24_store == 1 ? launch_rb24<R_, 8, false, 8, 1>(a, st)      \
+                                                                                                       : launch_rb24<R_, 8, false, 8, 0>(a, st)))
+        else rc = act_slope == 0.f ? RB24_PICK(true) : RB24_PICK(false);
+#undef RB24_PICK
         if (rc) return rc;
         cur = dst;
     }

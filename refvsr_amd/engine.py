@@ -50,6 +50,7 @@ class FrameCtx(object):
         self.idx = None         # int32 [Hf*Wf]
         self.aligned = None     # aa1 output nhwc16 [h,w,C]
         self.aligned_up = None  # aa2 output nhwc16 [2h,2w,C]
+        self.bw_head = None     # pipelined mode: (n, map) -- the first n layers of the backward branch's first step on this frame
         self.ready = None       # pipelined mode: HIP event recorded on the preparation stream once all of the above exist
 
 
@@ -188,6 +189,13 @@ class Engine(object):
         self.fuse_warp = self.C in (24, 32) and bool(getattr(config, 'fuse_warp', env_flag('REFVSR_FUSE_WARP')))
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
+        # pipelined mode: the backward branch restarts from zeros at the window's LAST frame (RefVSR.py:211-214), so the first
+        # layers of that step are a function of that frame alone: its input conv + the first `bw_head_blocks` residual blocks run
+        # with the frame's preparation on the P stream -- load balance between the two internal streams (results identical)
+        self.bw_head_blocks = min(self.nb, max(-1, int(getattr(config, 'bw_head_blocks', None) if getattr(config, 'bw_head_blocks', None) is not None
+                                                         else os.environ.get('REFVSR_BW_HEAD_BLOCKS', '-1'))))
+        self.warp_up2 = not env_flag('REFVSR_NO_WARP_UP2')          # A/B knob: flow_up2 as its own launch + 2x flow map (round 3)
+        self.fuse_conf = not env_flag('REFVSR_NO_FUSE_CONF')        # A/B knob: confidence fusions as separate launches (round 3)
         self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not env_flag('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
@@ -196,7 +204,9 @@ class Engine(object):
         # pipelined mode (opt-in, see forward()): internal streams M (backward branch + upsampler), F (forward branch),
         # P (per-frame preparation + flows); the caller's stream only receives the result
         self.pipelined = bool(getattr(config, 'pipelined', False))
+        self._zero_maps = {}
         self._pipe = None
+        self.pipe_depth = max(1, int(getattr(config, 'pipe_depth', None) or os.environ.get('REFVSR_PIPE_DEPTH') or 3))
         self._inflight = collections.deque()
         self.stream_events = None      # bench.py: list collecting per-call section events of the pipelined mode's streams
         self.kernel_events = None      # bench.py: list collecting (start, end) HIP events of match_top2 launches
@@ -309,6 +319,19 @@ class Engine(object):
     def cw(self, name):
         return self.W.conv[name]
 
+    def _zeros(self, shape, dtype, dev):
+        """Read-only zero maps (the start of a propagation branch, RefVSR.py:211-214,244-247): allocated and filled once per
+        geometry instead of three fill launches (31 MB at 270p) per call.  Never written by any kernel; the one-time host
+        synchronisation makes them valid on every stream."""
+        key = (tuple(shape), dtype, str(dev))
+        z = self._zero_maps.get(key)
+        if z is None:
+            if len(self._zero_maps) > 12:
+                self._zero_maps.clear()
+            z = self._zero_maps[key] = torch.zeros(shape, dtype=dtype, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+        return z
+
     def _block_chain(self, x, pairs, act):
         """A run of residual blocks x <- x + conv2(act(conv1 x)); pairs = [(conv1, conv2), ...] packed weights.
         One launch per block (fused kernel) or two launches per block (fuse_resblocks off / unsupported channel count).
@@ -351,12 +374,19 @@ class Engine(object):
         y = self._block_chain(x, pairs, 0.2)
         return ops.conv(self.cw(name + '.conv_tail'), y, res=x)
 
-    def resblocks(self, lr8, feat, name, flow=None):
+    def resblocks(self, lr8, feat, name, flow=None, stop=None, resume=None):
         """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources.  flow: the propagated
-        features are consumed as warp(feat, flow) (RefVSR.py:218,253,258), sampled inside the input conv's tile staging."""
-        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1, warp=None if flow is None else (1, flow))
+        features are consumed as warp(feat, flow) (RefVSR.py:218,253,258), sampled inside the input conv's tile staging.
+        stop = n: only the input conv and the first n blocks (returns the intermediate map); resume = (n, map): the blocks from n
+        on -- the two halves of one call, for running them on different streams (same launches, same results)."""
         pairs = [(self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i)))
                  for i in range(self.nb)]
+        if resume is not None:
+            n, x = resume
+            return self._block_chain(x, pairs[n:], 0.0) if n < self.nb else x
+        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1, warp=None if flow is None else (1, flow))
+        if stop is not None:
+            return self._block_chain(x, pairs[:stop], 0.0) if stop > 0 else x
         return self._block_chain(x, pairs, 0.0)
 
     def pyramid(self, fr):
@@ -443,8 +473,12 @@ class Engine(object):
                 x = ops.conv(cw if cw is not None else self.cw(p + '%d.conv' % j), x, act=0.0, batch=B)
             flow = ops.conv(self.cw(p + '4.conv'), x, planar_out=True, res_planar=fup, batch=B)
         h_up, w_up = flow.shape[2:]
-        out = ops.resize(flow.view(2 * B, h_up, w_up), (h, w), ops.RS_BILINEAR,
-                         chan_mul=[float(w) / float(w_up), float(h) / float(h_up)] * B).view(B, 2, h, w)
+        # back to the frame size, x / y components rescaled (SPyNet.py:128-137): refvsr_resize takes <= 4 channels with
+        # per-channel factors = two flows per launch
+        cm = [float(w) / float(w_up), float(h) / float(h_up)]
+        outs = [ops.resize(flow[b0:b0 + 2].reshape(-1, h_up, w_up), (h, w), ops.RS_BILINEAR, chan_mul=cm * min(2, B - b0))
+                for b0 in range(0, B, 2)]
+        out = outs[0].view(-1, 2, h, w) if len(outs) == 1 else torch.cat([o_.view(-1, 2, h, w) for o_ in outs], 0)
         ev = None
         if share:
             ev = torch.cuda.Event()
@@ -565,30 +599,42 @@ class Engine(object):
         """AA_AF_conf_prop (RefVSR.py:123-149).  flow_up: the propagated 2x features are consumed as warp(feat_up, flow_up)
         (RefVSR.py:220,254,259), sampled inside feat_fusion2_1's tile staging (their only consumer, :138-139)."""
         R = self.W.raw
-        pair = torch.cat([conf_prop, fr.conf], 0)                                        # [2,h,w] (:130)
-        a = ops.conv_direct(pair, *R['conf_fusion.0.0'], act=0.2, nhwc16_out=True)
-        alpha = ops.conv(self.cw('conf_fusion.1.0'), a, act=0.2)
+        fused = self.fuse_conf and ops.conf_alpha_ok(self.cw('conf_fusion.1.0')) and ops.conf_alpha_ok(self.cw('conf_fusion2.1.0'))
+        if fused:
+            # cat + conf_fusion.0 + conf_fusion.1 (+ the torch.max of :147) in one launch, likewise bicubic x2 + conf_fusion2
+            alpha, conf_next = ops.conf_alpha(conf_prop, fr.conf, 1, *R['conf_fusion.0.0'], self.cw('conf_fusion.1.0'), want_max=True)
+        else:
+            pair = torch.cat([conf_prop, fr.conf], 0)                                    # [2,h,w] (:130)
+            a = ops.conv_direct(pair, *R['conf_fusion.0.0'], act=0.2, nhwc16_out=True)
+            alpha = ops.conv(self.cw('conf_fusion.1.0'), a, act=0.2)
         t = ops.conv(self.cw('feat_fusion.0.0'), feat, fr.aligned, act=0.2)
         feat = ops.conv(self.cw('feat_fusion.1.0'), t, act=0.2, mul=alpha, res=feat)     # :131
         feat = self.res_list(feat, 'feat_decoder', 8)
         up1 = ops.conv(self.cw('upsample1.upsample_conv'), feat)                         # :138 (pixel shuffle fused)
         feat_up = ops.conv(self.cw('feat_fusion2_1.0.0'), feat_up, up1, act=0.2, warp=None if flow_up is None else (0, flow_up))
-        pair_up = ops.bicubic_scale(pair, 2, clamp01=True)                               # :140-141
-        a = ops.conv_direct(pair_up, *R['conf_fusion2.0.0'], act=0.2, nhwc16_out=True)
-        alpha2 = ops.conv(self.cw('conf_fusion2.1.0'), a, act=0.2)
+        if fused:
+            alpha2 = ops.conf_alpha(conf_prop, fr.conf, 2, *R['conf_fusion2.0.0'], self.cw('conf_fusion2.1.0'))   # :140-142
+        else:
+            pair_up = ops.bicubic_scale(pair, 2, clamp01=True)                           # :140-141
+            a = ops.conv_direct(pair_up, *R['conf_fusion2.0.0'], act=0.2, nhwc16_out=True)
+            alpha2 = ops.conv(self.cw('conf_fusion2.1.0'), a, act=0.2)
         t = ops.conv(self.cw('feat_fusion2.0.0'), feat_up, fr.aligned_up, act=0.2)
         feat_up = ops.conv(self.cw('feat_fusion2.1.0'), t, act=0.2, mul=alpha2, res=feat_up)   # :143
         feat_up = self.res_list(feat_up, 'feat_decoder2', 4)
-        conf_prop = ops.max2(conf_prop, fr.conf)                                         # :147
-        return feat, feat_up, conf_prop
+        if not fused:
+            conf_next = ops.max2(conf_prop, fr.conf)                                     # :147
+        return feat, feat_up, conf_next
 
     def compute_up(self, bw_up, fw_up, conf_bw, conf_fw, lr_center):
         """compute_up + base (RefVSR.py:104-119,288) + final clamp (:297)."""
         R = self.W.raw
-        pair_up = ops.bicubic_scale(torch.cat([conf_bw, conf_fw], 0), 2, clamp01=True)
         fus = ops.conv(self.cw('fusion_UP'), bw_up, fw_up)
-        a = ops.conv_direct(pair_up, *R['conf_fusion_BWFW.0.0'], act=0.2, nhwc16_out=True)
-        alpha = ops.conv(self.cw('conf_fusion_BWFW.1.0'), a, act=0.2)
+        if self.fuse_conf and ops.conf_alpha_ok(self.cw('conf_fusion_BWFW.1.0')):
+            alpha = ops.conf_alpha(conf_bw, conf_fw, 2, *R['conf_fusion_BWFW.0.0'], self.cw('conf_fusion_BWFW.1.0'))   # :107-109
+        else:
+            pair_up = ops.bicubic_scale(torch.cat([conf_bw, conf_fw], 0), 2, clamp01=True)
+            a = ops.conv_direct(pair_up, *R['conf_fusion_BWFW.0.0'], act=0.2, nhwc16_out=True)
+            alpha = ops.conv(self.cw('conf_fusion_BWFW.1.0'), a, act=0.2)
         t = ops.conv(self.cw('feat_fusion_BWFW.0.0'), bw_up, fw_up, act=0.2)
         out = ops.conv(self.cw('feat_fusion_BWFW.1.0'), t, act=0.2, mul=alpha, res=fus)
         out = self.res_list(out, 'feat_decoder_BWFW', 4)
@@ -702,7 +748,11 @@ class Engine(object):
         # state): calls may alternate between two M streams; for mid_channels = 24 M0 is M1 by default (see _pipe_streams)
         M, Mo = (M0, M1) if (self._pipe_calls & 1) == 0 else (M1, M0)
         self._pipe_calls += 1
-        while len(self._inflight) >= 2:
+        # the host may run at most pipe_depth calls ahead of the GPU (each call in flight holds its intermediates: ~0.3 GB at 270p).
+        # Depth 3 since round 4: with 2 the host had ~2.4 ms of slack when it issued a call (2.9 ms of host work per call against
+        # 5.3 ms of GPU work) and a 6 ms hiccup of the host -- a GC pass, a descheduled thread -- reached the GPU as a gap
+        # (profiles/r04_stream_layout_ab.txt: passes of 175 instead of 187 frames/s with unstretched stream sections).
+        while len(self._inflight) >= self.pipe_depth:
             self._inflight.popleft().synchronize()
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
             is_first_frame = True
@@ -758,6 +808,11 @@ class Engine(object):
                     if f.conf is None:
                         self.pyramid(f)
                         self.prepare_frame(f)
+                        if i == t - 1 and self.bw_head_blocks >= 0:
+                            zf = self._zeros((h, w, self._state_cs()), torch.float16, dev)
+                            f.bw_head = (self.bw_head_blocks, self.resblocks(f.lr8, zf, 'backward_resblocks', stop=self.bw_head_blocks))
+                            for st in share:
+                                f.bw_head[1].record_stream(st)
                         for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
                             for st in share:
                                 x.record_stream(st)
@@ -793,9 +848,10 @@ class Engine(object):
             # ---- M: backward branch + upsampler
             with ops.on_stream(M):
                 tev['M0'] = mark(M)
-                feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
-                feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
-                conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+                cs_ = self._state_cs()
+                feat = self._zeros((h, w, cs_), torch.float16, dev)
+                feat_up = self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)
+                conf = self._zeros((1, h, w), torch.float32, dev)
                 for i in range(t - 1, ctr - 1, -1):
                     if fr[i].ready is not None:
                         M.wait_event(fr[i].ready)
@@ -838,28 +894,35 @@ class Engine(object):
         their consumers' tile staging (ops.conv warp=) unless self.fuse_warp is off; the 1-channel confidence map keeps its
         own kernel.  up_from_lr: the 2x state is warp(warp(feat, fl), flow_up2(fl)) -- the reference's :254 quirk."""
         if fl is None:
-            feat = self.resblocks(f.lr8, feat, branch)
+            if branch == 'backward_resblocks' and f.bw_head is not None:
+                feat = self.resblocks(f.lr8, feat, branch, resume=f.bw_head)      # its head ran with the frame's preparation
+            else:
+                feat = self.resblocks(f.lr8, feat, branch)
             return self.rap(f, conf, feat, feat_up)
-        fl2 = ops.flow_up2(fl)
         conf = ops.warp_planar(conf, fl)
-        if up_from_lr:
-            feat = ops.warp_nhwc16(feat, fl)              # needed as a map: it is warped a second time onto the 2x grid
-            x = self.resblocks(f.lr8, feat, branch)
-            if self.fuse_warp:
-                return self.rap(f, conf, x, feat, flow_up=fl2)
-            return self.rap(f, conf, x, ops.warp_nhwc16(feat, fl2))
         if self.fuse_warp:
+            fl2 = ops.flow_up2(fl)
+            if up_from_lr:
+                feat = ops.warp_nhwc16(feat, fl)          # needed as a map: it is warped a second time onto the 2x grid
+                x = self.resblocks(f.lr8, feat, branch)
+                return self.rap(f, conf, x, feat, flow_up=fl2)
             x = self.resblocks(f.lr8, feat, branch, flow=fl)
             return self.rap(f, conf, x, feat_up, flow_up=fl2)
+        # the 2x state is warped by flow_up2(fl): evaluated inside the warp kernel (no 2x flow map) unless REFVSR_NO_WARP_UP2=1
+        warp2 = ops.warp_nhwc16_up2 if self.warp_up2 else (lambda m, fl_: ops.warp_nhwc16(m, ops.flow_up2(fl_)))
+        if up_from_lr:
+            feat = ops.warp_nhwc16(feat, fl)              # the reference's :254 quirk: the ALREADY WARPED LR state, on the 2x grid
+            x = self.resblocks(f.lr8, feat, branch)
+            return self.rap(f, conf, x, warp2(feat, fl))
         x = self.resblocks(f.lr8, ops.warp_nhwc16(feat, fl), branch)
-        return self.rap(f, conf, x, ops.warp_nhwc16(feat_up, fl2))
+        return self.rap(f, conf, x, warp2(feat_up, fl))
 
     def _backward_branch(self, fr, flow, t, h, w):
         """Backward propagation branch (RefVSR.py:211-238): restarts from zeros in every window."""
-        C, ctr, dev = self.C, t // 2, fr[0].lr.device
-        feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
-        feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
-        conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+        ctr, dev, cs_ = t // 2, fr[0].lr.device, self._state_cs()
+        feat = self._zeros((h, w, cs_), torch.float16, dev)
+        feat_up = self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)
+        conf = self._zeros((1, h, w), torch.float32, dev)
         for i in range(t - 1, ctr - 1, -1):
             fl = flow(i, i + 1) if i < t - 1 else None    # backward_flows[:, i] = FlowNet(lrs[i], lrs[i+1])
             feat, feat_up, conf = self._prop_step(fr[i], 'backward_resblocks', feat, feat_up, conf, fl)
@@ -867,11 +930,11 @@ class Engine(object):
 
     def _forward_branch(self, fr, flow, t, h, w, is_first_frame):
         """Forward propagation branch (RefVSR.py:240-283); updates the carried state.  Runs on the current stream."""
-        C, ctr, dev = self.C, t // 2, fr[0].lr.device
+        ctr, dev, cs_ = t // 2, fr[0].lr.device, self._state_cs()
         if is_first_frame:
-            feat = torch.zeros((h, w, C), dtype=torch.float16, device=dev)
-            feat_up = torch.zeros((2 * h, 2 * w, C), dtype=torch.float16, device=dev)
-            conf = torch.zeros((1, h, w), dtype=torch.float32, device=dev)
+            feat = self._zeros((h, w, cs_), torch.float16, dev)
+            feat_up = self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)
+            conf = self._zeros((1, h, w), torch.float32, dev)
             range_start = 0
         else:
             range_start = ctr

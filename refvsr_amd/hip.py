@@ -59,6 +59,7 @@ SIGNATURES = {
     'refvsr_resblock24_chain': [_P, _I, _I, _I, _P, _Z, _F, _P, _P, _P, _P],
     'refvsr_resblock24_kblock': [_I, _I],        # returns the packed K-block, not a status
     'refvsr_set_resblock24_waves': [_I],
+    'refvsr_set_resblock24_store': [_I],
     'refvsr_conv24_supported': [_I, _I],         # returns 0 / 1
     'refvsr_conv24_blob_bytes': [_I, _I],        # returns the size
     'refvsr_conv24_kblock': [_I, _I, _I],        # returns the packed K-block
@@ -82,8 +83,10 @@ SIGNATURES = {
     'refvsr_max2': [_P, _P, _P, _Z, _P],
     'refvsr_buffers_equal': [_P, _P, _I, _Z, _P, _P],
     'refvsr_warp_nhwc16': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
+    'refvsr_warp_nhwc16_up2': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_warp_planar': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_spynet_level_input': [_P, _P, _P, _I, _I, _P, _P, _P],
+    'refvsr_conf_alpha': [_P, _P, _I, _I, _I, _P, _P, _F, _P, _I, _F, _P, _P, _P],
     'refvsr_spynet_level_input_batch': [_P, _P, _I, _P, _I, _I, _P, _P, _P],
     'refvsr_match_patches': [_P, _I, _I, _P, _P, _P, _P],
     'refvsr_match_top2': [_P, _I, _P, _I, _I, _P, _P, _P],

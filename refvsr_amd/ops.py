@@ -350,6 +350,8 @@ def resblock24_chain(chain, x, act):
         _RB24_WAVES_SET = True
         if os.environ.get('REFVSR_RESBLOCK24_WAVES'):
             hip.check(hip.lib().refvsr_set_resblock24_waves(int(os.environ['REFVSR_RESBLOCK24_WAVES'])), 'set_resblock24_waves')
+        if os.environ.get('REFVSR_RB24_STORE'):           # A/B knob of the output store path (0 | 1 | 2, refvsr_set_resblock24_store)
+            hip.check(hip.lib().refvsr_set_resblock24_store(int(os.environ['REFVSR_RB24_STORE'])), 'set_resblock24_store')
     _nhwc(x)
     h, w, c = x.shape
     assert c == 24
@@ -385,6 +387,26 @@ def conv_direct(x, w, b, stride=1, pad=None, act=1.0, nhwc16_out=False):
                                                _ptr(out), int(nhwc16_out), cout if nhwc16_out else 0, _stream()),
               'conv_direct_f32')
     return out
+
+
+def conf_alpha(conf_a, conf_b, up, w0, b0, cw, slope0=0.2, slope1=0.2, want_max=False):
+    """refvsr_conf_alpha: conv_{16->C}(lrelu(conv_{2->16}(P))) with P = cat[conf_a, conf_b] (up = 1) or its clamped bicubic x2
+    up-sampling (up = 2), one launch.  conf_a / conf_b planar fp32 [1,h,w]; w0 / b0 the 2 -> 16 conv (fp32, device); cw the packed
+    16 -> C conv (ConvWeights with a conv24 / conv48 blob).  Returns alpha [up h, up w, C] (and max(conf_a, conf_b) [1,h,w])."""
+    _planar(conf_a, 1)
+    _planar(conf_b, 1)
+    assert conf_a.shape == conf_b.shape and cw.blob24 is not None and cw.cpads == [16] and cw.cout in (24, 48)
+    assert tuple(w0.shape) == (16, 2, 3, 3) and w0.is_cuda and w0.dtype == torch.float32 and w0.is_contiguous() and b0.numel() == 16
+    h, w = conf_a.shape[1:]
+    alpha = torch.empty((up * h, up * w, cw.cout), dtype=torch.float16, device=conf_a.device)
+    cmax = torch.empty_like(conf_a) if want_max else None
+    hip.check(hip.lib().refvsr_conf_alpha(_ptr(conf_a), _ptr(conf_b), h, w, up, _ptr(w0), _ptr(b0), slope0, _ptr(cw.blob24), cw.cout,
+                                          slope1, _ptr(alpha), _ptr(cmax), _stream()), 'conf_alpha')
+    return (alpha, cmax) if want_max else alpha
+
+
+def conf_alpha_ok(cw):
+    return cw.blob24 is not None and cw.cpads == [16] and cw.cout in (24, 48) and not cw.shuffle
 
 
 def pack_nhwc16(x, cs=None):
@@ -494,6 +516,17 @@ def warp_nhwc16(x, flow):
     hf, wf = flow.shape[1:]
     out = torch.empty((hf, wf, cs), dtype=torch.float16, device=x.device)
     hip.check(hip.lib().refvsr_warp_nhwc16(_ptr(x), hin, win, cs, _ptr(flow), hf, wf, _ptr(out), _stream()), 'warp_nhwc16')
+    return out
+
+
+def warp_nhwc16_up2(x, flow_lr):
+    """warp_nhwc16(x, flow_up2(flow_lr)) in one launch (the 2x flow map is evaluated per pixel, never written)."""
+    _nhwc(x)
+    _planar(flow_lr, 2)
+    hin, win, cs = x.shape
+    hl, wl = flow_lr.shape[1:]
+    out = torch.empty((2 * hl, 2 * wl, cs), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().refvsr_warp_nhwc16_up2(_ptr(x), hin, win, cs, _ptr(flow_lr), hl, wl, _ptr(out), _stream()), 'warp_nhwc16_up2')
     return out
 
 

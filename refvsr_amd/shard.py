@@ -189,102 +189,239 @@ def partition_chain(nframes, world, ratio=0.165):
     return out
 
 
+def as_blocks(parts, world=None):
+    """Normalise a partition to chain order: [(start, end, rank), ...] sorted by start, empty ranges dropped.  Accepts the
+    per-rank form [(start, end)] * world (contiguous shards: rank = position) or a block list [(start, end, rank), ...]
+    (a rank may own several blocks -- `partition_cyclic`)."""
+    parts = list(parts)
+    if parts and len(parts[0]) == 2:
+        blocks = [(a, b, r) for r, (a, b) in enumerate(parts) if b > a]
+    else:
+        blocks = [(a, b, r) for a, b, r in parts if b > a]
+    blocks.sort()
+    for (a0, b0, _), (a1, _, _) in zip(blocks, blocks[1:]):
+        assert b0 == a1, 'partition must cover the clip contiguously'
+    return blocks
+
+
+def partition_cyclic(nframes, world, size):
+    """Block-cyclic partition: blocks of `size` consecutive frames dealt to the ranks round-robin (the last block may be
+    shorter).  For a clip WITHOUT forward-branch restarts every rank then has part of the EARLY frames: the B1 chain does not
+    wait for one rank to walk a whole shard at the rate of its phase A (the start-up that bounds contiguous shards), at the price
+    of one cold window (two frames prepared twice) and one hand-off per block."""
+    assert size >= 1
+    return [(s0, min(s0 + size, nframes), (i % world)) for i, s0 in enumerate(range(0, nframes, size))]
+
+
+def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True, dt=0.01):
+    """Makespan of run_wavefront from per-frame phase times (any time unit): every rank executes ONE task at a time with
+    priorities  B1 (its phase A done, the previous frame's B1 done and -- across ranks -- handed over) > phase A (frame order)
+    > B2, pre-emptively (the kernels of the two streams interleave at ~10 us granularity).  t_cold: extra phase-A time of
+    the first frame of a block that does not start the clip (its window is not in the cache: two more frames to prepare).
+    interleaved=False: the round-3 order (B1 of a rank only after ALL its phase A).  Returns the makespan."""
+    blocks = as_blocks(parts)
+    owner, first = {}, set()
+    for a, b, r in blocks:
+        first.add(a)
+        for f in range(a, b):
+            owner[f] = r
+    assert sorted(owner) == list(range(nframes)), 'partition must cover every frame once'
+    frames_of = {r: [f for f in range(nframes) if owner[f] == r] for r in range(world)}
+    rem_a = {f: t_a + (t_cold if (f in first and f != 0) else 0.0) for f in range(nframes)}
+    rem_b1 = {f: t_b1 for f in range(nframes)}
+    rem_b2 = {f: t_b2 for f in range(nframes)}
+    done_a, done_b1, done_b2 = {}, {}, {}
+    nxt_a = {r: 0 for r in range(world)}
+    nxt_b1 = {r: 0 for r in range(world)}
+    nxt_b2 = {r: 0 for r in range(world)}
+    n_steps = 0
+    t = 0.0
+    limit = 100.0 * nframes * (t_a + t_b1 + t_b2 + t_cold + t_handoff) + 1.0
+    while len(done_b2) < nframes:
+        assert t < limit, 'schedule does not terminate'
+        for r in range(world):
+            fs = frames_of[r]
+            ran = False
+            if nxt_b1[r] < len(fs):
+                f = fs[nxt_b1[r]]
+                ok = f in done_a
+                if ok and needs_handoff(f, reset_branch):
+                    pf = f - 1
+                    ok = pf in done_b1 and t >= done_b1[pf] + (t_handoff if owner[pf] != r else 0.0)
+                if ok and not interleaved:
+                    ok = nxt_a[r] >= len(fs)
+                if ok:
+                    rem_b1[f] -= dt
+                    if rem_b1[f] <= 1e-9:
+                        done_b1[f] = t + dt
+                        nxt_b1[r] += 1
+                    ran = True
+            if not ran and nxt_a[r] < len(fs):
+                f = fs[nxt_a[r]]
+                rem_a[f] -= dt
+                if rem_a[f] <= 1e-9:
+                    done_a[f] = t + dt
+                    nxt_a[r] += 1
+                ran = True
+            if not ran and nxt_b2[r] < nxt_b1[r]:
+                f = fs[nxt_b2[r]]
+                rem_b2[f] -= dt
+                if rem_b2[f] <= 1e-9:
+                    done_b2[f] = t + dt
+                    nxt_b2[r] += 1
+        n_steps += 1
+        t = n_steps * dt
+    return t
+
+
+def predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True):
+    """(speedup over one rank, makespan) of run_wavefront for a partition (per-rank ranges or a block list) from per-frame
+    phase times: simulate_wavefront against nframes * (t_a + t_b1 + t_b2)."""
+    dt = max(1e-6, (t_a + t_b1 + t_b2) / 2000.0)
+    span = simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, interleaved, dt)
+    seq = nframes * (t_a + t_b1 + t_b2)
+    return (seq / span if span > 0 else 0.0), span
+
+
+def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.3, t_cold=None):
+    """The partition run_wavefront should use for these phase times: the best of the reset-aligned hybrid (when the forward
+    branch restarts), the balanced and the growing contiguous shards and the block-cyclic partitions with 1..8 frames per
+    block, by simulated makespan.  t_cold defaults to 0.85 t_a (two more frames to prepare: ~5.0 of 5.8 ms for RefVSR_small
+    at 270p).  Returns (block list, predicted speedup, name)."""
+    if t_cold is None:
+        t_cold = 0.85 * t_a
+    cands = []
+    if reset_branch:
+        cands.append(('hybrid_reset_aligned', partition_hybrid(nframes, world, reset_branch)))
+    cands.append(('balanced', partition(nframes, world)))
+    if nframes >= world:
+        cands.append(('growing_shards', partition_chain(nframes, world, t_b1 / t_a if t_a > 0 else 0.165)))
+    for size in range(1, 9):
+        if size * world < nframes:
+            cands.append(('block_cyclic_%d' % size, partition_cyclic(nframes, world, size)))
+    best = None
+    for name, parts in cands:
+        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold)
+        if best is None or sp > best[1] * (1.0 + 1e-9):
+            best = (as_blocks(parts), sp, name)
+    return best
+
+
+class _NullCtx(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
                   timings=None):
-    """Two-phase run of this rank's share (contiguous ranges, any boundary; default: the balanced partition).
+    """Two-phase run of this rank's share of the clip.  parts: per-rank ranges [(start, end)] * world or a block list
+    [(start, end, rank), ...] (default: the balanced contiguous partition).
 
-    executor.phase_a(lrs, refs, frame_index, first_hint) -> handle   (state-free; all ranks concurrently)
+    executor.phase_a(lrs, refs, frame_index, first_hint) -> handle   (state-free: preparation + backward branch)
     executor.phase_b1(handle, is_first_frame) -> handle              (forward-branch step: carries the state; in frame order)
     executor.phase_b2(handle) -> result                              (BW/FW fusion + upsampler: state-free)
-    Order on every rank: phase A of all local frames | receive the state | B1 of all local frames | send the state | B2 of
-    all local frames -- the serial chain over the ranks carries only the B1 steps; the upsamplers of rank r run while rank
-    r + 1 walks its B1 chain.  Executors without phase_b1 / phase_b2 run phase_b(handle, first) per frame instead (B2 then
-    sits on the chain).  Results are identical to the sequential run.  Returns {frame: result} for the local frames.
-    timings (optional dict): filled with host-side seconds of the three phases of this rank (after device synchronisation
-    when the executor offers .sync())."""
+
+    Order of issue on every rank (round 4): phase A of ALL local frames | per block in chain order: receive the state, B1 of the
+    block's frames, send the state | B2 of all local frames.  An executor with two execution lanes (EngineExecutor: two HIP
+    streams, `lane_a()` / `lane_b()` + the mark / wait hooks) runs the B1 chain on the second lane: B1(f) starts as soon as
+    ITS phase A is done and the state is there, while the first lane is still walking the phase A of later frames -- the serial
+    chain over the ranks no longer waits for a rank's whole phase A (round 3: `interleaved=False` of the model).  Executors
+    without lanes (the CPU oracle on gloo) run the three groups one after the other: same results, same messages.
+    Executors without phase_b1 / phase_b2 run phase_b(handle, first) per frame (B2 then sits on the chain).
+    Results are identical to the sequential run.  Returns {frame: result} for the local frames.  timings (optional dict):
+    'issue_a' / 'recv_wait' / 'issue_b1' / 'issue_b2' host seconds, 'handoff_messages' sent, 'blocks' local blocks."""
     import time
     rank, world = dist.get_rank(), dist.get_world_size()
-    if parts is None:
-        parts = partition(nframes, world)
-    start, end = parts[rank]
-    sync = getattr(executor, 'sync', lambda: None)
+    blocks = as_blocks(parts if parts is not None else partition(nframes, world), world)
+    mine = [(a, b) for a, b, r in blocks if r == rank]
+    owner_of = {}
+    for a, b, r in blocks:
+        for f in range(a, b):
+            owner_of[f] = r
+    lane_a = getattr(executor, 'lane_a', _NullCtx)
+    lane_b = getattr(executor, 'lane_b', _NullCtx)
+    mark = getattr(executor, 'mark', lambda what, f: None)          # record "what of frame f is enqueued up to here"
+    wait = getattr(executor, 'wait', lambda what, f: None)          # the CURRENT lane waits for that mark
+    tim = {'issue_a': 0.0, 'recv_wait': 0.0, 'issue_b1': 0.0, 'issue_b2': 0.0, 'handoff_messages': 0, 'blocks': len(mine)}
     t0 = time.perf_counter()
-    handles = {}
-    for f in range(start, end):                                   # ---- phase A: no communication, no state
-        lrs, refs = get_window(f)
-        hint = f == 0 or bool(reset_branch and f % reset_branch == 0) or (f == start and not needs_handoff(start, reset_branch))
-        handles[f] = executor.phase_a(lrs, refs, f, hint)
-    if timings is not None:
-        sync()
-        timings['phase_a'] = time.perf_counter() - t0
-    results = {}
-    if end > start and needs_handoff(start, reset_branch):        # ---- phase B: wavefront behind the hand-off
-        _import(executor, rank - 1, channels, device)
-        first = False
-    else:
-        first = True
-    t1 = time.perf_counter()
-    nxt = parts[rank + 1] if rank + 1 < world else None
-    handoff = nxt is not None and nxt[1] > nxt[0] and needs_handoff(nxt[0], reset_branch)
-    pending = []
-    if hasattr(executor, 'phase_b1'):
-        for f in range(start, end):                               # B1 chain: forward-branch steps only
-            handles[f] = executor.phase_b1(handles[f], first)
-            first = False
-        if handoff:                                               # the next rank's chain starts as soon as this one ends
-            pending.append(send_state(_export(executor), rank + 1, device, async_op=True))
-        if timings is not None:
-            sync()
-            timings['phase_b1'] = time.perf_counter() - t1
-        t2 = time.perf_counter()
-        for f in range(start, end):                               # B2: upsamplers, off the chain
-            out = executor.phase_b2(handles.pop(f))
-            results[f] = out
-            if on_result is not None:
-                on_result(f, out)
-        if timings is not None:
-            sync()
-            timings['phase_b2'] = time.perf_counter() - t2
-    else:
-        def start_send():    # called by phase_b of the LAST local frame as soon as its carried state is final:
-            pending.append(send_state(_export(executor), rank + 1, device, async_op=True))   # the upsampler runs under the send
-        early = handoff and getattr(executor, 'supports_after_state', False)
-        for f in range(start, end):
-            if early and f == end - 1:
-                out = executor.phase_b(handles.pop(f), first, after_state=start_send)
+    handles, keep = {}, []
+    with lane_a():
+        for a, b in mine:                                          # ---- phase A: no communication, no state
+            for f in range(a, b):
+                lrs, refs = get_window(f)
+                hint = f == 0 or bool(reset_branch and f % reset_branch == 0) or (f == a and not needs_handoff(a, reset_branch))
+                handles[f] = executor.phase_a(lrs, refs, f, hint)
+                mark('a', f)
+    tim['issue_a'] = time.perf_counter() - t0
+    results, pending = {}, []
+    split = hasattr(executor, 'phase_b1')
+    for a, b in mine:                                              # ---- the chain: one block at a time, in frame order
+        nxt_rank = owner_of.get(b)                                 # owner of the block that follows in chain order
+        handoff_out = nxt_rank is not None and nxt_rank != rank and needs_handoff(b, reset_branch)
+        with lane_b():
+            t1 = time.perf_counter()
+            if needs_handoff(a, reset_branch):
+                if owner_of[a - 1] != rank:
+                    _import(executor, owner_of[a - 1], channels, device)
+                first = False
             else:
-                out = executor.phase_b(handles.pop(f), first)
-            first = False
-            results[f] = out
-            if on_result is not None:
-                on_result(f, out)
-        if handoff and not pending:
-            send_state(_export(executor), rank + 1, device)
+                first = True
+            tim['recv_wait'] += time.perf_counter() - t1
+            t2 = time.perf_counter()
+            if split:
+                for f in range(a, b):                              # B1 chain: forward-branch steps only
+                    wait('a', f)
+                    handles[f] = executor.phase_b1(handles[f], first)
+                    mark('b1', f)
+                    first = False
+                if handoff_out:                                    # the next block's chain starts as soon as this one ends
+                    pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
+                    tim['handoff_messages'] += 1
+            else:
+                def start_send():    # called by phase_b of the block's LAST frame as soon as its carried state is final
+                    pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
+                early = handoff_out and getattr(executor, 'supports_after_state', False)
+                for f in range(a, b):
+                    wait('a', f)
+                    h = handles.pop(f)
+                    keep.append(h)
+                    if early and f == b - 1:
+                        out = executor.phase_b(h, first, after_state=start_send)
+                    else:
+                        out = executor.phase_b(h, first)
+                    first = False
+                    results[f] = out
+                    if on_result is not None:
+                        on_result(f, out)
+                if handoff_out:
+                    if not early:
+                        send_state(_export(executor), nxt_rank, device)
+                    tim['handoff_messages'] += 1
+            tim['issue_b1'] += time.perf_counter() - t2
+    t3 = time.perf_counter()
+    if split:
+        with lane_a():
+            for a, b in mine:                                      # ---- B2: upsamplers, off the chain
+                for f in range(a, b):
+                    wait('b1', f)
+                    h = handles.pop(f)
+                    keep.append(h)                                 # (two lanes: the handle's tensors stay allocated until the
+                    out = executor.phase_b2(h)                     #  final synchronisation -- they are read on both streams)
+                    results[f] = out
+                    if on_result is not None:
+                        on_result(f, out)
+    tim['issue_b2'] = time.perf_counter() - t3
     for wk in pending:
         if wk is not None:
             wk.wait()
+    getattr(executor, 'sync', lambda: None)()
+    del keep[:]
+    if timings is not None:
+        timings.update(tim)
     return results
-
-
-def predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0):
-    """Makespan model of run_wavefront from per-frame phase times: every rank runs its phase A frames, the B1 chain of a
-    shard that starts behind a hand-off begins when its predecessor's chain has ended (+ the hand-off), B2 follows B1 on the
-    same rank.  Returns (speedup over one rank, makespan in the same unit as the inputs)."""
-    end_b1 = []
-    span = 0.0
-    for r, (a, b) in enumerate(parts):
-        n = b - a
-        if n <= 0:
-            end_b1.append(end_b1[-1] if end_b1 else 0.0)
-            continue
-        ready = n * t_a
-        if needs_handoff(a, reset_branch) and r > 0:
-            ready = max(ready, end_b1[r - 1] + t_handoff)
-        e = ready + n * t_b1
-        end_b1.append(e)
-        span = max(span, e + n * t_b2)
-    seq = nframes * (t_a + t_b1 + t_b2)
-    return (seq / span if span > 0 else 0.0), span
 
 
 class EngineExecutor(object):
@@ -301,6 +438,34 @@ class EngineExecutor(object):
         # windows are resident and final before the run says so (inputs_materialised) and gets the full cross-call overlap
         self.eng.set_pipelined(bool(pipelined))
         self.input_ready = 'materialised' if inputs_materialised else None
+        # run_wavefront's two execution lanes: phase A (+ B2) on one HIP stream, the B1 chain (+ the hand-off) on another, ordered by
+        # per-frame events -- B1(f) runs as soon as phase A of ITS frame is done and the state has arrived
+        self._lanes = None
+        self._marks = {}
+
+    def _streams(self):
+        if self._lanes is None:
+            self._lanes = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            cur = torch.cuda.current_stream(self.dev)
+            for s_ in self._lanes:
+                s_.wait_stream(cur)                         # whatever produced the windows / the weights on the caller's stream
+        return self._lanes
+
+    def lane_a(self):
+        return torch.cuda.stream(self._streams()[0])
+
+    def lane_b(self):
+        return torch.cuda.stream(self._streams()[1])
+
+    def mark(self, what, f):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._marks[(what, f)] = ev
+
+    def wait(self, what, f):
+        ev = self._marks.get((what, f))
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
 
     def _ids(self, f):
         return [min(max(f - self.t // 2 + k, 0), self.nframes - 1) for k in range(self.t)]
@@ -326,8 +491,12 @@ class EngineExecutor(object):
         return self._out(self.net.Network.phase_b2(handles)['result'][0])
 
     def sync(self):
-        import torch as _t
-        _t.cuda.synchronize(self.dev)
+        torch.cuda.synchronize(self.dev)
+        if self._lanes is not None:                         # results were produced on the lanes: order them before the caller's stream
+            cur = torch.cuda.current_stream(self.dev)
+            for s_ in self._lanes:
+                cur.wait_stream(s_)
+        self._marks.clear()
 
     def state_nbytes(self):
         return self.eng.state_nbytes(self.h, self.w)

@@ -54,13 +54,26 @@ E2E = [('S_16x16_t3', 'config_RefVSR_small_L1'), ('S_18x26_t5', 'config_RefVSR_s
        ('S2_16x24_t3', 'config_RefVSR_small_L1')]           # x2 SR: config.scale = 2 (matching_ksize 4, VGG19[0:7] matching)
 
 
+@pytest.mark.parametrize('spynet_hi_lo', [False, True])
 @pytest.mark.parametrize('tag,name', E2E)
-def test_stream_against_reference_fixture(dev, tag, name):
+def test_stream_against_reference_fixture(dev, tag, name, spynet_hi_lo):
+    """spynet_hi_lo=False: the default engine (plain fp16 weights in SPyNet's streamed 7x7 convs since round 3).
+    spynet_hi_lo=True (config.spynet_hi_lo / REFVSR_SPYNET_HILO=1): the exact hi + lo path, held to the tighter flow / confidence
+    bars it had before round 3 (the default's wider bars must not be the only golden comparison)."""
     from refvsr_amd.synth import window_indices
     g = load_golden('e2e_' + tag)
     t = int(g['t'])
     rb = int(g['reset_branch'])
-    net, cfg, sd = make_net(name, t, dev, reset=None if rb < 0 else rb, scale=int(g.get('scale', 4)))
+    from refvsr_amd import SRNet, get_config, make_state_dict, set_scale
+    cfg = get_config('p', 'm', name)
+    if int(g.get('scale', 4)) != 4:
+        set_scale(cfg, int(g.get('scale', 4)))
+    cfg.frame_num, cfg.save_sample, cfg.cache_windows = t, True, True
+    cfg.reset_branch = None if rb < 0 else rb
+    cfg.spynet_hi_lo = bool(spynet_hi_lo)                # read when the weights are packed
+    sd = make_state_dict(cfg, 1234)
+    net = SRNet(cfg).to(dev).eval()
+    net.load_state_dict(sd)
     lr, rf = g['lr'], g['ref']
     nframes = lr.shape[1]
     worst = 0.0
@@ -84,6 +97,8 @@ def test_stream_against_reference_fixture(dev, tag, name):
         # -- the carried confidence map is sampled with that flow -- conf 1.9e-4
         assert e_res < 1.2e-2 and psnr(res, want) > 60.0
         assert e_feat < 2.5e-2 and e_up < 2.1e-2 and e_conf < 4e-4 and e_flow < 1.3e-3
+        if spynet_hi_lo:                                 # the bars these streams had before round 3 (hi + lo measured: flow 3.7e-4)
+            assert e_flow < 5e-4 and e_conf < 2.5e-4, (e_flow, e_conf)
         for k, v in outs['eval_vis'].items():
             assert maxdiff(v.cpu(), g['ev_%s_%d' % (k, f)]) < 1e-3, k
         # the `vis` debugging samples (RefVSR.py:219-221,262-263,301-316): same keys as the reference, values for the streams
@@ -671,7 +686,11 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
     lr, rf, _ = make_clip(6, 32, 48, seed=3)
     get = lambda f: (lr[window_indices(f, 6, 3)], rf[window_indices(f, 6, 3)])
     ex, cfg = _make_exec(reset, name)
-    if wavefront:
+    if wavefront == 'cyclic':        # blocks of ONE frame dealt round-robin: a hand-off at every frame, three blocks per rank,
+        tim = {}                     # B1 chain on the second HIP stream behind per-frame events (the two-lane schedule)
+        res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=shard.partition_cyclic(6, world, 1), timings=tim)
+        assert tim['blocks'] == 3 and tim['handoff_messages'] == (3 if rank == 0 else 2)
+    elif wavefront:
         res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu')
     else:
         res = shard.run_sharded(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', aligned=aligned)
@@ -684,7 +703,8 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
                                                           (3, True, False, 'config_RefVSR_small_L1'),
                                                           (None, False, True, 'config_RefVSR_small_L1'),
                                                           (4, False, True, 'config_RefVSR_small_MFID'),
-                                                          ('keep', False, True, 'config_RefVSR_small_MFID')])
+                                                          ('keep', False, True, 'config_RefVSR_small_MFID'),
+                                                          (None, False, 'cyclic', 'config_RefVSR_small_L1')])
 def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront, name):
     """Frame sharding across two ranks (state hand-off as ONE packed fp16 buffer, the exchange-free reset-aligned
     partition, and the phase-A / phase-B wavefront with the early send -- also with a reset inside a shard, also on
@@ -704,7 +724,7 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront,
         p.start()
     got = {}
     for _ in range(2):
-        _, res = q.get(timeout=600)
+        _, res = q.get(timeout=200)
         got.update({f: torch.from_numpy(v) for f, v in res.items()})
     for p in procs:
         p.join(120)
@@ -805,3 +825,48 @@ def test_fused_warp_engine_matches_default(dev):
         ops.CONV24 = c24
     for a, b in zip(plain, fused):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name,size', [('config_RefVSR_small_L1', (64, 96)), ('config_RefVSR_MFID', (40, 56))])
+def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, size):
+    """The launches round 4 removed from a frame -- torch.cat + 2 -> 16 conv + bicubic x2 + torch.max of the confidence fusions
+    (refvsr_conf_alpha), the 2x flow map (refvsr_warp_nhwc16_up2), one SPyNet pass per flow (RefvsrConv.batch), the zero fills
+    -- do not change a single output value: the default engine against the engine with every one of them switched off
+    (the round-3 launch list), sequential and pipelined, across a reset_branch rollover."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 7, 5
+    lr, rf, _ = make_clip(nfr, size[0], size[1], seed=21)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    wl = [lr[w][None].contiguous() for w in wins]
+    wr = [rf[w][None].contiguous() for w in wins]
+    torch.cuda.synchronize()
+    for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH'):
+        monkeypatch.setenv(k, '1')
+    old, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
+    e = old.Network.ensure_engines(1, dev)[0]
+    assert not e.fuse_conf and not e.warp_up2 and not e.spynet_batch
+    want = [old(wl[f], wr[f], f == 0)['result'].clone() for f in range(nfr)]
+    for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH'):
+        monkeypatch.delenv(k)
+    new, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
+    e = new.Network.ensure_engines(1, dev)[0]
+    assert e.fuse_conf and e.warp_up2 and e.spynet_batch
+    for f in range(nfr):
+        assert torch.equal(new(wl[f], wr[f], f == 0)['result'], want[f]), 'frame %d differs (sequential)' % f
+    new.Network.reset()
+    new.Network.set_pipelined(True)
+    outs = [new(wl[f], wr[f], f == 0, frame_ids=wins[f], input_ready='materialised')['result'] for f in range(nfr)]
+    torch.cuda.synchronize()
+    for f in range(nfr):
+        assert torch.equal(outs[f], want[f]), 'frame %d differs (pipelined)' % f
+    # the head of the backward branch's first step (input conv + n blocks) on the preparation stream: load balance only
+    for nhead in (0, 7, 99):
+        net3, cfg3, _ = make_net(name, t, dev, reset=4, save_sample=False)
+        cfg3.bw_head_blocks = nhead
+        net3.Network.set_pipelined(True)
+        outs = [net3(wl[f], wr[f], f == 0, frame_ids=wins[f], input_ready='materialised')['result'] for f in range(nfr)]
+        torch.cuda.synchronize()
+        assert net3.Network.engine(0).bw_head_blocks == min(nhead, cfg3.num_blocks)
+        for f in range(nfr):
+            assert torch.equal(outs[f], want[f]), 'frame %d differs (pipelined, backward head of %d blocks on P)' % (f, nhead)

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from conftest import load_golden, maxdiff
 
 pytestmark = pytest.mark.gpu
+RB24_STORE_DEFAULT = 0            # csrc/resblock24.hip: REFVSR_RB24_STORE_DEFAULT
 
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'gpu_ops_report.txt')
 
@@ -979,3 +980,120 @@ def test_conv_channel_padding_is_zeroed(dev):
     assert y.shape == (38, 54, 40) and float(y[:, :, 36:].float().abs().max()) == 0.0
     want = F.pixel_shuffle(F.conv2d(x.half().float()[None], ws, bs, padding=1), 2)[0]
     assert rel(planar(y)[:36], want) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ round 4: fused launches
+def _rand_conv_weights(cout, cins, seed, dev):
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(cout, sum(cins), 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    return ops.ConvWeights(pack_conv(w, b, cins), dev)
+
+
+@pytest.mark.parametrize('cout', [24, 48])
+@pytest.mark.parametrize('h,w', [(8, 32), (19, 45), (40, 70), (135, 240)])
+def test_conf_alpha_is_bit_identical_to_the_separate_launches(dev, cout, h, w):
+    """refvsr_conf_alpha (cat + [bicubic x2 + clamp] + 2 -> 16 conv + 16 -> C conv [+ max] in one launch, RefVSR.py:47-52,130,
+    141-142,147,107-109) against torch.cat + refvsr_resize + refvsr_conv_direct_f32 + refvsr_conv24/48 + refvsr_max2: the same
+    fp32 FMA orders and fp16 roundings, so EVERY element must be equal -- tiles at all four frame borders, partial tiles, maps
+    smaller than a tile, 24 and 48 output channels."""
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(100 * h + w + cout)
+    ca = torch.rand(1, h, w, generator=g).to(dev)
+    cb = (torch.rand(1, h, w, generator=g) * 1.2 - 0.1).to(dev)          # values outside [0, 1]: the clamp of the x2 path matters
+    w0 = (torch.randn(16, 2, 3, 3, generator=g) * 0.4).to(dev)
+    b0 = (torch.randn(16, generator=g) * 0.1).to(dev)
+    cw = _rand_conv_weights(cout, [16], 7 + cout, dev)
+    assert ops.conf_alpha_ok(cw)
+    pair = torch.cat([ca, cb], 0)
+    # up = 1 (+ the max by-product)
+    a16 = ops.conv_direct(pair, w0, b0, act=0.2, nhwc16_out=True)
+    want = ops.conv(cw, a16, act=0.2)
+    got, gmax = ops.conf_alpha(ca, cb, 1, w0, b0, cw, want_max=True)
+    assert got.shape == want.shape and torch.equal(got, want), 'up=1: %d elements differ' % int((got != want).sum())
+    assert torch.equal(gmax, ops.max2(ca, cb))
+    # up = 2
+    pair_up = ops.bicubic_scale(pair, 2, clamp01=True)
+    a16 = ops.conv_direct(pair_up, w0, b0, act=0.2, nhwc16_out=True)
+    want = ops.conv(cw, a16, act=0.2)
+    got = ops.conf_alpha(ca, cb, 2, w0, b0, cw)
+    assert got.shape == want.shape and torch.equal(got, want), 'up=2: %d elements differ' % int((got != want).sum())
+    report('conf_alpha %dx%d C=%d' % (h, w, cout), equal=1)
+
+
+@pytest.mark.parametrize('h,w,hin,win', [(17, 29, 34, 58), (64, 96, 128, 192), (33, 40, 33, 40)])
+def test_warp_up2_is_bit_identical(dev, h, w, hin, win):
+    """refvsr_warp_nhwc16_up2 == refvsr_resize(BILINEAR_AC x2, * 2) + refvsr_warp_nhwc16 (RefVSR.py:220,254,259), bit for bit;
+    the last case is the :254 quirk (an LR-size map sampled on the 2x grid)."""
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    x = nhwc(torch.randn(24, hin, win, generator=g), dev)
+    fl = (torch.randn(2, h, w, generator=g) * 3).to(dev)
+    want = ops.warp_nhwc16(x, ops.flow_up2(fl))
+    got = ops.warp_nhwc16_up2(x, fl)
+    assert got.shape == (2 * h, 2 * w, 24) and torch.equal(got, want)
+
+
+def test_batched_conv_and_spynet_level_input_equal_the_single_launches(dev):
+    """RefvsrConv.batch (blockIdx.y = image) and refvsr_spynet_level_input_batch: image b of the batched launch equals the
+    single-image launch bit for bit -- streamed 7x7 (plain fp16 and hi + lo, mt = 1 and 2), resident 7x7 8 -> 32, the planar
+    flow head with its planar residual."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(5)
+    for (co, ci, hh, ww, kw) in [(32, 8, 18, 30, {}), (64, 32, 18, 30, dict(hi_only=True)), (64, 32, 9, 15, dict(mt=1, hi_only=True)),
+                                 (32, 64, 36, 60, {}), (16, 32, 40, 72, dict(hi_only=True))]:
+        w_ = torch.randn(co, ci, 7, 7, generator=g) * 0.05
+        b_ = torch.randn(co, generator=g) * 0.1
+        cw = ops.ConvWeights(pack_conv(w_, b_, [ci], **kw), dev)
+        xs = [nhwc(torch.randn(ci, hh, ww, generator=g), dev) for _ in range(3)]
+        got = ops.conv(cw, torch.stack(xs, 0).contiguous(), act=0.0, batch=3)
+        for b in range(3):
+            assert torch.equal(got[b], ops.conv(cw, xs[b], act=0.0)), (co, ci, b)
+    w_ = torch.randn(2, 16, 7, 7, generator=g) * 0.05
+    cw = ops.ConvWeights(pack_conv(w_, torch.randn(2, generator=g), [16]), dev)
+    xs = [nhwc(torch.randn(16, 20, 36, generator=g), dev) for _ in range(2)]
+    rp = [torch.randn(2, 20, 36, generator=g).to(dev) for _ in range(2)]
+    got = ops.conv(cw, torch.stack(xs, 0).contiguous(), planar_out=True, res_planar=torch.stack(rp, 0).contiguous(), batch=2)
+    for b in range(2):
+        assert torch.equal(got[b], ops.conv(cw, xs[b], planar_out=True, res_planar=rp[b]))
+    refs = [torch.rand(3, 20, 36, generator=g).to(dev) for _ in range(2)]
+    sups = [torch.rand(3, 20, 36, generator=g).to(dev) for _ in range(2)]
+    fp = (torch.randn(2, 2, 10, 18, generator=g) * 2).to(dev)
+    for flow_prev in (None, fp):
+        x8, fup = ops.spynet_level_input_batch(refs, sups, flow_prev)
+        for b in range(2):
+            x1, f1 = ops.spynet_level_input(refs[b], sups[b], None if flow_prev is None else flow_prev[b].contiguous())
+            assert torch.equal(x8[b], x1) and torch.equal(fup[b], f1)
+
+
+@pytest.mark.parametrize('h,w', [(19, 45), (64, 96), (135, 240)])
+def test_resblock24_store_modes_are_bit_identical(dev, h, w):
+    """refvsr_set_resblock24_store: 16-byte stores after the v_permlane16_swap exchange (1) and their write-through form (2)
+    write exactly the bytes of the 8-byte stores (0) -- border tiles, partial tiles, ReLU and leaky blocks, 8- and 16-wave shapes."""
+    from refvsr_amd import hip, ops
+    g = torch.Generator().manual_seed(h + w)
+    raw = []
+    for _ in range(3):
+        ws = [torch.randn(24, 24, 3, 3, generator=g) / (24 * 9) ** 0.5 for _ in range(2)]
+        bs = [torch.randn(24, generator=g) * 0.1 for _ in range(2)]
+        raw.append(((ws[0], bs[0]), (ws[1], bs[1])))
+    ch = ops.Resblock24Chain(raw, dev)
+    x = nhwc(torch.randn(24, h, w, generator=g), dev)
+    lib = hip.lib()
+    try:
+        for waves in (8, 16):
+            lib.refvsr_set_resblock24_waves(waves)
+            for act in (0.0, 0.2):
+                lib.refvsr_set_resblock24_store(0)
+                want = ops.resblock24_chain(ch, x, act)
+                for mode in (1, 2):
+                    lib.refvsr_set_resblock24_store(mode)
+                    got = ops.resblock24_chain(ch, x, act)
+                    assert torch.equal(got, want), 'store mode %d, %d waves, act %.1f: %d elements differ' % (mode, waves, act, int((got != want).sum()))
+    finally:
+        lib.refvsr_set_resblock24_waves(0)
+        assert lib.refvsr_set_resblock24_store(7) != 0                      # rejected, mode unchanged
+        lib.refvsr_set_resblock24_store(int(os.environ.get('REFVSR_RB24_STORE', str(RB24_STORE_DEFAULT))))

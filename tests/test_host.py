@@ -185,7 +185,7 @@ def test_conv_shuffle2_row_groups(c):
     for z in range(nz):
         R = np.arange(48)
         rows = 4 * (R % 24) + 2 * z + R // 24 if c == 24 else 4 * R + z
-        assert torch.equal(blobs[z * per:(z + 1) * per], pack_conv24(w[rows], b[rows], [c]))
+        assert torch.equal(blobs[z * per:(z + 1) * per], pack_conv24(w[rows], b[rows], [c], shuffle_group=True))
         y = F.conv2d(x, w[rows], b[rows], padding=1)[0]                      # what the kernel's accumulators of group z hold
         for r in range(48):
             dy, dx, ch = (z, r // 24, r % 24) if c == 24 else (z >> 1, z & 1, r)
@@ -291,11 +291,31 @@ def test_wavefront_partitions_and_makespan_model():
     s_b, _ = shard.predicted_speedup(64, 8, shard.partition(64, 8), 9, ta, tb1, tb2, 0.3)
     s_n, _ = shard.predicted_speedup(64, 8, shard.partition(64, 8), None, ta, tb1, tb2, 0.3)
     s_c, _ = shard.predicted_speedup(64, 8, ch, None, ta, tb1, tb2, 0.3)
-    assert abs(s_h - 64 / 9.0) < 0.02                    # exchange-free shards of <= 9 frames: 7.1 x
-    assert 4.0 < s_b < 4.3 and abs(s_b - s_n) < 1e-9     # a hand-off at every boundary: the B1 chain of all 64 frames
+    assert abs(s_h - 64 / 9.0) < 0.03                    # exchange-free shards of <= 9 frames: 7.1 x
+    assert 4.0 < s_b < 4.3 and abs(s_b - s_n) < 0.02     # a hand-off at every boundary: the B1 chain of all 64 frames
     assert s_c > 4.7 and s_c > s_n + 0.6                 # growing shards: the chain arrives when phase A ends (4.76 x)
+    # round 4: block lists, the two-lane (interleaved) order, the cold window of a block start
+    cyc = shard.partition_cyclic(64, 8, 3)
+    assert cyc[:3] == [(0, 3, 0), (3, 6, 1), (6, 9, 2)] and cyc[-1] == (63, 64, 5) and len(cyc) == 22
+    assert shard.as_blocks(ch) == [(a, b, r) for r, (a, b) in enumerate(ch)]
+    cold = 4.9
+    s_cyc, _ = shard.predicted_speedup(64, 8, cyc, None, ta, tb1, tb2, 0.3, cold)
+    s_cyc_old, _ = shard.predicted_speedup(64, 8, cyc, None, ta, tb1, tb2, 0.3, cold, interleaved=False)
+    s_grow_cold, _ = shard.predicted_speedup(64, 8, ch, None, ta, tb1, tb2, 0.3, cold)
+    assert 5.2 < s_cyc < 5.5 and s_cyc_old < 3.7         # B1(f) as soon as ITS phase A is done: what makes small blocks pay
+    assert 4.4 < s_grow_cold < 4.6                       # the best contiguous partition under the same cost model
+    blocks, sp_, name = shard.choose_partition(64, 8, None, ta, tb1, tb2, 0.3, cold)
+    assert name == 'block_cyclic_3' and abs(sp_ - s_cyc) < 1e-9 and blocks == shard.as_blocks(cyc)
+    blocks, sp_, name = shard.choose_partition(64, 8, 9, ta, tb1, tb2, 0.3, cold)
+    assert name == 'hybrid_reset_aligned' and 6.4 < sp_ < 6.8      # (7.1 x without the cold block starts)
+    # every partition, every order: each frame's three phases run exactly once (the simulation terminates)
+    for parts_ in (shard.partition(13, 4), shard.partition_cyclic(13, 4, 2), shard.partition_chain(13, 4)):
+        for rb in (None, 4):
+            for il in (True, False):
+                sp2, span = shard.predicted_speedup(13, 4, parts_, rb, 2.0, 0.5, 0.25, 0.1, 1.0, il)
+                assert 1.0 <= sp2 <= 4.0 + 1e-9 and span >= 13 * 2.75 / 4 - 1e-9
     one, _ = shard.predicted_speedup(64, 1, [(0, 64)], 9, ta, tb1, tb2)
-    assert abs(one - 1.0) < 1e-12
+    assert abs(one - 1.0) < 2e-3                         # (time-stepped simulation: 1 / 2000 of a frame per step)
 
 
 def test_block_chain_applies_blocks_in_order(monkeypatch):
@@ -602,3 +622,47 @@ def test_conv24_blob_reproduces_conv(srcs, cout):
                 for m in range(cout // 16):
                     got[16 * m:16 * m + 16, oy, ox] = acc[m]
     assert np.abs(got - want).max() < 2e-5
+
+
+def test_conv24_ok_equals_the_library_predicates():
+    """packing.conv24_ok (which decides whether ConvWeights builds a specialised blob) must accept exactly the shapes
+    refvsr_conv{24,32,48}_supported accept -- a plain 24 -> 48 conv is NOT one of them (only the row groups of the pixel-shuffle
+    conv are packed that way, internally)."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import conv24_ok
+    lib = hip.lib()
+    sup = {24: lib.refvsr_conv24_supported, 32: lib.refvsr_conv32_supported, 48: lib.refvsr_conv48_supported}
+    for cout in (16, 24, 32, 48, 64):
+        for c0 in (3, 8, 16, 24, 32, 36, 48, 64):
+            for c1 in (0, 8, 24, 48):
+                srcs = [c0] + ([c1] if c1 else [])
+                p0 = (c0 + 7) // 8 * 8
+                want = bool(cout in sup and sup[cout](p0, c1))
+                assert conv24_ok((cout, c0 + c1, 3, 3), srcs) == want, (cout, srcs)
+    assert not conv24_ok((48, 24, 3, 3), [24]) and conv24_ok((48, 24, 3, 3), [24], shuffle_group=True)
+    assert not conv24_ok((24, 24, 5, 5), [24]) and not conv24_ok((24, 24, 3, 3), [24], f32=True)
+
+
+def test_partition_chain_gives_every_rank_a_frame():
+    """no empty shards for nframes >= world, sizes non-decreasing along the chain, every frame exactly once."""
+    from refvsr_amd import shard
+    for nframes in (4, 6, 8, 9, 12, 13, 20, 64, 100):
+        for world in (2, 4, 6, 8, 12):
+            for ratio in (0.05, 0.165, 0.5, 1.0, 2.0):
+                parts = shard.partition_chain(nframes, world, ratio)
+                sizes = [b - a for a, b in parts]
+                assert parts[0][0] == 0 and parts[-1][1] == nframes and all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+                if nframes >= world:
+                    assert min(sizes) >= 1, (nframes, world, ratio, sizes)
+                    assert sizes == sorted(sizes), (nframes, world, ratio, sizes)
+    assert [b - a for a, b in shard.partition_chain(64, 8, 0.165)] == [4, 5, 6, 7, 8, 10, 11, 13]
+
+
+def test_env_flag_parsing(monkeypatch):
+    """NAME=0 switches a knob off (string truthiness used to switch it ON)."""
+    from refvsr_amd.knobs import env_flag
+    monkeypatch.delenv('REFVSR_TEST_KNOB', raising=False)
+    assert env_flag('REFVSR_TEST_KNOB') is False and env_flag('REFVSR_TEST_KNOB', True) is True
+    for v, want in (('1', True), ('0', False), ('', False), ('false', False), ('off', False), ('yes', True)):
+        monkeypatch.setenv('REFVSR_TEST_KNOB', v)
+        assert env_flag('REFVSR_TEST_KNOB') is want, v

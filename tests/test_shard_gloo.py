@@ -45,6 +45,58 @@ class _ExecNoSplit(_Exec):
     phase_b2 = property(lambda self: (_ for _ in ()).throw(AttributeError('phase_b2')))
 
 
+class _ExecLanes(_Exec):
+    """An executor that offers run_wavefront's two-lane hooks (EngineExecutor: two HIP streams + events) and records what ran
+    where: phase A and B2 must be issued on lane a, the B1 chain and the hand-off on lane b, every B1(f) behind wait('a', f) and
+    every B2(f) behind wait('b1', f)."""
+
+    def __init__(self, cfg, sd):
+        _Exec.__init__(self, cfg, sd)
+        self.lane, self.log, self.marks = None, [], set()
+
+    class _Lane(object):
+        def __init__(self, ex, name):
+            self.ex, self.name = ex, name
+
+        def __enter__(self):
+            self.prev, self.ex.lane = self.ex.lane, self.name
+
+        def __exit__(self, *exc):
+            self.ex.lane = self.prev
+            return False
+
+    def lane_a(self):
+        return self._Lane(self, 'a')
+
+    def lane_b(self):
+        return self._Lane(self, 'b')
+
+    def mark(self, what, f):
+        self.marks.add((what, f))
+
+    def wait(self, what, f):
+        assert (what, f) in self.marks, 'wait for a mark that was never recorded: %s %d' % (what, f)
+        self.log.append(('wait', what, f, self.lane))
+
+    def phase_a(self, lrs, refs, f, hint):
+        assert self.lane == 'a'
+        h = _Exec.phase_a(self, lrs, refs, f, hint)
+        h['_frame'] = f
+        return h
+
+    def phase_b1(self, handle, first):
+        assert self.lane == 'b' and self.log and self.log[-1][:3] == ('wait', 'a', handle['_frame'])
+        return _Exec.phase_b1(self, handle, first)
+
+    def phase_b2(self, handle):
+        assert self.lane == 'a' and self.log[-1][:3] == ('wait', 'b1', handle['_frame'])
+        return _Exec.phase_b2(self, handle)
+
+    def import_state(self, st):
+        assert self.lane == 'b'
+        _Exec.import_state(self, st)
+
+
 def _setup(reset, nframes=6, name='config_RefVSR_small_L1'):
     from refvsr_amd import get_config, make_state_dict
     from refvsr_amd.synth import make_clip, window_indices
@@ -70,6 +122,14 @@ def _worker(rank, world, port, reset, aligned, q, wavefront=False, nframes=6, na
     if wavefront == 'hybrid':
         parts = shard.partition_hybrid(nframes, world, reset)
         res = shard.run_wavefront(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts)
+    elif wavefront == 'cyclic':                            # restart-free clip, block-cyclic partition: several blocks per rank
+        parts = shard.partition_cyclic(nframes, world, 2)
+        res = shard.run_wavefront(_ExecLanes(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts)
+    elif wavefront == 'growing':                           # restart-free clip, growing contiguous shards
+        parts = shard.partition_chain(nframes, world)
+        tim = {}
+        res = shard.run_wavefront(_ExecLanes(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim)
+        assert tim['blocks'] == 1 and tim['handoff_messages'] == (1 if rank + 1 < world else 0)
     elif wavefront == 'nosplit':
         res = shard.run_wavefront(_ExecNoSplit(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu')
     elif wavefront:
@@ -164,3 +224,18 @@ def test_world8_64_frame_clip_reset9_aligned():
     8 ranks, unbalanced tail), no communication at all."""
     got = _run(reset='keep', aligned=True, wavefront=False, world=8, nframes=64, name='config_RefVSR_small_MFID')
     assert sorted(got) == list(range(64))
+
+
+def test_world8_restart_free_clip_block_cyclic_and_growing_partitions():
+    """BASELINE configs[4]'s regime (reset_branch = None: a hand-off at EVERY block boundary) on 8 ranks: the block-cyclic
+    partition (blocks of 2 frames dealt round-robin -- ranks own two blocks, the chain visits every rank twice) and the
+    growing contiguous shards (shard.partition_chain), through the two-lane hooks of run_wavefront; bit-identical to the
+    sequential stream."""
+    from refvsr_amd import shard
+    blocks = shard.partition_cyclic(26, 8, 2)
+    assert len(blocks) == 13 and [r for _, _, r in blocks] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4] and blocks[-1][:2] == (24, 26)
+    got = _run(reset=None, aligned=False, wavefront='cyclic', world=8, nframes=26)
+    assert sorted(got) == list(range(26))
+    assert [b - a for a, b in shard.partition_chain(26, 8)] == sorted(b - a for a, b in shard.partition_chain(26, 8))
+    got = _run(reset=None, aligned=False, wavefront='growing', world=8, nframes=26)
+    assert sorted(got) == list(range(26))

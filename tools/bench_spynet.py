@@ -45,3 +45,23 @@ d = float((full.cpu() - torch.load(cmp_)).abs().max()) if cmp_ and os.path.exist
 print('spynet flow 270x480 [%s%s]: %.1f us per flow (min of 5x10; all %s) | vs reference fixture %.2e px | vs dumped flow %.2e px (|flow| max %.2f)'
       % ('hi+lo' if os.environ.get('REFVSR_SPYNET_HILO') == '1' else 'hi only', ', no nw8' if os.environ.get('REFVSR_CONV_NO_NW8') else '',
          min(ts), ' '.join('%.0f' % t for t in ts), err, d, float(full.abs().max())))
+# round 4: the two flows a frame needs as ONE batched pass (Engine.flows: RefvsrConv.batch, refvsr_spynet_level_input_batch)
+fc = FrameCtx(lr[1].to(dev), lr[1].to(dev))
+pairs = [(fa, fb), (fb, fa)]
+eng.flow_cache.clear()
+both = eng.flows(pairs)
+torch.cuda.synchronize()
+eng.flow_cache.clear()
+single = [eng.flow(x, y) for x, y in pairs]
+same = all(torch.equal(p, q) for p, q in zip(both, single))
+ts2 = []
+for _ in range(5):
+    e0.record()
+    for _ in range(10):
+        eng.flow_cache.clear()
+        eng.flows(pairs)
+    e1.record()
+    torch.cuda.synchronize()
+    ts2.append(e0.elapsed_time(e1) / 10 * 1e3)
+print('spynet two flows 270x480 batched: %.1f us per PAIR of flows (min of 5x10; all %s) = %.1f us per flow; equal to the single passes: %s'
+      % (min(ts2), ' '.join('%.0f' % t for t in ts2), min(ts2) / 2, same))
