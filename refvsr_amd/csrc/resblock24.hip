@@ -35,7 +35,7 @@
 #include "common.h"
 
 #ifndef REFVSR_RB24_STORE_DEFAULT
-#define REFVSR_RB24_STORE_DEFAULT 0
+#define REFVSR_RB24_STORE_DEFAULT 1
 #endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -160,6 +160,9 @@ __device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
 // (the store phase is issue bound: 8 waves x 6 stores of 8 bytes per tile).  2: the same as write-through stores (sc1): the tile is
 // on its way to memory while the workgroup is still running instead of being written back by the end-of-kernel release (every
 // workgroup of an LR launch ends at about the same time; the next launch reads the map through the fabric anyway).
+// Measured (profiles/r04_resblock_microbench.txt, us per block 0 / 1 / 2): LR 9.17 / 9.19 / 9.47, 2x 28.73 / 27.80 / 29.68, HR 103.3 /
+// 102.2 / 107.6; in the frame 199.2 / 199.5 / 197.1 frames/s (profiles/r04_knobs_ab.txt) -> 1 is the default: the stores were not what
+// an LR launch waits for, and write-through stores are slower than letting the L2 write the tile back.
 template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 4 ? 2 : 4, NWV == 4 ? 2 : 4))) void resblock24_kernel(RB24Args p) {
     static_assert((TH == 8 && (NWV == 4 || NWV == 8)) || (TH == 16 && NWV == 16), "tile height / waves");

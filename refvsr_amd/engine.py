@@ -191,9 +191,11 @@ class Engine(object):
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
         # pipelined mode: the backward branch restarts from zeros at the window's LAST frame (RefVSR.py:211-214), so the first
         # layers of that step are a function of that frame alone: its input conv + the first `bw_head_blocks` residual blocks run
-        # with the frame's preparation on the P stream -- load balance between the two internal streams (results identical)
+        # with the frame's preparation on the P stream -- load balance between the two internal streams (results identical).
+        # Measured (profiles/r04_knobs_ab.txt, same box, two rounds of five passes each): off 199.2 / 199.2 frames/s, 0 blocks 200.0 /
+        # 199.5, 12 blocks 205.8 / 206.2, all 24 blocks 203.6 / 203.6 -> 12 (M 4.66 ms per call, P + F 4.63).  -1 = off.
         self.bw_head_blocks = min(self.nb, max(-1, int(getattr(config, 'bw_head_blocks', None) if getattr(config, 'bw_head_blocks', None) is not None
-                                                         else os.environ.get('REFVSR_BW_HEAD_BLOCKS', '-1'))))
+                                                         else os.environ.get('REFVSR_BW_HEAD_BLOCKS', '12'))))
         self.warp_up2 = not env_flag('REFVSR_NO_WARP_UP2')          # A/B knob: flow_up2 as its own launch + 2x flow map (round 3)
         self.fuse_conf = not env_flag('REFVSR_NO_FUSE_CONF')        # A/B knob: confidence fusions as separate launches (round 3)
         self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3

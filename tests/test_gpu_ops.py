@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from conftest import load_golden, maxdiff
 
 pytestmark = pytest.mark.gpu
-RB24_STORE_DEFAULT = 0            # csrc/resblock24.hip: REFVSR_RB24_STORE_DEFAULT
+RB24_STORE_DEFAULT = 1            # csrc/resblock24.hip: REFVSR_RB24_STORE_DEFAULT
 
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'gpu_ops_report.txt')
 
