@@ -144,6 +144,16 @@ int refvsr_resblock24_kblock(int s, int q);
  * waves on 16 x 32 tiles (one workgroup per CU) when the map has at least four 8 x 32 tiles per CU; 4 | 8 | 16 force a
  * shape.  Results do not depend on it (bit-identical). */
 int refvsr_set_resblock24_waves(int waves);
+/* The 48-channel fused block (ABI 10; mid_channels = 48: configs/config_RefVSR_{L1,MFID,MFID_8K}.py, 30 ResidualBlockNoBN per
+ * branch + the ResBlocks of the ResLists): out = x + conv2(act(conv1 x)) in ONE launch per block.  One conv's 84 KB of hi + lo
+ * fragments is resident at a time; the two sets swap per 8 x 32-pixel tile by LDS-DMA under the phases that do not read them
+ * (csrc/resblock48.hip).  Block i's parameters are ONE blob of REFVSR_RESBLOCK48_BLOB_BYTES at blobs + i * blob_stride:
+ * [conv1: 14 K-steps x 6 fragments x 64 lanes x 8 halfs][conv2: same][b1: 64 floats, 48.. = 0][b2: 64 floats] -- the fragment
+ * parts of the two refvsr_conv48 blobs (K-blocks by refvsr_conv24_kblock(6, s, q)); refvsr_amd/packing.py:pack_resblock48.
+ * Same arithmetic as two refvsr_conv48 launches (bit-identical: same K order, same fp16 rounding of the intermediate). */
+#define REFVSR_RESBLOCK48_BLOB_BYTES 172544
+int refvsr_resblock48_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
+                            void* scratch0, void* scratch1, void* out, void* stream);
 /* Tuning knob: how the 24-channel kernel stores its output tile.  0: 8-byte stores (one per lane and pixel group); 1: 16-byte
  * stores after a v_permlane16_swap exchange between neighbouring lane rows (half the store instructions); 2: the same as
  * write-through (sc1) stores.  Results do not depend on it (bit-identical). */

@@ -181,6 +181,8 @@ class Engine(object):
         self.fuse_resblocks = (bool(getattr(config, 'fuse_resblocks', True)) and ops.resblock_fits(self.C)
                                and not env_flag('REFVSR_NO_FUSE'))
         self.rb24 = not env_flag('REFVSR_NO_RB24')               # A/B knob: the generic lean kernel for C = 24 as well
+        self.rb48 = (bool(getattr(config, 'fuse_resblocks', True)) and not env_flag('REFVSR_NO_FUSE')
+                     and not env_flag('REFVSR_NO_RB48'))                 # A/B knob: C = 48 blocks as two refvsr_conv48 launches (round 3)
         # inter-frame warp fused into its consumer's tile staging (RefvsrConv.warp_*; conv kernels with 16-row pairs:
         # mid_channels = 24 / 32).  Bit-identical to warp + conv (tests/test_gpu_ops.py), but OPT-IN: measured on MI355X it is
         # slower (169.3 vs 176.4 frames/s, profiles/r03_fused_warp_ab.txt) -- the gather makes the tile staging a chain of
@@ -354,6 +356,16 @@ class Engine(object):
             e1.record()
             self.chain_events.append((e0, e1, len(pairs), x.shape[0], x.shape[1]))
             return out
+        if (self.rb48 and x.shape[2] == 48 and pairs[0][0].raw is not None and 0.0 <= act <= 1.0 and
+                x.shape[0] * x.shape[1] * 96 < 2 ** 31):
+            # mid_channels = 48 (RefVSR / RefVSR_MFID / RefVSR_MFID_8K): one launch per block, the two 84 KB weight sets swap
+            # per tile through LDS-DMA (csrc/resblock48.hip); the intermediate map never reaches HBM
+            chains = self.W.chains
+            key = ('rb48',) + tuple(id(c1) for c1, _ in pairs)
+            ch = chains.get(key)
+            if ch is None:
+                ch = chains[key] = ops.Resblock48Chain(pairs, x.device)
+            return ops.resblock48_chain(ch, x, act)
         if self.fuse_resblocks and self.chain_calls and ops.resblock_chain_ok(x.shape[2]):
             # one library call per run (same launches, same results): 156 of the ~330 launches of a frame
             chains = self.W.chains

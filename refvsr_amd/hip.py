@@ -14,6 +14,7 @@ RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
 ABI_VERSION = 10
 RESBLOCK24_BLOB_BYTES = 43264
+RESBLOCK48_BLOB_BYTES = 172544
 
 
 class RefvsrConv(C.Structure):
@@ -57,6 +58,7 @@ SIGNATURES = {
     'refvsr_resblock_lean': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
     'refvsr_resblock_chain': [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
     'refvsr_resblock24_chain': [_P, _I, _I, _I, _P, _Z, _F, _P, _P, _P, _P],
+    'refvsr_resblock48_chain': [_P, _I, _I, _I, _P, _Z, _F, _P, _P, _P, _P],
     'refvsr_resblock24_kblock': [_I, _I],        # returns the packed K-block, not a status
     'refvsr_set_resblock24_waves': [_I],
     'refvsr_set_resblock24_store': [_I],

@@ -363,6 +363,35 @@ def resblock24_chain(chain, x, act):
     return out
 
 
+class Resblock48Chain(object):
+    """A run of 48-channel fused blocks for refvsr_resblock48_chain: one device buffer [n, 172544] of per-block blobs
+    (packing.pack_resblock48).  pairs: [(conv1, conv2)] ConvWeights whose packer kept the raw fp32 weights, or raw tensors."""
+
+    def __init__(self, pairs, device):
+        from .packing import pack_resblock48
+        blobs = []
+        for a, b in pairs:
+            (w1, b1), (w2, b2) = (a.raw if isinstance(a, ConvWeights) else a), (b.raw if isinstance(b, ConvWeights) else b)
+            blobs.append(pack_resblock48(w1, b1, w2, b2))
+        self.n = len(blobs)
+        self.blobs = torch.stack(blobs, 0).to(device).contiguous()
+        self.stride = self.blobs.shape[1]
+        assert self.stride == hip.RESBLOCK48_BLOB_BYTES and self.blobs.data_ptr() % 16 == 0
+
+
+def resblock48_chain(chain, x, act):
+    """refvsr_resblock48_chain: chain.n fused 48-channel blocks x <- x + conv2(act(conv1 x)), one launch per block."""
+    _nhwc(x)
+    h, w, c = x.shape
+    assert c == 48
+    out = torch.empty_like(x)
+    s0 = torch.empty_like(x) if chain.n >= 2 else None
+    s1 = torch.empty_like(x) if chain.n >= 3 else None
+    hip.check(hip.lib().refvsr_resblock48_chain(_ptr(x), h, w, chain.n, _ptr(chain.blobs), chain.stride, act, _ptr(s0), _ptr(s1),
+                                                _ptr(out), _stream()), 'resblock48_chain')
+    return out
+
+
 def resblock_chain_ok(c):
     _apply_resblock_knobs()
     return RESBLOCK_KERNEL == 'lean' and bool(hip.lib().refvsr_resblock_lean_fits(int(c)))

@@ -225,6 +225,24 @@ def c24_kblock(ncg, s, q):
     raise ValueError(ncg)
 
 
+RB48_WB = 14 * 6 * 1024                       # fragment bytes of one 48 -> 48 conv (csrc/resblock48.hip)
+RB48_BLOB = 2 * RB48_WB + 512
+
+
+def pack_resblock48(w1, b1, w2, b2):
+    """One fused 48-channel block -> uint8 [172544] for refvsr_resblock48_chain: the fragment parts of the two refvsr_conv48 blobs
+    (pack_conv24: [14 K-steps][6 fragments = hi | lo of output channels 0-15, 16-31, 32-47][64 lanes][8 halfs]) back to back, then
+    b1 and b2 as 64 floats each (48.. = 0)."""
+    out = np.zeros(RB48_BLOB, np.uint8)
+    for i, (w, b) in enumerate(((w1, b1), (w2, b2))):
+        assert tuple(w.shape) == (48, 48, 3, 3), tuple(w.shape)
+        blob = pack_conv24(w, b, [48]).numpy()
+        assert blob.size == RB48_WB + 256
+        out[i * RB48_WB:(i + 1) * RB48_WB] = blob[:RB48_WB]
+        out[2 * RB48_WB + i * 256:2 * RB48_WB + (i + 1) * 256] = blob[RB48_WB:]
+    return torch.from_numpy(out)
+
+
 def conv24_ok(w_shape, src_channels, shuffle=False, f32=False, shuffle_group=False):
     """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 / 32 / 48 output channels, the listed inputs --
     the same lists as the library's refvsr_conv{24,32,48}_supported (pinned against each other in tests/test_capi.py).

@@ -830,8 +830,9 @@ def test_fused_warp_engine_matches_default(dev):
 @pytest.mark.parametrize('name,size', [('config_RefVSR_small_L1', (64, 96)), ('config_RefVSR_MFID', (40, 56))])
 def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, size):
     """The launches round 4 removed from a frame -- torch.cat + 2 -> 16 conv + bicubic x2 + torch.max of the confidence fusions
-    (refvsr_conf_alpha), the 2x flow map (refvsr_warp_nhwc16_up2), one SPyNet pass per flow (RefvsrConv.batch), the zero fills
-    -- do not change a single output value: the default engine against the engine with every one of them switched off
+    (refvsr_conf_alpha), the 2x flow map (refvsr_warp_nhwc16_up2), one SPyNet pass per flow (RefvsrConv.batch), the zero fills,
+    and for mid_channels = 48 the second launch of every residual block (refvsr_resblock48_chain) -- do not change a single
+    output value: the default engine against the engine with every one of them switched off
     (the round-3 launch list), sequential and pipelined, across a reset_branch rollover."""
     from refvsr_amd.synth import make_clip, window_indices
     nfr, t = 7, 5
@@ -841,17 +842,17 @@ def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, 
     wl = [lr[w][None].contiguous() for w in wins]
     wr = [rf[w][None].contiguous() for w in wins]
     torch.cuda.synchronize()
-    for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH'):
+    for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH', 'REFVSR_NO_RB48'):
         monkeypatch.setenv(k, '1')
     old, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
     e = old.Network.ensure_engines(1, dev)[0]
-    assert not e.fuse_conf and not e.warp_up2 and not e.spynet_batch
+    assert not e.fuse_conf and not e.warp_up2 and not e.spynet_batch and not e.rb48
     want = [old(wl[f], wr[f], f == 0)['result'].clone() for f in range(nfr)]
-    for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH'):
+    for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH', 'REFVSR_NO_RB48'):
         monkeypatch.delenv(k)
     new, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
     e = new.Network.ensure_engines(1, dev)[0]
-    assert e.fuse_conf and e.warp_up2 and e.spynet_batch
+    assert e.fuse_conf and e.warp_up2 and e.spynet_batch and e.rb48
     for f in range(nfr):
         assert torch.equal(new(wl[f], wr[f], f == 0)['result'], want[f]), 'frame %d differs (sequential)' % f
     new.Network.reset()

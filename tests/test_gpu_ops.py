@@ -1097,3 +1097,36 @@ def test_resblock24_store_modes_are_bit_identical(dev, h, w):
         lib.refvsr_set_resblock24_waves(0)
         assert lib.refvsr_set_resblock24_store(7) != 0                      # rejected, mode unchanged
         lib.refvsr_set_resblock24_store(int(os.environ.get('REFVSR_RB24_STORE', str(RB24_STORE_DEFAULT))))
+
+
+@pytest.mark.parametrize('h,w', [(8, 32), (19, 45), (64, 96), (135, 240)])
+def test_resblock48_chain_equals_two_conv48_launches(dev, h, w):
+    """refvsr_resblock48_chain (one launch per block, the two 84 KB weight sets swapped per tile by LDS-DMA, intermediate tile
+    in LDS) against the round-3 path -- refvsr_conv48 with the activation, refvsr_conv48 with the residual -- on the same
+    packed weights: same K order, same fp16 rounding of the intermediate, residual added after the accumulation => every
+    element equal.  Border tiles on all sides, partial tiles, a map of one tile, persistent workgroups with two tiles
+    (135 x 240 has 136 tiles; 270 x 480 runs in the end-to-end tests), ReLU and leaky blocks, chains of three."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(48 * h + w)
+    pairs = []
+    for _ in range(3):
+        cws = []
+        for _ in range(2):
+            w_ = torch.randn(48, 48, 3, 3, generator=g) / (48 * 9) ** 0.5
+            b_ = torch.randn(48, generator=g) * 0.1
+            cws.append(ops.ConvWeights(pack_conv(w_, b_, [48]), dev))
+            assert cws[-1].blob24 is not None and cws[-1].raw is not None
+        pairs.append(tuple(cws))
+    ch = ops.Resblock48Chain(pairs, dev)
+    x = nhwc(torch.randn(48, h, w, generator=g), dev)
+    for act in (0.0, 0.2):
+        want = x
+        for c1, c2 in pairs:
+            t = ops.conv(c1, want, act=act)
+            want = ops.conv(c2, t, res=want)
+        got = ops.resblock48_chain(ch, x, act)
+        assert got.shape == want.shape
+        assert torch.equal(got, want), 'act %.1f: %d of %d elements differ, max %.3e' % (
+            act, int((got != want).sum()), got.numel(), float((got.float() - want.float()).abs().max()))
+    report('resblock48 %dx%d' % (h, w), equal=1)
