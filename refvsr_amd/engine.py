@@ -183,6 +183,7 @@ class Engine(object):
         self.rb24 = not env_flag('REFVSR_NO_RB24')               # A/B knob: the generic lean kernel for C = 24 as well
         self.rb48 = (bool(getattr(config, 'fuse_resblocks', True)) and not env_flag('REFVSR_NO_FUSE')
                      and not env_flag('REFVSR_NO_RB48'))                 # A/B knob: C = 48 blocks as two refvsr_conv48 launches (round 3)
+        self.rb48_max_pixels = int(os.environ.get('REFVSR_RB48_MAX_PIXELS', str(540 * 960)))
         # inter-frame warp fused into its consumer's tile staging (RefvsrConv.warp_*; conv kernels with 16-row pairs:
         # mid_channels = 24 / 32).  Bit-identical to warp + conv (tests/test_gpu_ops.py), but OPT-IN: measured on MI355X it is
         # slower (169.3 vs 176.4 frames/s, profiles/r03_fused_warp_ab.txt) -- the gather makes the tile staging a chain of
@@ -357,9 +358,13 @@ class Engine(object):
             self.chain_events.append((e0, e1, len(pairs), x.shape[0], x.shape[1]))
             return out
         if (self.rb48 and x.shape[2] == 48 and pairs[0][0].raw is not None and 0.0 <= act <= 1.0 and
-                x.shape[0] * x.shape[1] * 96 < 2 ** 31):
+                x.shape[0] * x.shape[1] <= self.rb48_max_pixels):
             # mid_channels = 48 (RefVSR / RefVSR_MFID / RefVSR_MFID_8K): one launch per block, the two 84 KB weight sets swap
-            # per tile through LDS-DMA (csrc/resblock48.hip); the intermediate map never reaches HBM
+            # per tile through LDS-DMA (csrc/resblock48.hip); the intermediate map never reaches HBM.  Maps up to 540 x 960:
+            # per block 12.9 vs 23.5 us at 135 x 240, 26.7 vs 30.2 us at 270 x 480 (RefVSR_MFID 85.0 vs 83.2 frames/s); at
+            # 1080 x 1920 the two forms are equal stand-alone (396 vs 405 us: 32 tiles per workgroup, each swapping 168 KB of
+            # weights, against conv48's 16 x 32 tiles on sixteen waves) and the 1080p -> 8K frame is 0.7 % slower with the fused
+            # block (6.76 vs 6.81 frames/s) -> the large maps keep the two launches (profiles/r04_resblock48.txt)
             chains = self.W.chains
             key = ('rb48',) + tuple(id(c1) for c1, _ in pairs)
             ch = chains.get(key)
