@@ -181,6 +181,21 @@ def kernel_rooflines(cfg, eng, h, w, dev):
     add('aligned_sample 2x (AlignedConv2d sampler)', lambda: ops.aligned_sample(x_2x, aff, 2), 0.0, 2.0 * C * 2 * 4 * h * w + 12.0 * h * w, 'hbm',
         'aligned_sample 2x')
     add('resize bicubic x4 (base)', lambda: ops.bicubic_scale(lr, 4, clamp01=True), 0.0, 3 * 4.0 * (h * w + 16 * h * w), 'hbm', 'bicubic x4')
+    # round 4: the launches that replaced several (algorithmic bytes = inputs once + outputs once)
+    add('warp_nhwc16_up2 2x (warp by the up-sampled LR flow, no 2x flow map)', lambda: ops.warp_nhwc16_up2(x_2x, flow), 0.0,
+        2.0 * C * 2 * 4 * h * w + 8.0 * h * w, 'hbm', 'warp up2 2x')
+    try:
+        ca, cb = torch.rand(1, h, w, generator=g).to(dev), torch.rand(1, h, w, generator=g).to(dev)
+        w0, b0 = eng.W.raw['conf_fusion2.0.0']
+        cwa = eng.cw('conf_fusion2.1.0')
+        if ops.conf_alpha_ok(cwa):
+            fl_ = lambda px: 2.0 * 9 * (2 * 16 + 16 * C) * px
+            add('conf_alpha LR (cat + 2->16 conv + 16->%d conv + max, one launch)' % C, lambda: ops.conf_alpha(ca, cb, 1, w0, b0, cwa, want_max=True),
+                fl_(h * w), 8.0 * h * w + 2.0 * C * h * w + 4.0 * h * w, 'hbm', 'conf_alpha LR')
+            add('conf_alpha 2x (cat + bicubic x2 + 2->16 conv + 16->%d conv, one launch)' % C, lambda: ops.conf_alpha(ca, cb, 2, w0, b0, cwa),
+                fl_(4 * h * w), 8.0 * h * w + 2.0 * C * 4 * h * w, 'hbm', 'conf_alpha 2x')
+    except Exception:  # noqa: BLE001
+        pass
     return out
 
 

@@ -203,7 +203,14 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         out = torch.empty((ho, wo, co), dtype=cw.odtype, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16, co
     d.out = out.data_ptr()
-    hip.check(hip.lib().refvsr_conv_mfma(C.byref(d), _stream()), 'conv_mfma')
+    rc = hip.lib().refvsr_conv_mfma(C.byref(d), _stream())
+    if rc != 0 and warp is not None:
+        # no fused-warp kernel for this shape (e.g. the sixteen-wave layout of the C = 48 convs): the stand-alone warp kernel +
+        # the plain conv give the same result bit for bit (a refused launch must not be a hard error)
+        warped = warp_nhwc16(src0 if wk == 0 else src1, flow)
+        return conv(cw, warped if wk == 0 else src0, src1 if wk == 0 else warped, stride=stride, pad=pad, act=act, mul=mul, res=res,
+                    post=post, planar_out=planar_out, res_planar=res_planar, add_const=add_const, clamp=clamp)
+    hip.check(rc, 'conv_mfma')
     return out
 
 

@@ -16,7 +16,7 @@ from refvsr_amd.engine import Engine, Weights  # noqa: E402
 
 dev = torch.device('cuda:0')
 GROUPS = ['resblock LR', 'resblock 2x', 'conv HR', 'conv shuffle 2x', 'warp LR', 'warp 2x', 'gather 2x', 'aligned_sample 2x',
-          'bicubic x4', 'match_top2']
+          'bicubic x4', 'match_top2', 'warp up2 2x', 'conf_alpha LR', 'conf_alpha 2x']
 REPS = 4
 
 
@@ -37,6 +37,9 @@ def main():
     ref_f = torch.randn(16, h // 2, w // 2, generator=g).to(dev)
     lr_rows, _ = ops.match_patches(lr_f, 512)
     ref_rows, _ = ops.match_patches(ref_f, 256)
+    ca, cb = torch.rand(1, h, w, generator=g).to(dev), torch.rand(1, h, w, generator=g).to(dev)
+    w0, b0 = eng.W.raw['conf_fusion2.0.0']
+    cwa = eng.cw('conf_fusion2.1.0')
     nb = cfg.num_blocks
     c1, c2 = eng.cw('backward_resblocks.main.2.%d.conv1' % (nb // 2)), eng.cw('backward_resblocks.main.2.%d.conv2' % (nb // 2))
     d1, d2 = eng.cw('feat_decoder2.RBs.1.conv1'), eng.cw('feat_decoder2.RBs.1.conv2')
@@ -51,6 +54,9 @@ def main():
         'aligned_sample 2x': lambda: ops.aligned_sample(x_2x, aff, 2),
         'bicubic x4': lambda: ops.bicubic_scale(lr, 4, clamp01=True),
         'match_top2': lambda: ops.match_top2(ref_rows, (h // 2) * (w // 2), lr_rows, h * w, 1),
+        'warp up2 2x': lambda: ops.warp_nhwc16_up2(x_2x, flow),
+        'conf_alpha LR': lambda: ops.conf_alpha(ca, cb, 1, w0, b0, cwa, want_max=True),
+        'conf_alpha 2x': lambda: ops.conf_alpha(ca, cb, 2, w0, b0, cwa),
     }
     torch.cuda.synchronize()
     for gi, name in enumerate(GROUPS):

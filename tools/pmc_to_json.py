@@ -51,7 +51,7 @@ if __name__ == '__main__':
     # pattern"): the streaming kernels (conv / resblock tile staging, match row stages: 16 B per lane, consecutive lanes
     # consecutive addresses) are under-reported 2x; for the gather kernels the RAW counter already equals the bytes a
     # perfect cache would fetch (warp 2x: raw 29.1 MB vs 24.9 MB map + 4.1 MB flow), so no correction applies there.
-    gathers = ('warp LR', 'warp 2x', 'gather 2x', 'aligned_sample 2x', 'bicubic x4')
+    gathers = ('warp LR', 'warp 2x', 'gather 2x', 'aligned_sample 2x', 'bicubic x4', 'warp up2 2x', 'conf_alpha LR', 'conf_alpha 2x')
     traffic, detail = {}, {}
     for name in GROUPS:
         if name in F and name in Wr:

@@ -33,7 +33,7 @@ def main():
         ksum[key] += e - s
         kcnt[key] += 1
         qs[q] += e - s
-    print('kernel time per frame: %.3f ms' % (sum(ksum.values()) / 1e6 / nfr))
+    print('kernel time per frame: %.3f ms in %.1f launches per frame (all kernels of the window, copies / fills included)' % (sum(ksum.values()) / 1e6 / nfr, len(win) / float(nfr)))
     for k, v in ksum.most_common(16):
         print('  %-48s %6.3f ms  %6.1f launches/frame  avg %7.1f us' % (k, v / 1e6 / nfr, kcnt[k] / float(nfr), v / kcnt[k] / 1e3))
     print('per HIP queue, ms per frame: ' + ', '.join('q%d %.3f' % (q, v / 1e6 / nfr) for q, v in sorted(qs.items())))
