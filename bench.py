@@ -254,18 +254,20 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
            'value': value, 'unit': 'frames/s', 'samples': [round(v, 2) for v in fps], 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 / value,
            'whole_path': {'algorithmic_tflop_per_frame': alg, 'achieved_tflops': alg * value, 'frac_of_f16_mfma_peak': alg * value / PEAK_F16_TFLOPS},
            'peak_memory_gib': round(torch.cuda.max_memory_allocated(dev) / 2.0 ** 30, 2)}
-    try:                                                # dominant kernel: the C -> C 3x3 conv of the propagation ResBlocks on the LR map
-        g = torch.Generator().manual_seed(5)
+    try:                                                # dominant kernel: the residual block of the propagation branches on the LR map,
+        g = torch.Generator().manual_seed(5)            # through the engine's own dispatch (resblock48 up to 540 x 960, else two conv48 launches)
         x = ops.pack_nhwc16(torch.randn(C_, h, w, generator=g).to(dev))
-        cw = eng.cw('backward_resblocks.main.2.%d.conv1' % (cfg.num_blocks // 2))
+        k_ = cfg.num_blocks // 2
+        pair = (eng.cw('backward_resblocks.main.2.%d.conv1' % k_), eng.cw('backward_resblocks.main.2.%d.conv2' % k_))
         big_a, big_b = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
-        us = queued_launch_us(lambda: ops.conv(cw, x, act=0.0), 20, lambda: torch.mm(big_a, big_b))
-        flops = 2.0 * 9 * C_ * C_ * h * w
+        us = queued_launch_us(lambda: eng._block_chain(x, [pair], 0.0), 20, lambda: torch.mm(big_a, big_b))
+        fused = bool(getattr(eng, 'rb48', False)) and C_ == 48 and h * w <= getattr(eng, 'rb48_max_pixels', 0)
+        flops = 2 * 2.0 * 9 * C_ * C_ * h * w
         tf = flops / us / 1e6
-        res['roofline'] = {'kernel': 'conv%d_kernel (3x3 %d -> %d of the propagation ResBlocks, LR map %dx%d; %d launches per frame)'
-                                     % (C_, C_, C_, h, w, 2 * cfg.num_blocks * (t - t // 2 + 1)),
+        res['roofline'] = {'kernel': '%s (conv3x3-ReLU-conv3x3 + residual of the propagation branches, %d channels, LR map %dx%d; %d blocks per frame)'
+                                     % ('resblock48_kernel, one launch' if fused else 'conv%d_kernel x 2 launches' % C_, C_, h, w, cfg.num_blocks * (t - t // 2 + 1)),
                            'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F16_TFLOPS,
-                           'traffic': None, 'us_per_launch': round(us, 2), 'flops_per_launch': flops}
+                           'traffic': None, 'us_per_block': round(us, 2), 'flops_per_block': flops}
     except Exception as e:  # noqa: BLE001
         res['roofline'] = {'error': repr(e)[:200]}
     del net, win_lr, win_rf
