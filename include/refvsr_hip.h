@@ -172,6 +172,18 @@ int refvsr_conv24_blob_bytes(int c0, int c1);
 int refvsr_conv24_kblock(int ncg, int s, int q);
 int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
                   const void* mul, const void* res, float post_slope, void* out, void* stream);
+/* The output head in ONE launch (ABI 10): RefVSR.py:92,118,288,297 --
+ *   out = clamp( conv_last(src) + clamp(F.interpolate(lr_centre, scale_factor=scale, mode='bicubic'), 0, 1), 0, 1 )
+ * -- planar fp32 [3][h][w].  src: fp16 HWC [h][w][c], c = 24 | 48; base_lr: planar fp32 [3][bh][bw], h / bh == w / bw = the SR factor;
+ * blob: refvsr_conv_last_blob_bytes(c) bytes = [S K-steps x ONE fragment x 64 lanes x 8 halfs][32 bias floats], fragment rows
+ * 0-2 = hi(W[r]), rows 8-10 = lo(W[r - 8]) (folded by the kernel), K-blocks by refvsr_conv24_kblock(c / 8, s, q);
+ * refvsr_amd/packing.py:pack_conv_last.  The base map (refvsr_resize bicubic x4: 25 MB written and read back at 1080p) is
+ * evaluated per output value instead.  Same arithmetic as refvsr_resize + refvsr_conv_mfma's planar mode up to the fp32
+ * summation order of the conv. */
+int refvsr_conv_last_supported(int c);
+int refvsr_conv_last_blob_bytes(int c);
+int refvsr_conv_last(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
+                     float* out, void* stream);
 /* The confidence fusions in ONE launch (ABI 10): conf_fusion / conf_fusion2 / conf_fusion_BWFW of RefVSR.py:47-52, called at
  * :130, :141-142 and :107-109 as  conv_{16->C}(lrelu(conv_{2->16}(cat[conf_a, conf_b])))  on the LR grid (up = 1) and on
  * clamp(F.interpolate(cat[conf_a, conf_b], scale_factor=2, mode='bicubic'), 0, 1) (up = 2).  conf_a / conf_b: planar fp32

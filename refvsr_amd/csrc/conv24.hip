@@ -49,6 +49,9 @@ struct C24Args {
     float* conf_max;                             // optional by-product max(conf_a, conf_b) [ch][cw] (CONF = 1)
     int ch, cw;                                  // size of the confidence maps (CONF = 2: half the conv's grid)
     float slope0;
+    // COUT = 3 (refvsr_conv_last): `out` is planar fp32 [3][h][w]; base_lr: the LR centre frame, planar fp32 [3][bh][bw], whose
+    // bicubic up-sampling (clamped to [0, 1]) is added before the final clamp
+    const float* base_lr; int bh, bw; float base_step;
 };
 
 __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l] + a[l ^ 32] (see resblock24.hip:rb_fold1)
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     static_assert(CONF == 0 || (NCG0 == 2 && NCG1 == 0 && SHUF == 0), "confidence variant: 16-channel single source");
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
     constexpr int S = c24_steps(NCG), NPAT = c24_npat(NCG);
-    constexpr int NF = COUT == 24 ? 3 : COUT / 8;                   // fragments per K-step (COUT = 32 | 48: [hi | lo] per 16 channels)
-    constexpr int NM = COUT == 24 ? 2 : COUT / 16;                  // accumulator tiles per pixel group
+    constexpr int NF = COUT == 24 ? 3 : COUT == 3 ? 1 : COUT / 8;   // fragments per K-step (COUT = 32 | 48: [hi | lo] per 16 channels)
+    constexpr int NM = COUT == 24 ? 2 : COUT == 3 ? 1 : COUT / 16;  // accumulator tiles per pixel group
     constexpr int BIASB = COUT == 48 ? 256 : 128;
     constexpr int WB = S * NF * 1024, BIAS = WB, XT = WB + BIASB;
     constexpr int NT = NWV * 64, T = 2 * TH / NWV;
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     constexpr int NCH = C24_NPX * NCG, KCH = (NCH + NT - 1) / NT;
     constexpr int PIXB0 = NCG0 * 16, PIXB1 = NCG1 * 16;
     constexpr int OPX = COUT * 2;                                   // bytes per pixel of the out / mul / res maps
-    static_assert((COUT == 24 || COUT == 32 || COUT == 48) && S > 0 && T >= 1 && T * NWV == 2 * TH, "unsupported shape");
+    static_assert((COUT == 3 || COUT == 24 || COUT == 32 || COUT == 48) && S > 0 && T >= 1 && T * NWV == 2 * TH, "unsupported shape");
+    static_assert(COUT != 3 || (NCG1 == 0 && SHUF == 0 && CONF == 0), "output head: single source");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.out), "s"(p.blob), "s"(p.mul), "s"(p.res), "s"(p.h), "s"(p.w), "s"(p.tiles_x),
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                     if (p.mul && lane_ok) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
                     if (p.res && lane_ok) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
                 }
+                (void)lane_ok;
             }
         }
         if constexpr (CONF == 0) { if (has_next) x_fetch(tl + 1); }  // next tile: in flight during the K loop
@@ -330,6 +335,10 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                     for (int t = 0; t < T; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_mx, *reinterpret_cast<const f16x8*>(&bf[t]), acc[1][t], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < T; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, *reinterpret_cast<const f16x8*>(&bf[t]), acc[0][t], 0, 0, 0);
+                } else if constexpr (COUT == 3) {                    // ONE fragment: rows 0-2 = hi, rows 8-10 = lo (folded in the epilogue)
+                    const f16x8 a_w = *reinterpret_cast<const f16x8*>(&af[0]);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_w, *reinterpret_cast<const f16x8*>(&bf[t]), acc[0][t], 0, 0, 0);
                 } else {                                             // [hi | lo] of channels 0-15, 16-31, 32-47: all hi, then all lo
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
@@ -369,7 +378,29 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             __syncthreads();                                         // every wave is done reading the x tile
             if constexpr (CONF == 0) x_park();
         }
-        if constexpr (SHUF != 0) {
+        if constexpr (COUT == 3) {
+            // ---------------- output head (RefVSR.py:118,288,297): clamp( conv + bias + clamp01(bicubic(lr_centre)), 0, 1 ) -> planar fp32.
+            // After the fold lane (0, n) holds the three channel sums of pixel n of the group; lane (q, n), q < 3, takes channel q
+            // (ds_bpermute), evaluates ITS channel's bicubic sample (rv_bicubic_at: resize_kernel<BICUBIC>'s FMA chains) and stores one
+            // value: 48 lanes x 4 bytes = three 64-byte row segments per group
+            const size_t plane_o = (size_t)p.h * p.w, plane_b = (size_t)p.bh * p.bw;
+            float* op = reinterpret_cast<float*>(p.out);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 y = acc[0][t];
+                const float s0 = c24_fold1(y[0]), s1 = c24_fold1(y[1]), s2 = c24_fold1(y[2]);
+                const int srcl = lane & 15;
+                const float v0 = __shfl(s0, srcl), v1 = __shfl(s1, srcl), v2 = __shfl(s2, srcl);
+                const float v = q == 0 ? v0 : q == 1 ? v1 : v2;
+                int lpe = lp;
+                if (!interior) asm volatile("" : "+v"(lpe));
+                const int oy = ty0 + oy0 + (t >> 1), ox = tx0 + (t & 1) * 16 + lpe;
+                if (q < 3 && oy < p.h && ox < p.w) {
+                    const float b = fminf(fmaxf(rv_bicubic_at(p.base_lr + q * plane_b, p.bh, p.bw, oy, ox, p.base_step, p.base_step), 0.0f), 1.0f);
+                    op[q * plane_o + (size_t)oy * p.w + ox] = fminf(fmaxf(v + b, 0.0f), 1.0f);
+                }
+            }
+        } else if constexpr (SHUF != 0) {
             // ---------------- pixel-shuffle epilogue: rows 16 m + 4 q .. of group z -> channels ch0 .. of sub-pixel (dy, dx) -------
             const int z = (int)blockIdx.y;
             const unsigned w2 = 2u * (unsigned)p.w;
@@ -440,7 +471,7 @@ template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, 
 static int launch_c24(C24Args& a, hipStream_t st) {
     constexpr int NZ = SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;          // row groups of the pixel-shuffle variant (blockIdx.y)
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
-    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : COUT / 8) * 1024 + (COUT == 48 ? 256 : 128) + (TH + 2) * C24_XW * PS * 16 +
+    constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : COUT == 3 ? 1 : COUT / 8) * 1024 + (COUT == 48 ? 256 : 128) + (TH + 2) * C24_XW * PS * 16 +
                         (CONF ? 2 * (TH + 4) * (C24_XW + 2) * 4 + 18 * 16 * 4 + 64 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done[RV_MAX_DEVICES] = {};
@@ -579,4 +610,24 @@ extern "C" int refvsr_conf_alpha(const float* conf_a, const float* conf_b, int h
     hipStream_t st = (hipStream_t)stream;
     if (cout == 24) return up == 1 ? launch_c24<24, 2, 0, 8, 8, 4, 0, 1>(a, st) : launch_c24<24, 2, 0, 8, 8, 4, 0, 2>(a, st);
     return up == 1 ? launch_c24<48, 2, 0, 8, 8, 4, 0, 1>(a, st) : launch_c24<48, 2, 0, 8, 8, 4, 0, 2>(a, st);
+}
+
+// The output head in ONE launch (RefVSR.py:92,118,288,297: conv_last 3x3 C -> 3, + F.interpolate(lr_centre, scale, bicubic).clamp(0, 1),
+// final clamp): out planar fp32 [3][h][w] = clamp( conv(src) + bias + clamp01(bicubic(base_lr)), 0, 1 ).  src: fp16 HWC [h][w][c],
+// c = 24 | 48; base_lr: planar fp32 [3][bh][bw] with h / bh == w / bw the SR factor of this stage; blob: refvsr_conv_last_blob_bytes(c)
+// bytes = [S K-steps x ONE fragment x 64 lanes x 8 halfs][32 bias floats]: fragment rows 0-2 = hi(W[r]), rows 8-10 = lo(W[r - 8]),
+// K-blocks by refvsr_conv24_kblock(c / 8, s, q) (refvsr_amd/packing.py:pack_conv_last).  Replaces refvsr_resize (the x4 base map)
+// + refvsr_conv_mfma's planar mode: the 3-channel base never exists in HBM, one MFMA per K-step instead of two 16-row tiles.
+extern "C" int refvsr_conv_last_supported(int c) { return c == 24 || c == 48; }
+extern "C" int refvsr_conv_last_blob_bytes(int c) { return refvsr_conv_last_supported(c) ? c24_steps(c / 8) * 1024 + 128 : -1; }
+extern "C" int refvsr_conv_last(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
+                                float* out, void* stream) {
+    RV_CHECK(refvsr_conv_last_supported(c), "conv_last: %d input channels not supported (24 | 48)", c);
+    RV_CHECK(base_lr && bh > 0 && bw > 0 && h % bh == 0 && w % bw == 0 && h / bh == w / bw, "conv_last: base frame %dx%d does not divide the output %dx%d", bh, bw, h, w);
+    C24Args a;
+    if (c24_fill(a, "conv_last", c, src, nullptr, 0, h, w, blob, 1.0f, nullptr, nullptr, 1.0f, out)) return 1;
+    a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h;
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 24) return launch_c24<3, 3, 0, 8, 8, 4>(a, st);
+    return launch_c24<3, 6, 0, 8, 8, 4>(a, st);
 }

@@ -441,6 +441,22 @@ def conf_alpha(conf_a, conf_b, up, w0, b0, cw, slope0=0.2, slope1=0.2, want_max=
     return (alpha, cmax) if want_max else alpha
 
 
+def conv_last(blob, src, base_lr):
+    """refvsr_conv_last: clamp(conv3x3_{C->3}(src) + bias + clamp01(bicubic(base_lr)), 0, 1) -> planar fp32 [3, h, w] in one launch.
+    blob: packing.pack_conv_last on the device; src nhwc16 [h, w, C]; base_lr planar fp32 [3, h / s, w / s]."""
+    _nhwc(src)
+    _planar(base_lr, 3)
+    h, w, c = src.shape
+    bh, bw = base_lr.shape[1:]
+    out = torch.empty((3, h, w), dtype=torch.float32, device=src.device)
+    hip.check(hip.lib().refvsr_conv_last(_ptr(src), c, h, w, _ptr(blob), _ptr(base_lr), bh, bw, _ptr(out), _stream()), 'conv_last')
+    return out
+
+
+def conv_last_ok(c, h, w):
+    return bool(hip.lib().refvsr_conv_last_supported(int(c))) and h * w * c * 2 < 2 ** 31
+
+
 def conf_alpha_ok(cw):
     return cw.blob24 is not None and cw.cpads == [16] and cw.cout in (24, 48) and not cw.shuffle
 

@@ -225,6 +225,36 @@ def c24_kblock(ncg, s, q):
     raise ValueError(ncg)
 
 
+def pack_conv_last(w, b):
+    """uint8 blob of the output head for refvsr_conv_last: 3x3, C -> 3 (C = 24 | 48).  [S K-steps][ONE fragment: 64 lanes x 8 halfs]
+    + 32 bias floats; lane l = (q, r) of K-step s holds the 8 input channels of K-block c24_kblock(C / 8, s, q) for fragment row r:
+    rows 0-2 = hi(W[r]) = fp16(w), rows 8-10 = lo(W[r - 8]) = fp16(w - hi), all other rows zero (the kernel folds rows r and r + 8)."""
+    w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
+    b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
+    assert w.shape[0] == 3 and w.shape[1] in (24, 48) and tuple(w.shape[2:]) == (3, 3), w.shape
+    Wk, _, ncg = kmatrix(w, [w.shape[1]])                       # [3, 9 * ncg * 8]
+    S = c24_steps(ncg)
+    hi = Wk.astype(np.float16)
+    lo = (Wk - hi.astype(np.float32)).astype(np.float16)
+    frag = np.zeros((S, 1, 4, 16, 8), np.float16)
+    for s_ in range(S):
+        for q in range(4):
+            kb = c24_kblock(ncg, s_, q)
+            if kb is None:
+                continue
+            ty, tx, cg = kb
+            g = (ty * 3 + tx) * ncg + cg
+            frag[s_, 0, q, 0:3] = hi[:, g * 8:g * 8 + 8]
+            frag[s_, 0, q, 8:11] = lo[:, g * 8:g * 8 + 8]
+    out = np.zeros(S * 1024 + 128, np.uint8)
+    raw = frag.reshape(-1).view(np.uint8)
+    out[:raw.size] = raw
+    bb = np.zeros(32, np.float32)
+    bb[:3] = b
+    out[raw.size:] = bb.view(np.uint8)
+    return torch.from_numpy(out)
+
+
 RB48_WB = 14 * 6 * 1024                       # fragment bytes of one 48 -> 48 conv (csrc/resblock48.hip)
 RB48_BLOB = 2 * RB48_WB + 512
 

@@ -842,6 +842,9 @@ def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, 
     wl = [lr[w][None].contiguous() for w in wins]
     wr = [rf[w][None].contiguous() for w in wins]
     torch.cuda.synchronize()
+    # (the fused output head, refvsr_conv_last, sums its conv in another K order: equal to the generic head to fp32 rounding, not
+    #  bit for bit -- both sides of the strict comparison use the generic head, the fused one is compared at the end)
+    monkeypatch.setenv('REFVSR_NO_FUSE_HEAD', '1')
     for k in ('REFVSR_NO_FUSE_CONF', 'REFVSR_NO_WARP_UP2', 'REFVSR_NO_SPYNET_BATCH', 'REFVSR_NO_RB48'):
         monkeypatch.setenv(k, '1')
     old, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
@@ -871,3 +874,9 @@ def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, 
         assert net3.Network.engine(0).bw_head_blocks == min(nhead, cfg3.num_blocks)
         for f in range(nfr):
             assert torch.equal(outs[f], want[f]), 'frame %d differs (pipelined, backward head of %d blocks on P)' % (f, nhead)
+    # the fused output head (conv_last + bicubic base + clamps in one launch): fp32 summation order only
+    monkeypatch.delenv('REFVSR_NO_FUSE_HEAD')
+    net4, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
+    assert net4.Network.ensure_engines(1, dev)[0].fuse_head
+    worst = max(maxdiff(net4(wl[f], wr[f], f == 0)['result'], want[f]) for f in range(nfr))
+    assert worst < 2e-5, worst

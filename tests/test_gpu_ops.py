@@ -1130,3 +1130,34 @@ def test_resblock48_chain_equals_two_conv48_launches(dev, h, w):
         assert torch.equal(got, want), 'act %.1f: %d of %d elements differ, max %.3e' % (
             act, int((got != want).sum()), got.numel(), float((got.float() - want.float()).abs().max()))
     report('resblock48 %dx%d' % (h, w), equal=1)
+
+
+@pytest.mark.parametrize('c', [24, 48])
+@pytest.mark.parametrize('bh,bw,scale', [(19, 45, 4), (64, 96, 4), (33, 50, 2), (2, 8, 4)])
+def test_conv_last_fused_head(dev, c, bh, bw, scale):
+    """refvsr_conv_last (conv_last 3x3 C -> 3 + the bicubic base + both clamps in one launch, RefVSR.py:92,118,288,297) against
+    refvsr_resize (bicubic, clamped) + refvsr_conv_mfma's planar mode: the base values are the same FMA chains (shared device
+    function), the conv is summed in conv24's K order instead of the generic one => equal to fp32 rounding (bar 2e-5 on values in
+    [0, 1]); against an fp32 torch restatement of the whole head to 2e-3 (fp16 activations, hi + lo weights).  Border and partial
+    tiles, x4 and x2, 24 and 48 channels, values that hit both clamps."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv, pack_conv_last
+    g = torch.Generator().manual_seed(c + bh * bw + scale)
+    h, w = bh * scale, bw * scale
+    w_ = torch.randn(3, c, 3, 3, generator=g) * 0.03          # conv std ~0.45-0.6 around the base: both clamps hit, most values inside
+    b_ = torch.randn(3, generator=g) * 0.1
+    xf = torch.randn(c, h, w, generator=g)
+    base = (torch.rand(3, bh, bw, generator=g) * 1.2 - 0.1).to(dev)
+    x = nhwc(xf, dev)
+    cw = ops.ConvWeights(pack_conv(w_, b_, [c]), dev)
+    want = ops.conv(cw, x, planar_out=True, res_planar=ops.bicubic_scale(base, scale, clamp01=True), clamp=(0.0, 1.0))
+    assert ops.conv_last_ok(c, h, w)
+    got = ops.conv_last(pack_conv_last(w_, b_).to(dev), x, base)
+    assert got.shape == want.shape == (3, h, w)
+    e = maxdiff(got, want)
+    ref = (F.conv2d(planar(x, c)[None], w_, b_, padding=1)[0] +
+           F.interpolate(base.cpu()[None], scale_factor=scale, mode='bicubic', align_corners=False)[0].clamp(0, 1)).clamp(0, 1)
+    e_ref = maxdiff(got.cpu(), ref)
+    report('conv_last %dx%d x%d C=%d' % (bh, bw, scale, c), vs_generic=e, vs_torch=e_ref)
+    assert e < 2e-5 and e_ref < 2e-3
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0 and float((got == 0).float().mean()) > 0.01 and float((got == 1).float().mean()) > 0.01

@@ -64,3 +64,12 @@ echo "== micro-benchmarks ==" | tee -a $L
 RB_ITERS=6 timeout 200 python tools/bench_resblock.py 2>&1 | grep resblock | tee gpurun_out/r04_resblock_microbench.txt | grep -v "4 waves\|lean\|sc1" | tee -a $L
 timeout 120 python tools/bench_spynet.py 2>&1 | grep "spynet" | tee gpurun_out/r04_spynet_microbench.txt | tee -a $L
 timeout 120 python tools/bench_match.py 2>&1 | grep match_top2 | tee gpurun_out/r04_match_microbench.txt | tee -a $L
+echo "== cross-process stability of the headline: three more fresh processes ==" | tee -a $L
+for i in 1 2 3; do
+  timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernels --no-wavefront --no-other-configs 2>/dev/null | tail -1 | python -c "$fmt" | tee -a $L
+done
+echo "== RefVSR_MFID: backward head on the preparation stream (-1 = off | 12 | 15) ==" | tee -a $L
+for H in -1 12 15; do
+  echo "REFVSR_BW_HEAD_BLOCKS=$H" | tee -a $L
+  REFVSR_BW_HEAD_BLOCKS=$H timeout 240 python bench.py --config config_RefVSR_MFID --steps 12 --warmup 3 --no-cpu-baseline --no-kernels --no-wavefront --no-other-configs 2>/dev/null | tail -1 | python -c "$fmt" | tee -a $L
+done
