@@ -333,6 +333,7 @@ def test_block_chain_applies_blocks_in_order(monkeypatch):
         _block_chain = engine.Engine._block_chain
         fuse_resblocks = True
         rb24 = False                             # the generic kernels (the 24-channel kernel is dispatched below)
+        rb48, rb48_max_pixels = False, 0         # (the fused 48-channel block has its own dispatch test on the GPU)
         chain_events = None
         chain_calls = False                      # per-block launches from Python
     e = E()
@@ -666,3 +667,42 @@ def test_env_flag_parsing(monkeypatch):
     for v, want in (('1', True), ('0', False), ('', False), ('false', False), ('off', False), ('yes', True)):
         monkeypatch.setenv('REFVSR_TEST_KNOB', v)
         assert env_flag('REFVSR_TEST_KNOB') is want, v
+
+
+def test_round4_blobs_follow_the_library_k_plan():
+    """pack_resblock48 / pack_conv_last (host side of refvsr_resblock48_chain / refvsr_conv_last): sizes equal the library's
+    constants, the 48-channel block blob is the two refvsr_conv48 blobs' fragment parts + both biases, and the output head's
+    single fragment per K-step holds hi(W) in rows 0-2 and lo(W) in rows 8-10 of the K-block the library's plan
+    (refvsr_conv24_kblock) assigns to (K-step, lane quarter) -- decoded back, hi + lo reproduces the fp32 weights to 2^-21."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import RB48_BLOB, RB48_WB, pack_conv24, pack_conv_last, pack_resblock48
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(4)
+    w1, w2 = torch.randn(48, 48, 3, 3, generator=g), torch.randn(48, 48, 3, 3, generator=g)
+    b1, b2 = torch.randn(48, generator=g), torch.randn(48, generator=g)
+    blob = pack_resblock48(w1, b1, w2, b2)
+    assert blob.numel() == RB48_BLOB == hip.RESBLOCK48_BLOB_BYTES == 2 * lib.refvsr_conv48_blob_bytes(48, 0)
+    c1, c2 = pack_conv24(w1, b1, [48]), pack_conv24(w2, b2, [48])
+    assert torch.equal(blob[:RB48_WB], c1[:RB48_WB]) and torch.equal(blob[RB48_WB:2 * RB48_WB], c2[:RB48_WB])
+    assert torch.equal(blob[2 * RB48_WB:2 * RB48_WB + 256], c1[RB48_WB:]) and torch.equal(blob[2 * RB48_WB + 256:], c2[RB48_WB:])
+    for c in (24, 48):
+        w = torch.randn(3, c, 3, 3, generator=g) * 0.1
+        b = torch.randn(3, generator=g)
+        hb = pack_conv_last(w, b).numpy()
+        assert hb.size == lib.refvsr_conv_last_blob_bytes(c) and lib.refvsr_conv_last_supported(c) == 1
+        ncg = c // 8
+        S = (hb.size - 128) // 1024
+        frag = hb[:S * 1024].view(np.float16).reshape(S, 4, 16, 8).astype(np.float32)      # [s][q][row][8 channels]
+        assert np.allclose(hb[S * 1024:].view(np.float32)[:3], b.numpy()) and not hb[S * 1024:].view(np.float32)[3:].any()
+        seen = np.zeros((3, c, 3, 3), np.float32)
+        for s_ in range(S):
+            for q in range(4):
+                kb = lib.refvsr_conv24_kblock(ncg, s_, q)
+                if kb < 0:
+                    assert not frag[s_, q].any()                                           # zero block
+                    continue
+                ty, tx, cg = kb >> 16, (kb >> 8) & 255, kb & 255
+                seen[:, cg * 8:cg * 8 + 8, ty, tx] += frag[s_, q, 0:3] + frag[s_, q, 8:11]
+                assert not frag[s_, q, 3:8].any() and not frag[s_, q, 11:].any()
+        assert np.abs(seen - w.numpy()).max() < 0.1 * 2.0 ** -20
+    assert lib.refvsr_conv_last_supported(36) == 0 and lib.refvsr_conv_last_blob_bytes(36) == -1
