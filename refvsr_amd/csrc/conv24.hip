@@ -68,8 +68,13 @@ __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l
 // is evaluated per staged pixel from the two fp32 confidence maps instead of being read: torch.cat, [F.interpolate,] the
 // 2 -> 16 conv (refvsr_conv_direct_f32's fp32 FMA order, fp16 rounding) and for CONF = 1 the torch.max of the two maps
 // (RefVSR.py:147) leave the launch list; results are bit-identical to the separate launches.
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0>
+// HALF = 1 (48 + 48 -> 48, the two-source convs of the mid_channels = 48 models: feat_fusion*.0 / feat_fusion2_1 / fusion_UP on
+// cat([a, b]), RefVSR.py:53-62,87): one conv's hi + lo weights are 166 KB -- no resident form.  The OUTPUT channels are split
+// instead: blockIdx.y = z computes channels 24 z .. 24 z + 23 with the 24-row fragment trick (81 KB of weights per half, NCG = 12
+// plan, 70 KB tile: one sixteen-wave workgroup per CU) and stores them into the 48-channel maps at byte offset 48 z.
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0, int HALF = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void conv24_kernel(C24Args p) {
+    static_assert(HALF == 0 || (COUT == 24 && SHUF == 0 && CONF == 0), "channel-half variant: 24 computed channels per workgroup");
     static_assert(SHUF == 0 || (COUT == 48 && (SHUF == 24 || SHUF == 48) && NCG0 * 8 == SHUF && NCG1 == 0), "pixel-shuffle variant");
     static_assert(CONF == 0 || (NCG0 == 2 && NCG1 == 0 && SHUF == 0), "confidence variant: 16-channel single source");
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     constexpr int C24_TH = TH, C24_XH = TH + 2, C24_NPX = C24_XH * C24_XW;
     constexpr int NCH = C24_NPX * NCG, KCH = (NCH + NT - 1) / NT;
     constexpr int PIXB0 = NCG0 * 16, PIXB1 = NCG1 * 16;
-    constexpr int OPX = COUT * 2;                                   // bytes per pixel of the out / mul / res maps
+    constexpr int OPX = HALF ? 96 : COUT * 2;                       // bytes per pixel of the out / mul / res maps
     static_assert((COUT == 3 || COUT == 24 || COUT == 32 || COUT == 48) && S > 0 && T >= 1 && T * NWV == 2 * TH, "unsupported shape");
     static_assert(COUT != 3 || (NCG1 == 0 && SHUF == 0 && CONF == 0), "output head: single source");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     // ---- weights + bias: global -> LDS (1 KiB per wave instruction), issued first
     {
         constexpr int NPC = WB / 1024;                               // full pieces; the 128-byte bias tail: 8 lanes
-        const unsigned char* g = p.blob + (SHUF ? (int)blockIdx.y * (WB + BIASB) : 0) + lane * 16;       // SHUF: one blob per row group
+        const unsigned char* g = p.blob + ((SHUF || HALF) ? (int)blockIdx.y * (WB + BIASB) : 0) + lane * 16;   // SHUF / HALF: one blob per row group
 #pragma unroll
         for (int j = 0; j < (NPC + NWV - 1) / NWV; ++j) {
             const int c = wave + j * NWV;
@@ -109,6 +114,12 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                                              (__attribute__((address_space(3))) void*)(smem + NPC * 1024), 16, 0, 0);
     }
 
+    if constexpr (HALF != 0) {                                       // this workgroup's 24 channels inside the 48-channel maps
+        const int zoff = (int)blockIdx.y * 48;
+        p.out += zoff;
+        if (p.mul) p.mul += zoff;
+        if (p.res) p.res += zoff;
+    }
     // ---- x-tile chunks of this thread: i = tid + k NT = pixel * NCG + cg; global offset relative to the tile origin of its
     //      source, LDS offset, source flag -- computed once
     const int rowp = p.w;
@@ -246,12 +257,15 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     const int q = lane >> 4;
     const int lp = rv_pix16(lane & 15);
     const int la = lane * 16;
-    const int oy0 = (wave * T) >> 1;
+    // pixel group t of this wave = group wave * T + t of the tile: output row RW(t), left | right half CG(t) (T odd: NWV = 2 TH)
+    const int g0w = wave * T;
+#define RW(t) ((g0w + (t)) >> 1)
+#define CG(t) ((g0w + (t)) & 1)
     auto sel4 = [&](const int v0, const int v1, const int v2, const int v3) { return q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3; };
     int pb[T];                                                       // window origin of each output group + this lane's pattern-0 offset
 #pragma unroll
     for (int t = 0; t < T; ++t)
-        pb[t] = XT + (oy0 + (t >> 1)) * ROWB + ((t & 1) * 16 + lp) * PXB +
+        pb[t] = XT + RW(t) * ROWB + (CG(t) * 16 + lp) * PXB +
                 sel4(c24_off(NCG, 0, 0), c24_off(NCG, 0, 1), c24_off(NCG, 0, 2), c24_off(NCG, 0, 3)) - c24_off(NCG, 0, 0);
     int pd[NPAT];                                                    // pattern p relative to pattern 0, per lane
 #pragma unroll
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                  (sel4(c24_off(NCG, 0, 0), c24_off(NCG, 0, 1), c24_off(NCG, 0, 2), c24_off(NCG, 0, 3)) - c24_off(NCG, 0, 0));
     }
     const int rowb_o = p.w * OPX;
-    const unsigned oo = (unsigned)(oy0 * rowb_o + lp * OPX + q * 8);  // this lane's channels 4q.. of group 0, relative to the tile origin
+    const unsigned oo = (unsigned)(lp * OPX + q * 8);                // this lane's channels 4q.. of its pixel, relative to the group's origin
 
     if constexpr (CONF == 0) { if (tl < k_hi) x_park(); }
     __syncthreads();                                                 // weights, bias, first tile (CONF: first-conv weights)
@@ -286,9 +300,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             if (!interior) {
                 int lpe = lp;
                 asm volatile("" : "+v"(lpe));
-                okt[t] = ty0 + oy0 + (t >> 1) < p.h && tx0 + (t & 1) * 16 + lpe < p.w;
+                okt[t] = ty0 + RW(t) < p.h && tx0 + CG(t) * 16 + lpe < p.w;
             }
-            const unsigned eo = (unsigned)((t >> 1) * rowb_o) + oo + (t & 1) * 16 * OPX;
+            const unsigned eo = (unsigned)(RW(t) * rowb_o) + oo + CG(t) * 16 * OPX;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 mv[m][t] = rv[m][t] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                 const float v = q == 0 ? v0 : q == 1 ? v1 : v2;
                 int lpe = lp;
                 if (!interior) asm volatile("" : "+v"(lpe));
-                const int oy = ty0 + oy0 + (t >> 1), ox = tx0 + (t & 1) * 16 + lpe;
+                const int oy = ty0 + RW(t), ox = tx0 + CG(t) * 16 + lpe;
                 if (q < 3 && oy < p.h && ox < p.w) {
                     const float b = fminf(fmaxf(rv_bicubic_at(p.base_lr + q * plane_b, p.bh, p.bw, oy, ox, p.base_step, p.base_step), 0.0f), 1.0f);
                     op[q * plane_o + (size_t)oy * p.w + ox] = fminf(fmaxf(v + b, 0.0f), 1.0f);
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             for (int t = 0; t < T; ++t) {
                 int lpe = lp;
                 if (!interior) asm volatile("" : "+v"(lpe));
-                const unsigned oy = (unsigned)(ty0 + oy0 + (t >> 1)), ox = (unsigned)(tx0 + (t & 1) * 16 + lpe);
+                const unsigned oy = (unsigned)(ty0 + RW(t)), ox = (unsigned)(tx0 + CG(t) * 16 + lpe);
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     const int r0 = 16 * m + 4 * q;
@@ -431,14 +445,14 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             unsigned char* ob = p.out + oorg;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                unsigned char* d = ob + (unsigned)((t >> 1) * rowb_o) + oo + (t & 1) * 16 * OPX;
+                unsigned char* d = ob + (unsigned)(RW(t) * rowb_o) + oo + CG(t) * 16 * OPX;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     f32x4 y = acc[m][t];
                     if constexpr (COUT == 24) {
                         if (m == 1) y = (f32x4){c24_fold1(y[0]), c24_fold1(y[1]), c24_fold1(y[2]), c24_fold1(y[3])};
                     } else {
-                        const unsigned eo = (unsigned)((t >> 1) * rowb_o) + oo + (t & 1) * 16 * OPX;
+                        const unsigned eo = (unsigned)(RW(t) * rowb_o) + oo + CG(t) * 16 * OPX;
                         if (p.mul && okt[t]) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
                         if (p.res && okt[t]) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
                     }
@@ -465,11 +479,13 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
         }
         if constexpr (CONF == 0) { if (has_next) __syncthreads(); }  // next x tile visible
     }
+#undef RW
+#undef CG
 }
 
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0>
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0, int HALF = 0>
 static int launch_c24(C24Args& a, hipStream_t st) {
-    constexpr int NZ = SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;          // row groups of the pixel-shuffle variant (blockIdx.y)
+    constexpr int NZ = HALF ? 2 : SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;   // row groups of the pixel-shuffle / channel-half variants (blockIdx.y)
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
     constexpr int LDS = c24_steps(NCG) * (COUT == 24 ? 3 : COUT == 3 ? 1 : COUT / 8) * 1024 + (COUT == 48 ? 256 : 128) + (TH + 2) * C24_XW * PS * 16 +
                         (CONF ? 2 * (TH + 4) * (C24_XW + 2) * 4 + 18 * 16 * 4 + 64 : 0);
@@ -478,10 +494,10 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF>, NWV * 64, LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF>, NWV * 64, LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
@@ -490,7 +506,7 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     int cap = (rv_num_cus() * occ_dev[dev] / NZ) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
+    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -498,7 +514,7 @@ static int launch_c24(C24Args& a, hipStream_t st) {
 extern "C" int refvsr_conv24_supported(int c0, int c1) {
     return (c0 == 24 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 8 && c1 == 24) || (c0 == 24 && c1 == 24);
 }
-extern "C" int refvsr_conv48_supported(int c0, int c1) { return (c0 == 48 && c1 == 0) || (c0 == 16 && c1 == 0); }
+extern "C" int refvsr_conv48_supported(int c0, int c1) { return (c0 == 48 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 48 && c1 == 48); }
 extern "C" int refvsr_conv32_supported(int c0, int c1) { return (c0 == 32 && c1 == 0) || (c0 == 8 && c1 == 0); }
 
 extern "C" int refvsr_conv24_blob_bytes(int c0, int c1) {
@@ -511,6 +527,7 @@ extern "C" int refvsr_conv32_blob_bytes(int c0, int c1) {
 }
 extern "C" int refvsr_conv48_blob_bytes(int c0, int c1) {
     if (!refvsr_conv48_supported(c0, c1)) return -1;
+    if (c1 == 48) return 2 * (c24_steps(12) * 3 * 1024 + 128);      // two channel-half blobs of the 24-output layout, back to back
     return c24_steps((c0 + c1) / 8) * 6 * 1024 + 256;
 }
 
@@ -573,6 +590,7 @@ extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1,
     // 84 KB of weights + 18 x 34-pixel tile: one workgroup per CU.  Sixteen waves with two pixel groups each (default), or eight
     // waves with four (A/B knob REFVSR_CONV48_WAVES=8: 37 % fewer LDS fragment reads, half the waves per SIMD)
     static const bool w8 = getenv("REFVSR_CONV48_WAVES") && atoi(getenv("REFVSR_CONV48_WAVES")) == 8;
+    if (c0 == 48 && c1 == 48) return launch_c24<24, 6, 6, 16, 8, 4, 0, 0, 1>(a, st);      // two channel halves on blockIdx.y
     if (c0 == 48) return w8 ? launch_c24<48, 6, 0, 8, 16, 2>(a, st) : launch_c24<48, 6, 0, 16, 16, 4>(a, st);
     return launch_c24<48, 2, 0, 8, 8, 4>(a, st);
 }

@@ -102,7 +102,9 @@ class ConvWeights(object):
         self.blob24 = None
         if self.raw is not None and pk.get('src_channels') is not None and CONV24 and not self.hi_only:
             from .packing import conv24_ok, conv_shuffle2_ok, pack_conv24, pack_conv_shuffle2
-            if conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32) and not (self.cout == 32 and env_flag('REFVSR_NO_CONV32')):
+            two48 = self.cout == 48 and len(pk['src_channels']) == 2     # 48 + 48 -> 48 as two channel halves (A/B knob)
+            if (conv24_ok(tuple(self.raw[0].shape), pk['src_channels'], self.shuffle, self.f32) and not (self.cout == 32 and env_flag('REFVSR_NO_CONV32'))
+                    and not (two48 and env_flag('REFVSR_NO_CONV48X2'))):
                 self.blob24 = pack_conv24(self.raw[0], self.raw[1], pk['src_channels']).to(device).contiguous()
             elif self.shuffle and conv_shuffle2_ok(tuple(self.raw[0].shape), pk['src_channels'], self.f32) and not env_flag('REFVSR_NO_CONV_SHUFFLE2'):
                 self.blob24 = pack_conv_shuffle2(self.raw[0], self.raw[1]).to(device).contiguous()     # refvsr_conv_shuffle2

@@ -189,7 +189,7 @@ def pack_resblock24(w1, b1, w2, b2):
 
 # ---- 24-output-channel 3x3 convs (csrc/conv24.hip) -----------------------------------------------------------------------
 def c24_steps(ncg):
-    return {1: 3, 2: 5, 3: 7, 4: 9, 6: 14}[ncg]
+    return {1: 3, 2: 5, 3: 7, 4: 9, 6: 14, 12: 27}[ncg]
 
 
 def c24_kblock(ncg, s, q):
@@ -214,6 +214,8 @@ def c24_kblock(ncg, s, q):
         if s == 3:
             return q & 1, 2, q >> 1
         return None if q & 1 else (2, 2, q >> 1)
+    if ncg == 12:                                   # three steps per tap: cg = 4 j + {0, 2, 1, 3}
+        return s // 9, (s // 3) % 3, 4 * (s % 3) + perm[q]
     if ncg == 6:
         if s < 9:
             return s // 3, s % 3, perm[q]
@@ -273,7 +275,7 @@ def pack_resblock48(w1, b1, w2, b2):
     return torch.from_numpy(out)
 
 
-def conv24_ok(w_shape, src_channels, shuffle=False, f32=False, shuffle_group=False):
+def conv24_ok(w_shape, src_channels, shuffle=False, f32=False, shuffle_group=False, half_group=False):
     """Shapes served by the specialised kernels (csrc/conv24.hip): 3x3, 24 / 32 / 48 output channels, the listed inputs --
     the same lists as the library's refvsr_conv{24,32,48}_supported (pinned against each other in tests/test_capi.py).
     shuffle_group=True (internal, pack_conv_shuffle2 only): the 24 -> 48 row groups of the pixel-shuffle conv, which
@@ -283,11 +285,11 @@ def conv24_ok(w_shape, src_channels, shuffle=False, f32=False, shuffle_group=Fal
     if ks != 3 or shuffle or f32:
         return False
     if cout == 24:
-        return pads in ([24], [16], [8, 24], [24, 24])
+        return pads in ([24], [16], [8, 24], [24, 24]) or (half_group and pads == [48, 48])
     if cout == 32:
         return pads in ([32], [8])              # AlignedConv2d: the 32 -> 32 convs and the RGB stem
     if cout == 48:
-        return pads in ([48], [16]) or (shuffle_group and pads == [24])
+        return pads in ([48], [16], [48, 48]) or (shuffle_group and pads == [24])
     return False
 
 
@@ -297,7 +299,7 @@ def conv_shuffle2_ok(w_shape, src_channels, f32=False):
     return ks == 3 and not f32 and list(src_channels) in ([24], [48]) and cin == src_channels[0] and cout == 4 * cin
 
 
-def pack_conv24(w, b, src_channels, shuffle_group=False):
+def pack_conv24(w, b, src_channels, shuffle_group=False, half_group=False):
     """uint8 blob of one conv for refvsr_conv24 / refvsr_conv48: fp16 [S][NF][64 lanes][8] + bias floats (32 | 64).  Lane
     l = (q = l >> 4, r = l & 15) of K-step s holds the 8 (padded) input channels of K-block c24_kblock(ncg, s, q) for row r of
     fragment f (hi = fp16(w), lo = fp16(w - hi)):
@@ -305,8 +307,11 @@ def pack_conv24(w, b, src_channels, shuffle_group=False):
       32 | 48 outputs (NF = 4 | 6): f = 2 m: hi(W[16 m + r])   f = 2 m + 1: lo(W[16 m + r])"""
     w = w.detach().cpu().float().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, np.float32)
     b = b.detach().cpu().float().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float32)
-    assert conv24_ok(w.shape, src_channels, shuffle_group=shuffle_group), (w.shape, src_channels)
+    assert conv24_ok(w.shape, src_channels, shuffle_group=shuffle_group, half_group=half_group), (w.shape, src_channels)
     cout = w.shape[0]
+    if cout == 48 and [_pad8(c) for c in src_channels] == [48, 48]:
+        # 48 + 48 -> 48 (refvsr_conv48's two-source form): two channel-half blobs of the 24-output layout (NCG = 12 plan), back to back
+        return torch.cat([pack_conv24(w[0:24], b[0:24], src_channels, half_group=True), pack_conv24(w[24:48], b[24:48], src_channels, half_group=True)])
     Wk, _, ncg = kmatrix(w, src_channels)                       # [cout, 9 * ncg * 8], K-block g = tap * ncg + cg
     S = c24_steps(ncg)
     nf = 3 if cout == 24 else cout // 8

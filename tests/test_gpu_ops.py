@@ -1161,3 +1161,42 @@ def test_conv_last_fused_head(dev, c, bh, bw, scale):
     report('conv_last %dx%d x%d C=%d' % (bh, bw, scale, c), vs_generic=e, vs_torch=e_ref)
     assert e < 2e-5 and e_ref < 2e-3
     assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0 and float((got == 0).float().mean()) > 0.01 and float((got == 1).float().mean()) > 0.01
+
+
+@pytest.mark.parametrize('h,w,act,post,use_mul,use_res', [(8, 32, 0.2, 1.0, False, False), (19, 45, 0.2, 1.0, False, False),
+                                                          (33, 70, 1.0, 1.0, False, False), (61, 130, 0.2, 1.0, True, True),
+                                                          (7, 5, 1.0, 0.2, False, True), (270, 480, 0.2, 1.0, False, False),
+                                                          (540, 960, 0.2, 1.0, False, False)])
+def test_conv48_two_source_channel_halves(dev, h, w, act, post, use_mul, use_res):
+    """refvsr_conv48 with two 48-channel sources (feat_fusion*.0 / feat_fusion2_1 / fusion_UP of the mid_channels = 48 models,
+    RefVSR.py:53-62,87): the output channels are computed in two halves of 24 on blockIdx.y (NCG = 12 K plan, 81 KB of weights per
+    half resident) and stored into the 48-channel map.  Against torch fp32 on the same fp16 maps and against the runtime-generic
+    streamed kernel it replaces (same arithmetic up to fp32 summation order); every epilogue combination, border / partial tiles,
+    maps smaller than a tile, sixteen waves with ONE pixel group each (odd group count per wave)."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h * 5 + w)
+    wt = torch.randn(48, 96, 3, 3, generator=g) / (96 * 9) ** 0.5
+    b = torch.randn(48, generator=g) * 0.1
+    x = torch.randn(1, 96, h, w, generator=g)
+    cw = ops.ConvWeights(pack_conv(wt, b, [48, 48]), dev)
+    assert cw.blob24 is not None and cw.blob24.numel() == 2 * (27 * 3 * 1024 + 128)
+    s0, s1 = nhwc(x[0, :48], dev), nhwc(x[0, 48:], dev)
+    mul = torch.rand(48, h, w, generator=g) if use_mul else None
+    res = torch.randn(48, h, w, generator=g) if use_res else None
+    kw = dict(act=act, post=post, mul=nhwc(mul, dev) if use_mul else None, res=nhwc(res, dev) if use_res else None)
+    got = ops.conv(cw, s0, s1, **kw)
+    blob, cw.blob24 = cw.blob24, None                      # the same call through the generic (streamed) kernel
+    gen = ops.conv(cw, s0, s1, **kw)
+    cw.blob24 = blob
+    want = F.leaky_relu(F.conv2d(x.half().float(), wt, b, padding=1), act)[0]
+    if use_mul:
+        want = want * mul.half().float()
+    if use_res:
+        want = want + res.half().float()
+    want = F.leaky_relu(want, post)
+    e, d = rel(planar(got), want), maxdiff(planar(got), planar(gen))
+    report('conv48 48+48 %dx%d act%.1f%s%s' % (h, w, act, ' mul' if use_mul else '', ' res' if use_res else ''), rel=e, vs_generic=d)
+    assert got.shape == gen.shape == (h, w, 48)
+    assert e < 1e-3
+    assert d < 4e-3                                        # an fp16 ulp where the fp32 sums round differently

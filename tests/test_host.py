@@ -706,3 +706,49 @@ def test_round4_blobs_follow_the_library_k_plan():
                 assert not frag[s_, q, 3:8].any() and not frag[s_, q, 11:].any()
         assert np.abs(seen - w.numpy()).max() < 0.1 * 2.0 ** -20
     assert lib.refvsr_conv_last_supported(36) == 0 and lib.refvsr_conv_last_blob_bytes(36) == -1
+
+
+def test_conv48_two_source_blob_is_two_channel_half_blobs():
+    """refvsr_conv48's 48 + 48 -> 48 form (the two-source convs of the mid_channels = 48 models): the blob is two 24-output blobs
+    (channels 0-23 | 24-47) on the NCG = 12 K plan -- three K-steps per tap, channel groups 4 j + {0, 2, 1, 3}.  The python plan
+    equals the library's, every (tap, channel group) occurs exactly once, and each half's fragments contracted with the staged
+    window of the concatenated sources reproduce F.conv2d for that half (hi + lo rows, half-wave fold of the third fragment)."""
+    from refvsr_amd import hip
+    from refvsr_amd.packing import c24_kblock, c24_steps, pack_conv24
+    lib = hip.lib()
+    ncg, S = 12, c24_steps(12)
+    assert S == 27 and lib.refvsr_conv48_supported(48, 48) == 1 and lib.refvsr_conv48_blob_bytes(48, 48) == 2 * (S * 3 * 1024 + 128)
+    seen = set()
+    for s in range(S):
+        for q in range(4):
+            kb = c24_kblock(ncg, s, q)
+            assert kb is not None and lib.refvsr_conv24_kblock(ncg, s, q) == (kb[0] << 16 | kb[1] << 8 | kb[2])
+            seen.add(kb)
+    assert len(seen) == 9 * 12
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(48, 96, 3, 3, generator=g) / (96 * 9) ** 0.5
+    b = torch.randn(48, generator=g) * 0.1
+    blob = pack_conv24(w, b, [48, 48]).numpy()
+    half = S * 3 * 1024 + 128
+    assert blob.size == 2 * half
+    h_, w_ = 3, 4
+    x = torch.randn(96, h_, w_, generator=g).half().float()
+    xp = np.zeros((h_ + 2, w_ + 2, ncg, 8), np.float32)
+    xp[1:-1, 1:-1] = x.permute(1, 2, 0).numpy().reshape(h_, w_, ncg, 8)        # src0 groups 0-5, src1 groups 6-11
+    want = F.conv2d(x[None], w, b, padding=1)[0].numpy()
+    for z in range(2):
+        hb = blob[z * half:(z + 1) * half]
+        frag = hb[:S * 3 * 1024].view(np.float16).astype(np.float32).reshape(S, 3, 4, 16, 8)
+        bias = hb[S * 3 * 1024:].view(np.float32)
+        for oy in range(h_):
+            for ox in range(w_):
+                a0, a1 = bias[0:16].copy(), bias[16:32].copy()
+                a1[8:] = 0.0
+                for s in range(S):
+                    for q in range(4):
+                        ty, tx, cg = c24_kblock(ncg, s, q)
+                        bvec = xp[oy + ty, ox + tx, cg]
+                        a0 += frag[s, 0, q] @ bvec + frag[s, 1, q] @ bvec
+                        a1 += frag[s, 2, q] @ bvec
+                got = np.concatenate([a0, a1[:8] + a1[8:]])
+                assert np.abs(got - want[24 * z:24 * z + 24, oy, ox]).max() < 2e-5, (z, oy, ox)
