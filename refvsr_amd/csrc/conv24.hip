@@ -514,7 +514,9 @@ static int launch_c24(C24Args& a, hipStream_t st) {
 extern "C" int refvsr_conv24_supported(int c0, int c1) {
     return (c0 == 24 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 8 && c1 == 24) || (c0 == 24 && c1 == 24);
 }
-extern "C" int refvsr_conv48_supported(int c0, int c1) { return (c0 == 48 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 48 && c1 == 48); }
+extern "C" int refvsr_conv48_supported(int c0, int c1) {
+    return (c0 == 48 && c1 == 0) || (c0 == 16 && c1 == 0) || (c0 == 48 && c1 == 48) || (c0 == 8 && c1 == 48);
+}
 extern "C" int refvsr_conv32_supported(int c0, int c1) { return (c0 == 32 && c1 == 0) || (c0 == 8 && c1 == 0); }
 
 extern "C" int refvsr_conv24_blob_bytes(int c0, int c1) {
@@ -527,7 +529,7 @@ extern "C" int refvsr_conv32_blob_bytes(int c0, int c1) {
 }
 extern "C" int refvsr_conv48_blob_bytes(int c0, int c1) {
     if (!refvsr_conv48_supported(c0, c1)) return -1;
-    if (c1 == 48) return 2 * (c24_steps(12) * 3 * 1024 + 128);      // two channel-half blobs of the 24-output layout, back to back
+    if (c0 == 48 && c1 == 48) return 2 * (c24_steps(12) * 3 * 1024 + 128);   // two channel-half blobs of the 24-output layout, back to back
     return c24_steps((c0 + c1) / 8) * 6 * 1024 + 256;
 }
 
@@ -591,6 +593,9 @@ extern "C" int refvsr_conv48(const void* src0, int c0, const void* src1, int c1,
     // waves with four (A/B knob REFVSR_CONV48_WAVES=8: 37 % fewer LDS fragment reads, half the waves per SIMD)
     static const bool w8 = getenv("REFVSR_CONV48_WAVES") && atoi(getenv("REFVSR_CONV48_WAVES")) == 8;
     if (c0 == 48 && c1 == 48) return launch_c24<24, 6, 6, 16, 8, 4, 0, 0, 1>(a, st);      // two channel halves on blockIdx.y
+    // 8 + 48 -> 48: the input conv of ResidualBlocksWithInputConv on cat([lr, feat]) (RefVSR.py:340-343): NCG = 7 plan, 108 KB of
+    // weights resident next to the 38 KB tile, sixteen waves with one pixel group each
+    if (c0 == 8 && c1 == 48) return launch_c24<48, 1, 6, 16, 8, 4>(a, st);
     if (c0 == 48) return w8 ? launch_c24<48, 6, 0, 8, 16, 2>(a, st) : launch_c24<48, 6, 0, 16, 16, 4>(a, st);
     return launch_c24<48, 2, 0, 8, 8, 4>(a, st);
 }

@@ -9,7 +9,7 @@
 namespace {
 constexpr int C24_TW = 32, C24_XW = 34;                       // tile width; staged row of the single convs = 34 pixels
 
-__host__ __device__ constexpr int c24_steps(int ncg) { return ncg == 1 ? 3 : ncg == 2 ? 5 : ncg == 3 ? 7 : ncg == 4 ? 9 : ncg == 6 ? 14 : ncg == 12 ? 27 : 0; }
+__host__ __device__ constexpr int c24_steps(int ncg) { return ncg == 1 ? 3 : ncg == 2 ? 5 : ncg == 3 ? 7 : ncg == 4 ? 9 : ncg == 6 ? 14 : ncg == 7 ? 18 : ncg == 12 ? 27 : 0; }
 // K-block (K-step s, quarter q) -> ty << 16 | tx << 8 | cg, or -1 for a zero block
 __host__ __device__ constexpr int c24_kblock(int ncg, int s, int q) {
     const int perm[4] = {0, 2, 1, 3};
@@ -26,6 +26,9 @@ __host__ __device__ constexpr int c24_kblock(int ncg, int s, int q) {
         if (s < 3) { const int u4[4] = {0, 4, 1, 3}; ty = s; tx = u4[q] / 3; cg = u4[q] % 3; }
         else if (s == 3) { ty = q & 1; tx = 2; cg = q >> 1; }
         else { if (q & 1) return -1; ty = 2; tx = 2; cg = q >> 1; }
+    } else if (ncg == 7) {                                         // two steps per tap: cg = {0, 2, 1, 3}, then {4, 6, 5, zero block}
+        ty = s / 6; tx = (s / 2) % 3;
+        if (s & 1) { if (q == 3) return -1; cg = 4 + perm[q]; } else { cg = perm[q]; }
     } else if (ncg == 12) {                                        // three steps per tap: cg = 4 j + {0, 2, 1, 3}
         ty = s / 9; tx = (s / 3) % 3; cg = 4 * (s % 3) + perm[q];
     } else if (ncg == 6) {
@@ -48,12 +51,12 @@ __host__ __device__ constexpr int c24_off(int ncg, int s, int q, int xw = C24_XW
 }
 // pattern of a K-step: steps of one pattern differ only by an immediate
 __host__ __device__ constexpr int c24_pat(int ncg, int s) {
-    return ncg == 1 ? 0 : ncg == 3 ? (s < 6 ? 0 : 1) : ncg == 4 ? 0 : ncg == 12 ? 0 : ncg == 2 ? (s < 3 ? 0 : s - 2) : (s < 9 ? 0 : s < 12 ? 1 : s - 10);
+    return ncg == 1 ? 0 : ncg == 3 ? (s < 6 ? 0 : 1) : ncg == 4 ? 0 : ncg == 12 ? 0 : ncg == 7 ? (s & 1) : ncg == 2 ? (s < 3 ? 0 : s - 2) : (s < 9 ? 0 : s < 12 ? 1 : s - 10);
 }
-__host__ __device__ constexpr int c24_npat(int ncg) { return ncg == 1 ? 1 : ncg == 3 ? 2 : ncg == 4 ? 1 : ncg == 12 ? 1 : ncg == 2 ? 3 : 4; }
+__host__ __device__ constexpr int c24_npat(int ncg) { return ncg == 1 ? 1 : ncg == 3 ? 2 : ncg == 4 ? 1 : ncg == 12 ? 1 : ncg == 7 ? 2 : ncg == 2 ? 3 : 4; }
 // first K-step of a pattern
 __host__ __device__ constexpr int c24_pat_step(int ncg, int p) {
-    return ncg == 1 ? 0 : ncg == 3 ? (p ? 6 : 0) : ncg == 4 ? 0 : ncg == 12 ? 0 : ncg == 2 ? (p ? p + 2 : 0) : (p == 0 ? 0 : p == 1 ? 9 : p + 10);
+    return ncg == 1 ? 0 : ncg == 3 ? (p ? 6 : 0) : ncg == 4 ? 0 : ncg == 12 ? 0 : ncg == 7 ? p : ncg == 2 ? (p ? p + 2 : 0) : (p == 0 ? 0 : p == 1 ? 9 : p + 10);
 }
 
 // compile-time proof of the plans: every K-block of the 3 x 3 x ncg window exactly once, K-steps of one pattern differ by an
@@ -84,7 +87,7 @@ __host__ __device__ constexpr bool c24_plan_ok(int ncg, int xw = C24_XW) {
         if (c24_pat(ncg, c24_pat_step(ncg, p)) != p) return false;
     return true;
 }
-static_assert(c24_plan_ok(1) && c24_plan_ok(2) && c24_plan_ok(3) && c24_plan_ok(4) && c24_plan_ok(6) && c24_plan_ok(12), "conv24 K plan");
+static_assert(c24_plan_ok(1) && c24_plan_ok(2) && c24_plan_ok(3) && c24_plan_ok(4) && c24_plan_ok(6) && c24_plan_ok(7) && c24_plan_ok(12), "conv24 K plan");
 
 template <class F, int... I>
 __device__ __forceinline__ void c24_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }

@@ -189,7 +189,7 @@ def pack_resblock24(w1, b1, w2, b2):
 
 # ---- 24-output-channel 3x3 convs (csrc/conv24.hip) -----------------------------------------------------------------------
 def c24_steps(ncg):
-    return {1: 3, 2: 5, 3: 7, 4: 9, 6: 14, 12: 27}[ncg]
+    return {1: 3, 2: 5, 3: 7, 4: 9, 6: 14, 7: 18, 12: 27}[ncg]
 
 
 def c24_kblock(ncg, s, q):
@@ -214,6 +214,10 @@ def c24_kblock(ncg, s, q):
         if s == 3:
             return q & 1, 2, q >> 1
         return None if q & 1 else (2, 2, q >> 1)
+    if ncg == 7:                                    # two steps per tap: cg = {0, 2, 1, 3}, then {4, 6, 5, zero block}
+        if s & 1:
+            return None if q == 3 else (s // 6, (s // 2) % 3, 4 + perm[q])
+        return s // 6, (s // 2) % 3, perm[q]
     if ncg == 12:                                   # three steps per tap: cg = 4 j + {0, 2, 1, 3}
         return s // 9, (s // 3) % 3, 4 * (s % 3) + perm[q]
     if ncg == 6:
@@ -289,7 +293,7 @@ def conv24_ok(w_shape, src_channels, shuffle=False, f32=False, shuffle_group=Fal
     if cout == 32:
         return pads in ([32], [8])              # AlignedConv2d: the 32 -> 32 convs and the RGB stem
     if cout == 48:
-        return pads in ([48], [16], [48, 48]) or (shuffle_group and pads == [24])
+        return pads in ([48], [16], [48, 48], [8, 48]) or (shuffle_group and pads == [24])
     return False
 
 

@@ -1200,3 +1200,27 @@ def test_conv48_two_source_channel_halves(dev, h, w, act, post, use_mul, use_res
     assert got.shape == gen.shape == (h, w, 48)
     assert e < 1e-3
     assert d < 4e-3                                        # an fp16 ulp where the fp32 sums round differently
+
+
+@pytest.mark.parametrize('h,w', [(8, 32), (19, 45), (64, 96), (270, 480)])
+def test_conv48_input_conv_8_plus_48(dev, h, w):
+    """refvsr_conv48 on cat([lr (3 channels in an 8-channel map), feat (48)]) -- the input conv of ResidualBlocksWithInputConv for
+    mid_channels = 48 (RefVSR.py:340-343) -- on the NCG = 7 K plan (two K-steps per tap, one zero block each), 108 KB of weights
+    resident, sixteen waves with one pixel group each; against torch fp32 and the generic kernel it replaces."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h + w)
+    wt = torch.randn(48, 51, 3, 3, generator=g) / (51 * 9) ** 0.5
+    b = torch.randn(48, generator=g) * 0.1
+    x = torch.randn(1, 51, h, w, generator=g)
+    cw = ops.ConvWeights(pack_conv(wt, b, [3, 48]), dev)
+    assert cw.blob24 is not None and cw.blob24.numel() == 18 * 6 * 1024 + 256
+    s0, s1 = nhwc(x[0, :3], dev, 8), nhwc(x[0, 3:], dev)
+    got = ops.conv(cw, s0, s1, act=0.1)
+    blob, cw.blob24 = cw.blob24, None
+    gen = ops.conv(cw, s0, s1, act=0.1)
+    cw.blob24 = blob
+    want = F.leaky_relu(F.conv2d(x.half().float(), wt, b, padding=1), 0.1)[0]
+    e, d = rel(planar(got), want), maxdiff(planar(got), planar(gen))
+    report('conv48 8+48 %dx%d' % (h, w), rel=e, vs_generic=d)
+    assert got.shape == gen.shape == (h, w, 48) and e < 1e-3 and d < 4e-3

@@ -554,7 +554,7 @@ def test_resblock24_blob_and_address_model(relu):
     assert len(covered) == (13 * 32 + 5 * 8) * 24                    # tiles (0,0), (1,0) whole, (1,1): 5 rows x 8 columns
 
 
-@pytest.mark.parametrize('srcs,cout', [([24], 24), ([16], 24), ([3, 24], 24), ([24, 24], 24), ([48], 48), ([16], 48), ([32], 32), ([3], 32)])
+@pytest.mark.parametrize('srcs,cout', [([24], 24), ([16], 24), ([3, 24], 24), ([24, 24], 24), ([48], 48), ([16], 48), ([3, 48], 48), ([32], 32), ([3], 32)])
 def test_conv24_blob_reproduces_conv(srcs, cout):
     """packing.pack_conv24: the K-block table equals the library's (csrc/conv24.hip:c24_kblock, whose plan -- every block once,
     one immediate per step and pattern, equal slot parity inside a ds_read_b128 lane group -- is proven by a static_assert at
