@@ -198,7 +198,12 @@ int refvsr_conf_alpha(const float* conf_a, const float* conf_b, int h, int w, in
  * ResidualBlockNoBN, sr_backbone_utils.py:42-97, and conf_fusion*.1): (c0, c1) in {(48,0), (16,0)}; out / mul / res are
  * 48-channel maps; blob: [S x 6 fragments x 64 lanes x 8 halfs][64 bias floats], fragments [hi | lo] of output channels 0-15,
  * 16-31, 32-47, K-blocks by refvsr_conv24_kblock(ncg, s, q).  48 -> 48 keeps its 84 KB weight set resident next to a
- * 16 x 32-pixel tile walked by sixteen waves (one workgroup per CU). */
+ * 16 x 32-pixel tile walked by sixteen waves (one workgroup per CU).
+ * Two-source forms (ABI 10): (8, 48) -- the input conv of ResidualBlocksWithInputConv on cat([lr, feat]), RefVSR.py:340-343: the
+ * same blob layout on the ncg = 7 plan (18 K-steps, one zero block per tap) -- and (48, 48) -- feat_fusion*.0 / feat_fusion2_1 /
+ * fusion_UP on cat([a, b]), RefVSR.py:53-62,87: one conv's 166 KB of weights have no resident form, so the OUTPUT channels are
+ * computed in two halves of 24 on blockIdx.y; blob = two blobs of the 24-output layout (refvsr_conv24's: [27 K-steps x 3 fragments
+ * x 64 lanes x 8 halfs][32 bias floats], ncg = 12 plan) for channels 0-23 and 24-47, back to back. */
 /* The same for 32 output channels (AlignedConv2d, RefVSR_/alignment.py:18-24,53-100: the RGB stem and the 32 -> 32 convs of its
  * ResBlocks, at the 2x / HD resolutions): (c0, c1) in {(32,0), (8,0)}; blob: [S x 4 fragments x 64 lanes x 8 halfs][32 bias floats],
  * fragments [hi | lo] of output channels 0-15, 16-31. */
