@@ -184,6 +184,14 @@ int refvsr_conv_last_supported(int c);
 int refvsr_conv_last_blob_bytes(int c);
 int refvsr_conv_last(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
                      float* out, void* stream);
+/* conv_hr AND the head in one launch (ABI 10; mid_channels = 24): RefVSR.py:91-92,116-118,288,297 --
+ *   out = clamp( conv_last( lrelu_{act_slope}( conv_hr(src) ) ) + clamp(F.interpolate(lr_centre, bicubic), 0, 1), 0, 1 )
+ * on the two-conv skeleton of refvsr_resblock24_chain: the intermediate HR map (100 MB at 1080 x 1920) stays in LDS.  src: fp16
+ * HWC [h][w][24]; blob: REFVSR_RESBLOCK24_BLOB_BYTES in the block layout with conv1 = conv_hr and conv2's fragment slot (s, 0) =
+ * [rows 0-2: hi(W_last), rows 8-10: lo(W_last)], slots (s, 1), (s, 2) zero, b1 = conv_hr's bias, b2 = [b_last, 0 ...]
+ * (refvsr_amd/packing.py:pack_conv_hr_last); base_lr / out as in refvsr_conv_last. */
+int refvsr_conv_hr_last(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
+                        float* out, void* stream);
 /* The confidence fusions in ONE launch (ABI 10): conf_fusion / conf_fusion2 / conf_fusion_BWFW of RefVSR.py:47-52, called at
  * :130, :141-142 and :107-109 as  conv_{16->C}(lrelu(conv_{2->16}(cat[conf_a, conf_b])))  on the LR grid (up = 1) and on
  * clamp(F.interpolate(cat[conf_a, conf_b], scale_factor=2, mode='bicubic'), 0, 1) (up = 2).  conf_a / conf_b: planar fp32

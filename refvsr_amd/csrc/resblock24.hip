@@ -62,6 +62,8 @@ struct RB24Args {
     float act_slope;
     unsigned long long* probe;           // PROBE kernels: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
     int probe_iter;                      // which tile iteration of the workgroup is stamped
+    // HEAD kernels (refvsr_conv_hr_last): `out` is planar fp32 [3][h][w]; base_lr = the LR centre frame, planar fp32 [3][bh][bw]
+    const float* base_lr; int bh, bw; float base_step;
 };
 
 // lane l: a[l] + a[l ^ 32]   (v_mov, v_permlane32_swap, v_add per register).  The two results are taken out of the builtin's
@@ -129,6 +131,49 @@ __device__ __forceinline__ void rb_kloop(f32x4 (&acc0)[TA], f32x4 (&acc1)[TA], c
     mfma(a[0], b[0]);
 }
 
+// K loop of the output head's conv (HEAD kernels): ONE fragment per K-step -- rows 0-2 = hi, rows 8-10 = lo of the three output
+// channels -- at the blob's fragment slot (s, 0); the other two slots of the 3-fragment layout are not read.
+template <int T>
+__device__ __forceinline__ void rb_kloop_head(f32x4 (&acc0)[T], const unsigned char* smem, const int wofs, const int la,
+                                              const int (&pb)[T], const int delta6) {
+    uint4 a[2], b[2][T];
+    auto load = [&](auto sc, uint4& af, uint4 (&bf)[T]) {
+        constexpr int s = decltype(sc)::value;
+        af = *reinterpret_cast<const uint4*>(smem + wofs + s * RB_NF * 1024 + la);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if constexpr (s < 6) bf[t] = *reinterpret_cast<const uint4*>(smem + pb[t] + (s >> 1) * RB_ROWB + (s & 1) * 64);
+            else bf[t] = *reinterpret_cast<const uint4*>(smem + pb[t] + delta6);
+        }
+    };
+    auto mfma = [&](const uint4& af, const uint4 (&bf)[T]) {
+        const f16x8 a_w = *reinterpret_cast<const f16x8*>(&af);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_w, *reinterpret_cast<const f16x8*>(&bf[t]), acc0[t], 0, 0, 0);
+    };
+    load(std::integral_constant<int, 0>{}, a[0], b[0]);
+    load(std::integral_constant<int, 1>{}, a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+    load(std::integral_constant<int, 2>{}, a[0], b[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[1], b[1]);
+    load(std::integral_constant<int, 3>{}, a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+    load(std::integral_constant<int, 4>{}, a[0], b[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[1], b[1]);
+    load(std::integral_constant<int, 5>{}, a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+    load(std::integral_constant<int, 6>{}, a[0], b[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[1], b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(a[0], b[0]);
+}
+
 // act(y) of four fp32 values -> two packed fp16 pairs.  RELU: conversion first, v_pk_max_f16 on the pairs (ReLU commutes with
 // the rounding); leaky ReLU (0 < slope <= 1): max(y, slope * y) in fp32.
 template <bool RELU>
@@ -163,9 +208,15 @@ __device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
 // Measured (profiles/r04_resblock_microbench.txt, us per block 0 / 1 / 2): LR 9.17 / 9.19 / 9.47, 2x 28.73 / 27.80 / 29.68, HR 103.3 /
 // 102.2 / 107.6; in the frame 199.2 / 199.5 / 197.1 frames/s (profiles/r04_knobs_ab.txt) -> 1 is the default: the stores were not what
 // an LR launch waits for, and write-through stores are slower than letting the L2 write the tile back.
-template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0>
+// HEAD = 1 (refvsr_conv_hr_last, round 4): not a residual block but the last two convs of the upsampler, conv_hr (24 -> 24,
+// LeakyReLU 0.1) and conv_last (24 -> 3) + the bicubic base + the clamps (RefVSR.py:91-92,116-118,288,297), on this kernel's
+// two-conv skeleton: conv1 = conv_hr, the intermediate tile stays in LDS (the 100 MB HR map between the two convs never exists),
+// conv2 = ONE fragment per K-step (rows 0-2 hi, rows 8-10 lo), no residual, the epilogue of refvsr_conv_last (fold, one lane per
+// channel, rv_bicubic_at, planar fp32 stores).  The blob keeps the block layout (conv2's fragment slots 1 and 2 unused).
+template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0, int HEAD = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 4 ? 2 : 4, NWV == 4 ? 2 : 4))) void resblock24_kernel(RB24Args p) {
     static_assert((TH == 8 && (NWV == 4 || NWV == 8)) || (TH == 16 && NWV == 16), "tile height / waves");
+    static_assert(HEAD == 0 || (!RELU && !PROBE && NWV != 4), "output-head variant");
     constexpr int RB_TH = TH, RB_XH = TH + 4, RB_IH = TH + 2;    // TH = 8: x tile 12 x 36, intermediate 10 x 34 (22 sixteen-pixel groups)
     constexpr int RB_NI = RB_IH * RB_IW;                         // TH = 16: 20 x 36, 18 x 34 (39 groups), 16 waves, ONE workgroup per CU
     constexpr int RB_G1 = (RB_NI + 15) / 16;                     //   (the large maps, see refvsr_resblock24_chain)
@@ -310,11 +361,13 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
         if (has_next) x_fetch(tl + 1);                           // next tile: in flight from here to the end of conv2
         // residual x values of this lane's outputs: the x tile is about to be overwritten by t
         f16x4 xr0[T2], xr1[T2];
+        if constexpr (HEAD == 0) {
 #pragma unroll
-        for (int t = 0; t < T2; ++t) {
-            xr0[t] = *reinterpret_cast<const f16x4*>(smem + pb2[t] + dq);
-            // lanes 32-63 of the third accumulator collect lo sums only: they start from zeros (the pad of b1)
-            xr1[t] = *reinterpret_cast<const f16x4*>(smem + (q < 2 ? pb2[t] + dq + 32 : RB_BIAS + 96));
+            for (int t = 0; t < T2; ++t) {
+                xr0[t] = *reinterpret_cast<const f16x4*>(smem + pb2[t] + dq);
+                // lanes 32-63 of the third accumulator collect lo sums only: they start from zeros (the pad of b1)
+                xr1[t] = *reinterpret_cast<const f16x4*>(smem + (q < 2 ? pb2[t] + dq + 32 : RB_BIAS + 96));
+            }
         }
 #pragma unroll
         for (int t = 0; t < T1; ++t) a1[t] = rb_fold_halves(a1[t]);
@@ -353,19 +406,45 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
             const f32x4 bv1 = *reinterpret_cast<const f32x4*>(smem + RB_BIAS + 192 + q * 16);
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
-                const f16x4 x0 = xr0[t], x1 = xr1[t];
-                c0[t] = (f32x4){bv0[0] + (float)x0[0], bv0[1] + (float)x0[1], bv0[2] + (float)x0[2], bv0[3] + (float)x0[3]};
-                c1[t] = (f32x4){bv1[0] + (float)x1[0], bv1[1] + (float)x1[1], bv1[2] + (float)x1[2], bv1[3] + (float)x1[3]};
+                if constexpr (HEAD != 0) {
+                    c0[t] = bv0;                                     // [b0, b1, b2, 0] in lanes q = 0, zeros elsewhere (lo rows, pads)
+                    c1[t] = bv1;
+                } else {
+                    const f16x4 x0 = xr0[t], x1 = xr1[t];
+                    c0[t] = (f32x4){bv0[0] + (float)x0[0], bv0[1] + (float)x0[1], bv0[2] + (float)x0[2], bv0[3] + (float)x0[3]};
+                    c1[t] = (f32x4){bv1[0] + (float)x1[0], bv1[1] + (float)x1[1], bv1[2] + (float)x1[2], bv1[3] + (float)x1[3]};
+                }
             }
         }
-        rb_kloop<T2, T2>(c0, c1, smem, RB_WB, la, pb2, delta6);
+        if constexpr (HEAD != 0) rb_kloop_head<T2>(c0, smem, RB_WB, la, pb2, delta6);
+        else rb_kloop<T2, T2>(c0, c1, smem, RB_WB, la, pb2, delta6);
         if (stamp) RB_STAMP(7);
         if (has_next) {
             __syncthreads();                                     // C: every wave is done reading t
             x_park();
         }
         if (stamp) RB_STAMP(8);
-        if constexpr (STORE == 0) {
+        if constexpr (HEAD != 0) {
+            // clamp( conv_last + bias + clamp01(bicubic(lr_centre)), 0, 1 ) -> planar fp32: after the fold lane (0, n) holds the
+            // three channel sums of pixel n, lane (q, n), q < 3, takes channel q and evaluates ITS channel's bicubic sample
+            const size_t plane_o = (size_t)p.h * p.w, plane_b = (size_t)p.bh * p.bw;
+            float* op = reinterpret_cast<float*>(p.out);
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                const f32x4 y = c0[t];
+                const float s0 = rb_fold1(y[0]), s1 = rb_fold1(y[1]), s2 = rb_fold1(y[2]);
+                const int srcl = lane & 15;
+                const float v0 = __shfl(s0, srcl), v1 = __shfl(s1, srcl), v2 = __shfl(s2, srcl);
+                const float v = q == 0 ? v0 : q == 1 ? v1 : v2;
+                int lpe = lp;
+                if (!interior) asm volatile("" : "+v"(lpe));
+                const int oy = ty0 + oy0 + (t >> 1), ox = tx0 + (t & 1) * 16 + lpe;
+                if (q < 3 && oy < p.h && ox < p.w) {
+                    const float b = fminf(fmaxf(rv_bicubic_at(p.base_lr + q * plane_b, p.bh, p.bw, oy, ox, p.base_step, p.base_step), 0.0f), 1.0f);
+                    op[q * plane_o + (size_t)oy * p.w + ox] = fminf(fmaxf(v + b, 0.0f), 1.0f);
+                }
+            }
+        } else if constexpr (STORE == 0) {
             unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -442,7 +521,7 @@ extern "C" int refvsr_set_resblock24_waves(int waves) {
     return 0;
 }
 
-template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0>
+template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0, int HEAD = 0>
 static int launch_rb24(RB24Args& a, hipStream_t st) {
     constexpr int RB_LDS = rb_lds(TH);
     a.tiles_x = rv_cdiv(a.w, RB_TW);
@@ -451,17 +530,17 @@ static int launch_rb24(RB24Args& a, hipStream_t st) {
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE, TH, STORE>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock24_kernel<RELU, NWV, PROBE, TH, STORE, HEAD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE, TH, STORE>, NWV * 64, RB_LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock24_kernel<RELU, NWV, PROBE, TH, STORE, HEAD>, NWV * 64, RB_LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH, STORE>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
+    hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH, STORE, HEAD>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -511,6 +590,30 @@ extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, con
         cur = dst;
     }
     return 0;
+}
+
+// The last two convs of the upsampler in ONE launch (RefVSR.py:91-92,116-118,288,297, mid_channels = 24):
+//   out = clamp( conv_last( lrelu_{act_slope}( conv_hr(src) ) ) + clamp01( F.interpolate(base_lr, bicubic) ), 0, 1 )   planar fp32 [3][h][w]
+// src: fp16 HWC [h][w][24]; blob: REFVSR_RESBLOCK24_BLOB_BYTES in the block layout with conv1 = conv_hr and conv2's fragment slot
+// (s, 0) = [rows 0-2: hi(W_last), rows 8-10: lo(W_last)], slots (s, 1), (s, 2) zero, b1 = conv_hr's bias, b2 = [b_last, 0 ...]
+// (refvsr_amd/packing.py:pack_conv_hr_last).  The HR intermediate map (100 MB at 1080 x 1920) stays in LDS.
+extern "C" int refvsr_conv_hr_last(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
+                                   float* out, void* stream) {
+    RV_CHECK(src && out && blob && base_lr && h > 0 && w > 0, "conv_hr_last: bad args");
+    RV_CHECK(((uintptr_t)blob & 15) == 0, "conv_hr_last: blob must be 16-byte aligned");
+    RV_CHECK(act_slope > 0.f && act_slope <= 1.f, "conv_hr_last: activation slope must lie in (0, 1]");
+    RV_CHECK(bh > 0 && bw > 0 && h % bh == 0 && w % bw == 0 && h / bh == w / bw, "conv_hr_last: base frame %dx%d does not divide the output %dx%d", bh, bw, h, w);
+    RV_CHECK((long long)h * w * RB_PXB < (1ll << 31), "conv_hr_last: map too large for 32-bit offsets");
+    RV_CHECK(refvsr_init() == 0, "init failed");
+    RB24Args a;
+    memset(&a, 0, sizeof(a));
+    a.h = h; a.w = w; a.act_slope = act_slope;
+    a.src = (const unsigned char*)src; a.out = (unsigned char*)out; a.blob = (const unsigned char*)blob;
+    a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h;
+    hipStream_t st = (hipStream_t)stream;
+    const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8);
+    const int waves = g_rb24_waves == 8 || g_rb24_waves == 16 ? g_rb24_waves : (nt8 >= 4 * rv_num_cus() ? 16 : 8);
+    return waves == 16 ? launch_rb24<false, 16, false, 16, 0, 1>(a, st) : launch_rb24<false, 8, false, 8, 0, 1>(a, st);
 }
 
 // K-block (K-step s, quarter q) of the blob's fragment order -> (ty, tx, cg) of the 3x3 x 24-channel window, or -1 for the

@@ -201,6 +201,7 @@ class Engine(object):
                                                          else os.environ.get('REFVSR_BW_HEAD_BLOCKS', '12'))))
         self.warp_up2 = not env_flag('REFVSR_NO_WARP_UP2')          # A/B knob: flow_up2 as its own launch + 2x flow map (round 3)
         self.fuse_head = not env_flag('REFVSR_NO_FUSE_HEAD')        # A/B knob: bicubic base map + generic planar conv (round 3)
+        self.fuse_tail = self.fuse_head and not env_flag('REFVSR_NO_FUSE_TAIL')   # A/B knob: conv_hr and the head as two launches
         self.fuse_conf = not env_flag('REFVSR_NO_FUSE_CONF')        # A/B knob: confidence fusions as separate launches (round 3)
         self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not env_flag('REFVSR_NO_OVERLAP')
@@ -660,6 +661,13 @@ class Engine(object):
         out = self.res_list(out, 'feat_decoder_BWFW', 4)
         if self.cfg.scale == 4:                                               # :114-115
             out = ops.conv(self.cw('upsample2.upsample_conv'), out, act=0.1)  # lrelu commutes with pixel_shuffle
+        if self.fuse_tail and self.C == 24 and ops.conv_last_ok(24, out.shape[0], out.shape[1]):
+            # conv_hr + conv_last + the bicubic base + the clamps in one launch: the HR map between the two convs stays in LDS
+            blob = self.W.chains.get('conv_hr_last_blob')
+            if blob is None:
+                from .packing import pack_conv_hr_last
+                blob = self.W.chains['conv_hr_last_blob'] = pack_conv_hr_last(*self.cw('conv_hr').raw, *self.cw('conv_last').raw).to(out.device).contiguous()
+            return ops.conv_hr_last(blob, out, lr_center, act=0.1)
         out = ops.conv(self.cw('conv_hr'), out, act=0.1)
         if self.fuse_head and ops.conv_last_ok(self.C, out.shape[0], out.shape[1]):
             # conv_last + the bicubic base + the clamps in one launch: the base map is evaluated per output value

@@ -88,6 +88,7 @@ SIGNATURES = {
     'refvsr_warp_nhwc16_up2': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_warp_planar': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'refvsr_spynet_level_input': [_P, _P, _P, _I, _I, _P, _P, _P],
+    'refvsr_conv_hr_last': [_P, _I, _I, _P, _F, _P, _I, _I, _P, _P],
     'refvsr_conv_last_supported': [_I],          # returns 0 / 1
     'refvsr_conv_last_blob_bytes': [_I],         # returns the size
     'refvsr_conv_last': [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],

@@ -455,6 +455,19 @@ def conv_last(blob, src, base_lr):
     return out
 
 
+def conv_hr_last(blob, src, base_lr, act=0.1):
+    """refvsr_conv_hr_last: clamp(conv_last(lrelu(conv_hr(src))) + clamp01(bicubic(base_lr)), 0, 1) -> planar fp32 [3, h, w], one launch
+    (mid_channels = 24).  blob: packing.pack_conv_hr_last on the device."""
+    _nhwc(src)
+    _planar(base_lr, 3)
+    h, w, c = src.shape
+    assert c == 24 and blob.numel() == hip.RESBLOCK24_BLOB_BYTES
+    bh, bw = base_lr.shape[1:]
+    out = torch.empty((3, h, w), dtype=torch.float32, device=src.device)
+    hip.check(hip.lib().refvsr_conv_hr_last(_ptr(src), h, w, _ptr(blob), act, _ptr(base_lr), bh, bw, _ptr(out), _stream()), 'conv_hr_last')
+    return out
+
+
 def conv_last_ok(c, h, w):
     return bool(hip.lib().refvsr_conv_last_supported(int(c))) and h * w * c * 2 < 2 ** 31
 

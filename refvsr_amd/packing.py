@@ -231,6 +231,34 @@ def c24_kblock(ncg, s, q):
     raise ValueError(ncg)
 
 
+def pack_conv_hr_last(w_hr, b_hr, w_last, b_last):
+    """uint8 [43264] blob for refvsr_conv_hr_last (mid_channels = 24): the resblock24 block layout with conv1 = conv_hr (24 -> 24)
+    and conv2 = the output head conv_last (24 -> 3): its fragment slot (s, 0) holds hi(W_last) in rows 0-2 and lo(W_last) in rows
+    8-10 of K-block rb24_kblock(s, q), slots (s, 1) and (s, 2) stay zero; b1 = conv_hr's bias, b2 = [b_last, 0, ...]."""
+    w_last = w_last.detach().cpu().float().numpy() if isinstance(w_last, torch.Tensor) else np.asarray(w_last, np.float32)
+    b_last = b_last.detach().cpu().float().numpy() if isinstance(b_last, torch.Tensor) else np.asarray(b_last, np.float32)
+    assert tuple(w_last.shape) == (3, 24, 3, 3), w_last.shape
+    out = pack_resblock24(w_hr, b_hr, np.zeros((24, 24, 3, 3), np.float32), np.zeros(24, np.float32)).numpy().copy()
+    hi = w_last.astype(np.float16)
+    lo = (w_last - hi.astype(np.float32)).astype(np.float16)
+    frag = np.zeros((RB24_S, RB24_NF, 4, 16, 8), np.float16)
+    for s_ in range(RB24_S):
+        for q in range(4):
+            kb = rb24_kblock(s_, q)
+            if kb is None:
+                continue
+            ty, tx, cg = kb
+            ch = slice(cg * 8, cg * 8 + 8)
+            frag[s_, 0, q, 0:3] = hi[:, ch, ty, tx]
+            frag[s_, 0, q, 8:11] = lo[:, ch, ty, tx]
+    wb = RB24_S * RB24_NF * 1024
+    out[wb:2 * wb] = frag.reshape(-1).view(np.uint8)
+    bb = np.zeros(32, np.float32)
+    bb[:3] = b_last
+    out[2 * wb + 128:2 * wb + 256] = bb.view(np.uint8)
+    return torch.from_numpy(out)
+
+
 def pack_conv_last(w, b):
     """uint8 blob of the output head for refvsr_conv_last: 3x3, C -> 3 (C = 24 | 48).  [S K-steps][ONE fragment: 64 lanes x 8 halfs]
     + 32 bias floats; lane l = (q, r) of K-step s holds the 8 input channels of K-block c24_kblock(C / 8, s, q) for fragment row r:

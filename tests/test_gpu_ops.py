@@ -1224,3 +1224,36 @@ def test_conv48_input_conv_8_plus_48(dev, h, w):
     e, d = rel(planar(got), want), maxdiff(planar(got), planar(gen))
     report('conv48 8+48 %dx%d' % (h, w), rel=e, vs_generic=d)
     assert got.shape == gen.shape == (h, w, 48) and e < 1e-3 and d < 4e-3
+
+
+@pytest.mark.parametrize('bh,bw,scale', [(19, 45, 4), (2, 8, 4), (33, 50, 2), (64, 96, 4), (270, 480, 4)])
+def test_conv_hr_last_fused_tail(dev, bh, bw, scale):
+    """refvsr_conv_hr_last (conv_hr + LeakyReLU + conv_last + bicubic base + clamps in one launch on the fused block's skeleton,
+    RefVSR.py:91-92,116-118,288,297) against refvsr_conv24 + refvsr_conv_last: the intermediate tile holds the same fp16 values
+    the HR map would (same K plan, same rounding), the head is summed in another K order => equal to fp32 rounding (bar 2e-5);
+    against fp32 torch to 2e-3.  8-wave 8 x 32 tiles and (1080 x 1920) the 16-wave 16 x 32 tiles, border / partial tiles."""
+    from refvsr_amd import ops
+    from refvsr_amd.packing import pack_conv, pack_conv_hr_last, pack_conv_last
+    g = torch.Generator().manual_seed(7 * bh + bw + scale)
+    h, w = bh * scale, bw * scale
+    w1 = torch.randn(24, 24, 3, 3, generator=g) / (24 * 9) ** 0.5
+    b1 = torch.randn(24, generator=g) * 0.1
+    w2 = torch.randn(3, 24, 3, 3, generator=g) * 0.04
+    b2 = torch.randn(3, generator=g) * 0.1
+    xf = torch.randn(24, h, w, generator=g)
+    base = (torch.rand(3, bh, bw, generator=g) * 1.2 - 0.1).to(dev)
+    x = nhwc(xf, dev)
+    t = ops.conv(ops.ConvWeights(pack_conv(w1, b1, [24]), dev), x, act=0.1)
+    want = ops.conv_last(pack_conv_last(w2, b2).to(dev), t, base)
+    got = ops.conv_hr_last(pack_conv_hr_last(w1, b1, w2, b2).to(dev), x, base, act=0.1)
+    assert got.shape == want.shape == (3, h, w)
+    e = maxdiff(got, want)
+    e_ref = float('nan')
+    if h * w <= 512 * 512:
+        tt = F.leaky_relu(F.conv2d(planar(x, 24)[None], w1, b1, padding=1), 0.1).half().float()
+        ref = (F.conv2d(tt, w2, b2, padding=1)[0] + F.interpolate(base.cpu()[None], scale_factor=scale, mode='bicubic', align_corners=False)[0].clamp(0, 1)).clamp(0, 1)
+        e_ref = maxdiff(got.cpu(), ref)
+        assert e_ref < 2e-3
+    report('conv_hr_last %dx%d x%d' % (bh, bw, scale), vs_two_launches=e, vs_torch=e_ref)
+    assert e < 2e-5
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0

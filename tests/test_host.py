@@ -706,6 +706,24 @@ def test_round4_blobs_follow_the_library_k_plan():
                 assert not frag[s_, q, 3:8].any() and not frag[s_, q, 11:].any()
         assert np.abs(seen - w.numpy()).max() < 0.1 * 2.0 ** -20
     assert lib.refvsr_conv_last_supported(36) == 0 and lib.refvsr_conv_last_blob_bytes(36) == -1
+    # refvsr_conv_hr_last: the block blob with conv1 = conv_hr and the head in conv2's fragment slot (s, 0)
+    from refvsr_amd.packing import RB24_NF, RB24_S, pack_conv_hr_last, pack_resblock24, rb24_kblock
+    w1, b1 = torch.randn(24, 24, 3, 3, generator=g), torch.randn(24, generator=g)
+    w2, b2 = torch.randn(3, 24, 3, 3, generator=g) * 0.1, torch.randn(3, generator=g)
+    hb = pack_conv_hr_last(w1, b1, w2, b2).numpy()
+    blk = pack_resblock24(w1, b1, torch.zeros(24, 24, 3, 3), torch.zeros(24)).numpy()
+    wb = RB24_S * RB24_NF * 1024
+    assert hb.size == hip.RESBLOCK24_BLOB_BYTES and (hb[:wb] == blk[:wb]).all() and (hb[2 * wb:2 * wb + 128] == blk[2 * wb:2 * wb + 128]).all()
+    f2 = hb[wb:2 * wb].view(np.float16).astype(np.float32).reshape(RB24_S, RB24_NF, 4, 16, 8)
+    assert not f2[:, 1:].any() and not f2[:, 0, :, 3:8].any() and not f2[:, 0, :, 11:].any()
+    seen = np.zeros((3, 24, 3, 3), np.float32)
+    for s_ in range(RB24_S):
+        for q in range(4):
+            kb = rb24_kblock(s_, q)
+            if kb is not None:
+                seen[:, kb[2] * 8:kb[2] * 8 + 8, kb[0], kb[1]] += f2[s_, 0, q, 0:3] + f2[s_, 0, q, 8:11]
+    assert np.abs(seen - w2.numpy()).max() < 0.1 * 2.0 ** -19
+    assert np.allclose(hb[2 * wb + 128:].view(np.float32)[:3], b2.numpy()) and not hb[2 * wb + 128:].view(np.float32)[3:].any()
 
 
 def test_conv48_two_source_blob_is_two_channel_half_blobs():
