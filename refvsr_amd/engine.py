@@ -201,7 +201,10 @@ class Engine(object):
                                                          else os.environ.get('REFVSR_BW_HEAD_BLOCKS', '12'))))
         self.warp_up2 = not env_flag('REFVSR_NO_WARP_UP2')          # A/B knob: flow_up2 as its own launch + 2x flow map (round 3)
         self.fuse_head = not env_flag('REFVSR_NO_FUSE_HEAD')        # A/B knob: bicubic base map + generic planar conv (round 3)
-        self.fuse_tail = self.fuse_head and not env_flag('REFVSR_NO_FUSE_TAIL')   # A/B knob: conv_hr and the head as two launches
+        # conv_hr + head as ONE launch on the fused block's skeleton (refvsr_conv_hr_last): bit-identical to the two launches, 112 vs
+        # 132 us stand-alone at 1080p, but NEUTRAL in the frame (209.3 / 209.9 vs 210.1 / 210.1 frames/s, profiles/
+        # r04_tail_and_mfid_run.log: the HR intermediate it saves is 6 % of a launch pair that a 19 % larger conv1 pays for) -> opt-in
+        self.fuse_tail = self.fuse_head and (env_flag('REFVSR_FUSE_TAIL') or bool(getattr(config, 'fuse_tail', False)))
         self.fuse_conf = not env_flag('REFVSR_NO_FUSE_CONF')        # A/B knob: confidence fusions as separate launches (round 3)
         self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not env_flag('REFVSR_NO_OVERLAP')

@@ -827,6 +827,10 @@ def test_fused_warp_engine_matches_default(dev):
         assert torch.equal(a, b)
 
 
+def cfg_name_is_small(name):
+    return 'small' in name
+
+
 @pytest.mark.parametrize('name,size', [('config_RefVSR_small_L1', (64, 96)), ('config_RefVSR_MFID', (40, 56))])
 def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, size):
     """The launches round 4 removed from a frame -- torch.cat + 2 -> 16 conv + bicubic x2 + torch.max of the confidence fusions
@@ -880,3 +884,12 @@ def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, 
     assert net4.Network.ensure_engines(1, dev)[0].fuse_head
     worst = max(maxdiff(net4(wl[f], wr[f], f == 0)['result'], want[f]) for f in range(nfr))
     assert worst < 2e-5, worst
+    # ... and conv_hr + head in one launch (opt-in: config.fuse_tail / REFVSR_FUSE_TAIL=1; mid_channels = 24): bit-identical to
+    # the fused head behind a separate conv_hr
+    if cfg_name_is_small(name):
+        net5, cfg5, _ = make_net(name, t, dev, reset=4, save_sample=False)
+        cfg5.fuse_tail = True
+        assert net5.Network.ensure_engines(1, dev)[0].fuse_tail
+        net4.Network.reset()
+        for f in range(nfr):
+            assert torch.equal(net5(wl[f], wr[f], f == 0)['result'], net4(wl[f], wr[f], f == 0)['result']), 'frame %d differs (fused tail)' % f

@@ -25,7 +25,7 @@ run() {
 }
 for round in 1 2; do
   run "default (round $round)" X=1
-  run "REFVSR_NO_FUSE_TAIL=1 (round $round)" REFVSR_NO_FUSE_TAIL=1
+  run "REFVSR_NO_FUSE_TAIL=1 (round $round)" REFVSR_NO_FUSE_TAIL=1   # (at the time of this run the fused tail was the default; it is opt-in since: REFVSR_FUSE_TAIL=1)
   run "default, REFVSR_BW_HEAD_BLOCKS=10 (round $round)" REFVSR_BW_HEAD_BLOCKS=10
 done
 echo "== tail microbench at 1080x1920: conv_hr + conv_last vs refvsr_conv_hr_last ==" | tee -a $L
