@@ -49,6 +49,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's buffer exchange fails with `hipIpcGetMemHandle: invalid argument`
+# otherwise); the image exports it -- kept here for launchers that build their own environment.  Before the HIP runtime starts.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -632,16 +635,18 @@ def main():
     # BOTH modes, clocks and power state settled
     tw = time.perf_counter()
     nwarm = 0
-    while nwarm < 1 or time.perf_counter() - tw < args.warm_seconds:
+    while True:
         timed_pass(use_ids, pipelined, False, timed=False)
         if want_dropin:
             timed_pass(False, False, False, timed=False)
         nwarm += 1
-        if world > 1:                      # the ranks must agree on the number of passes (they hold barriers)
-            flag = torch.tensor([1.0 if time.perf_counter() - tw < args.warm_seconds else 0.0], device=dev if backend == 'nccl' else 'cpu')
+        more = time.perf_counter() - tw < args.warm_seconds
+        if world > 1:                      # the ranks must agree on the number of passes (they hold barriers): ONE decision, reduced
+            flag = torch.tensor([1.0 if more else 0.0], device=dev if backend == 'nccl' else 'cpu')
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) == 0.0:
-                break
+            more = float(flag.item()) != 0.0
+        if not more:
+            break
     warm_s = time.perf_counter() - tw
     # the collector must not stop the host inside a 100 ms timed pass: everything allocated so far (model, windows, warm pools)
     # goes to the permanent generation, the young generations are collected between the passes

@@ -64,6 +64,8 @@ struct RB48Args {
     const unsigned char* src; unsigned char* out; const unsigned char* blob;
     int h, w, tiles_x, n_tiles, grid;
     float act_slope;
+    unsigned long long* probe;           // PROBE kernel: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
+    int probe_iter;                      // which tile iteration of the workgroup is stamped
 };
 
 // K loop of one conv: T pixel groups of this wave; fragments at LDS offset 0, B windows at pb[t] + pd[pattern] + immediate.
@@ -119,8 +121,14 @@ __device__ __forceinline__ r48_u32x2 r48_act_pack(const f32x4 y, const float slo
     return (r48_u32x2){a.u, b.u};
 }
 
-template <bool RELU>
+// PROBE (tools/probe_resblock48.py): stamps 0 entry; of tile `probe_iter`: 1 tile start (iteration 0: the first barrier -- W1, biases
+// and the first x tile have landed), 2 conv1 K loop done, 3 barrier A, 4 t -> LDS issued and drained, 5 barrier B (W2 landed), 6 conv2 K loop done, 7 barrier C,
+// 8 W1 DMA issued + next x tile parked, 9 output stores issued, 10 barrier D; 11 exit ([7]/[8]/[10] = the previous stamp when
+// there is no next tile)
+template <bool RELU, bool PROBE = false>
 __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock48_kernel(RB48Args p) {
+#define R48_STAMP(i) do { if constexpr (PROBE) { if (p.probe && threadIdx.x == 0) p.probe[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    R48_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     asm volatile("" :: "s"(p.src), "s"(p.out), "s"(p.blob), "s"(p.h), "s"(p.w), "s"(p.tiles_x), "s"(p.n_tiles), "s"(p.grid),
                  "s"(p.act_slope));
@@ -240,8 +248,10 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                 // W1, biases, first x tile
 
-    for (; tl < k_hi; ++tl) {
+    for (int iter = 0; tl < k_hi; ++tl, ++iter) {
         const bool has_next = tl + 1 < k_hi;
+        const bool stamp = PROBE && iter == p.probe_iter;
+        if (stamp) R48_STAMP(1);
         const int tyi = tl / p.tiles_x;
         const int ty0 = tyi * R48_TH, tx0 = (tl - tyi * p.tiles_x) * R48_TW;
         const bool interior = ty0 >= 2 && ty0 + R48_TH + 2 <= p.h && tx0 >= 2 && tx0 + R48_TW + 2 <= p.w;
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         if (full1) r48_kloop<R48_T1, R48_T1>(a1, smem, la, pb1, pd);
         else r48_kloop<R48_T1 - 1, R48_T1>(a1, smem, la, pb1, pd);
+        if (stamp) R48_STAMP(2);
         if (has_next) x_fetch(tl + 1);                               // next tile: in flight until it is parked after conv2
         // residual x values of this lane's outputs (the x tile is about to be overwritten by t)
         f16x4 xr[R48_NM][R48_T2];
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int m = 0; m < R48_NM; ++m) xr[m][t] = *reinterpret_cast<const f16x4*>(smem + wo2[t] + cen + 32 * m);
         __syncthreads();                                             // A: every wave is done with the x tile and W1
+        if (stamp) R48_STAMP(3);
         w_dma(1);                                                    // W2 in flight under the t epilogue
         {
             auto epi1 = [&](auto tc) {
@@ -291,7 +303,9 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (full1) epi1(std::integral_constant<int, R48_T1>{}); else epi1(std::integral_constant<int, R48_T1 - 1>{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the asm stores above are invisible to hipcc's waitcnt pass
+        if (stamp) R48_STAMP(4);
         __syncthreads();                                             // B: t complete, W2 landed (the fence waits for the DMA)
+        if (stamp) R48_STAMP(5);
 
         // ---------------- phase 2: out = (b2 + conv2(t)) + x: the summation order of refvsr_conv48 with a residual operand ---------
         f32x4 c2[R48_NM][R48_T2];
@@ -302,11 +316,17 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int t = 0; t < R48_T2; ++t) c2[m][t] = bv;
         }
         r48_kloop<R48_T2, R48_T2>(c2, smem, la, pb2, pd);
+        if (stamp) R48_STAMP(6);
         if (has_next) {
             __syncthreads();                                         // C: every wave is done with t and W2
+            if (stamp) R48_STAMP(7);
             w_dma(0);                                                // W1 for the next tile, in flight under the park and the stores
             x_park();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (stamp) R48_STAMP(8);
+        } else if (stamp) {
+            R48_STAMP(7);
+            R48_STAMP(8);
         }
         {
             unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * R48_GPX;
@@ -328,16 +348,23 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 }
             }
         }
+        if (stamp) R48_STAMP(9);
         if (has_next) __syncthreads();                               // D: W1 landed, next x tile visible
+        if (stamp) R48_STAMP(10);
     }
+    R48_STAMP(11);
+#undef R48_STAMP
 }
 
-template <bool RELU>
+extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
+extern int g_rb_probe_iter;
+
+template <bool RELU, bool PROBE = false>
 static int launch_rb48(RB48Args& a, hipStream_t st) {
     static bool attr_done[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock48_kernel<RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, R48_LDS));
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock48_kernel<RELU, PROBE>), hipFuncAttributeMaxDynamicSharedMemorySize, R48_LDS));
         attr_done[dev] = true;
     }
     a.tiles_x = rv_cdiv(a.w, R48_TW);
@@ -345,7 +372,7 @@ static int launch_rb48(RB48Args& a, hipStream_t st) {
     int cap = rv_num_cus() & ~7;                                     // one 135 KB workgroup per CU
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((resblock48_kernel<RELU>), dim3(a.grid), dim3(R48_NT), R48_LDS, st, a);
+    hipLaunchKernelGGL((resblock48_kernel<RELU, PROBE>), dim3(a.grid), dim3(R48_NT), R48_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -373,7 +400,9 @@ extern "C" int refvsr_resblock48_chain(const void* src, int h, int w, int n, con
     for (int i = 0; i < n; ++i) {
         unsigned char* dst = (unsigned char*)((i == n - 1) ? out : ((i & 1) ? scratch1 : scratch0));
         a.src = cur; a.out = dst; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
-        const int rc = act_slope == 0.f ? launch_rb48<true>(a, st) : launch_rb48<false>(a, st);
+        a.probe = g_rb_probe; a.probe_iter = g_rb_probe_iter;
+        const int rc = (g_rb_probe && act_slope == 0.f) ? launch_rb48<true, true>(a, st)       // tools/probe_resblock48.py
+                       : act_slope == 0.f ? launch_rb48<true>(a, st) : launch_rb48<false>(a, st);
         if (rc) return rc;
         cur = dst;
     }
