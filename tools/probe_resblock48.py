@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where does the 48-channel fused ResBlock kernel (csrc/resblock48.hip) spend its time?  s_memtime stamps recorded by wave 0 of
 every workgroup (refvsr_set_probe switches the ReLU launches to the PROBE instantiation) at twelve points of the kernel, for the
-LR map of RefVSR_MFID (270 x 480: 510 tiles of 8 x 32 on 256 persistent workgroups, two tiles each), LR/2 and the 2x map.  Cycles of
-the 100 MHz-independent shader clock counter (s_memtime), differences inside one workgroup only.
+LR map of RefVSR_MFID (270 x 480: 510 tiles of 8 x 32 on 256 persistent workgroups, two tiles each), LR/2 and the 2x map.  Shader cycles
+(s_memtime), differences inside one workgroup only; one v_mfma_f32_16x16x32_f16 occupies a SIMD's matrix pipe for 16 of them.
 
 VERDICT r3 item 6: "build the PROBE variant and show cycles" -- the output goes to profiles/r04_resblock48_probe.txt."""
 import os
