@@ -287,7 +287,13 @@ def wavefront_model(per_frame, nfr, reset_branch):
     cold = per_frame.get('phase_a_cold_extra_ms')
     cold = 0.85 * ta if cold is None else cold
     tot = ta + tb1 + tb2
-    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'handoff_ms_assumed': 0.3, 'cold_block_start_ms': cold, 'predicted_speedup': {}}
+    ex = exchange_terms(per_frame)
+    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'handoff_ms_assumed': 0.3, 'cold_block_start_ms': cold,
+           'cold_block_start_ms_at_a_restart': 2.0 * cold,
+           'context_exchange': {'context_prepare_ms': ex['t_prep'], 'cold_window_extra_with_contexts_ms': ex['t_cold_x'], 'message_ms_assumed': ex['t_ctx'],
+                                'what': 'shard.run_wavefront(exchange_contexts=True): every per-frame context (matching, reference encoders, aligned '
+                                        'attention) prepared ONCE, by the owner of its frame, and sent to the ranks whose windows need it'},
+           'predicted_speedup': {}}
     sp = lambda n, parts, rb, il=True: round(shard.predicted_speedup(nfr, n, parts, rb, ta, tb1, tb2, 0.3, cold, il)[0], 3)
     for n in (2, 4, 8):
         bal = shard.partition(nfr, n)
@@ -298,8 +304,14 @@ def wavefront_model(per_frame, nfr, reset_branch):
             ent['with_restarts (reset_branch=%d)' % reset_branch] = {'chosen': nm, 'speedup': round(s_, 3),
                                                                     'hybrid_reset_aligned': sp(n, shard.partition_hybrid(nfr, n, reset_branch), reset_branch),
                                                                     'balanced_handoff_at_every_boundary': sp(n, bal, reset_branch)}
+        if reset_branch:
+            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, 0.3, cold, exchange=ex)
+            ent['with_restarts (reset_branch=%d)' % reset_branch]['with_context_exchange'] = {'chosen': nm, 'speedup': round(s_, 3)}
+        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, 0.3, cold, exchange=ex)
+        ex_free = {'chosen': nm, 'speedup': round(s_, 3), 'block_sizes': [b_ - a_ for a_, b_, _ in blk]}
         blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, 0.3, cold)
         ent['no_restarts (reset_branch=None, configs[4] regime)'] = {
+            'with_context_exchange': ex_free,
             'chosen': nm, 'speedup': round(s_, 3), 'balanced': sp(n, bal, None), 'growing_shards': sp(n, grow, None),
             'block_cyclic_3': sp(n, shard.partition_cyclic(nfr, n, 3), None) if 3 * n < nfr else None,
             'growing_shards_round3_order (B1 after ALL local phase A)': sp(n, grow, None, False)}
@@ -349,7 +361,39 @@ def measure_phases(net, cfg, dev, h, w, t=5):
     N.reset()
     # (the first-frame call of the restart unit is in the phase-A mean: compare the cold window with the steady frames only)
     per_frame['phase_a_cold_extra_ms'] = max(0.0, min(cold[1:]) - per_frame['phase_a_ms'])
+    # the context exchange of shard.run_wavefront: one per-frame context prepared on its own (Engine.prepare_context), and phase A of
+    # the same cold window when its three contexts are there already (prepared / received ahead): what is left of the cold start
+    eng = N.ensure_engines(1, dev)[0]
+    prep, coldx = [], []
+    for rep in range(3):
+        N.reset()
+        x, r, ids = win(R // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.prepare_context(x[0, t // 2], r[0, t // 2], ids[t // 2])
+        torch.cuda.synchronize()
+        prep.append(1e3 * (time.perf_counter() - t0))
+        for j in range(t // 2 + 1, t):
+            eng.prepare_context(x[0, j], r[0, j], ids[j])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        N.phase_a(x, r, frame_ids=ids, first_hint=False)
+        torch.cuda.synchronize()
+        coldx.append(1e3 * (time.perf_counter() - t0))
+    N.reset()
+    per_frame['context_prepare_ms'] = min(prep[1:])
+    per_frame['phase_a_cold_with_contexts_ms'] = min(coldx[1:])
     return per_frame
+
+
+def exchange_terms(per_frame, ctx_ms=0.3):
+    """simulate_wavefront's `exchange` argument from measure_phases: t_prep = one context prepared alone (capped by phase A), t_cold_x =
+    what a cold window costs beyond a steady window's remainder once its contexts are there, t_ctx = one 32 MB message over one
+    xGMI link + latency (assumed, like the hand-off)."""
+    ta = per_frame['phase_a_ms']
+    tp = min(per_frame.get('context_prepare_ms', 0.35 * ta), ta)
+    cx = per_frame.get('phase_a_cold_with_contexts_ms')
+    return dict(t_prep=tp, t_ctx=ctx_ms, t_cold_x=max(0.0, cx - (ta - tp)) if cx is not None else 0.1 * ta)
 
 
 def wavefront_model_single_gpu(args, dev, h, w):
@@ -385,21 +429,24 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     net.load_state_dict(make_state_dict(cfg, 1234))
     comm_dev = dev if backend == 'nccl' else torch.device('cpu')
     pf = measure_phases(net, cfg, dev, h, w)
-    keys = ('phase_a_ms', 'phase_b1_ms', 'phase_b2_ms', 'phase_a_cold_extra_ms')
+    keys = ('phase_a_ms', 'phase_b1_ms', 'phase_b2_ms', 'phase_a_cold_extra_ms', 'context_prepare_ms', 'phase_a_cold_with_contexts_ms')
     v = torch.tensor([pf[k] for k in keys], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(v, op=dist.ReduceOp.SUM)
     per_frame = {k: float(x) / world for k, x in zip(keys, v.cpu().tolist())}
+    exch = None if args.no_wavefront_exchange else exchange_terms(per_frame)
     blocks, predicted, pname = shard.choose_partition(nfr, world, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                                      per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'])
+                                                      per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'], exchange=exch)
     if args.wavefront_partition:                           # A/B: force a partition family
         fam = args.wavefront_partition
         parts = {'balanced': shard.partition(nfr, world), 'growing': shard.partition_chain(nfr, world),
-                 'hybrid': shard.partition_hybrid(nfr, world, cfg.reset_branch or 9)}.get(fam)
+                 'hybrid': shard.partition_hybrid(nfr, world, cfg.reset_branch or 9),
+                 'cyclic_growing': shard.partition_cyclic_growing(nfr, world, per_frame['phase_a_ms'], per_frame['phase_b1_ms'] + 0.15,
+                                                                  per_frame['phase_a_ms'] + per_frame['context_prepare_ms'])}.get(fam)
         if parts is None and fam.startswith('cyclic'):
             parts = shard.partition_cyclic(nfr, world, int(fam[6:] or 3))
         blocks, pname = shard.as_blocks(parts), fam
         predicted = shard.predicted_speedup(nfr, world, blocks, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                            per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'])[0]
+                                            per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'], True, exch)[0]
     mine = [(a, b) for a, b, r in blocks if r == rank]
     need = sorted(set(i for a, b in mine for f in range(a, b) for i in window_indices(f, nfr, t)))
     clip = {}
@@ -431,11 +478,28 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
         handoff_ms.append(1e3 * (time.perf_counter() - t0) / 2.0)      # two messages in series per rank
     hv = torch.tensor([min(handoff_ms[1:])], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(hv, op=dist.ReduceOp.MAX)
+    if exch is not None and world > 1:
+        # the context messages use their own process group and, with one-frame blocks, rank pairs two apart as well: every pair of
+        # the plan exchanges one small message before the clock starts (every rank walks the SAME sorted pair list: a sequence of
+        # two-party rendezvous in one global order cannot deadlock)
+        plan = shard.ContextPlan(nfr, world, blocks, cfg.reset_branch, t)
+        grp = shard.context_group()
+        pairs = sorted(set((min(plan.owner[i], q), max(plan.owner[i], q)) for i in range(nfr) for q in plan.consumers[i]))
+        tiny = torch.zeros(1024, dtype=torch.uint8, device=comm_dev)
+        for a_, b_ in pairs:
+            if rank == a_:
+                dist.send(tiny, b_, group=grp)
+                dist.recv(tiny, b_, group=grp)
+            elif rank == b_:
+                dist.recv(tiny, a_, group=grp)
+                dist.send(tiny, a_, group=grp)
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     tim = {}
-    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=blocks, timings=tim)
+    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=blocks, timings=tim,
+                              exchange_contexts=exch is not None)
     torch.cuda.synchronize()
     dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
@@ -446,7 +510,8 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
         rd = r.double()
         sums[f, 0], sums[f, 1] = rd.sum().to(comm_dev), (rd * rd).sum().to(comm_dev)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    msgs = torch.tensor([float(tim.get('handoff_messages', 0)), float(tim.get('recv_wait', 0.0))], dtype=torch.float64, device=comm_dev)
+    msgs = torch.tensor([float(tim.get('handoff_messages', 0)), float(tim.get('recv_wait', 0.0)), float(tim.get('context_messages', 0)),
+                         float(tim.get('context_wait', 0.0))], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(msgs, op=dist.ReduceOp.SUM)
     out = None
     if rank == 0:
@@ -479,6 +544,12 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                            'how': 'the packed state of this model sent round the ring of ranks (send / recv pairs), host clock around two '
                                   'messages in series after device synchronisation, best of 2 after one warm-up, max over ranks',
                            'host_seconds_blocked_in_recv_all_ranks': float(msgs[1].item())},
+               'context_exchange': None if exch is None else {
+                   'messages': int(msgs[2].item()), 'bytes_per_message': ex.context_nbytes() if ex._ctx_spec is not None else None,
+                   'format': 'one packed buffer: conf fp32 + index map int32 + the two aligned-attention maps fp16 HWC',
+                   'host_seconds_blocked_waiting_all_ranks': float(msgs[3].item()), 'model_terms_ms': exch,
+                   'what': 'every per-frame context prepared once, by the owner of its frame, sent point to point (own process group) to '
+                           'the ranks whose windows need it; --no-wavefront-exchange: every rank prepares what its windows need'},
                'frames_checked_against_single_rank_run': ncheck, 'frames_equal': bool(ok)}
     dist.barrier()
     return out
@@ -504,7 +575,8 @@ def main():
     ap.add_argument('--clip', type=int, default=64, help='N > 1: frames of the sharded clip (BASELINE configs[3]: 64)')
     ap.add_argument('--clip-check', type=int, default=12, help='frames of the sharded clip re-run on one rank and compared')
     ap.add_argument('--wavefront-timeout', type=float, default=240.0)
-    ap.add_argument('--wavefront-partition', default=None, help='N > 1 A/B: balanced | growing | hybrid | cyclicK (default: shard.choose_partition)')
+    ap.add_argument('--no-wavefront-exchange', action='store_true', help='N > 1: every rank prepares all contexts its windows need (round-4 call 1 schedule)')
+    ap.add_argument('--wavefront-partition', default=None, help='N > 1 A/B: balanced | growing | hybrid | cyclicK | cyclic_growing (default: shard.choose_partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--match-margin', type=float, default=None, help='A/B knob: margin of the exact-search flagging (0 = top-2 re-rank only)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)

@@ -549,8 +549,10 @@ class OracleNetwork(object):
         return conv(out, W, 'Network.conv_last') + base
 
     # -- forward -----------------------------------------------------------------------------
-    def phase_a(self, lrs, refs, first_hint=False):
-        """State-independent part of Network.forward: flows, matching and the backward branch (RefVSR.py:182-238)."""
+    def phase_a(self, lrs, refs, first_hint=False, contexts=None):
+        """State-independent part of Network.forward: flows, matching and the backward branch (RefVSR.py:182-238).
+        contexts: {window position: (conf_map, index_map)} matchings computed elsewhere (by this same function of the same
+        frame pair: the multi-rank context exchange of shard.run_wavefront) -- used instead of recomputing them."""
         W = self.W
         n, t, c, h, w = lrs.shape
         C = self.C
@@ -563,7 +565,10 @@ class OracleNetwork(object):
             bf.append(torch.zeros(n, 2, h, w) if gradio else spynet(lrs[:, j - 1], lrs[:, j], W))
         conf_maps, index_maps = [None] * t, [None] * t
         for i in range(0 if first_hint else ctr, t):                         # :196-204
-            conf_maps[i], index_maps[i] = self._feature_match(lrs[:, i], refs[:, i])
+            if contexts is not None and i in contexts:
+                conf_maps[i], index_maps[i] = contexts[i]
+            else:
+                conf_maps[i], index_maps[i] = self._feature_match(lrs[:, i], refs[:, i])
         # backward branch :211-238
         feat = torch.zeros(n, C, h, w)
         feat_up = torch.zeros(n, C, 2 * h, 2 * w)

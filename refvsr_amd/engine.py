@@ -234,6 +234,7 @@ class Engine(object):
         self.prev_window = []
         self.flow_cache = {}
         self.id_cache = {}
+        self.ctx_pinned = {}
 
     def set_pipelined(self, on=True):
         """Opt in to cross-call pipelining: forward() is then given `frame_ids` (one hashable id per window frame; equal ids
@@ -324,6 +325,80 @@ class Engine(object):
             import numpy as np
             self.keyframe_idx = np.asarray(hdr[5:5 + nk], dtype=np.int64)
         assert dev == self.fw_feat.device
+
+    # ---- per-frame contexts ahead of their windows (shard.run_wavefront with exchange_contexts: every context is prepared by ONE
+    #      rank and sent to the others whose windows need it).  A context = everything prepare_frame derives from one (lr_i, ref_i)
+    #      pair (RefVSR.py:196-204,233-234,127,136); the message carries the four expensive maps [conf fp32 | idx int32 | aligned
+    #      fp16 HWC | aligned_up fp16 HWC] as they lie in HBM (32.2 MB for RefVSR_small at 270p), the cheap ones (the 8-channel
+    #      copy of the frame, the SPyNet pyramid) are rebuilt by the receiver from its own copy of the frame.
+    CTX_FIELDS = ('conf', 'idx', 'aligned', 'aligned_up')
+
+    def _ctx(self, fid):
+        fr = self.id_cache.get(fid)
+        return fr if fr is not None else self.ctx_pinned.get(fid)
+
+    @torch.no_grad()
+    def prepare_context(self, lr, ref, fid):
+        """The context of frame `fid` (its id in forward(frame_ids=...) / phase_a), prepared now on the current stream and kept
+        until a window that contains the id has used it."""
+        assert self.cache, 'contexts are kept by the id-keyed window cache (config.cache_windows)'
+        fr = self._ctx(fid)
+        if fr is None:
+            fr = self.ctx_pinned[fid] = FrameCtx(lr, ref)
+        with torch.cuda.device(lr.device), ops.on_stream(torch.cuda.current_stream(lr.device)):
+            self.pyramid(fr)
+            self.prepare_frame(fr)
+        return fr
+
+    def context_spec(self, fid):
+        """[(field, shape, dtype)] of the message of a PREPARED context: what a receiver needs to size and slice it."""
+        fr = self._ctx(fid)
+        assert fr is not None and fr.conf is not None, 'context %r is not prepared' % (fid,)
+        return [(k, tuple(getattr(fr, k).shape), getattr(fr, k).dtype) for k in self.CTX_FIELDS]
+
+    @staticmethod
+    def context_nbytes(spec):
+        n = 0
+        for _, shape, dtype in spec:
+            m = torch.empty((), dtype=dtype).element_size()
+            for d in shape:
+                m *= d
+            n += (m + 15) // 16 * 16
+        return n
+
+    @torch.no_grad()
+    def export_context(self, fid):
+        """One uint8 device buffer holding CTX_FIELDS of a prepared context, 16-byte aligned parts (current stream)."""
+        spec = self.context_spec(fid)
+        fr = self._ctx(fid)
+        buf = torch.empty(self.context_nbytes(spec), dtype=torch.uint8, device=fr.conf.device)
+        o = 0
+        for k, shape, dtype in spec:
+            t = getattr(fr, k)
+            n = t.numel() * t.element_size()
+            buf[o:o + n].view(dtype).copy_(t.reshape(-1))
+            o += (n + 15) // 16 * 16
+        return buf
+
+    @torch.no_grad()
+    def import_context(self, lr, ref, fid, buf, spec):
+        """Install a context another rank prepared: its maps are views into `buf` (kept alive by the context), the frame copy, its
+        8-channel HWC form and the SPyNet pyramid are made here (current stream)."""
+        assert self.cache and buf.dtype == torch.uint8 and buf.numel() == self.context_nbytes(spec)
+        assert self._ctx(fid) is None, 'context %r exists already' % (fid,)
+        fr = FrameCtx(lr, ref)
+        with torch.cuda.device(lr.device), ops.on_stream(torch.cuda.current_stream(lr.device)):
+            fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
+            self.pyramid(fr)
+        o = 0
+        for k, shape, dtype in spec:
+            n = torch.empty((), dtype=dtype).element_size()
+            for d in shape:
+                n *= d
+            setattr(fr, k, buf[o:o + n].view(dtype).view(shape))
+            o += (n + 15) // 16 * 16
+        self.ctx_pinned[fid] = fr
+        return fr
 
     # ------------------------------------------------------------------ building blocks
     def cw(self, name):
@@ -696,7 +771,10 @@ class Engine(object):
             for i, fid in enumerate(frame_ids):
                 fr = self.id_cache.get(fid)
                 if fr is None:
-                    fr = self.id_cache[fid] = FrameCtx(lrs[i], refs[i])
+                    fr = self.ctx_pinned.pop(fid, None)            # prepared / imported ahead of its first window (prepare_context)
+                    if fr is None:
+                        fr = FrameCtx(lrs[i], refs[i])
+                    self.id_cache[fid] = fr
                 frames[i] = fr
             keep = set(frame_ids)
             self.id_cache = {k: v for k, v in self.id_cache.items() if k in keep}

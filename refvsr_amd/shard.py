@@ -213,12 +213,174 @@ def partition_cyclic(nframes, world, size):
     return [(s0, min(s0 + size, nframes), (i % world)) for i, s0 in enumerate(range(0, nframes, size))]
 
 
-def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True, dt=0.01):
+def partition_cyclic_growing(nframes, world, t_window, t_chain_step, t_start, scale=1.0, cap=8):
+    """Block-cyclic partition whose blocks GROW along the clip, for clips without forward-branch restarts.  The B1 chain reaches
+    frame f about t_start + f * t_chain_step after the start; the owner of the block that starts there must have finished phase A
+    of all its earlier frames (f / world of them) and of this block by then: n <= (t_start + f t_chain_step) / t_window - f / world.
+    One-frame blocks get the chain going (its first step waits for ONE window, not a block of them), larger blocks later save
+    hand-offs -- the chain is what bounds such a clip.  scale: safety factor on n (choose_partition tries several)."""
+    import math
+    assert t_window > 0 and cap >= 1
+    out, f0, k = [], 0, 0
+    while f0 < nframes:
+        n = int(math.floor(scale * ((t_start + f0 * t_chain_step) / t_window - f0 / float(world))))
+        n = max(1, min(n, cap, nframes - f0))
+        out.append((f0, f0 + n, k % world))
+        f0 += n
+        k += 1
+    return out
+
+
+def window_ids(f, nframes, frame_num):
+    """Frame indices of the window whose output frame is f (clip edges replicate frames, datasets.py:233-234)."""
+    return [min(max(f - frame_num // 2 + k, 0), nframes - 1) for k in range(frame_num)]
+
+
+def window_is_hinted(f, reset_branch):
+    """Phase A of window f prepares ALL its frames (not only centre .. last): the forward branch restarts there (clip start or a
+    multiple of reset_branch, RefVSR.py:168-176) and walks frames 0 .. centre itself."""
+    return f == 0 or bool(reset_branch and f % reset_branch == 0)
+
+
+class ContextPlan(object):
+    """Who prepares which per-frame context and who needs it, for run_wavefront(exchange_contexts=True).
+
+    A per-frame context is everything that is a function of ONE (lr_i, ref_i) pair -- matching, reference encoders, both
+    aligned-attention outputs (Engine.prepare_frame, RefVSR.py:196-204,233-234,127,136): ~35 % of a frame's phase A.  Window f
+    needs the contexts of its frames centre .. last (all of them when the forward branch restarts at f).  Without the exchange a
+    rank prepares every context its windows need -- the first window of every block pays for two (four at a restart) contexts
+    that the neighbouring block's owner prepares as well.  With it, context i is prepared ONCE, by the owner of output frame i,
+    and sent to the other ranks whose windows need it (one message of ~32 MB at 270p, point to point, off the B1 chain).
+
+    tasks[r]     lane-a order of rank r: ('prep', i) | ('a1', f): windows in block order, a context right before its first own use
+                 or earlier when another rank's window needs it earlier on the B1 chain (see __init__)
+    consumers[i] ranks other than the owner that need context i (sorted)
+    imports[r][f] contexts rank r must have received before phase A of window f (first use only)
+    Both ends of a rank pair issue their messages in increasing frame order (`pair_order`): matching order = no deadlock on
+    in-order transports (one RCCL stream per pair)."""
+
+    def __init__(self, nframes, world, parts, reset_branch, frame_num, lead=3):
+        blocks = as_blocks(parts, world)
+        t, ctr = frame_num, frame_num // 2
+        self.blocks, self.nframes, self.world, self.t = blocks, nframes, world, t
+        self.owner = {}
+        for a, b, r in blocks:
+            for f in range(a, b):
+                self.owner[f] = r
+        assert sorted(self.owner) == list(range(nframes)), 'partition must cover every frame once'
+        self.windows = {r: [f for a, b, q in blocks if q == r for f in range(a, b)] for r in range(world)}
+        self.needed = {}
+        for f in range(nframes):
+            ids = window_ids(f, nframes, t)
+            self.needed[f] = sorted(set(ids[0 if window_is_hinted(f, reset_branch) else ctr:]))
+        # first use of every context per rank: (window position, window)
+        first_use = {r: {} for r in range(world)}
+        for r in range(world):
+            for pos, f in enumerate(self.windows[r]):
+                for i in self.needed[f]:
+                    first_use[r].setdefault(i, (pos, f))
+        self.consumers = {i: sorted(r for r in range(world) if r != self.owner[i] and i in first_use[r]) for i in range(nframes)}
+        self.imports = {r: {} for r in range(world)}
+        for r in range(world):
+            for i, (pos, f) in first_use[r].items():
+                if self.owner[i] != r:
+                    self.imports[r].setdefault(f, []).append(i)
+            for f in self.imports[r]:
+                self.imports[r][f].sort()
+        # Lane-a order.  The windows of a rank keep their block order (the window cache follows the sliding window); a context is
+        # prepared right before the first OWN window that needs it -- or earlier, when another rank needs it earlier.  "Earlier" is
+        # measured on the B1 chain, which paces everything: window f's phase A is needed when the chain gets there, ct(f) = f - (the
+        # last restart <= f) steps after its chain started (restart units are independent chains that start together); a context
+        # for a foreign window f' has to be on its way `lead` steps before that (its transfer + the consumer's phase A).
+        ct = {}
+        for f in range(nframes):
+            ct[f] = 0 if window_is_hinted(f, reset_branch) else ct[f - 1] + 1
+        self.tasks = {}
+        for r in range(world):
+            own = [i for i in range(nframes) if self.owner[i] == r]
+            seq = self.windows[r]
+            due = {}
+            for i in own:
+                pos = first_use[r][i][0] if i in first_use[r] else len(seq)
+                when = float(ct[seq[pos]]) if pos < len(seq) else float('inf')
+                for q in self.consumers[i]:
+                    dl = ct[first_use[q][i][1]] - lead
+                    p2 = next((p for p, f in enumerate(seq) if ct[f] > dl), len(seq))
+                    if p2 < pos or (p2 == pos and dl < when):
+                        pos, when = min(pos, p2), min(when, float(dl))
+                due[i] = (pos, when, i)
+            todo = sorted(own, key=lambda i: due[i])
+            out, k = [], 0
+            for pos, f in enumerate(seq):
+                while k < len(todo) and due[todo[k]][0] <= pos:
+                    out.append(('prep', todo[k]))
+                    k += 1
+                out.append(('a1', f))
+            assert k == len(todo), 'a context nobody needs'
+            self.tasks[r] = out
+
+    def program(self, r):
+        """The host program of rank r's lane a: ('prep', i) | ('post_recv', i, peer) | ('send', i, peer) | ('wait_recv', i, peer) |
+        ('a1', f), in issue order.  tasks[r] with the messages put in: a context is sent right after its preparation, a receive is
+        posted (and waited for) right before the first window that needs it -- and whatever the pair's frame order puts before
+        either is issued first (a receive is just posted early; a send whose context is not prepared yet prepares it on the spot)."""
+        order = {p: self.pair_order(r, p) for p in range(self.world) if p != r}
+        ptr = {p: 0 for p in order}
+        prepared, out = set(), []
+
+        def prepare(i):
+            if i not in prepared:
+                out.append(('prep', i))
+                prepared.add(i)
+
+        def issue_until(p, upto):
+            while ptr[p] < len(order[p]) and order[p][ptr[p]][0] <= upto:
+                i, kind = order[p][ptr[p]]
+                ptr[p] += 1
+                if kind == 'recv':
+                    out.append(('post_recv', i, p))
+                else:
+                    prepare(i)
+                    out.append(('send', i, p))
+
+        for kind, x in self.tasks[r]:
+            if kind == 'prep':
+                prepare(x)
+                for p in self.consumers[x]:
+                    issue_until(p, x)
+            else:
+                for i in self.imports[r].get(x, ()):
+                    issue_until(self.owner[i], i)
+                    out.append(('wait_recv', i, self.owner[i]))
+                out.append(('a1', x))
+        for p in order:
+            issue_until(p, self.nframes)
+        return out
+
+    def pair_order(self, r, peer):
+        """All context messages between r and peer, in the order both ends issue them: [(frame, 'send' | 'recv')] from r's view."""
+        out = []
+        for i in range(self.nframes):
+            if self.owner[i] == r and peer in self.consumers[i]:
+                out.append((i, 'send'))
+            elif self.owner[i] == peer and r in self.consumers[i]:
+                out.append((i, 'recv'))
+        return out
+
+
+def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True, dt=0.01,
+                       exchange=None, frame_num=5):
     """Makespan of run_wavefront from per-frame phase times (any time unit): every rank executes ONE task at a time with
-    priorities  B1 (its phase A done, the previous frame's B1 done and -- across ranks -- handed over) > phase A (frame order)
-    > B2, pre-emptively (the kernels of the two streams interleave at ~10 us granularity).  t_cold: extra phase-A time of
-    the first frame of a block that does not start the clip (its window is not in the cache: two more frames to prepare).
-    interleaved=False: the round-3 order (B1 of a rank only after ALL its phase A).  Returns the makespan."""
+    priorities  B1 (its phase A done, the previous frame's B1 done and -- across ranks -- handed over) > phase A (lane-a order)
+    > B2, pre-emptively (the kernels of the two streams interleave at ~10 us granularity).
+    t_cold: extra phase-A time of the first frame of a block that does not start the clip (its window is not in the cache: TWO more
+    contexts to prepare; FOUR when the forward branch restarts at that frame -- a reset-aligned block start prepares the whole
+    window -- i.e. 2 t_cold).
+    interleaved=False: the round-3 order (B1 of a rank only after ALL its phase A).
+    exchange: None | dict(t_prep, t_ctx, t_cold_x=0, lookahead=1) -- run_wavefront(exchange_contexts=True): every context is
+    prepared once, by the owner of its frame (t_prep of the t_a), and sent to the ranks that need it (t_ctx after its preparation
+    it is usable there); lane a follows ContextPlan.tasks (in order: a window waiting for an import blocks the lane), a block start
+    costs t_cold_x (the flows of a cold window) instead of t_cold.  Returns the makespan."""
     blocks = as_blocks(parts)
     owner, first = {}, set()
     for a, b, r in blocks:
@@ -227,16 +389,28 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
             owner[f] = r
     assert sorted(owner) == list(range(nframes)), 'partition must cover every frame once'
     frames_of = {r: [f for f in range(nframes) if owner[f] == r] for r in range(world)}
-    rem_a = {f: t_a + (t_cold if (f in first and f != 0) else 0.0) for f in range(nframes)}
+    if exchange is None:
+        cold = lambda f: 0.0 if (f not in first or f == 0) else (2.0 * t_cold if window_is_hinted(f, reset_branch) else t_cold)
+        lane = {r: [('a1', f, t_a + cold(f)) for f in frames_of[r]] for r in range(world)}
+        imports = {r: {} for r in range(world)}
+        t_ctx = 0.0
+    else:
+        plan = ContextPlan(nframes, world, blocks, reset_branch, frame_num) if exchange.get('plan') is None else exchange['plan']
+        t_prep, t_ctx, t_cold_x = exchange['t_prep'], exchange.get('t_ctx', 0.0), exchange.get('t_cold_x', 0.0)
+        assert 0.0 <= t_prep <= t_a
+        lane = {r: [(k, x, t_prep if k == 'prep' else (t_a - t_prep) + (t_cold_x if (x in first and x != 0) else 0.0))
+                    for k, x in (op[:2] for op in plan.program(r) if op[0] in ('prep', 'a1'))] for r in range(world)}
+        imports = plan.imports
+    rem_lane = {r: [d for _, _, d in lane[r]] for r in range(world)}
     rem_b1 = {f: t_b1 for f in range(nframes)}
     rem_b2 = {f: t_b2 for f in range(nframes)}
-    done_a, done_b1, done_b2 = {}, {}, {}
-    nxt_a = {r: 0 for r in range(world)}
+    done_a, done_b1, done_b2, done_prep = {}, {}, {}, {}
+    nxt_l = {r: 0 for r in range(world)}
     nxt_b1 = {r: 0 for r in range(world)}
     nxt_b2 = {r: 0 for r in range(world)}
     n_steps = 0
     t = 0.0
-    limit = 100.0 * nframes * (t_a + t_b1 + t_b2 + t_cold + t_handoff) + 1.0
+    limit = 100.0 * nframes * (t_a + t_b1 + t_b2 + 2.0 * t_cold + t_handoff + t_ctx) + 1.0
     while len(done_b2) < nframes:
         assert t < limit, 'schedule does not terminate'
         for r in range(world):
@@ -249,20 +423,26 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
                     pf = f - 1
                     ok = pf in done_b1 and t >= done_b1[pf] + (t_handoff if owner[pf] != r else 0.0)
                 if ok and not interleaved:
-                    ok = nxt_a[r] >= len(fs)
+                    ok = nxt_l[r] >= len(lane[r])
                 if ok:
                     rem_b1[f] -= dt
                     if rem_b1[f] <= 1e-9:
                         done_b1[f] = t + dt
                         nxt_b1[r] += 1
                     ran = True
-            if not ran and nxt_a[r] < len(fs):
-                f = fs[nxt_a[r]]
-                rem_a[f] -= dt
-                if rem_a[f] <= 1e-9:
-                    done_a[f] = t + dt
-                    nxt_a[r] += 1
-                ran = True
+            if not ran and nxt_l[r] < len(lane[r]):
+                kind, x, _ = lane[r][nxt_l[r]]
+                ready = True
+                if kind == 'a1':
+                    for i in imports[r].get(x, ()):
+                        ready = ready and i in done_prep and t >= done_prep[i] + t_ctx
+                if ready:
+                    j = nxt_l[r]
+                    rem_lane[r][j] -= dt
+                    if rem_lane[r][j] <= 1e-9:
+                        (done_a if kind == 'a1' else done_prep)[x] = t + dt
+                        nxt_l[r] += 1
+                    ran = True
             if not ran and nxt_b2[r] < nxt_b1[r]:
                 f = fs[nxt_b2[r]]
                 rem_b2[f] -= dt
@@ -274,20 +454,22 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
     return t
 
 
-def predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True):
+def predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True, exchange=None,
+                      frame_num=5, steps_per_frame=2000.0):
     """(speedup over one rank, makespan) of run_wavefront for a partition (per-rank ranges or a block list) from per-frame
     phase times: simulate_wavefront against nframes * (t_a + t_b1 + t_b2)."""
-    dt = max(1e-6, (t_a + t_b1 + t_b2) / 2000.0)
-    span = simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, interleaved, dt)
+    dt = max(1e-6, (t_a + t_b1 + t_b2) / steps_per_frame)
+    span = simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, interleaved, dt, exchange, frame_num)
     seq = nframes * (t_a + t_b1 + t_b2)
     return (seq / span if span > 0 else 0.0), span
 
 
-def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.3, t_cold=None):
+def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.3, t_cold=None, exchange=None, frame_num=5):
     """The partition run_wavefront should use for these phase times: the best of the reset-aligned hybrid (when the forward
     branch restarts), the balanced and the growing contiguous shards and the block-cyclic partitions with 1..8 frames per
     block, by simulated makespan.  t_cold defaults to 0.85 t_a (two more frames to prepare: ~5.0 of 5.8 ms for RefVSR_small
-    at 270p).  Returns (block list, predicted speedup, name)."""
+    at 270p).  exchange: see simulate_wavefront (the context exchange of run_wavefront).  Returns (block list, predicted speedup,
+    name)."""
     if t_cold is None:
         t_cold = 0.85 * t_a
     cands = []
@@ -299,12 +481,37 @@ def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.
     for size in range(1, 9):
         if size * world < nframes:
             cands.append(('block_cyclic_%d' % size, partition_cyclic(nframes, world, size)))
-    best = None
+    if nframes > world:
+        # growing blocks: phase-A time of a window and of the chain's first step with / without the context exchange
+        t_w = t_a if exchange is not None else t_a + 0.5 * t_cold
+        t_0 = (t_a + exchange['t_prep']) if exchange is not None else t_a
+        for sc in (0.8, 1.0, 1.2):
+            cands.append(('block_cyclic_growing_%.1f' % sc, partition_cyclic_growing(nframes, world, t_w, t_b1 + 0.5 * t_handoff, t_0, sc)))
+    # rank the candidates at a quarter of the time resolution, re-simulate the best three at the full one
+    rough = []
     for name, parts in cands:
-        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold)
+        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num, 500.0)
+        rough.append((sp, name, parts))
+    rough.sort(key=lambda v: -v[0])
+    best = None
+    for _, name, parts in rough[:3]:
+        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num)
         if best is None or sp > best[1] * (1.0 + 1e-9):
             best = (as_blocks(parts), sp, name)
     return best
+
+
+_CTX_GROUP = None
+
+
+def context_group():
+    """A second process group for the context messages of run_wavefront(exchange_contexts=True): its own RCCL communicators and
+    streams, so that a hand-off of the B1 chain never queues behind a 32 MB context transfer between the same two ranks.
+    Collective on first use (every rank calls run_wavefront)."""
+    global _CTX_GROUP
+    if _CTX_GROUP is None:
+        _CTX_GROUP = dist.new_group(ranks=list(range(dist.get_world_size())))
+    return _CTX_GROUP
 
 
 class _NullCtx(object):
@@ -316,7 +523,7 @@ class _NullCtx(object):
 
 
 def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
-                  timings=None):
+                  timings=None, exchange_contexts=False):
     """Two-phase run of this rank's share of the clip.  parts: per-rank ranges [(start, end)] * world or a block list
     [(start, end, rank), ...] (default: the balanced contiguous partition).
 
@@ -331,8 +538,15 @@ def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channe
     chain over the ranks no longer waits for a rank's whole phase A (round 3: `interleaved=False` of the model).  Executors
     without lanes (the CPU oracle on gloo) run the three groups one after the other: same results, same messages.
     Executors without phase_b1 / phase_b2 run phase_b(handle, first) per frame (B2 then sits on the chain).
+    exchange_contexts (executors with prepare_context / export_context / import_context): every per-frame context is prepared
+    ONCE, by the owner of its output frame, and sent to the other ranks whose windows need it (ContextPlan) -- the first window
+    of a block no longer prepares two (four at a restart) contexts its neighbour prepares as well.  Lane a then walks
+    ContextPlan.tasks: ('prep', i) = prepare context i (+ isend to its consumers), ('a1', f) = receive what window f lacks, then
+    phase A of f (which finds every context prepared).  Context messages travel in their own process group, per rank pair in
+    increasing frame order on both ends.
     Results are identical to the sequential run.  Returns {frame: result} for the local frames.  timings (optional dict):
-    'issue_a' / 'recv_wait' / 'issue_b1' / 'issue_b2' host seconds, 'handoff_messages' sent, 'blocks' local blocks."""
+    'issue_a' / 'recv_wait' / 'issue_b1' / 'issue_b2' host seconds, 'handoff_messages' sent, 'blocks' local blocks,
+    'context_messages' sent, 'context_wait' host seconds blocked waiting for contexts."""
     import time
     rank, world = dist.get_rank(), dist.get_world_size()
     blocks = as_blocks(parts if parts is not None else partition(nframes, world), world)
@@ -345,18 +559,56 @@ def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channe
     lane_b = getattr(executor, 'lane_b', _NullCtx)
     mark = getattr(executor, 'mark', lambda what, f: None)          # record "what of frame f is enqueued up to here"
     wait = getattr(executor, 'wait', lambda what, f: None)          # the CURRENT lane waits for that mark
-    tim = {'issue_a': 0.0, 'recv_wait': 0.0, 'issue_b1': 0.0, 'issue_b2': 0.0, 'handoff_messages': 0, 'blocks': len(mine)}
+    tim = {'issue_a': 0.0, 'recv_wait': 0.0, 'issue_b1': 0.0, 'issue_b2': 0.0, 'handoff_messages': 0, 'blocks': len(mine),
+           'context_messages': 0, 'context_wait': 0.0}
     t0 = time.perf_counter()
     handles, keep = {}, []
-    with lane_a():
-        for a, b in mine:                                          # ---- phase A: no communication, no state
-            for f in range(a, b):
-                lrs, refs = get_window(f)
-                hint = f == 0 or bool(reset_branch and f % reset_branch == 0) or (f == a and not needs_handoff(a, reset_branch))
-                handles[f] = executor.phase_a(lrs, refs, f, hint)
-                mark('a', f)
-    tim['issue_a'] = time.perf_counter() - t0
     results, pending = {}, []
+    if not exchange_contexts:
+        with lane_a():
+            for a, b in mine:                                      # ---- phase A: no communication, no state
+                for f in range(a, b):
+                    lrs, refs = get_window(f)
+                    handles[f] = executor.phase_a(lrs, refs, f, window_is_hinted(f, reset_branch))
+                    mark('a', f)
+    else:
+        plan = ContextPlan(nframes, world, blocks, reset_branch, frame_num)
+        grp = context_group()
+        comm_lane = getattr(executor, 'comm_lane', _NullCtx)       # an idle lane to post receives from (they then wait for nothing)
+        wins, frame_in = {}, {}
+        for a, b in mine:
+            for f in range(a, b):
+                wins[f] = get_window(f)
+                for j, i in enumerate(window_ids(f, nframes, frame_num)):
+                    frame_in.setdefault(i, (wins[f][0][j], wins[f][1][j]))
+        rx = {}
+        with lane_a():
+            for op in plan.program(rank):
+                kind, x = op[0], op[1]
+                if kind == 'prep':
+                    executor.prepare_context(x, frame_in[x][0], frame_in[x][1])
+                elif kind == 'post_recv':
+                    with comm_lane():
+                        buf = torch.empty(executor.context_nbytes(), dtype=torch.uint8, device=device)
+                        rx[x] = (dist.irecv(buf, op[2], group=grp), buf)
+                elif kind == 'send':
+                    buf = executor.export_context(x)
+                    buf = buf if str(buf.device).startswith(str(device)) else buf.to(device)
+                    pending.append(dist.isend(buf, op[2], group=grp))
+                    keep.append(buf)
+                    tim['context_messages'] += 1
+                elif kind == 'wait_recv':
+                    wk, buf = rx.pop(x)
+                    t1 = time.perf_counter()
+                    wk.wait()
+                    tim['context_wait'] += time.perf_counter() - t1
+                    executor.import_context(x, frame_in[x][0], frame_in[x][1], buf)
+                else:
+                    lrs, refs = wins[x]
+                    handles[x] = executor.phase_a(lrs, refs, x, window_is_hinted(x, reset_branch))
+                    mark('a', x)
+        assert not rx
+    tim['issue_a'] = time.perf_counter() - t0
     split = hasattr(executor, 'phase_b1')
     for a, b in mine:                                              # ---- the chain: one block at a time, in frame order
         nxt_rank = owner_of.get(b)                                 # owner of the block that follows in chain order
@@ -442,14 +694,39 @@ class EngineExecutor(object):
         # per-frame events -- B1(f) runs as soon as phase A of ITS frame is done and the state has arrived
         self._lanes = None
         self._marks = {}
+        self._ctx_spec = None
 
     def _streams(self):
         if self._lanes is None:
-            self._lanes = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            self._lanes = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
             cur = torch.cuda.current_stream(self.dev)
             for s_ in self._lanes:
                 s_.wait_stream(cur)                         # whatever produced the windows / the weights on the caller's stream
         return self._lanes
+
+    def comm_lane(self):
+        """An otherwise idle stream to post context receives from: a receive posted from lane a would first wait for everything
+        lane a has queued (ProcessGroupNCCL orders its stream behind the caller's), i.e. the transfer would not overlap."""
+        return torch.cuda.stream(self._streams()[2])
+
+    # ---- per-frame contexts (run_wavefront with exchange_contexts)
+    def prepare_context(self, f, lr, ref):
+        self.eng.prepare_context(lr.to(self.dev), ref.to(self.dev), f)
+        if self._ctx_spec is None:
+            self._ctx_spec = self.eng.context_spec(f)
+
+    def context_nbytes(self):
+        assert self._ctx_spec is not None, 'no context prepared yet: the message layout comes from the first own context'
+        return self.eng.context_nbytes(self._ctx_spec)
+
+    def export_context(self, f):
+        return self.eng.export_context(f)
+
+    def import_context(self, f, lr, ref, buf):
+        b = buf.to(self.dev)
+        if b.is_cuda:
+            b.record_stream(torch.cuda.current_stream(self.dev))
+        self.eng.import_context(lr.to(self.dev), ref.to(self.dev), f, b, self._ctx_spec)
 
     def lane_a(self):
         return torch.cuda.stream(self._streams()[0])

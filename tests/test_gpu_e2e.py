@@ -690,6 +690,17 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
         tim = {}                     # B1 chain on the second HIP stream behind per-frame events (the two-lane schedule)
         res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=shard.partition_cyclic(6, world, 1), timings=tim)
         assert tim['blocks'] == 3 and tim['handoff_messages'] == (3 if rank == 0 else 2)
+    elif wavefront in ('exchange_cyclic', 'exchange_balanced'):
+        # every per-frame context prepared by ONE rank and sent to the other (run_wavefront(exchange_contexts=True)): block-cyclic
+        # blocks of one frame (contexts travel in both directions of the pair, two per window) / two contiguous shards
+        parts = shard.partition_cyclic(6, world, 1) if wavefront == 'exchange_cyclic' else shard.partition(6, world)
+        tim = {}
+        prepared = []
+        orig = ex.eng.prepare_frame
+        ex.eng.prepare_frame = lambda fr: (prepared.append(fr.uid) if fr.conf is None else None, orig(fr))[1]
+        res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=parts, timings=tim, exchange_contexts=True)
+        own = sum(b - a for a, b, r in shard.as_blocks(parts, world) if r == rank)
+        assert len(prepared) == own and tim['context_messages'] > 0, (prepared, own, tim)     # nothing prepared twice, nothing lazily
     elif wavefront:
         res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu')
     else:
@@ -704,7 +715,9 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
                                                           (None, False, True, 'config_RefVSR_small_L1'),
                                                           (4, False, True, 'config_RefVSR_small_MFID'),
                                                           ('keep', False, True, 'config_RefVSR_small_MFID'),
-                                                          (None, False, 'cyclic', 'config_RefVSR_small_L1')])
+                                                          (None, False, 'cyclic', 'config_RefVSR_small_L1'),
+                                                          (None, False, 'exchange_cyclic', 'config_RefVSR_small_L1'),
+                                                          (4, False, 'exchange_balanced', 'config_RefVSR_small_MFID')])
 def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront, name):
     """Frame sharding across two ranks (state hand-off as ONE packed fp16 buffer, the exchange-free reset-aligned
     partition, and the phase-A / phase-B wavefront with the early send -- also with a reset inside a shard, also on
@@ -734,6 +747,41 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront,
     for f in range(6):
         w = window_indices(f, 6, 3)
         assert torch.equal(got[f], ex(lr[w], rf[w], f == 0)), 'frame %d differs from the sequential run' % f
+
+
+def test_context_export_import_roundtrip(dev):
+    """Engine.prepare_context / export_context / import_context (the context message of the multi-GPU exchange): a stream whose
+    per-frame contexts were all prepared by ANOTHER engine and imported equals the plain stream bit for bit, the importing engine
+    never runs prepare_frame's kernels, and the message has the documented size."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 5, 3
+    lr, rf, _ = make_clip(nfr, 32, 48, seed=29)
+    lr, rf = lr.to(dev), rf.to(dev)
+    a, cfg, _ = make_net('config_RefVSR_small_L1', t, dev, save_sample=False)
+    b, _, _ = make_net('config_RefVSR_small_L1', t, dev, save_sample=False)
+    want = [a(lr[window_indices(f, nfr, t)][None], rf[window_indices(f, nfr, t)][None], f == 0, frame_ids=window_indices(f, nfr, t))['result'].clone()
+            for f in range(nfr)]
+    a.Network.reset()
+    ea, eb = a.Network.ensure_engines(1, dev)[0], b.Network.ensure_engines(1, dev)[0]
+    bufs = {}
+    for i in range(nfr):
+        ea.prepare_context(lr[i], rf[i], i)
+        bufs[i] = ea.export_context(i)
+    spec = ea.context_spec(0)
+    C = cfg.mid_channels
+    assert [k for k, _, _ in spec] == ['conf', 'idx', 'aligned', 'aligned_up']
+    assert bufs[0].numel() == ea.context_nbytes(spec) == 32 * 48 * (4 + 4 + 2 * C + 8 * C)
+    calls = []
+    orig = eb.prepare_frame
+    eb.prepare_frame = lambda fr: (calls.append(fr.conf is None), orig(fr))[1]
+    for i in range(nfr):
+        eb.import_context(lr[i], rf[i], i, bufs[i].clone(), spec)
+    for f in range(nfr):
+        ids = window_indices(f, nfr, t)
+        got = b(lr[ids][None], rf[ids][None], f == 0, frame_ids=ids)['result']
+        assert torch.equal(got, want[f]), 'frame %d differs with imported contexts' % f
+    assert calls and not any(calls), 'prepare_frame had work to do on an imported context'
+    assert not eb.ctx_pinned                                # every imported context was taken over by its first window
 
 
 def test_packed_state_roundtrip(dev):

@@ -97,6 +97,50 @@ class _ExecLanes(_Exec):
         _Exec.import_state(self, st)
 
 
+class _ExecCtx(_ExecLanes):
+    """+ the context hooks of run_wavefront(exchange_contexts=True).  A context of the oracle = the matching of one frame pair
+    (conf map + index map: its per-frame work that windows share); phase A must find the matching of EVERY frame it needs already
+    there -- prepared here or received -- and every frame's matching is computed exactly once across the ranks."""
+
+    def __init__(self, cfg, sd, nframes, t):
+        _ExecLanes.__init__(self, cfg, sd)
+        self.nframes, self.t, self.ctx, self.prepared_here, self.imported_here, self.shapes = nframes, t, {}, [], [], None
+
+    def prepare_context(self, f, lr, ref):
+        assert self.lane == 'a' and f not in self.ctx
+        conf, idx = self.o._feature_match(lr[None], ref[None])
+        self.ctx[f] = (conf, idx)
+        self.prepared_here.append(f)
+        if self.shapes is None:
+            self.shapes = (tuple(conf.shape), conf.dtype, tuple(idx.shape), idx.dtype)
+
+    def context_nbytes(self):
+        cs, cd, is_, id_ = self.shapes
+        n = lambda shp, dt: int(torch.tensor(shp).prod()) * torch.empty((), dtype=dt).element_size()
+        return n(cs, cd) + n(is_, id_)
+
+    def export_context(self, f):
+        conf, idx = self.ctx[f]
+        return torch.cat([conf.contiguous().reshape(-1).view(torch.uint8), idx.contiguous().reshape(-1).view(torch.uint8)])
+
+    def import_context(self, f, lr, ref, buf):
+        assert self.lane == 'a' and f not in self.ctx and buf.numel() == self.context_nbytes()
+        cs, cd, is_, id_ = self.shapes
+        nc = int(torch.tensor(cs).prod()) * torch.empty((), dtype=cd).element_size()
+        self.ctx[f] = (buf[:nc].clone().view(cd).view(cs), buf[nc:].clone().view(id_).view(is_))
+        self.imported_here.append(f)
+
+    def phase_a(self, lrs, refs, f, hint):
+        from refvsr_amd import shard
+        assert self.lane == 'a'
+        ids = shard.window_ids(f, self.nframes, self.t)
+        need = range(0 if hint else self.t // 2, self.t)
+        assert all(ids[j] in self.ctx for j in need), 'window %d: a context is missing (%s)' % (f, [ids[j] for j in need if ids[j] not in self.ctx])
+        h = self.o.phase_a(lrs[None], refs[None], first_hint=hint, contexts={j: self.ctx[ids[j]] for j in need})
+        h['_frame'] = f
+        return h
+
+
 def _setup(reset, nframes=6, name='config_RefVSR_small_L1'):
     from refvsr_amd import get_config, make_state_dict
     from refvsr_amd.synth import make_clip, window_indices
@@ -119,6 +163,7 @@ def _worker(rank, world, port, reset, aligned, q, wavefront=False, nframes=6, na
     from refvsr_amd import shard
     cfg, sd, get = _setup(reset, nframes, name)
     reset = cfg.reset_branch
+    info = {}
     if wavefront == 'hybrid':
         parts = shard.partition_hybrid(nframes, world, reset)
         res = shard.run_wavefront(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts)
@@ -130,13 +175,22 @@ def _worker(rank, world, port, reset, aligned, q, wavefront=False, nframes=6, na
         tim = {}
         res = shard.run_wavefront(_ExecLanes(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim)
         assert tim['blocks'] == 1 and tim['handoff_messages'] == (1 if rank + 1 < world else 0)
+    elif isinstance(wavefront, str) and wavefront.startswith('exchange'):   # per-frame contexts prepared once and exchanged
+        fam = wavefront.split('_', 1)[1]
+        parts = {'cyclic': lambda: shard.partition_cyclic(nframes, world, 2), 'hybrid': lambda: shard.partition_hybrid(nframes, world, reset),
+                 'balanced': lambda: shard.partition(nframes, world),
+                 'growing': lambda: shard.partition_cyclic_growing(nframes, world, 5.3, 1.0, 7.2)}[fam]()
+        ex = _ExecCtx(cfg, sd, nframes, 3)
+        tim = {}
+        res = shard.run_wavefront(ex, get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim, exchange_contexts=True)
+        info = {'prepared': ex.prepared_here, 'imported': ex.imported_here, 'messages': tim['context_messages']}
     elif wavefront == 'nosplit':
         res = shard.run_wavefront(_ExecNoSplit(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu')
     elif wavefront:
         res = shard.run_wavefront(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu')
     else:
         res = shard.run_sharded(_Exec(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', aligned=aligned)
-    q.put((rank, {f: v.clone().numpy() for f, v in res.items()}))     # by value: no fd passing after exit
+    q.put((rank, {f: v.clone().numpy() for f, v in res.items()}, info))     # by value: no fd passing after exit
     dist.barrier()
     dist.destroy_process_group()
 
@@ -156,10 +210,11 @@ def _run(reset, aligned, wavefront=False, world=2, nframes=6, name='config_RefVS
     procs = [ctx.Process(target=_worker, args=(r, world, port, reset, aligned, q, wavefront, nframes, name)) for r in range(world)]
     for p in procs:
         p.start()
-    got = {}
+    got, infos = {}, {}
     for _ in range(world):
-        rank, res = q.get(timeout=600)
+        rank, res, info = q.get(timeout=600)
         got.update({f: torch.from_numpy(v) for f, v in res.items()})
+        infos[rank] = info
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -173,6 +228,8 @@ def _run(reset, aligned, wavefront=False, world=2, nframes=6, name='config_RefVS
             assert torch.equal(got[f], want), 'frame %d differs from the sequential run' % f
     finally:
         torch.set_num_threads(nthr)
+    if isinstance(wavefront, str) and wavefront.startswith('exchange'):
+        return got, infos
     return got
 
 
@@ -239,3 +296,31 @@ def test_world8_restart_free_clip_block_cyclic_and_growing_partitions():
     assert [b - a for a, b in shard.partition_chain(26, 8)] == sorted(b - a for a, b in shard.partition_chain(26, 8))
     got = _run(reset=None, aligned=False, wavefront='growing', world=8, nframes=26)
     assert sorted(got) == list(range(26))
+
+
+def _check_exchange(got, infos, nframes, world):
+    assert sorted(got) == list(range(nframes))
+    prepared = sorted(f for r in infos for f in infos[r]['prepared'])
+    assert prepared == list(range(nframes)), 'every context is prepared exactly once across the ranks: %s' % prepared
+    assert sum(infos[r]['messages'] for r in infos) == sum(len(infos[r]['imported']) for r in infos) > 0
+
+
+def test_context_exchange_world2_cyclic_and_reset():
+    """run_wavefront(exchange_contexts=True) on two ranks: block-cyclic blocks of 2 (contexts flow in BOTH directions of the one
+    rank pair, in frame order) without restarts, and a balanced split with reset_branch = 4 (a restart inside a shard: its
+    window needs all five contexts).  Bit-identical to the sequential stream; every context prepared once."""
+    got, infos = _run(reset=None, aligned=False, wavefront='exchange_cyclic', world=2, nframes=9)
+    _check_exchange(got, infos, 9, 2)
+    got, infos = _run(reset=4, aligned=False, wavefront='exchange_balanced', world=2, nframes=9)
+    _check_exchange(got, infos, 9, 2)
+
+
+def test_context_exchange_world8_partitions():
+    """The same on 8 ranks: BASELINE configs[3] in miniature (64 frames, reset 9) on the reset-aligned hybrid partition -- the
+    restart windows at the block starts import the two contexts before them instead of preparing four extra -- and a
+    restart-free 26-frame clip on the block-cyclic and the growing block-cyclic partitions."""
+    got, infos = _run(reset='keep', aligned=False, wavefront='exchange_hybrid', world=8, nframes=64, name='config_RefVSR_small_MFID')
+    _check_exchange(got, infos, 64, 8)
+    for fam in ('exchange_cyclic', 'exchange_growing'):
+        got, infos = _run(reset=None, aligned=False, wavefront=fam, world=8, nframes=26)
+        _check_exchange(got, infos, 26, 8)
