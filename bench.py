@@ -370,11 +370,11 @@ def measure_phases(net, cfg, dev, h, w, t=5):
         x, r, ids = win(R // 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.prepare_context(x[0, t // 2], r[0, t // 2], ids[t // 2])
+        eng.prepare_context(x[0, t // 2], r[0, t // 2], (0, ids[t // 2]))       # (engine-level id of frame f of batch element 0)
         torch.cuda.synchronize()
         prep.append(1e3 * (time.perf_counter() - t0))
         for j in range(t // 2 + 1, t):
-            eng.prepare_context(x[0, j], r[0, j], ids[j])
+            eng.prepare_context(x[0, j], r[0, j], (0, ids[j]))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         N.phase_a(x, r, frame_ids=ids, first_hint=False)

@@ -235,6 +235,7 @@ class Engine(object):
         self.flow_cache = {}
         self.id_cache = {}
         self.ctx_pinned = {}
+        self.ctx_strict = False
 
     def set_pipelined(self, on=True):
         """Opt in to cross-call pipelining: forward() is then given `frame_ids` (one hashable id per window frame; equal ids
@@ -339,15 +340,19 @@ class Engine(object):
 
     @torch.no_grad()
     def prepare_context(self, lr, ref, fid):
-        """The context of frame `fid` (its id in forward(frame_ids=...) / phase_a), prepared now on the current stream and kept
-        until a window that contains the id has used it."""
+        """The context of frame `fid` -- its id in THIS engine's forward(frame_ids=...) / phase_a: Network names frame f of batch
+        element b (b, f) -- prepared now on the current stream and kept until a window that contains the id has used it."""
         assert self.cache, 'contexts are kept by the id-keyed window cache (config.cache_windows)'
         fr = self._ctx(fid)
         if fr is None:
             fr = self.ctx_pinned[fid] = FrameCtx(lr, ref)
         with torch.cuda.device(lr.device), ops.on_stream(torch.cuda.current_stream(lr.device)):
             self.pyramid(fr)
-            self.prepare_frame(fr)
+            strict, self.ctx_strict = self.ctx_strict, False
+            try:
+                self.prepare_frame(fr)
+            finally:
+                self.ctx_strict = strict
         return fr
 
     def context_spec(self, fid):
@@ -662,6 +667,10 @@ class Engine(object):
         encoders (:233-234) and both AlignedAttention outputs (:127,136)."""
         if fr.conf is not None:
             return
+        if self.ctx_strict:
+            # shard.run_wavefront(exchange_contexts=True): every context a window needs was prepared ahead (prepare_context) or
+            # received (import_context); preparing one here would silently redo another rank's work
+            raise RuntimeError('a window needs a per-frame context that was neither prepared ahead nor imported (strict mode)')
         h, w = fr.lr.shape[1:]
         fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
         # the reference encoders do not depend on the matching: with stream overlap they run on a second side

@@ -256,8 +256,8 @@ class ContextPlan(object):
                  or earlier when another rank's window needs it earlier on the B1 chain (see __init__)
     consumers[i] ranks other than the owner that need context i (sorted)
     imports[r][f] contexts rank r must have received before phase A of window f (first use only)
-    Both ends of a rank pair issue their messages in increasing frame order (`pair_order`): matching order = no deadlock on
-    in-order transports (one RCCL stream per pair)."""
+    Every rank issues its messages in increasing frame order (`messages`, `program`): one global order = no deadlock on in-order
+    transports."""
 
     def __init__(self, nframes, world, parts, reset_branch, frame_num, lead=3):
         blocks = as_blocks(parts, world)
@@ -322,10 +322,13 @@ class ContextPlan(object):
     def program(self, r):
         """The host program of rank r's lane a: ('prep', i) | ('post_recv', i, peer) | ('send', i, peer) | ('wait_recv', i, peer) |
         ('a1', f), in issue order.  tasks[r] with the messages put in: a context is sent right after its preparation, a receive is
-        posted (and waited for) right before the first window that needs it -- and whatever the pair's frame order puts before
-        either is issued first (a receive is just posted early; a send whose context is not prepared yet prepares it on the spot)."""
-        order = {p: self.pair_order(r, p) for p in range(self.world) if p != r}
-        ptr = {p: 0 for p in order}
+        posted (and waited for) right before the first window that needs it -- and EVERY rank issues its messages in increasing
+        frame order (`messages`): whatever that order puts before a message is issued first (a receive is just posted early; a send
+        whose context is not prepared yet prepares it on the spot).  One global order on all ranks = no deadlock on any in-order
+        transport: per rank pair (lazily initialised ProcessGroupNCCL: a communicator and a stream per pair) and even when all
+        operations of a rank share ONE stream (eagerly initialised groups serialise unbatched send / recv with everything else)."""
+        msgs = self.messages(r)
+        state = {'ptr': 0}
         prepared, out = set(), []
 
         def prepare(i):
@@ -333,10 +336,10 @@ class ContextPlan(object):
                 out.append(('prep', i))
                 prepared.add(i)
 
-        def issue_until(p, upto):
-            while ptr[p] < len(order[p]) and order[p][ptr[p]][0] <= upto:
-                i, kind = order[p][ptr[p]]
-                ptr[p] += 1
+        def issue_until(upto):
+            while state['ptr'] < len(msgs) and msgs[state['ptr']][0] <= upto:
+                i, kind, p = msgs[state['ptr']]
+                state['ptr'] += 1
                 if kind == 'recv':
                     out.append(('post_recv', i, p))
                 else:
@@ -346,15 +349,24 @@ class ContextPlan(object):
         for kind, x in self.tasks[r]:
             if kind == 'prep':
                 prepare(x)
-                for p in self.consumers[x]:
-                    issue_until(p, x)
+                if self.consumers[x]:
+                    issue_until(x)
             else:
                 for i in self.imports[r].get(x, ()):
-                    issue_until(self.owner[i], i)
+                    issue_until(i)
                     out.append(('wait_recv', i, self.owner[i]))
                 out.append(('a1', x))
-        for p in order:
-            issue_until(p, self.nframes)
+        issue_until(self.nframes)
+        return out
+
+    def messages(self, r):
+        """All context messages of rank r in the order it issues them: [(frame, 'send' | 'recv', peer)] by frame, then peer."""
+        out = []
+        for i in range(self.nframes):
+            if self.owner[i] == r:
+                out += [(i, 'send', q) for q in self.consumers[i]]
+            elif r in self.consumers[i]:
+                out.append((i, 'recv', self.owner[i]))
         return out
 
     def pair_order(self, r, peer):
@@ -493,12 +505,14 @@ def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.
         sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num, 500.0)
         rough.append((sp, name, parts))
     rough.sort(key=lambda v: -v[0])
-    best = None
+    fine = []
     for _, name, parts in rough[:3]:
         sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num)
-        if best is None or sp > best[1] * (1.0 + 1e-9):
-            best = (as_blocks(parts), sp, name)
-    return best
+        fine.append((as_blocks(parts), sp, name))
+    top = max(v[1] for v in fine)
+    # within 1 % of the best: the partition with the fewest blocks (fewest hand-offs and messages: the model's terms for those are
+    # the assumed ones)
+    return min((v for v in fine if v[1] >= 0.99 * top), key=lambda v: (len(v[0]), -v[1]))
 
 
 _CTX_GROUP = None
@@ -524,6 +538,17 @@ class _NullCtx(object):
 
 def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
                   timings=None, exchange_contexts=False):
+    """See _run_wavefront (this wrapper only makes sure the executor's strict-context mode ends with the run)."""
+    try:
+        return _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result, parts, timings,
+                              exchange_contexts)
+    finally:
+        if exchange_contexts and hasattr(executor, 'strict_contexts'):
+            executor.strict_contexts(False)
+
+
+def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
+                   timings=None, exchange_contexts=False):
     """Two-phase run of this rank's share of the clip.  parts: per-rank ranges [(start, end)] * world or a block list
     [(start, end, rank), ...] (default: the balanced contiguous partition).
 
@@ -582,6 +607,8 @@ def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channe
                 for j, i in enumerate(window_ids(f, nframes, frame_num)):
                     frame_in.setdefault(i, (wins[f][0][j], wins[f][1][j]))
         rx = {}
+        strict = getattr(executor, 'strict_contexts', lambda on: None)
+        strict(True)                                               # a context that is missing is a bug, not something to recompute
         with lane_a():
             for op in plan.program(rank):
                 kind, x = op[0], op[1]
@@ -709,24 +736,29 @@ class EngineExecutor(object):
         lane a has queued (ProcessGroupNCCL orders its stream behind the caller's), i.e. the transfer would not overlap."""
         return torch.cuda.stream(self._streams()[2])
 
-    # ---- per-frame contexts (run_wavefront with exchange_contexts)
+    # ---- per-frame contexts (run_wavefront with exchange_contexts).  Network.forward / phase_a name the frames of batch element b
+    #      (b, frame id) towards its engine: the engine-level id of frame f of this single-clip executor is (0, f)
     def prepare_context(self, f, lr, ref):
-        self.eng.prepare_context(lr.to(self.dev), ref.to(self.dev), f)
+        self.eng.prepare_context(lr.to(self.dev), ref.to(self.dev), (0, f))
         if self._ctx_spec is None:
-            self._ctx_spec = self.eng.context_spec(f)
+            self._ctx_spec = self.eng.context_spec((0, f))
 
     def context_nbytes(self):
         assert self._ctx_spec is not None, 'no context prepared yet: the message layout comes from the first own context'
         return self.eng.context_nbytes(self._ctx_spec)
 
     def export_context(self, f):
-        return self.eng.export_context(f)
+        return self.eng.export_context((0, f))
+
+    def strict_contexts(self, on):
+        """While on, a window that finds one of its contexts missing raises instead of preparing it (Engine.prepare_frame)."""
+        self.eng.ctx_strict = bool(on)
 
     def import_context(self, f, lr, ref, buf):
         b = buf.to(self.dev)
         if b.is_cuda:
             b.record_stream(torch.cuda.current_stream(self.dev))
-        self.eng.import_context(lr.to(self.dev), ref.to(self.dev), f, b, self._ctx_spec)
+        self.eng.import_context(lr.to(self.dev), ref.to(self.dev), (0, f), b, self._ctx_spec)
 
     def lane_a(self):
         return torch.cuda.stream(self._streams()[0])

@@ -736,12 +736,18 @@ def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront,
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
-        _, res = q.get(timeout=200)
-        got.update({f: torch.from_numpy(v) for f, v in res.items()})
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        for _ in range(2):
+            _, res = q.get(timeout=200)
+            got.update({f: torch.from_numpy(v) for f, v in res.items()})
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                      # a worker that died leaves its peer waiting in a receive: never leave it behind
+            if p.is_alive():                 # (an orphan spinning on the host skews every later timing on the box)
+                p.kill()
+                p.join(10)
     lr, rf, _ = make_clip(6, 32, 48, seed=3)
     ex, _ = _make_exec(reset, name)
     for f in range(6):
@@ -762,12 +768,12 @@ def test_context_export_import_roundtrip(dev):
     want = [a(lr[window_indices(f, nfr, t)][None], rf[window_indices(f, nfr, t)][None], f == 0, frame_ids=window_indices(f, nfr, t))['result'].clone()
             for f in range(nfr)]
     a.Network.reset()
-    ea, eb = a.Network.ensure_engines(1, dev)[0], b.Network.ensure_engines(1, dev)[0]
+    ea, eb = a.Network.ensure_engines(1, lr.device)[0], b.Network.ensure_engines(1, lr.device)[0]    # (the device the calls will name)
     bufs = {}
-    for i in range(nfr):
-        ea.prepare_context(lr[i], rf[i], i)
-        bufs[i] = ea.export_context(i)
-    spec = ea.context_spec(0)
+    for i in range(nfr):                                   # (engine-level ids: Network names frame f of batch element b (b, f))
+        ea.prepare_context(lr[i], rf[i], (0, i))
+        bufs[i] = ea.export_context((0, i))
+    spec = ea.context_spec((0, 0))
     C = cfg.mid_channels
     assert [k for k, _, _ in spec] == ['conf', 'idx', 'aligned', 'aligned_up']
     assert bufs[0].numel() == ea.context_nbytes(spec) == 32 * 48 * (4 + 4 + 2 * C + 8 * C)
@@ -775,7 +781,7 @@ def test_context_export_import_roundtrip(dev):
     orig = eb.prepare_frame
     eb.prepare_frame = lambda fr: (calls.append(fr.conf is None), orig(fr))[1]
     for i in range(nfr):
-        eb.import_context(lr[i], rf[i], i, bufs[i].clone(), spec)
+        eb.import_context(lr[i], rf[i], (0, i), bufs[i].clone(), spec)
     for f in range(nfr):
         ids = window_indices(f, nfr, t)
         got = b(lr[ids][None], rf[ids][None], f == 0, frame_ids=ids)['result']

@@ -211,13 +211,19 @@ def _run(reset, aligned, wavefront=False, world=2, nframes=6, name='config_RefVS
     for p in procs:
         p.start()
     got, infos = {}, {}
-    for _ in range(world):
-        rank, res, info = q.get(timeout=600)
-        got.update({f: torch.from_numpy(v) for f, v in res.items()})
-        infos[rank] = info
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        for _ in range(world):
+            rank, res, info = q.get(timeout=600)
+            got.update({f: torch.from_numpy(v) for f, v in res.items()})
+            infos[rank] = info
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                      # a worker that died leaves its peers waiting in a receive: never leave them behind
+            if p.is_alive():
+                p.kill()
+                p.join(10)
     cfg, sd, get = _setup(reset, nframes, name)
     ex = _Exec(cfg, sd)
     nthr = torch.get_num_threads()
