@@ -700,7 +700,7 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
         ex.eng.prepare_frame = lambda fr: (prepared.append(fr.uid) if fr.conf is None else None, orig(fr))[1]
         res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=parts, timings=tim, exchange_contexts=True)
         own = sum(b - a for a, b, r in shard.as_blocks(parts, world) if r == rank)
-        assert len(prepared) == own and tim['context_messages'] > 0, (prepared, own, tim)     # nothing prepared twice, nothing lazily
+        assert len(prepared) == own, (prepared, own, tim)      # nothing prepared twice, nothing lazily (a rank may have nothing to send)
     elif wavefront:
         res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu')
     else:
