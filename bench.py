@@ -27,7 +27,9 @@ What the JSON line carries beside the contract fields:
   roofline_match_top2 -- the fused matching GEMM + arg-max (one launch per frame, ~16 % of the device time): algorithmic FLOPs per
                         launch / mean duration from HIP events around every launch inside the timed region
   wavefront_model    -- (N = 1) phase A / B1 / B2 times of one restart unit of BASELINE configs[3], host-synchronised per phase,
-                        and the makespan model's predicted speed-up at 2 / 4 / 8 ranks per partition (refvsr_amd/shard.py)
+                        one per-frame context prepared alone, a cold window with and without its contexts, and the makespan
+                        model's predicted speed-up at 2 / 4 / 8 ranks per partition, with and without the context exchange
+                        (refvsr_amd/shard.py)
   kernels            -- device time per launch (HIP events around back-to-back launches queued behind a long kernel, so
                         the host launch rate does not enter) of the time-dominant conv kernels (MFMA and HBM fractions)
                         and of the HBM-bound warp / gather / sampler / resize kernels (GB/s of algorithmic bytes against
@@ -35,8 +37,9 @@ What the JSON line carries beside the contract fields:
   whole_path         -- algorithmic TFLOP per output frame (refvsr_amd/flops.py, config-aware) x frames/s against the
                         dense fp16 MFMA peak
   wavefront (N > 1)  -- BASELINE configs[3]: a 64-frame clip of config_RefVSR_small_MFID (reset_branch = 9) sharded over
-                        the N ranks by frame index with the forward-state hand-off over RCCL send/recv
-                        (shard.run_wavefront); per-frame checksums are compared with a single-rank run
+                        the N ranks by frame index with the forward-state hand-off over RCCL send/recv and the per-frame
+                        contexts prepared once and exchanged (shard.run_wavefront(exchange_contexts=True);
+                        --no-wavefront-exchange for the A/B); per-frame checksums are compared with a single-rank run
   cpu_baseline       -- the CPU oracle (a port of the reference's algorithm; the reference itself cannot travel) timed on
                         this host: ONE full steady-state forward as the reference executes it, nothing sampled
 """
