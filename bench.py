@@ -436,32 +436,10 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     v = torch.tensor([pf[k] for k in keys], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(v, op=dist.ReduceOp.SUM)
     per_frame = {k: float(x) / world for k, x in zip(keys, v.cpu().tolist())}
-    exch = None if args.no_wavefront_exchange else exchange_terms(per_frame)
-    blocks, predicted, pname = shard.choose_partition(nfr, world, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                                      per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'], exchange=exch)
-    if args.wavefront_partition:                           # A/B: force a partition family
-        fam = args.wavefront_partition
-        parts = {'balanced': shard.partition(nfr, world), 'growing': shard.partition_chain(nfr, world),
-                 'hybrid': shard.partition_hybrid(nfr, world, cfg.reset_branch or 9),
-                 'cyclic_growing': shard.partition_cyclic_growing(nfr, world, per_frame['phase_a_ms'], per_frame['phase_b1_ms'] + 0.15,
-                                                                  per_frame['phase_a_ms'] + per_frame['context_prepare_ms'])}.get(fam)
-        if parts is None and fam.startswith('cyclic'):
-            parts = shard.partition_cyclic(nfr, world, int(fam[6:] or 3))
-        blocks, pname = shard.as_blocks(parts), fam
-        predicted = shard.predicted_speedup(nfr, world, blocks, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                            per_frame['phase_b2_ms'], 0.3, per_frame['phase_a_cold_extra_ms'], True, exch)[0]
-    mine = [(a, b) for a, b, r in blocks if r == rank]
-    need = sorted(set(i for a, b in mine for f in range(a, b) for i in window_indices(f, nfr, t)))
-    clip = {}
-    for i in need:                                         # this rank's frames (+ input halos), resident in HBM
-        if i not in clip:
-            l1, r1, _ = make_clip(1, h, w, seed=0, start=i, want_gt=False)
-            clip[i] = (l1[0].to(dev), r1[0].to(dev))
-    win = {f: (torch.stack([clip[i][0] for i in window_indices(f, nfr, t)], 0).contiguous(),
-               torch.stack([clip[i][1] for i in window_indices(f, nfr, t)], 0).contiguous()) for a, b in mine for f in range(a, b)}
     ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
-    # warm-up: the point-to-point communicators (their first use costs seconds) and the hand-off time itself: the packed state of
-    # this model goes round the ring once, timed on every rank around recv
+    # warm-up of the point-to-point communicators (their first use costs seconds) and the hand-off time itself: the packed state of
+    # this model goes round the ring of ranks, timed on every rank -- BEFORE the partition is chosen: the model's message terms
+    # (hand-off, context) are this measurement, not an assumption
     net.Network.reset()
     nb = ex.state_nbytes()
     buf = torch.zeros(nb, dtype=torch.uint8, device=comm_dev)
@@ -481,6 +459,30 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
         handoff_ms.append(1e3 * (time.perf_counter() - t0) / 2.0)      # two messages in series per rank
     hv = torch.tensor([min(handoff_ms[1:])], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(hv, op=dist.ReduceOp.MAX)
+    t_msg = max(0.05, float(hv.item()))
+    exch = None if args.no_wavefront_exchange else exchange_terms(per_frame, ctx_ms=t_msg)
+    blocks, predicted, pname = shard.choose_partition(nfr, world, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
+                                                      per_frame['phase_b2_ms'], t_msg, per_frame['phase_a_cold_extra_ms'], exchange=exch)
+    if args.wavefront_partition:                           # A/B: force a partition family
+        fam = args.wavefront_partition
+        parts = {'balanced': shard.partition(nfr, world), 'growing': shard.partition_chain(nfr, world),
+                 'hybrid': shard.partition_hybrid(nfr, world, cfg.reset_branch or 9),
+                 'cyclic_growing': shard.partition_cyclic_growing(nfr, world, per_frame['phase_a_ms'], per_frame['phase_b1_ms'] + 0.5 * t_msg,
+                                                                  per_frame['phase_a_ms'] + per_frame['context_prepare_ms'])}.get(fam)
+        if parts is None and fam.startswith('cyclic'):
+            parts = shard.partition_cyclic(nfr, world, int(fam[6:] or 3))
+        blocks, pname = shard.as_blocks(parts), fam
+        predicted = shard.predicted_speedup(nfr, world, blocks, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
+                                            per_frame['phase_b2_ms'], t_msg, per_frame['phase_a_cold_extra_ms'], True, exch)[0]
+    mine = [(a, b) for a, b, r in blocks if r == rank]
+    need = sorted(set(i for a, b in mine for f in range(a, b) for i in window_indices(f, nfr, t)))
+    clip = {}
+    for i in need:                                         # this rank's frames (+ input halos), resident in HBM
+        if i not in clip:
+            l1, r1, _ = make_clip(1, h, w, seed=0, start=i, want_gt=False)
+            clip[i] = (l1[0].to(dev), r1[0].to(dev))
+    win = {f: (torch.stack([clip[i][0] for i in window_indices(f, nfr, t)], 0).contiguous(),
+               torch.stack([clip[i][1] for i in window_indices(f, nfr, t)], 0).contiguous()) for a, b in mine for f in range(a, b)}
     if exch is not None and world > 1:
         # the context messages use their own process group and, with one-frame blocks, rank pairs two apart as well: every pair of
         # the plan exchanges one small message before the clock starts (every rank walks the SAME sorted pair list: a sequence of
@@ -533,7 +535,9 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
         out = {'ranks_seen': dist.get_world_size(), 'backend': backend + (' (= RCCL)' if backend == 'nccl' else ''),
                'gpus_visible': torch.cuda.device_count(),
                'partition': {'name': pname, 'blocks': [list(b_) for b_ in blocks], 'predicted_speedup': round(float(predicted), 3)},
-               'phase_ms_per_frame_measured': per_frame, 'model': wavefront_model(per_frame, nfr, cfg.reset_branch),
+               'phase_ms_per_frame_measured': per_frame,
+               'partition_chosen_with': {'message_ms': t_msg, 'what': 'hand-off and context messages priced at the measured hand-off time'},
+               'model': wavefront_model(per_frame, nfr, cfg.reset_branch),
                'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
                            '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
                'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
