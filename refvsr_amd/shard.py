@@ -566,9 +566,9 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
     exchange_contexts (executors with prepare_context / export_context / import_context): every per-frame context is prepared
     ONCE, by the owner of its output frame, and sent to the other ranks whose windows need it (ContextPlan) -- the first window
     of a block no longer prepares two (four at a restart) contexts its neighbour prepares as well.  Lane a then walks
-    ContextPlan.tasks: ('prep', i) = prepare context i (+ isend to its consumers), ('a1', f) = receive what window f lacks, then
-    phase A of f (which finds every context prepared).  Context messages travel in their own process group, per rank pair in
-    increasing frame order on both ends.
+    ContextPlan.program(rank): prepare context i (+ isend to its consumers) | receive what window f lacks, then phase A of f (which
+    finds every context prepared: a missing one raises, executor.strict_contexts).  Context messages travel in their own process
+    group; every rank issues them in increasing frame order.
     Results are identical to the sequential run.  Returns {frame: result} for the local frames.  timings (optional dict):
     'issue_a' / 'recv_wait' / 'issue_b1' / 'issue_b2' host seconds, 'handoff_messages' sent, 'blocks' local blocks,
     'context_messages' sent, 'context_wait' host seconds blocked waiting for contexts."""
