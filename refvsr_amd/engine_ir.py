@@ -86,7 +86,11 @@ class EngineIR(Engine):
         self.keyframe_idx = None
 
     def set_pipelined(self, on=True):
-        self.pipelined = False               # RefVSR_IR runs sequentially
+        """Cross-call pipelining (round 4; Engine.set_pipelined's contract): everything that is a function of the window's frames
+        only -- matching and alignment of the new frame, its EDVR pyramid features, the flows, the refill features of the key frames
+        (PCD alignment + TSA fusion, RefVSR_IR.py:193-217) -- runs on the preparation stream while the other stream is still
+        walking the previous call's two propagation branches."""
+        self.pipelined = bool(on)
 
     # ------------------------------------------------------------------ EDVR-M feature extractor
     def _pyramid_feats(self, fr, ph, pw):
@@ -170,20 +174,79 @@ class EngineIR(Engine):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, lrs, refs, is_first_frame, want_vis=False, frame_ids=None, want_log=False, input_ready=None):
+        if self.takes_pipelined_path(frame_ids, want_log) and not want_vis:
+            with torch.cuda.device(lrs.device):
+                return self._forward_ir_pipelined(lrs, refs, is_first_frame, frame_ids, input_ready), None
         with torch.cuda.device(lrs.device), ops.on_stream(torch.cuda.current_stream()):
             if isinstance(input_ready, torch.cuda.Stream):
                 torch.cuda.current_stream().wait_stream(input_ready)
             elif isinstance(input_ready, torch.cuda.Event):
                 torch.cuda.current_stream().wait_event(input_ready)
             out, dbg = self._forward_ir(lrs, refs, is_first_frame, frame_ids, bool(want_log and want_vis))
+            if self._pipe is not None:           # a sequential call (is_log) between pipelined ones: the internal streams see its state
+                for st in set(self._pipe):
+                    st.wait_stream(torch.cuda.current_stream())
         # RefVSR_IR returns no 'eval_vis' (RefVSR_IR.py:366-386); `vis` holds the save_sample block only (:374-384)
         return out, ((None, dbg) if want_log else None)
 
+    @torch.no_grad()
+    def _forward_ir_pipelined(self, lrs, refs, is_first_frame, frame_ids, input_ready=None):
+        """_forward_ir over two internal streams (Engine._forward_pipelined's rules: dependencies by HIP events, every tensor that
+        crosses streams recorded on its consumers, the host at most pipe_depth calls ahead): P = _ir_part_a of this call, M = the
+        previous call's _ir_part_b, then this one's.  Restarts of the forward branch run both parts on M, after everything in
+        flight.  Results are bit-identical to the sequential call."""
+        dev = lrs.device
+        caller = torch.cuda.current_stream()
+        M, _, _, P = self._pipe_streams(dev)
+        while len(self._inflight) >= self.pipe_depth:
+            self._inflight.popleft().synchronize()
+        if input_ready is None:
+            input_ready = torch.cuda.Event()
+            input_ready.record(caller)
+        if not isinstance(input_ready, str):
+            for st in (M, P):
+                if isinstance(input_ready, torch.cuda.Stream):
+                    st.wait_stream(input_ready)
+                else:
+                    st.wait_event(input_ready)
+        elif input_ready != 'materialised':
+            raise ValueError("input_ready must be None, 'materialised', a torch.cuda.Event or a torch.cuda.Stream")
+        for st in (M, P):
+            lrs.record_stream(st)
+            refs.record_stream(st)
+        restart = is_first_frame or self.fw_feat is None or (self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num)
+        if restart:
+            M.wait_stream(P)
+            with ops.on_stream(M):
+                out, _ = self._forward_ir(lrs, refs, is_first_frame, frame_ids)
+            P.wait_stream(M)
+        else:
+            with ops.on_stream(P):
+                pa = self._ir_part_a(lrs, refs, False, frame_ids, share=(M, P))
+                ev_p = torch.cuda.Event()
+                ev_p.record()
+            with ops.on_stream(M):
+                M.wait_event(ev_p)
+                out, _ = self._ir_part_b(pa)
+        done = torch.cuda.Event()
+        done.record(M)
+        caller.wait_event(done)
+        out.record_stream(caller)
+        self._inflight.append(done)
+        return out
+
     def _forward_ir(self, lrs, refs, is_first_frame, frame_ids, sample=False):
+        pa = self._ir_part_a(lrs, refs, is_first_frame, frame_ids)
+        return self._ir_part_b(pa, sample)
+
+    def _ir_part_a(self, lrs, refs, is_first_frame, frame_ids, share=None):
+        """Everything of a call that is a function of the window's frames (and of the key-frame schedule, a host-side counter):
+        per-frame preparation, the refill features of the key frames, every flow the branches will ask for.  share: the streams
+        that will consume the results besides the current one (pipelined mode)."""
         t, h, w = self._check_window(lrs, refs)
         if h < 64 or w < 64 or t < 5:
             raise RuntimeError('RefVSR_IR needs frames of at least 64x64 and a window of at least 5 frames (RefVSR_IR.py:244-246,203)')
-        ctr, dev, Cs = t // 2, lrs.device, self.Cs
+        ctr = t // 2
         if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
             is_first_frame = True
         if not is_first_frame and self.fw_feat is None:
@@ -191,7 +254,6 @@ class EngineIR(Engine):
         if is_first_frame and frame_ids is not None:
             self.id_cache, self.flow_cache = {}, {}
         fr = self._frames(lrs, refs, frame_ids)
-        flow = lambda a, b: self.flow(fr[a], fr[b])
         if is_first_frame:                                                   # :262-272
             self.keyframe_idx = np.arange(0, t, self.stride)
         else:
@@ -204,6 +266,23 @@ class EngineIR(Engine):
         for f in fr:
             self.prepare_frame(f)                                            # matching of EVERY frame (:279-285), cached per frame
         refill = self._refill(fr, t, h, w)
+        if share:
+            # the flows of both branches in batched SPyNet passes, each carrying an event for its consumers
+            self.flows([(fr[i], fr[i + 1]) for i in range(t - 1)] + [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)], share)
+            for f in fr:
+                for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr or []) + list(getattr(f, 'edvr', None) or []):
+                    for st in share:
+                        x.record_stream(st)
+            for x in refill.values():
+                for st in share:
+                    x.record_stream(st)
+        return dict(fr=fr, t=t, h=h, w=w, keys=keys, refill=refill, is_first_frame=is_first_frame, share=share)
+
+    def _ir_part_b(self, pa, sample=False):
+        """The two propagation branches and the upsampler (RefVSR_IR.py:292-365): the part that carries the state."""
+        fr, t, h, w, keys, refill, is_first_frame, share = (pa[k] for k in ('fr', 't', 'h', 'w', 'keys', 'refill', 'is_first_frame', 'share'))
+        ctr, dev, Cs = t // 2, fr[0].lr.device, self.Cs
+        flow = lambda a, b: self.flow(fr[a], fr[b], share)
         zeros = lambda hh, ww: torch.zeros((hh, ww, Cs), dtype=torch.float16, device=dev)
         # ---- backward branch over all frames (:292-326)
         feat, feat_up = zeros(h, w), zeros(2 * h, 2 * w)

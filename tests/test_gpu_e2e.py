@@ -154,6 +154,41 @@ def test_refvsr_ir_stream_against_reference_fixture(dev):
         assert e_res < 2e-2 and psnr(res, want) > 55.0 and e_feat < 3e-2 and e_conf < 1e-3 and e_flow < 1e-3
 
 
+def test_refvsr_ir_pipelined_equals_sequential(dev):
+    """RefVSR_IR on the two internal streams (EngineIR.set_pipelined, round 4): preparation + refill of call k + 1 under the
+    propagation branches of call k.  A 9-frame stream with a reset_branch rollover, the input_ready forms of the contract and
+    key-frame bookkeeping: bit-identical to the sequential engine, frame by frame, also when the calls are issued back to back
+    without a host synchronisation in between."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 9, 5
+    lr, rf, _ = make_clip(nfr, 64, 80, seed=31)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    wl = [lr[w][None].contiguous() for w in wins]
+    wr = [rf[w][None].contiguous() for w in wins]
+    torch.cuda.synchronize()
+    seq, cfg, _ = make_net('config_RefVSR_IR_MFID', t, dev, reset=4, save_sample=False)
+    want, keys = [], []
+    for f in range(nfr):
+        want.append(seq(wl[f], wr[f], f == 0, frame_ids=wins[f])['result'].clone())
+        keys.append([int(k) for k in seq.Network.engine(0).keyframe_idx])
+    for ready in ('materialised', None, 'event'):
+        net, _, _ = make_net('config_RefVSR_IR_MFID', t, dev, reset=4, save_sample=False)
+        net.Network.set_pipelined(True)
+        outs = []
+        for f in range(nfr):
+            r = ready
+            if ready == 'event':
+                r = torch.cuda.Event()
+                r.record()
+            outs.append(net(wl[f], wr[f], f == 0, frame_ids=wins[f], input_ready=r)['result'])
+            assert net.Network.engine(0).takes_pipelined_path(wins[f]) and [int(k) for k in net.Network.engine(0).keyframe_idx] == keys[f]
+        torch.cuda.synchronize()
+        for f in range(nfr):
+            assert torch.equal(outs[f], want[f]), 'frame %d differs (pipelined RefVSR_IR, input_ready=%s)' % (f, ready)
+        assert net.Network.frame_itr_num == seq.Network.frame_itr_num
+
+
 def test_refvsr_ir_padded_size_against_live_oracle(dev):
     """RefVSR_IR at 66x70 (neither side a multiple of 4): the EDVR extractor's reflect padding to 68x72 and the crop of its
     features (RefVSR_IR.py:171-217) -- the path the 270x480 bench line of this model runs -- against the live oracle:
