@@ -62,6 +62,7 @@ struct RB24Args {
     float act_slope;
     unsigned long long* probe;           // PROBE kernels: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
     int probe_iter;                      // which tile iteration of the workgroup is stamped
+    int prio;                            // REFVSR_WAVE_PRIO (common.h:rv_wave_prio): the younger half of the waves at priority 1
     // HEAD kernels (refvsr_conv_hr_last): `out` is planar fp32 [3][h][w]; base_lr = the LR centre frame, planar fp32 [3][bh][bw]
     const float* base_lr; int bh, bw; float base_step;
 };
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
 
     int tl, k_hi;
     rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
+    if (p.prio && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
     if (tl < k_hi) x_fetch(tl);
     __builtin_amdgcn_sched_barrier(0);                           // weights and first tile in flight before the rest of the set-up
     RB_STAMP(1);
@@ -540,6 +542,7 @@ static int launch_rb24(RB24Args& a, hipStream_t st) {
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
+    a.prio = rv_wave_prio();
     hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH, STORE, HEAD>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
