@@ -281,38 +281,41 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
     return res
 
 
-def wavefront_model(per_frame, nfr, reset_branch):
+def wavefront_model(per_frame, nfr, reset_branch, t_msg=0.3, head_fraction=0.24):
     """serial_fraction and predicted strong-scaling speedups of shard.run_wavefront from measured per-frame phase times
-    (shard.simulate_wavefront: pre-emptive makespan model of the two-lane schedule; hand-off 0.3 ms = 33 MB over one xGMI link +
-    latency; cold = extra phase-A time of a block's first frame, measured or 0.85 x phase A)."""
+    (shard.simulate_wavefront: pre-emptive makespan model of the two-lane schedule; t_msg = one 33 MB message over one xGMI link +
+    latency, 0.3 ms assumed at N = 1, the measured ring time at N > 1: what a context costs; the hand-off goes in two messages and
+    the chain only waits for the first -- header + LR state, head_fraction of the bytes -- plus 0.03 ms; cold = extra phase-A time
+    of a block's first frame, measured or 0.85 x phase A)."""
     from refvsr_amd import shard
     ta, tb1, tb2 = per_frame['phase_a_ms'], per_frame['phase_b1_ms'], per_frame['phase_b2_ms']
     cold = per_frame.get('phase_a_cold_extra_ms')
     cold = 0.85 * ta if cold is None else cold
     tot = ta + tb1 + tb2
-    ex = exchange_terms(per_frame)
-    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'handoff_ms_assumed': 0.3, 'cold_block_start_ms': cold,
+    ex = exchange_terms(per_frame, ctx_ms=t_msg)
+    th = head_fraction * t_msg + 0.03                     # chain-critical part of a hand-off (shard.EngineExecutor.split_handoff)
+    out = {'serial_fraction': tb1 / tot if tot > 0 else None, 'message_ms': t_msg, 'handoff_ms_on_the_chain': th, 'cold_block_start_ms': cold,
            'cold_block_start_ms_at_a_restart': 2.0 * cold,
            'context_exchange': {'context_prepare_ms': ex['t_prep'], 'cold_window_extra_with_contexts_ms': ex['t_cold_x'], 'message_ms_assumed': ex['t_ctx'],
                                 'what': 'shard.run_wavefront(exchange_contexts=True): every per-frame context (matching, reference encoders, aligned '
                                         'attention) prepared ONCE, by the owner of its frame, and sent to the ranks whose windows need it'},
            'predicted_speedup': {}}
-    sp = lambda n, parts, rb, il=True: round(shard.predicted_speedup(nfr, n, parts, rb, ta, tb1, tb2, 0.3, cold, il)[0], 3)
+    sp = lambda n, parts, rb, il=True: round(shard.predicted_speedup(nfr, n, parts, rb, ta, tb1, tb2, th, cold, il)[0], 3)
     for n in (2, 4, 8):
         bal = shard.partition(nfr, n)
         grow = shard.partition_chain(nfr, n, tb1 / ta if ta > 0 else 0.165)
         ent = {}
         if reset_branch:
-            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, 0.3, cold)
+            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, th, cold)
             ent['with_restarts (reset_branch=%d)' % reset_branch] = {'chosen': nm, 'speedup': round(s_, 3),
                                                                     'hybrid_reset_aligned': sp(n, shard.partition_hybrid(nfr, n, reset_branch), reset_branch),
                                                                     'balanced_handoff_at_every_boundary': sp(n, bal, reset_branch)}
         if reset_branch:
-            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, 0.3, cold, exchange=ex)
+            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, th, cold, exchange=ex)
             ent['with_restarts (reset_branch=%d)' % reset_branch]['with_context_exchange'] = {'chosen': nm, 'speedup': round(s_, 3)}
-        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, 0.3, cold, exchange=ex)
+        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, th, cold, exchange=ex)
         ex_free = {'chosen': nm, 'speedup': round(s_, 3), 'block_sizes': [b_ - a_ for a_, b_, _ in blk]}
-        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, 0.3, cold)
+        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, th, cold)
         ent['no_restarts (reset_branch=None, configs[4] regime)'] = {
             'with_context_exchange': ex_free,
             'chosen': nm, 'speedup': round(s_, 3), 'balanced': sp(n, bal, None), 'growing_shards': sp(n, grow, None),
@@ -460,20 +463,22 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     hv = torch.tensor([min(handoff_ms[1:])], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(hv, op=dist.ReduceOp.MAX)
     t_msg = max(0.05, float(hv.item()))
+    nb_head = ex.state_split_nbytes()[0] if ex.split_handoff else nb
+    t_chain = t_msg * nb_head / float(nb) + (0.03 if ex.split_handoff else 0.0)      # what the B1 chain waits for per hand-off
     exch = None if args.no_wavefront_exchange else exchange_terms(per_frame, ctx_ms=t_msg)
     blocks, predicted, pname = shard.choose_partition(nfr, world, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                                      per_frame['phase_b2_ms'], t_msg, per_frame['phase_a_cold_extra_ms'], exchange=exch)
+                                                      per_frame['phase_b2_ms'], t_chain, per_frame['phase_a_cold_extra_ms'], exchange=exch)
     if args.wavefront_partition:                           # A/B: force a partition family
         fam = args.wavefront_partition
         parts = {'balanced': shard.partition(nfr, world), 'growing': shard.partition_chain(nfr, world),
                  'hybrid': shard.partition_hybrid(nfr, world, cfg.reset_branch or 9),
-                 'cyclic_growing': shard.partition_cyclic_growing(nfr, world, per_frame['phase_a_ms'], per_frame['phase_b1_ms'] + 0.5 * t_msg,
+                 'cyclic_growing': shard.partition_cyclic_growing(nfr, world, per_frame['phase_a_ms'], per_frame['phase_b1_ms'] + 0.5 * t_chain,
                                                                   per_frame['phase_a_ms'] + per_frame['context_prepare_ms'])}.get(fam)
         if parts is None and fam.startswith('cyclic'):
             parts = shard.partition_cyclic(nfr, world, int(fam[6:] or 3))
         blocks, pname = shard.as_blocks(parts), fam
         predicted = shard.predicted_speedup(nfr, world, blocks, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                            per_frame['phase_b2_ms'], t_msg, per_frame['phase_a_cold_extra_ms'], True, exch)[0]
+                                            per_frame['phase_b2_ms'], t_chain, per_frame['phase_a_cold_extra_ms'], True, exch)[0]
     mine = [(a, b) for a, b, r in blocks if r == rank]
     need = sorted(set(i for a, b in mine for f in range(a, b) for i in window_indices(f, nfr, t)))
     clip = {}
@@ -536,8 +541,10 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                'gpus_visible': torch.cuda.device_count(),
                'partition': {'name': pname, 'blocks': [list(b_) for b_ in blocks], 'predicted_speedup': round(float(predicted), 3)},
                'phase_ms_per_frame_measured': per_frame,
-               'partition_chosen_with': {'message_ms': t_msg, 'what': 'hand-off and context messages priced at the measured hand-off time'},
-               'model': wavefront_model(per_frame, nfr, cfg.reset_branch),
+               'partition_chosen_with': {'message_ms': t_msg, 'handoff_ms_on_the_chain': t_chain, 'split_handoff': bool(ex.split_handoff),
+                                         'what': 'context messages priced at the measured ring time of the packed state; a hand-off at its '
+                                                 'first message (header + LR state) when it goes in two'},
+               'model': wavefront_model(per_frame, nfr, cfg.reset_branch, t_msg, nb_head / float(nb)),
                'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
                            '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
                'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
@@ -546,7 +553,9 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                            'frames on lane 1; the B1 chain (forward-branch steps) on lane 2, B1(f) as soon as phase A of frame f is done and '
                            'the state has arrived, state sent right after a block\'s last B1; B2 (BW/FW fusion + upsampler) afterwards on lane 1',
                'handoff': {'messages': int(msgs[0].item()), 'bytes_per_message': 64 + h * w * (10 * C + 12),
-                           'format': 'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
+                           'format': ('two messages: [header | fp16 HWC feat | fp32 flow + conf] (%d bytes: the receiver\'s forward-branch step starts '
+                                      'on it), then fp16 HWC feat_up as it lies' % nb_head) if ex.split_handoff else
+                                     'one packed buffer: fp16 HWC feat + feat_up, fp32 flow + conf',
                            'ms_per_message_measured': float(hv.item()),
                            'how': 'the packed state of this model sent round the ring of ranks (send / recv pairs), host clock around two '
                                   'messages in series after device synchronisation, best of 2 after one warm-up, max over ranks',

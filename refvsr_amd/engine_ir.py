@@ -75,6 +75,8 @@ class WeightsIR(Weights):
 
 
 class EngineIR(Engine):
+    split_state_ok = False               # its branches read fw_feat_up directly: one-message hand-off only
+
     def __init__(self, config, weights):
         Engine.__init__(self, config, weights)
         self.stride = config.keyframe_stride

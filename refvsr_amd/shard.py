@@ -101,8 +101,19 @@ def recv_state(src, channels, device, nbytes=None):
     return st
 
 
-def _import(executor, src, channels, device):
-    """Receive the state from rank src into the executor (packed single-message form when the executor offers it)."""
+def _import(executor, src, channels, device, split=False):
+    """Receive the state from rank src into the executor (packed single-message form when the executor offers it; split=True:
+    the two-message form -- the executor starts its forward-branch step on the small message and waits for the 2x state inside it)."""
+    if split:
+        nb_head, nb_tail = executor.state_split_nbytes()
+        head = torch.empty(nb_head, dtype=torch.uint8, device=device)
+        tail = executor.state_tail_buffer(device)
+        assert tail.dtype == torch.uint8 and tail.numel() == nb_tail
+        w_head = dist.irecv(head, src)
+        w_tail = dist.irecv(tail, src)
+        w_head.wait()
+        executor.import_state_split(head, tail, w_tail.wait)
+        return
     nb = executor.state_nbytes() if hasattr(executor, 'state_nbytes') else None
     st = recv_state(src, channels, device, nb)
     if nb is not None:
@@ -113,6 +124,17 @@ def _import(executor, src, channels, device):
 
 def _export(executor):
     return executor.export_state_packed() if hasattr(executor, 'export_state_packed') else executor.export_state()
+
+
+def _send_split(executor, dst, device, keep):
+    """The state as two messages, small one first (Engine.export_state_split); returns the two work handles."""
+    head, tail = executor.export_state_split()
+    out = []
+    for buf in (head, tail):
+        buf = buf if str(buf.device).startswith(str(device)) else buf.to(device)
+        keep.append(buf)
+        out.append(dist.isend(buf, dst))
+    return out
 
 
 def run_sharded(executor, get_window, nframes, frame_num, reset_branch, channels, device, aligned=False,
@@ -637,6 +659,8 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
         assert not rx
     tim['issue_a'] = time.perf_counter() - t0
     split = hasattr(executor, 'phase_b1')
+    # the hand-off in two messages (the receiver's step starts on the small one): executors that offer it, with the B1 / B2 split
+    two_msg = split and bool(getattr(executor, 'split_handoff', False))
     for a, b in mine:                                              # ---- the chain: one block at a time, in frame order
         nxt_rank = owner_of.get(b)                                 # owner of the block that follows in chain order
         handoff_out = nxt_rank is not None and nxt_rank != rank and needs_handoff(b, reset_branch)
@@ -644,7 +668,7 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
             t1 = time.perf_counter()
             if needs_handoff(a, reset_branch):
                 if owner_of[a - 1] != rank:
-                    _import(executor, owner_of[a - 1], channels, device)
+                    _import(executor, owner_of[a - 1], channels, device, split=two_msg)
                 first = False
             else:
                 first = True
@@ -657,7 +681,10 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
                     mark('b1', f)
                     first = False
                 if handoff_out:                                    # the next block's chain starts as soon as this one ends
-                    pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
+                    if two_msg:
+                        pending.extend(_send_split(executor, nxt_rank, device, keep))
+                    else:
+                        pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
                     tim['handoff_messages'] += 1
             else:
                 def start_send():    # called by phase_b of the block's LAST frame as soon as its carried state is final
@@ -708,10 +735,14 @@ class EngineExecutor(object):
     indices (id-keyed window cache, no content compare), the hand-off uses the packed single-message state."""
     supports_after_state = True
 
-    def __init__(self, net, device, h, w, nframes, frame_num, keep_on_device=True, pipelined=True, inputs_materialised=False):
+    def __init__(self, net, device, h, w, nframes, frame_num, keep_on_device=True, pipelined=True, inputs_materialised=False,
+                 split_handoff=True):
         self.net, self.dev, self.h, self.w, self.nframes, self.t = net, device, h, w, nframes, frame_num
         self.keep = keep_on_device
         self.eng = net.Network.ensure_engines(1, device)[0]
+        # run_wavefront: the hand-off as [header | feat | flow | conf] + [feat_up]; the forward-branch step of the receiver starts on
+        # the first message (Engine.export_state_split).  RefVSR_IR keeps the one-message form.
+        self.split_handoff = bool(split_handoff) and bool(getattr(self.eng, 'split_state_ok', False))
         # cross-call pipelining of forward() (run_sharded): safe by default since round 4 -- the engine's internal streams wait for
         # the caller's stream, on which the windows are copied right before each call (Engine.set_pipelined); a caller whose
         # windows are resident and final before the run says so (inputs_materialised) and gets the full cross-call overlap
@@ -815,3 +846,31 @@ class EngineExecutor(object):
 
     def import_state_packed(self, buf):
         self.eng.import_state_packed(buf.to(self.dev))
+
+    # ---- the two-message hand-off
+    def state_split_nbytes(self):
+        cs = self.eng._state_cs()
+        return self.eng.state_head_nbytes(self.h, self.w), 2 * self.h * 2 * self.w * cs * 2
+
+    def export_state_split(self):
+        head, feat_up = self.eng.export_state_split()
+        return head, feat_up.reshape(-1).view(torch.uint8)
+
+    def state_tail_buffer(self, device):
+        """The buffer the second message is received into: the engine's next 2x state itself when the transport writes device
+        memory (RCCL), a host buffer otherwise (gloo: copied to the device by the deferred wait)."""
+        cs = self.eng._state_cs()
+        self._tail = torch.empty((2 * self.h, 2 * self.w, cs), dtype=torch.float16, device=self.dev)
+        if str(device).startswith('cuda'):
+            return self._tail.view(-1).view(torch.uint8)
+        return torch.empty(self._tail.numel() * 2, dtype=torch.uint8, device=device)
+
+    def import_state_split(self, head, tail, wait_tail):
+        feat_up = self._tail
+        if tail.is_cuda:
+            waiter = wait_tail
+        else:
+            def waiter():
+                wait_tail()
+                feat_up.copy_(tail.view(torch.float16).view(feat_up.shape))
+        self.eng.import_state_head(head.to(self.dev), feat_up, waiter)

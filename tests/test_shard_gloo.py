@@ -141,6 +141,57 @@ class _ExecCtx(_ExecLanes):
         return h
 
 
+class _ExecSplit(_ExecLanes):
+    """+ the two-message hand-off of run_wavefront (EngineExecutor.split_handoff): [iteration counter | feat | flow | conf] first,
+    the 2x state second; the receiver may start its forward-branch step on the first message and must wait for the second one
+    before it reads the 2x state -- here: the wait is deferred into phase_b1 and recorded."""
+    split_handoff = True
+
+    def __init__(self, cfg, sd):
+        _ExecLanes.__init__(self, cfg, sd)
+        self._pending, self.deferred_waits, self.shapes = None, 0, None
+
+    def _shapes(self):
+        if self.shapes is None:
+            st = self.o.export_state()
+            self.shapes = {k: tuple(st[k].shape) for k in ('feat', 'flow', 'conf', 'feat_up')}
+        return self.shapes
+
+    def state_split_nbytes(self):
+        sh = self._probe_shapes
+        n = lambda k: 4 * int(torch.tensor(sh[k]).prod())
+        return 4 + n('feat') + n('flow') + n('conf'), n('feat_up')
+
+    def export_state_split(self):
+        st = self.o.export_state()
+        head = torch.cat([torch.tensor([float(st['frame_itr_num'])])] + [st[k].float().reshape(-1) for k in ('feat', 'flow', 'conf')])
+        return head.contiguous().view(torch.uint8), st['feat_up'].float().contiguous().reshape(-1).view(torch.uint8)
+
+    def state_tail_buffer(self, device):
+        return torch.empty(self.state_split_nbytes()[1], dtype=torch.uint8)
+
+    def import_state_split(self, head, tail, wait_tail):
+        assert self.lane == 'b'
+        sh = self._probe_shapes
+        v = head.view(torch.float32)
+        st, o = {'frame_itr_num': int(v[0])}, 1
+        for k in ('feat', 'flow', 'conf'):
+            n = int(torch.tensor(sh[k]).prod())
+            st[k] = v[o:o + n].clone().view(sh[k])
+            o += n
+        self._pending = (st, tail, wait_tail)
+
+    def phase_b1(self, handle, first):
+        if self._pending is not None:                      # the first step behind a hand-off: the 2x state is awaited HERE
+            st, tail, wait_tail = self._pending
+            self._pending = None
+            wait_tail()
+            self.deferred_waits += 1
+            st['feat_up'] = tail.view(torch.float32).clone().view(self._probe_shapes['feat_up'])
+            _Exec.import_state(self, st)
+        return _ExecLanes.phase_b1(self, handle, first)
+
+
 def _setup(reset, nframes=6, name='config_RefVSR_small_L1'):
     from refvsr_amd import get_config, make_state_dict
     from refvsr_amd.synth import make_clip, window_indices
@@ -184,6 +235,14 @@ def _worker(rank, world, port, reset, aligned, q, wavefront=False, nframes=6, na
         tim = {}
         res = shard.run_wavefront(ex, get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim, exchange_contexts=True)
         info = {'prepared': ex.prepared_here, 'imported': ex.imported_here, 'messages': tim['context_messages']}
+    elif wavefront == 'two_message':                       # the hand-off as two messages, the second awaited inside the step
+        ex = _ExecSplit(cfg, sd)
+        C, hh = cfg.mid_channels, 16
+        ex._probe_shapes = {'feat': (C, hh, hh), 'flow': (2, hh, hh), 'conf': (1, hh, hh), 'feat_up': (C, 2 * hh, 2 * hh)}    # (batch dim dropped)
+        tim = {}
+        res = shard.run_wavefront(ex, get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=shard.partition_cyclic(nframes, world, 2), timings=tim)
+        nblocks = len([1 for a, b, r in shard.partition_cyclic(nframes, world, 2) if r == rank])
+        assert ex.deferred_waits == nblocks - (1 if rank == 0 else 0), (ex.deferred_waits, nblocks)
     elif wavefront == 'nosplit':
         res = shard.run_wavefront(_ExecNoSplit(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu')
     elif wavefront:
@@ -213,7 +272,7 @@ def _run(reset, aligned, wavefront=False, world=2, nframes=6, name='config_RefVS
     got, infos = {}, {}
     try:
         for _ in range(world):
-            rank, res, info = q.get(timeout=600)
+            rank, res, info = q.get(timeout=300)
             got.update({f: torch.from_numpy(v) for f, v in res.items()})
             infos[rank] = info
         for p in procs:
@@ -330,3 +389,11 @@ def test_context_exchange_world8_partitions():
     for fam in ('exchange_cyclic', 'exchange_growing'):
         got, infos = _run(reset=None, aligned=False, wavefront=fam, world=8, nframes=26)
         _check_exchange(got, infos, 26, 8)
+
+
+def test_two_message_handoff():
+    """run_wavefront with an executor that offers the two-message hand-off (split_handoff): block-cyclic blocks of 2 on three
+    ranks, a hand-off behind every block; the second message is awaited inside the receiver's forward-branch step.  Bit-identical
+    to the sequential stream."""
+    got = _run(reset=None, aligned=False, wavefront='two_message', world=3, nframes=11)
+    assert sorted(got) == list(range(11))
