@@ -245,6 +245,11 @@ int refvsr_set_probe(void* buf, int iter);
 int refvsr_conv_direct_f32(const float* src, int cin, int h, int w,
                            const float* wgt, const float* bias, int cout, int ksize, int stride, int pad,
                            float act_slope, void* out, int out_nhwc16, int out_c, void* stream);
+/* 1x1 conv cin -> 16 + LeakyReLU in fp32 (ABI 10): the map64 / map128 block that ends the matching's feature extractor
+ * (RefVSR_/attention.py:41-42).  src: fp32 HWC [h][w][cin] (cin % 4 == 0, the f32 conv mode's output), wgt: fp32 [16][cin], bias [16];
+ * out: planar fp32 [16][h][w].  Channels are summed in order with fp32 FMAs. */
+int refvsr_conv1x1_f32(const float* src, int cin, int h, int w, const float* wgt, const float* bias, float act_slope,
+                       float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout conversion

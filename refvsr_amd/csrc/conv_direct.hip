@@ -121,3 +121,70 @@ extern "C" int refvsr_conv_direct_f32(const float* src, int cin, int h, int w,
     RV_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 conv, C_in -> 16, LeakyReLU, fp32 HWC in -> planar fp32 out: the `map64` / `map128` block that ends FeatureMatching's feature
+// extractor (RefVSR_/attention.py:41-42: BasicBlock(default_conv, 64 | 128, 16, 1) + LeakyReLU(0.2)).  On the generic kernel's
+// fp32 mode this was 118 us at 270 x 480 (0.28 TB/s: 33 MB read for 0.27 GFLOP); it is HBM work: a workgroup stages 64 pixels x
+// C_in floats with coalesced 16-byte loads (row stride C_in + 1 floats: odd, so the per-pixel reads of the compute phase are
+// bank-conflict free), thread (pixel, og) accumulates outputs 4 og .. 4 og + 3 over the channels in order (fp32 FMA chains, one float4
+// broadcast read of the weights per channel), stores are 256-byte row segments of the planar output.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1x1_f32_kernel(const float* __restrict__ src, int cin, int npix, const float* __restrict__ wgt,
+                                                         const float* __restrict__ bias, float slope, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+    const int ST = cin + 1;                                          // floats per staged pixel (odd: lanes = pixels hit distinct banks)
+    float* xs = c1_lds;                                              // [64][ST]
+    float* ws = c1_lds + ((64 * ST + 3) & ~3);                       // [cin][16]: output fastest, 16-byte aligned
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * 64;
+    const int q4 = cin >> 2;                                         // float4 per pixel
+    for (int i = tid; i < 64 * q4; i += 256) {
+        const int px = i / q4, c4 = i - px * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + px < npix) v = *reinterpret_cast<const float4*>(src + (size_t)(p0 + px) * cin + c4 * 4);
+        float* d = xs + px * ST + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = tid; i < cin * 16; i += 256) {
+        const int c = i >> 4, o = i & 15;
+        ws[i] = wgt[o * cin + c];
+    }
+    __syncthreads();
+    const int px = tid & 63, og = tid >> 6;
+    const float* xp = xs + px * ST;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < cin; ++c) {
+        const float x = xp[c];
+        const float4 w4 = *reinterpret_cast<const float4*>(ws + c * 16 + og * 4);
+        a0 = fmaf(x, w4.x, a0); a1 = fmaf(x, w4.y, a1); a2 = fmaf(x, w4.z, a2); a3 = fmaf(x, w4.w, a3);
+    }
+    if (p0 + px < npix) {
+        float* o = out + (size_t)(og * 4) * npix + p0 + px;
+        o[0] = rv_lrelu(a0 + bias[og * 4 + 0], slope);
+        o[(size_t)npix] = rv_lrelu(a1 + bias[og * 4 + 1], slope);
+        o[2 * (size_t)npix] = rv_lrelu(a2 + bias[og * 4 + 2], slope);
+        o[3 * (size_t)npix] = rv_lrelu(a3 + bias[og * 4 + 3], slope);
+    }
+}
+
+extern "C" int refvsr_conv1x1_f32(const float* src, int cin, int h, int w, const float* wgt, const float* bias, float act_slope,
+                                  float* out, void* stream) {
+    RV_CHECK(src && wgt && bias && out && h > 0 && w > 0, "conv1x1_f32: bad args");
+    RV_CHECK(cin >= 4 && cin <= 256 && cin % 4 == 0, "conv1x1_f32: cin must be a multiple of 4 in [4, 256] (got %d)", cin);
+    RV_CHECK(((uintptr_t)src & 15) == 0, "conv1x1_f32: src must be 16-byte aligned");
+    RV_CHECK(act_slope >= 0.f && act_slope <= 1.f, "conv1x1_f32: activation slope must lie in [0, 1]");
+    RV_CHECK(refvsr_init() == 0, "init failed");
+    const int npix = h * w;
+    const size_t lds = ((size_t)((64 * (cin + 1) + 3) & ~3) + (size_t)cin * 16) * sizeof(float);
+    static bool attr_done[RV_MAX_DEVICES] = {};
+    const int dev = rv_device();
+    if (!attr_done[dev]) {
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(conv1x1_f32_kernel, dim3(rv_cdiv(npix, 64)), dim3(256), lds, (hipStream_t)stream, src, cin, npix, wgt, bias,
+                       act_slope, out);
+    RV_LAUNCH_CHECK();
+    return 0;
+}

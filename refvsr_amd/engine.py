@@ -103,8 +103,12 @@ class Weights(object):
         if self.vgg7:                     # VGG19[0:7] + map128 (attention.py:33-40)
             mf32(fe + '5', [64])
             mf32(fe + 'map128.0', [128])
+            self.raw[fe + 'map128.0'] = tuple(t.detach().to(device, torch.float32).contiguous() for t in
+                                              (g(fe + 'map128.0')[0].reshape(16, 128), g(fe + 'map128.0')[1]))
         else:
             mf32(fe + 'map64.0', [64])
+            self.raw[fe + 'map64.0'] = tuple(t.detach().to(device, torch.float32).contiguous() for t in
+                                             (g(fe + 'map64.0')[0].reshape(16, 64), g(fe + 'map64.0')[1]))
 
         def aligned(prefix):
             mf(prefix + '.conv1.0', [3])
@@ -206,6 +210,9 @@ class Engine(object):
         # r04_tail_and_mfid_run.log: the HR intermediate it saves is 6 % of a launch pair that a 19 % larger conv1 pays for) -> opt-in
         self.fuse_tail = self.fuse_head and (env_flag('REFVSR_FUSE_TAIL') or bool(getattr(config, 'fuse_tail', False)))
         self.fuse_conf = not env_flag('REFVSR_NO_FUSE_CONF')        # A/B knob: confidence fusions as separate launches (round 3)
+        # the 1x1 map that ends the matching's feature extractor on its own HBM-bound kernel (refvsr_conv1x1_f32) instead of the
+        # generic conv's fp32 mode (118 us at 270 x 480 for 33 MB of reads); A/B knob REFVSR_NO_MAP1X1=1
+        self.map1x1 = not env_flag('REFVSR_NO_MAP1X1')
         self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not env_flag('REFVSR_NO_OVERLAP')
         # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
@@ -664,10 +671,14 @@ class Engine(object):
             x = ops.conv(self.cw(fe + '0'), x, act=0.0)
             if not self.vgg7:
                 x = ops.conv(self.cw(fe + '2'), x, act=0.0)
+                if self.map1x1:
+                    return ops.conv1x1_f32(x, *R[fe + 'map64.0'], act=0.2)
                 return ops.conv(self.cw(fe + 'map64.0'), x, act=0.2, planar_out=True)
             x = ops.conv(self.cw(fe + '2'), x, act=0.0, planar_out=True)
             x = ops.pack_nhwc32(ops.maxpool2(x))                                   # VGG19[4]
             x = ops.conv(self.cw(fe + '5'), x, act=0.0)
+            if self.map1x1:
+                return ops.conv1x1_f32(x, *R[fe + 'map128.0'], act=0.2)
             return ops.conv(self.cw(fe + 'map128.0'), x, act=0.2, planar_out=True)
         lr_n = ops.conv_direct(fr.lr, *R['feature_match.sub_mean'])
         ref_n = ops.conv_direct(fr.ref, *R['feature_match.sub_mean'])

@@ -76,6 +76,7 @@ SIGNATURES = {
     'refvsr_conv_shuffle2_blob_bytes': [_I],     # returns the size
     'refvsr_conv_shuffle2': [_P, _I, _I, _I, _P, _F, _P, _P],
     'refvsr_conv_direct_f32': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
+    'refvsr_conv1x1_f32': [_P, _I, _I, _I, _P, _P, _F, _P, _P],
     'refvsr_pack_nhwc16': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_pack_nhwc32': [_P, _I, _I, _I, _P, _I, _P],
     'refvsr_unpack_nhwc16': [_P, _I, _I, _I, _I, _P, _P],

@@ -485,6 +485,16 @@ def pack_nhwc16(x, cs=None):
     return out
 
 
+def conv1x1_f32(x, w, b, act=0.2):
+    """refvsr_conv1x1_f32: fp32 HWC [h][w][cin] -> planar fp32 [16][h][w], 1x1 conv + LeakyReLU (the matching's map64 / map128 block)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+    h, w_, cin = x.shape
+    assert tuple(w.shape) == (16, cin) and w.dtype == torch.float32 and w.is_contiguous() and tuple(b.shape) == (16,)
+    out = torch.empty((16, h, w_), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().refvsr_conv1x1_f32(_ptr(x), cin, h, w_, _ptr(w), _ptr(b), float(act), _ptr(out), _stream()), 'conv1x1_f32')
+    return out
+
+
 def pack_nhwc32(x, cs=None):
     _planar(x)
     c, h, w = x.shape

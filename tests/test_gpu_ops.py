@@ -1257,3 +1257,25 @@ def test_conv_hr_last_fused_tail(dev, bh, bw, scale):
     report('conv_hr_last %dx%d x%d' % (bh, bw, scale), vs_two_launches=e, vs_torch=e_ref)
     assert e < 2e-5
     assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,size', [(64, (270, 480)), (64, (19, 45)), (128, (68, 120)), (64, (1, 3))])
+def test_conv1x1_f32_map(dev, cin, size):
+    """refvsr_conv1x1_f32 (the map64 / map128 block of the matching's feature extractor, RefVSR_/attention.py:41-42) against
+    F.conv2d + leaky_relu in float64 and against the generic conv's fp32 mode it replaces: fp32 accuracy (the arg-max of the
+    matching is decided on these features)."""
+    from refvsr_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(7)
+    h, w = size
+    x = (torch.randn(cin, h, w, generator=g).abs() * 2.0).to(dev)
+    wt = (torch.randn(16, cin, 1, 1, generator=g) * 0.2).to(dev)
+    b = (torch.randn(16, generator=g) * 0.1).to(dev)
+    xh = ops.pack_nhwc32(x, cin)
+    got = ops.conv1x1_f32(xh, wt.reshape(16, cin).contiguous(), b, 0.2)
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double()[None], wt.double(), b.double()), 0.2)[0]
+    old = ops.conv(ops.ConvWeights(pack_conv(wt.cpu(), b.cpu(), [cin], f32=True), dev), xh, act=0.2, planar_out=True)
+    scale = float(want.abs().max())
+    e_new, e_old = maxdiff(got.double(), want) / scale, maxdiff(old.double(), want) / scale
+    report('conv1x1_f32 %d->16 %dx%d' % (cin, h, w), rel_vs_f64=e_new, generic_rel_vs_f64=e_old)
+    assert got.shape == (16, h, w) and e_new < 2e-6 and e_old < 2e-6
