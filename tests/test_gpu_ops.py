@@ -1265,6 +1265,7 @@ def test_conv1x1_f32_map(dev, cin, size):
     """refvsr_conv1x1_f32 (the map64 / map128 block of the matching's feature extractor, RefVSR_/attention.py:41-42) against
     F.conv2d + leaky_relu in float64 and against the generic conv's fp32 mode it replaces: fp32 accuracy (the arg-max of the
     matching is decided on these features)."""
+    from refvsr_amd import ops
     from refvsr_amd.packing import pack_conv
     g = torch.Generator().manual_seed(7)
     h, w = size
