@@ -950,3 +950,51 @@ def test_context_exchange_model():
     cyc = shard.partition_cyclic(64, 8, 2)
     assert shard.predicted_speedup(64, 8, cyc, None, ta, tb1, tb2, 0.3, cold, True, dict(t_prep=1.9, t_ctx=0.0))[0] > \
         shard.predicted_speedup(64, 8, cyc, None, ta, tb1, tb2, 0.3, cold)[0]
+
+
+def test_growing_block_cyclic_partition_and_choice_are_well_formed():
+    """partition_cyclic_growing: contiguous cover of the clip, block sizes >= 1, non-decreasing up to the cap and the tail, owners
+    dealt round-robin; choose_partition returns a valid block list for every (world, clip, restart) and never predicts more than
+    the rank count or less than one; the exchange with free messages never loses to the same partition without it."""
+    from refvsr_amd import shard
+    ta, tb1, tb2, cold = 5.35, 0.89, 0.45, 3.9
+    for world in (2, 3, 8):
+        for nfr in (world + 1, 20, 64, 100):
+            for scale in (0.8, 1.0, 1.2):
+                blocks = shard.partition_cyclic_growing(nfr, world, ta, tb1 + 0.05, ta + 2.2, scale)
+                assert blocks[0][0] == 0 and blocks[-1][1] == nfr and all(b0[1] == b1[0] for b0, b1 in zip(blocks, blocks[1:]))
+                sizes = [b - a for a, b, _ in blocks]
+                assert min(sizes) >= 1 and max(sizes) <= 8 and sizes[:-1] == sorted(sizes[:-1])
+                assert [r for _, _, r in blocks] == [k % world for k in range(len(blocks))]
+            for rb in (None, 9):
+                for ex in (None, dict(t_prep=2.2, t_ctx=0.3, t_cold_x=0.0)):
+                    blk, sp, name = shard.choose_partition(nfr, world, rb, ta, tb1, tb2, 0.1, cold, exchange=ex)
+                    assert shard.as_blocks(blk, world) == blk and 1.0 - 1e-6 <= sp <= world + 1e-6, (world, nfr, rb, name, sp)
+    cyc = shard.partition_cyclic(64, 8, 2)
+    for rb in (None, 9):
+        free = shard.predicted_speedup(64, 8, cyc, rb, ta, tb1, tb2, 0.1, cold, True, dict(t_prep=2.2, t_ctx=0.0, t_cold_x=0.0))[0]
+        assert free >= shard.predicted_speedup(64, 8, cyc, rb, ta, tb1, tb2, 0.1, cold)[0] - 1e-6
+
+
+def test_context_plan_leads_and_programs():
+    """ContextPlan: the lead (how many chain steps ahead of a foreign window a context is prepared) only reorders a rank's tasks --
+    every window still follows the contexts it needs, every context is prepared once, whatever the lead."""
+    from refvsr_amd import shard
+    for lead in (0, 1, 3, 8):
+        for parts in (shard.partition_cyclic(26, 4, 2), shard.partition_hybrid(40, 4, 9), shard.partition_chain(26, 4)):
+            rb = 9 if parts == shard.partition_hybrid(40, 4, 9) else None
+            nfr = 40 if rb else 26
+            plan = shard.ContextPlan(nfr, 4, parts, rb, 5, lead=lead)
+            seen = []
+            for r in range(4):
+                have = set()
+                for op in plan.program(r):
+                    if op[0] == 'prep':
+                        seen.append(op[1])
+                        have.add(op[1])
+                    elif op[0] == 'wait_recv':
+                        have.add(op[1])
+                    elif op[0] == 'a1':
+                        assert set(plan.needed[op[1]]) <= have, (lead, r, op)
+            assert sorted(seen) == list(range(nfr))
+            assert _context_protocol_completes(plan, False) and _context_protocol_completes(plan, True)
