@@ -998,3 +998,27 @@ def test_context_plan_leads_and_programs():
                         assert set(plan.needed[op[1]]) <= have, (lead, r, op)
             assert sorted(seen) == list(range(nfr))
             assert _context_protocol_completes(plan, False) and _context_protocol_completes(plan, True)
+
+
+def test_bench_wavefront_model_runs_on_cpu():
+    """bench.wavefront_model (the N = 1 bench line's prediction object) is pure host code: it must run without a GPU, carry the
+    context-exchange and two-message terms, and order its predictions sensibly."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pf = {'phase_a_ms': 5.35, 'phase_b1_ms': 0.89, 'phase_b2_ms': 0.45, 'phase_a_cold_extra_ms': 3.9, 'context_prepare_ms': 2.2,
+          'phase_a_cold_with_contexts_ms': 2.9}
+    ex = bench.exchange_terms(pf)
+    assert abs(ex['t_prep'] - 2.2) < 1e-9 and ex['t_cold_x'] == 0.0 and ex['t_ctx'] == 0.3
+    m = bench.wavefront_model(pf, 64, 9)
+    assert abs(m['handoff_ms_on_the_chain'] - (0.24 * 0.3 + 0.03)) < 1e-9 and m['message_ms'] == 0.3
+    e8 = m['predicted_speedup']['8']
+    wr, nr = e8['with_restarts (reset_branch=9)'], e8['no_restarts (reset_branch=None, configs[4] regime)']
+    assert 6.0 < wr['speedup'] < wr['with_context_exchange']['speedup'] <= 8.0
+    assert 5.0 < nr['speedup'] < nr['with_context_exchange']['speedup'] < 6.5 and nr['with_context_exchange']['speedup'] >= 5.5
+    assert sum(nr['with_context_exchange']['block_sizes']) == 64
+    for n in ('2', '4'):
+        assert m['predicted_speedup'][n]['no_restarts (reset_branch=None, configs[4] regime)']['speedup'] <= float(n) + 1e-6
