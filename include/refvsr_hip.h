@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 10  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 11  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
@@ -32,7 +32,11 @@ extern "C" {
                                   8: RefvsrConv.f32 = 2 (plain fp16 weights in the streamed convs);
                                   9: refvsr_conv_shuffle2 (compile-time-specialised C -> 4 C conv + pixel shuffle), refvsr_conv32;
                                   10: RefvsrConv.batch (one launch over several images that share the weights),
-                                      refvsr_spynet_level_input_batch, refvsr_conf_alpha, refvsr_warp_nhwc16's flow_scale */
+                                      refvsr_spynet_level_input_batch, refvsr_conf_alpha, refvsr_warp_nhwc16's flow_scale;
+                                  11: multi-map launches (REFVSR_MAX_MAPS maps of one geometry behind one launch and one weight fill):
+                                      refvsr_resblock24_chain_batch, refvsr_conv24_batch, refvsr_conv_shuffle2_batch,
+                                      refvsr_conf_alpha_batch, refvsr_warp_nhwc16_batch, refvsr_warp_nhwc16_up2_batch,
+                                      refvsr_warp_planar_batch */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -93,6 +97,10 @@ typedef struct RefvsrConv {
     int batch; size_t bs_src0, bs_src1, bs_out, bs_res_planar;
 } RefvsrConv;
 
+/* Return codes: 0 = ok, 1 = bad arguments, 2 = HIP runtime error, REFVSR_ERR_UNSUPPORTED = valid arguments, but no kernel of this
+ * library covers the shape (refvsr_conv_mfma with warp_flow on a shape without a fused-warp kernel: the caller runs
+ * refvsr_warp_nhwc16 + the plain conv instead, bit-identical).  Only this code licenses a fallback. */
+#define REFVSR_ERR_UNSUPPORTED 3
 int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
 /* Tuning / test knob (no reference counterpart): upper bound on the workgroups one single-chunk conv launches; each
  * workgroup walks the remaining pixel tiles.  0 = automatic (occupancy x CUs).  Results do not depend on it. */
@@ -138,6 +146,17 @@ int refvsr_resblock_lean(const void* src, int c, int h, int w, const void* w1, c
 #define REFVSR_RESBLOCK24_BLOB_BYTES 43264
 int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
                             void* scratch0, void* scratch1, void* out, void* stream);
+/* Multi-map launches (ABI 11).  The propagation branches of CONSECUTIVE output frames are independent chains over identical
+ * weights (the backward branch restarts from zeros in every window, RefVSR.py:211-238), and so are the n samples of a batch
+ * (lrs [n,t,3,h,w], RefVSR.py:151): `batch` <= REFVSR_MAX_MAPS maps of one geometry run behind ONE launch per layer.  A workgroup
+ * walks its share of the batch x tiles on one weight fill (at 270 x 480 a launch is one 8 x 32 tile per workgroup and a third of its
+ * life is the fill).  Maps are given as HOST arrays of `batch` device pointers (they need not be contiguous: per-frame cached maps
+ * enter the chains).  Map b of a batched call == the single-map call on map b, bit for bit (tests/test_gpu_ops.py). */
+#define REFVSR_MAX_MAPS 4
+/* refvsr_resblock24_chain over `batch` maps: src / out host arrays of batch pointers ([h][w][24] fp16 each), scratch0 / scratch1:
+ * [batch][h][w][24] contiguous (needed as in the single-map call). */
+int refvsr_resblock24_chain_batch(const void* const* src, int batch, int h, int w, int n, const void* blobs, size_t blob_stride,
+                                  float act_slope, void* scratch0, void* scratch1, void* const* out, void* stream);
 /* (ty << 16 | tx << 8 | cg) of K-block (K-step s = 0..6, quarter q = 0..3) of the blob's K order, -1 for the zero block. */
 int refvsr_resblock24_kblock(int s, int q);
 /* Tuning knob: workgroup shape of the 24-channel kernel.  0 (default): by map size -- 8 waves on 8 x 32-pixel tiles, or 16
@@ -172,6 +191,11 @@ int refvsr_conv24_blob_bytes(int c0, int c1);
 int refvsr_conv24_kblock(int ncg, int s, int q);
 int refvsr_conv24(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
                   const void* mul, const void* res, float post_slope, void* out, void* stream);
+/* refvsr_conv24 over `batch` maps (ABI 11; 24 output channels): every per-map operand is a host array of `batch` device pointers --
+ * src0, src1 (NULL array when c1 = 0), mul / res (NULL array = none; else every entry non-NULL), out. */
+int refvsr_conv24_batch(const void* const* src0, int c0, const void* const* src1, int c1, int batch, int h, int w, const void* blob,
+                        float act_slope, const void* const* mul, const void* const* res, float post_slope, void* const* out,
+                        void* stream);
 /* The output head in ONE launch (ABI 10): RefVSR.py:92,118,288,297 --
  *   out = clamp( conv_last(src) + clamp(F.interpolate(lr_centre, scale_factor=scale, mode='bicubic'), 0, 1), 0, 1 )
  * -- planar fp32 [3][h][w].  src: fp16 HWC [h][w][c], c = 24 | 48; base_lr: planar fp32 [3][bh][bw], h / bh == w / bw = the SR factor;
@@ -202,6 +226,11 @@ int refvsr_conv_hr_last(const void* src, int h, int w, const void* blob, float a
  * [+ refvsr_max2] (tests/test_gpu_ops.py). */
 int refvsr_conf_alpha(const float* conf_a, const float* conf_b, int h, int w, int up, const float* w0, const float* b0,
                       float slope0, const void* blob, int cout, float slope1, void* alpha, float* conf_max, void* stream);
+/* refvsr_conf_alpha over `batch` map pairs (ABI 11, cout = 24): conf_a / conf_b / alpha / conf_max (NULL array = none) are host
+ * arrays of `batch` device pointers. */
+int refvsr_conf_alpha_batch(const float* const* conf_a, const float* const* conf_b, int batch, int h, int w, int up, const float* w0,
+                            const float* b0, float slope0, const void* blob, int cout, float slope1, void* const* alpha,
+                            float* const* conf_max, void* stream);
 /* The same for 48 output channels (mid_channels = 48: configs/config_RefVSR_{L1,MFID,MFID_8K}.py -- the two convs of every
  * ResidualBlockNoBN, sr_backbone_utils.py:42-97, and conf_fusion*.1): (c0, c1) in {(48,0), (16,0)}; out / mul / res are
  * 48-channel maps; blob: [S x 6 fragments x 64 lanes x 8 halfs][64 bias floats], fragments [hi | lo] of output channels 0-15,
@@ -233,6 +262,9 @@ int refvsr_conv48(const void* src0, int c0, const void* src1, int c1, int h, int
 int refvsr_conv_shuffle2_supported(int c);
 int refvsr_conv_shuffle2_blob_bytes(int c);
 int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs, float act_slope, void* out, void* stream);
+/* refvsr_conv_shuffle2 over `batch` maps (ABI 11, c = 24): src / out host arrays of `batch` device pointers. */
+int refvsr_conv_shuffle2_batch(const void* const* src, int batch, int c, int h, int w, const void* blobs, float act_slope,
+                               void* const* out, void* stream);
 /* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
  * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its
  * iter-th tile at buf[12 * workgroup + i] (uint64; [8], [9] = 100 MHz s_memrealtime at entry / exit, [10] = s_memtime at exit) -- tools/probe_resblock.py.  NULL switches it off (default). */
@@ -298,6 +330,14 @@ int refvsr_warp_nhwc16_up2(const void* x, int hin, int win, int cs, const float*
                            void* out, void* stream);
 int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flow, int hf, int wf,
                        float* out, void* stream);
+/* The three warps over `batch` (map, flow) pairs in one launch each (ABI 11; blockIdx.z = pair): x / flow / out are host arrays of
+ * `batch` device pointers, all pairs of one geometry.  Pair b == the single call, bit for bit. */
+int refvsr_warp_nhwc16_batch(const void* const* x, int batch, int hin, int win, int cs, const float* const* flow, int hf, int wf,
+                             void* const* out, void* stream);
+int refvsr_warp_nhwc16_up2_batch(const void* const* x, int batch, int hin, int win, int cs, const float* const* flow_lr, int hl, int wl,
+                                 void* const* out, void* stream);
+int refvsr_warp_planar_batch(const float* const* x, int batch, int c, int hin, int win, const float* const* flow, int hf, int wf,
+                             float* const* out, void* stream);
 /* One SPyNet pyramid level input (SPyNet.py:83-103): flow_up = 2*bilinear_x2(flow_prev, align_corners)
  * (or zeros when flow_prev == NULL), warped = flow_warp(supp, flow_up, border, align_corners=True)
  * (mmedit flow_warp.py:6-47); writes cat[ref, warped, flow_up] as nhwc16 [h][w][8] and flow_up as

@@ -53,6 +53,13 @@ struct C24Args {
     // COUT = 3 (refvsr_conv_last): `out` is planar fp32 [3][h][w]; base_lr: the LR centre frame, planar fp32 [3][bh][bw], whose
     // bicubic up-sampling (clamped to [0, 1]) is added before the final clamp
     const float* base_lr; int bh, bw; float base_step;
+    // Multi-map launches (refvsr_*_batch, ABI 11): batch > 1 maps of one geometry share the launch and the weight fill; flat tile
+    // index t = b * tpm + (tile of map b); map b's operands come from the tables (entry 0 == the scalar fields above, which stay
+    // the "operand present" flags).  Not for the HALF variant.
+    int batch, tpm;
+    const unsigned char* bsrc0[REFVSR_MAX_MAPS]; const unsigned char* bsrc1[REFVSR_MAX_MAPS]; unsigned char* bout[REFVSR_MAX_MAPS];
+    const unsigned char* bmul[REFVSR_MAX_MAPS]; const unsigned char* bres[REFVSR_MAX_MAPS];
+    const float* bconf_a[REFVSR_MAX_MAPS]; const float* bconf_b[REFVSR_MAX_MAPS]; float* bconf_max[REFVSR_MAX_MAPS];
 };
 
 __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l] + a[l ^ 32] (see resblock24.hip:rb_fold1)
@@ -73,9 +80,12 @@ __device__ __forceinline__ float c24_fold1(const float a) {       // lane l: a[l
 // cat([a, b]), RefVSR.py:53-62,87): one conv's hi + lo weights are 166 KB -- no resident form.  The OUTPUT channels are split
 // instead: blockIdx.y = z computes channels 24 z .. 24 z + 23 with the 24-row fragment trick (81 KB of weights per half, NCG = 12
 // plan, 70 KB tile: one sixteen-wave workgroup per CU) and stores them into the 48-channel maps at byte offset 48 z.
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0, int HALF = 0>
+// MM = 1 (ABI 11): multi-map launch -- p.batch maps behind one weight fill (the batched entry points; the single-map instantiations
+// are untouched by it).
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0, int HALF = 0, int MM = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void conv24_kernel(C24Args p) {
     static_assert(HALF == 0 || (COUT == 24 && SHUF == 0 && CONF == 0), "channel-half variant: 24 computed channels per workgroup");
+    static_assert(MM == 0 || (HALF == 0 && COUT != 3), "multi-map variant");
     static_assert(SHUF == 0 || (COUT == 48 && (SHUF == 24 || SHUF == 48) && NCG0 * 8 == SHUF && NCG1 == 0), "pixel-shuffle variant");
     static_assert(CONF == 0 || (NCG0 == 2 && NCG1 == 0 && SHUF == 0), "confidence variant: 16-channel single source");
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1, PXB = PS * 16, ROWB = C24_XW * PXB;
@@ -137,13 +147,22 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
         xs1 |= s1 ? (1u << k) : 0u;
     }
     uint4 xv[KCH];
-    auto x_fetch = [&](const int t) {
+    auto x_fetch = [&](const int tf) {
+        int t = tf;
+        const unsigned char* s0p = p.src0;
+        const unsigned char* s1p = p.src1;
+        if constexpr (MM != 0) {                                     // flat tile index -> (map, tile of the map); uniform
+            const int bm = (int)((unsigned)tf / (unsigned)p.tpm);
+            t = tf - bm * p.tpm;
+            s0p = p.bsrc0[bm];
+            if constexpr (NCG1 != 0) s1p = p.bsrc1[bm];
+        }
         const int tyi = t / p.tiles_x;
         const int ty0 = tyi * C24_TH, tx0 = (t - tyi * p.tiles_x) * C24_TW;
         const bool interior = ty0 >= 1 && ty0 + C24_TH + 1 <= p.h && tx0 >= 1 && tx0 + C24_TW + 1 <= p.w;
         const long long org = (long long)(ty0 - 1) * p.w + (tx0 - 1);          // origin pixel (may lie outside the frame)
-        const unsigned char* b0 = p.src0 + org * PIXB0;
-        const unsigned char* b1 = NCG1 ? p.src1 + org * PIXB1 : b0;
+        const unsigned char* b0 = s0p + org * PIXB0;
+        const unsigned char* b1 = NCG1 ? s1p + org * PIXB1 : b0;
         if (interior) {
 #pragma unroll
             for (int k = 0; k < KCH; ++k)
@@ -160,7 +179,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                 const bool ok = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
                 const bool s1 = cg >= NCG0;
                 const unsigned pix = (unsigned)(min(max(iy, 0), p.h - 1) * p.w + min(max(ix, 0), p.w - 1));
-                const unsigned char* g = s1 ? p.src1 + pix * PIXB1 + (cg - NCG0) * 16 : p.src0 + pix * PIXB0 + cg * 16;
+                const unsigned char* g = s1 ? s1p + pix * PIXB1 + (cg - NCG0) * 16 : s0p + pix * PIXB0 + cg * 16;
                 uint4 v = *reinterpret_cast<const uint4*>(g);        // clamped address, masked value (32-bit offsets: host check)
                 const unsigned keep = ok ? 0xffffffffu : 0u;
                 v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
@@ -187,7 +206,17 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     // the whole x tile of tile t, computed: stage 1 = the (TH + 4) x 36 window of the pair (zero outside the frame = the first
     // conv's padding; CONF = 2: clamp01(bicubic x2) of the half-size maps), stage 2 = lrelu(conv 2 -> 16) per staged pixel
     // (zero outside the frame = the second conv's padding).  Called by all threads; contains one barrier.
-    auto conf_stage = [&](const int t) {
+    auto conf_stage = [&](const int tf) {
+        int t = tf;
+        const float* cap = p.conf_a;
+        const float* cbp = p.conf_b;
+        float* cmp_ = p.conf_max;
+        if constexpr (MM != 0) {
+            const int bm = (int)((unsigned)tf / (unsigned)p.tpm);
+            t = tf - bm * p.tpm;
+            cap = p.bconf_a[bm]; cbp = p.bconf_b[bm];
+            if (p.conf_max) cmp_ = p.bconf_max[bm];
+        }
         const int tyi = t / p.tiles_x;
         const int ty0 = tyi * C24_TH, tx0 = (t - tyi * p.tiles_x) * C24_TW;
         float* pt = reinterpret_cast<float*>(smem + PT);
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             const int y = ty0 - 2 + r, x = tx0 - 2 + cc;
             float v = 0.0f;
             if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w) {
-                const float* src = c ? p.conf_b : p.conf_a;
+                const float* src = c ? cbp : cap;
                 if constexpr (CONF == 1) v = src[(size_t)y * p.cw + x];
                 else v = fminf(fmaxf(rv_bicubic_at(src, p.ch, p.cw, y, x, 0.5f, 0.5f), 0.0f), 1.0f);
             }
@@ -244,7 +273,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                     const int r = i / C24_TW, c = i - r * C24_TW;
                     const int y = ty0 + r, x = tx0 + c;
                     if (y < p.h && x < p.w)
-                        p.conf_max[(size_t)y * p.w + x] = fmaxf(pt[(r + 2) * PTW + c + 2], pt[PTH * PTW + (r + 2) * PTW + c + 2]);
+                        cmp_[(size_t)y * p.w + x] = fmaxf(pt[(r + 2) * PTW + c + 2], pt[PTH * PTW + (r + 2) * PTW + c + 2]);
                 }
             }
         }
@@ -288,8 +317,19 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             conf_stage(tl);
             __syncthreads();
         }
-        const int tyi = tl / p.tiles_x;
-        const int ty0 = tyi * C24_TH, tx0 = (tl - tyi * p.tiles_x) * C24_TW;
+        int tm = tl;
+        unsigned char* outp = p.out;
+        const unsigned char* mulp = p.mul;
+        const unsigned char* resp = p.res;
+        if constexpr (MM != 0) {
+            const int bm = (int)((unsigned)tl / (unsigned)p.tpm);
+            tm = tl - bm * p.tpm;
+            outp = p.bout[bm];
+            if (p.mul) mulp = p.bmul[bm];
+            if (p.res) resp = p.bres[bm];
+        }
+        const int tyi = tm / p.tiles_x;
+        const int ty0 = tyi * C24_TH, tx0 = (tm - tyi * p.tiles_x) * C24_TW;
         const bool interior = ty0 >= 1 && ty0 + C24_TH + 1 <= p.h && tx0 >= 1 && tx0 + C24_TW + 1 <= p.w;
         const long long oorg = ((long long)ty0 * p.w + tx0) * OPX;
         // epilogue operands of this tile, in flight during the K loop.  Accumulator tile m of a pixel group holds channels
@@ -310,8 +350,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                 mv[m][t] = rv[m][t] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
                 const bool lane_ok = okt[t] && (COUT != 24 || m == 0 || q < 2);
                 if constexpr (COUT == 24) {                          // (COUT = 48: fetched in the epilogue -- register budget)
-                    if (p.mul && lane_ok) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
-                    if (p.res && lane_ok) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
+                    if (p.mul && lane_ok) mv[m][t] = *reinterpret_cast<const f16x4*>(mulp + oorg + eo + 32 * m);
+                    if (p.res && lane_ok) rv[m][t] = *reinterpret_cast<const f16x4*>(resp + oorg + eo + 32 * m);
                 }
                 (void)lane_ok;
             }
@@ -400,7 +440,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             // (ds_bpermute), evaluates ITS channel's bicubic sample (rv_bicubic_at: resize_kernel<BICUBIC>'s FMA chains) and stores one
             // value: 48 lanes x 4 bytes = three 64-byte row segments per group
             const size_t plane_o = (size_t)p.h * p.w, plane_b = (size_t)p.bh * p.bw;
-            float* op = reinterpret_cast<float*>(p.out);
+            float* op = reinterpret_cast<float*>(outp);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const f32x4 y = acc[0][t];
@@ -438,13 +478,13 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                     }
                     const f16x4 o = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
                     if (okt[t])
-                        *reinterpret_cast<f16x4*>(p.out + ((2u * oy + dy) * w2 + 2u * ox + dx) * (unsigned)(SHUF * 2) + ch0 * 2) = o;
+                        *reinterpret_cast<f16x4*>(outp + ((2u * oy + dy) * w2 + 2u * ox + dx) * (unsigned)(SHUF * 2) + ch0 * 2) = o;
                 }
             }
         } else
         // ---------------- epilogue: out = post(act(acc) * mul + res) ----------------------------------------------------------
         {
-            unsigned char* ob = p.out + oorg;
+            unsigned char* ob = outp + oorg;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 unsigned char* d = ob + (unsigned)(RW(t) * rowb_o) + oo + CG(t) * 16 * OPX;
@@ -455,8 +495,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                         if (m == 1) y = (f32x4){c24_fold1(y[0]), c24_fold1(y[1]), c24_fold1(y[2]), c24_fold1(y[3])};
                     } else {
                         const unsigned eo = (unsigned)(RW(t) * rowb_o) + oo + CG(t) * 16 * OPX;
-                        if (p.mul && okt[t]) mv[m][t] = *reinterpret_cast<const f16x4*>(p.mul + oorg + eo + 32 * m);
-                        if (p.res && okt[t]) rv[m][t] = *reinterpret_cast<const f16x4*>(p.res + oorg + eo + 32 * m);
+                        if (p.mul && okt[t]) mv[m][t] = *reinterpret_cast<const f16x4*>(mulp + oorg + eo + 32 * m);
+                        if (p.res && okt[t]) rv[m][t] = *reinterpret_cast<const f16x4*>(resp + oorg + eo + 32 * m);
                     }
                     if (p.act_slope != 1.0f) {
 #pragma unroll
@@ -485,7 +525,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
 #undef CG
 }
 
-template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0, int HALF = 0>
+template <int COUT, int NCG0, int NCG1, int NWV, int TH, int WPS, int SHUF = 0, int CONF = 0, int HALF = 0, int MM = 0>
 static int launch_c24(C24Args& a, hipStream_t st) {
     constexpr int NZ = HALF ? 2 : SHUF == 0 ? 1 : SHUF == 24 ? 2 : 4;   // row groups of the pixel-shuffle / channel-half variants (blockIdx.y)
     constexpr int NCG = NCG0 + NCG1, PS = NCG | 1;
@@ -496,20 +536,21 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF, MM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int occ = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF>, NWV * 64, LDS));
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF, MM>, NWV * 64, LDS));
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
     a.tiles_x = rv_cdiv(a.w, C24_TW);
-    a.n_tiles = a.tiles_x * rv_cdiv(a.h, TH);
+    a.tpm = a.tiles_x * rv_cdiv(a.h, TH);
+    a.n_tiles = a.tpm * (MM ? a.batch : 1);
     int cap = (rv_num_cus() * occ_dev[dev] / NZ) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
     a.prio = rv_wave_prio();
-    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
+    hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF, MM>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -575,6 +616,32 @@ extern "C" int refvsr_conv24(const void* src0, int c0, const void* src1, int c1,
     return launch_c24<24, 3, 3, 8, 8, 4>(a, st);
 }
 
+// The same conv over `batch` maps of one geometry in ONE launch (ABI 11): the per-map operands are host arrays of device pointers.
+extern "C" int refvsr_conv24_batch(const void* const* src0, int c0, const void* const* src1, int c1, int batch, int h, int w, const void* blob,
+                                   float act_slope, const void* const* mul, const void* const* res, float post_slope, void* const* out,
+                                   void* stream) {
+    RV_CHECK(refvsr_conv24_supported(c0, c1), "conv24_batch: %d + %d input channels not supported", c0, c1);
+    RV_CHECK(src0 && out && batch >= 1 && batch <= REFVSR_MAX_MAPS, "conv24_batch: 1..%d maps per launch", REFVSR_MAX_MAPS);
+    RV_CHECK((c1 == 0) == (src1 == nullptr), "conv24_batch: src1 / c1 mismatch");
+    C24Args a;
+    if (c24_fill(a, "conv24_batch", 24, src0[0], src1 ? src1[0] : nullptr, c1, h, w, blob, act_slope, mul ? mul[0] : nullptr,
+                 res ? res[0] : nullptr, post_slope, out[0])) return 1;
+    a.batch = batch;
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(src0[b] && out[b] && (!src1 || src1[b]) && (!mul || mul[b]) && (!res || res[b]), "conv24_batch: null map pointer (map %d)", b);
+        for (int c = 0; c < batch; ++c)
+            RV_CHECK(src0[c] != out[b] && (!src1 || src1[c] != out[b]) && (c == b || out[c] != out[b]), "conv24_batch: in-place operation is not supported");
+        a.bsrc0[b] = (const unsigned char*)src0[b]; a.bsrc1[b] = src1 ? (const unsigned char*)src1[b] : nullptr;
+        a.bout[b] = (unsigned char*)out[b];
+        a.bmul[b] = mul ? (const unsigned char*)mul[b] : nullptr; a.bres[b] = res ? (const unsigned char*)res[b] : nullptr;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (c0 == 24 && c1 == 0) return launch_c24<24, 3, 0, 8, 8, 4, 0, 0, 0, 1>(a, st);
+    if (c0 == 16 && c1 == 0) return launch_c24<24, 2, 0, 8, 8, 4, 0, 0, 0, 1>(a, st);
+    if (c0 == 8 && c1 == 24) return launch_c24<24, 1, 3, 8, 8, 4, 0, 0, 0, 1>(a, st);
+    return launch_c24<24, 3, 3, 8, 8, 4, 0, 0, 0, 1>(a, st);
+}
+
 // 32 output channels (AlignedConv2d, RefVSR_/alignment.py:18-24,53-100: the 3 -> 32 stem and the 32 -> 32 convs of its ResBlocks)
 extern "C" int refvsr_conv32(const void* src0, int c0, const void* src1, int c1, int h, int w, const void* blob, float act_slope,
                              const void* mul, const void* res, float post_slope, void* out, void* stream) {
@@ -614,6 +681,22 @@ extern "C" int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const 
     return launch_c24<48, 6, 0, 16, 16, 4, 48>(a, st);
 }
 
+// PixelShufflePack over `batch` maps in ONE launch (ABI 11, C = 24: upsample1 of the RAP steps, RefVSR.py:138)
+extern "C" int refvsr_conv_shuffle2_batch(const void* const* src, int batch, int c, int h, int w, const void* blobs, float act_slope,
+                                          void* const* out, void* stream) {
+    RV_CHECK(c == 24, "conv_shuffle2_batch: %d channels not supported (24)", c);
+    RV_CHECK(src && out && batch >= 1 && batch <= REFVSR_MAX_MAPS, "conv_shuffle2_batch: 1..%d maps per launch", REFVSR_MAX_MAPS);
+    C24Args a;
+    if (c24_fill(a, "conv_shuffle2_batch", 4 * c, src[0], nullptr, 0, h, w, blobs, act_slope, nullptr, nullptr, 1.0f, out[0])) return 1;
+    a.batch = batch;
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(src[b] && out[b], "conv_shuffle2_batch: null map pointer (map %d)", b);
+        for (int c2 = 0; c2 < batch; ++c2) RV_CHECK(src[c2] != out[b] && (c2 == b || out[c2] != out[b]), "conv_shuffle2_batch: in-place operation is not supported");
+        a.bsrc0[b] = (const unsigned char*)src[b]; a.bout[b] = (unsigned char*)out[b];
+    }
+    return launch_c24<48, 3, 0, 8, 8, 4, 24, 0, 0, 1>(a, (hipStream_t)stream);
+}
+
 // The confidence fusions of AA_AF_conf_prop / compute_up in ONE launch (RefVSR.py:47-52 conf_fusion / conf_fusion2 /
 // conf_fusion_BWFW, called at :130, :141-142, :107-109):
 //   alpha = lrelu_{slope1}( conv3x3_{16 -> cout}( lrelu_{slope0}( conv3x3_{2 -> 16}( P ) ) ) ),
@@ -636,6 +719,29 @@ extern "C" int refvsr_conf_alpha(const float* conf_a, const float* conf_b, int h
     hipStream_t st = (hipStream_t)stream;
     if (cout == 24) return up == 1 ? launch_c24<24, 2, 0, 8, 8, 4, 0, 1>(a, st) : launch_c24<24, 2, 0, 8, 8, 4, 0, 2>(a, st);
     return up == 1 ? launch_c24<48, 2, 0, 8, 8, 4, 0, 1>(a, st) : launch_c24<48, 2, 0, 8, 8, 4, 0, 2>(a, st);
+}
+
+// The confidence fusion over `batch` pairs of maps in ONE launch (ABI 11, cout = 24)
+extern "C" int refvsr_conf_alpha_batch(const float* const* conf_a, const float* const* conf_b, int batch, int h, int w, int up, const float* w0,
+                                       const float* b0, float slope0, const void* blob, int cout, float slope1, void* const* alpha,
+                                       float* const* conf_max, void* stream) {
+    RV_CHECK(conf_a && conf_b && w0 && b0 && alpha && batch >= 1 && batch <= REFVSR_MAX_MAPS, "conf_alpha_batch: bad args (1..%d maps)", REFVSR_MAX_MAPS);
+    RV_CHECK(up == 1 || up == 2, "conf_alpha_batch: up must be 1 or 2");
+    RV_CHECK(cout == 24, "conf_alpha_batch: %d output channels not supported (24)", cout);
+    RV_CHECK(conf_max == nullptr || up == 1, "conf_alpha_batch: the max by-product exists at up = 1 only");
+    RV_CHECK(slope0 >= 0.f && slope0 <= 1.f, "conf_alpha_batch: activation slopes must lie in [0, 1]");
+    C24Args a;
+    if (c24_fill(a, "conf_alpha_batch", cout, conf_a[0], nullptr, 0, up * h, up * w, blob, slope1, nullptr, nullptr, 1.0f, alpha[0])) return 1;
+    a.src0 = nullptr;
+    a.conf_a = conf_a[0]; a.conf_b = conf_b[0]; a.cw0 = w0; a.cb0 = b0; a.conf_max = conf_max ? conf_max[0] : nullptr; a.ch = h; a.cw = w; a.slope0 = slope0;
+    a.batch = batch;
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(conf_a[b] && conf_b[b] && alpha[b] && (!conf_max || conf_max[b]), "conf_alpha_batch: null map pointer (map %d)", b);
+        a.bconf_a[b] = conf_a[b]; a.bconf_b[b] = conf_b[b]; a.bconf_max[b] = conf_max ? conf_max[b] : nullptr;
+        a.bout[b] = (unsigned char*)alpha[b];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return up == 1 ? launch_c24<24, 2, 0, 8, 8, 4, 0, 1, 0, 1>(a, st) : launch_c24<24, 2, 0, 8, 8, 4, 0, 2, 0, 1>(a, st);
 }
 
 // The output head in ONE launch (RefVSR.py:92,118,288,297: conv_last 3x3 C -> 3, + F.interpolate(lr_centre, scale, bicubic).clamp(0, 1),

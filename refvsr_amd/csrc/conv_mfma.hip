@@ -944,7 +944,10 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
                         : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
     }
     if (d->warp_flow) {                            // RefVSR.py:218,253 / 220,254,259: 8+24 -> 24 and 24+24 -> 24 (16 output rows x 2)
-        RV_CHECK(lean && MT == 2 && !w16, "conv: no fused-warp kernel for this shape (MT=%d tiles=%d lean=%d)", MT, tiles, (int)lean);
+        if (!(lean && MT == 2 && !w16)) {          // rc 3 = REFVSR_ERR_UNSUPPORTED: the caller may run warp + conv instead (same results)
+            refvsr_set_error("conv: no fused-warp kernel for this shape (MT=%d tiles=%d lean=%d)", MT, tiles, (int)lean);
+            return REFVSR_ERR_UNSUPPORTED;
+        }
 #define RV_WARP_CASE(T, NW_)                                                                              \
         return d->warp_src == 0 ? launch_conv<2, T, false, false, true, 1, NW_, 1>(a, nz, lds, st)        \
                                 : launch_conv<2, T, false, false, true, 1, NW_, 2>(a, nz, lds, st);

@@ -261,8 +261,20 @@ extern "C" int refvsr_buffers_equal(const void* const* a, const void* const* b, 
 // ------------------------------------------------------------------------------------------------
 // warp (models/utils.py:35-43): zeros padding, align_corners=False sampling of a linspace(-1,1) grid
 // ------------------------------------------------------------------------------------------------
-__global__ void warp_nhwc16_kernel(const f16* __restrict__ x, int hin, int win, int cs, const float* __restrict__ flow,
-                                   int hf, int wf, f16* __restrict__ out) {
+// Up to REFVSR_MAX_MAPS (map, flow) pairs of one geometry per launch (blockIdx.z = pair; ABI 11: the propagation chains of consecutive
+// output frames warp their states in one launch per layer).  The single-pair entry points are the batch = 1 case of the same kernels.
+struct WarpArgs {
+    const void* x[REFVSR_MAX_MAPS]; const float* flow[REFVSR_MAX_MAPS]; void* out[REFVSR_MAX_MAPS];
+    int c, hin, win, cs, hf, wf;         // c: planar channels (warp_planar); cs: channel stride (nhwc16); hf x wf: the flow map (up2: hl x wl)
+};
+#define WARP_SEL(tbl, bi) ((bi) == 0 ? (tbl)[0] : (bi) == 1 ? (tbl)[1] : (bi) == 2 ? (tbl)[2] : (tbl)[3])
+
+__global__ void warp_nhwc16_kernel(WarpArgs a) {
+    const int bi = blockIdx.z;
+    const f16* __restrict__ x = (const f16*)WARP_SEL(a.x, bi);
+    const float* __restrict__ flow = WARP_SEL(a.flow, bi);
+    f16* __restrict__ out = (f16*)WARP_SEL(a.out, bi);
+    const int hin = a.hin, win = a.win, cs = a.cs, hf = a.hf, wf = a.wf;
     const int ng = cs / 8;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (pixel-in-row, group)
     const int y = blockIdx.y;
@@ -274,21 +286,43 @@ __global__ void warp_nhwc16_kernel(const f16* __restrict__ x, int hin, int win, 
         warp_group16(reinterpret_cast<const unsigned char*>(x), cs * 2, hin, win, c, g * 16);
 }
 
-extern "C" int refvsr_warp_nhwc16(const void* x, int hin, int win, int cs, const float* flow, int hf, int wf,
-                                  void* out, void* stream) {
-    RV_CHECK(x && flow && out && hin > 1 && win > 1 && hf > 1 && wf > 1 && cs % 8 == 0, "warp_nhwc16: bad args");
+static int warp_fill(WarpArgs& a, const char* who, const void* const* x, const float* const* flow, void* const* out, int batch) {
+    RV_CHECK(x && flow && out && batch >= 1 && batch <= REFVSR_MAX_MAPS, "%s: 1..%d (map, flow) pairs per launch", who, REFVSR_MAX_MAPS);
+    memset(&a, 0, sizeof(a));
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(x[b] && flow[b] && out[b], "%s: null pointer (pair %d)", who, b);
+        a.x[b] = x[b]; a.flow[b] = flow[b]; a.out[b] = out[b];
+    }
+    return 0;
+}
+
+extern "C" int refvsr_warp_nhwc16_batch(const void* const* x, int batch, int hin, int win, int cs, const float* const* flow, int hf, int wf,
+                                        void* const* out, void* stream) {
+    RV_CHECK(hin > 1 && win > 1 && hf > 1 && wf > 1 && cs % 8 == 0 && cs > 0, "warp_nhwc16: bad args");
+    WarpArgs a;
+    if (warp_fill(a, "warp_nhwc16", x, flow, out, batch)) return 1;
+    a.hin = hin; a.win = win; a.cs = cs; a.hf = hf; a.wf = wf;
     const int ng = cs / 8;
-    hipLaunchKernelGGL(warp_nhwc16_kernel, dim3(rv_cdiv(wf * ng, 256), hf), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, hin, win, cs, flow, hf, wf, (f16*)out);
+    hipLaunchKernelGGL(warp_nhwc16_kernel, dim3(rv_cdiv(wf * ng, 256), hf, batch), dim3(256), 0, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int refvsr_warp_nhwc16(const void* x, int hin, int win, int cs, const float* flow, int hf, int wf,
+                                  void* out, void* stream) {
+    RV_CHECK(x && flow && out, "warp_nhwc16: bad args");
+    return refvsr_warp_nhwc16_batch(&x, 1, hin, win, cs, &flow, hf, wf, &out, stream);
 }
 
 // warp(x, flow_up2(flow_lr)) without the 2x flow map: the flow of grid pixel (y, px) is F.interpolate(flow_lr, x2, bilinear,
 // align_corners=True) * 2 evaluated in place (RefVSR.py:220,254,259: the 2x state is warped by the up-sampled LR flow) --
 // the arithmetic of refvsr_resize(BILINEAR_AC, chan_mul = 2) followed by refvsr_warp_nhwc16, bit for bit
-__global__ void warp_nhwc16_up2_kernel(const f16* __restrict__ x, int hin, int win, int cs, const float* __restrict__ flow_lr,
-                                       int hl, int wl, f16* __restrict__ out) {
+__global__ void warp_nhwc16_up2_kernel(WarpArgs a) {
+    const int bi = blockIdx.z;
+    const f16* __restrict__ x = (const f16*)WARP_SEL(a.x, bi);
+    const float* __restrict__ flow_lr = WARP_SEL(a.flow, bi);
+    f16* __restrict__ out = (f16*)WARP_SEL(a.out, bi);
+    const int hin = a.hin, win = a.win, cs = a.cs, hl = a.hf, wl = a.wf;
     const int ng = cs / 8;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -304,18 +338,30 @@ __global__ void warp_nhwc16_up2_kernel(const f16* __restrict__ x, int hin, int w
         warp_group16(reinterpret_cast<const unsigned char*>(x), cs * 2, hin, win, c, g * 16);
 }
 
-extern "C" int refvsr_warp_nhwc16_up2(const void* x, int hin, int win, int cs, const float* flow_lr, int hl, int wl,
-                                      void* out, void* stream) {
-    RV_CHECK(x && flow_lr && out && hin > 1 && win > 1 && hl > 0 && wl > 0 && cs % 8 == 0, "warp_nhwc16_up2: bad args");
+extern "C" int refvsr_warp_nhwc16_up2_batch(const void* const* x, int batch, int hin, int win, int cs, const float* const* flow_lr, int hl,
+                                            int wl, void* const* out, void* stream) {
+    RV_CHECK(hin > 1 && win > 1 && hl > 0 && wl > 0 && cs % 8 == 0 && cs > 0, "warp_nhwc16_up2: bad args");
+    WarpArgs a;
+    if (warp_fill(a, "warp_nhwc16_up2", x, flow_lr, out, batch)) return 1;
+    a.hin = hin; a.win = win; a.cs = cs; a.hf = hl; a.wf = wl;
     const int ng = cs / 8;
-    hipLaunchKernelGGL(warp_nhwc16_up2_kernel, dim3(rv_cdiv(2 * wl * ng, 256), 2 * hl), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, hin, win, cs, flow_lr, hl, wl, (f16*)out);
+    hipLaunchKernelGGL(warp_nhwc16_up2_kernel, dim3(rv_cdiv(2 * wl * ng, 256), 2 * hl, batch), dim3(256), 0, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
 
-__global__ void warp_planar_kernel(const float* __restrict__ x, int c, int hin, int win, const float* __restrict__ flow,
-                                   int hf, int wf, float* __restrict__ out) {
+extern "C" int refvsr_warp_nhwc16_up2(const void* x, int hin, int win, int cs, const float* flow_lr, int hl, int wl,
+                                      void* out, void* stream) {
+    RV_CHECK(x && flow_lr && out, "warp_nhwc16_up2: bad args");
+    return refvsr_warp_nhwc16_up2_batch(&x, 1, hin, win, cs, &flow_lr, hl, wl, &out, stream);
+}
+
+__global__ void warp_planar_kernel(WarpArgs a) {
+    const int bi = blockIdx.z;
+    const float* __restrict__ x = (const float*)WARP_SEL(a.x, bi);
+    const float* __restrict__ flow = WARP_SEL(a.flow, bi);
+    float* __restrict__ out = (float*)WARP_SEL(a.out, bi);
+    const int c = a.c, hin = a.hin, win = a.win, hf = a.hf, wf = a.wf;
     const int px = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (px >= wf) return;
@@ -331,13 +377,21 @@ __global__ void warp_planar_kernel(const float* __restrict__ x, int c, int hin, 
     }
 }
 
-extern "C" int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flow, int hf, int wf,
-                                  float* out, void* stream) {
-    RV_CHECK(x && flow && out && c > 0 && hin > 1 && win > 1 && hf > 1 && wf > 1, "warp_planar: bad args");
-    hipLaunchKernelGGL(warp_planar_kernel, dim3(rv_cdiv(wf, 128), hf), dim3(128), 0, (hipStream_t)stream,
-                       x, c, hin, win, flow, hf, wf, out);
+extern "C" int refvsr_warp_planar_batch(const float* const* x, int batch, int c, int hin, int win, const float* const* flow, int hf, int wf,
+                                        float* const* out, void* stream) {
+    RV_CHECK(c > 0 && hin > 1 && win > 1 && hf > 1 && wf > 1, "warp_planar: bad args");
+    WarpArgs a;
+    if (warp_fill(a, "warp_planar", (const void* const*)x, flow, (void* const*)out, batch)) return 1;
+    a.c = c; a.hin = hin; a.win = win; a.hf = hf; a.wf = wf;
+    hipLaunchKernelGGL(warp_planar_kernel, dim3(rv_cdiv(wf, 128), hf, batch), dim3(128), 0, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int refvsr_warp_planar(const float* x, int c, int hin, int win, const float* flow, int hf, int wf,
+                                  float* out, void* stream) {
+    RV_CHECK(x && flow && out, "warp_planar: bad args");
+    return refvsr_warp_planar_batch(&x, 1, c, hin, win, &flow, hf, wf, &out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

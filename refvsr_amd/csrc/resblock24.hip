@@ -65,6 +65,10 @@ struct RB24Args {
     int prio;                            // REFVSR_WAVE_PRIO (common.h:rv_wave_prio): the younger half of the waves at priority 1
     // HEAD kernels (refvsr_conv_hr_last): `out` is planar fp32 [3][h][w]; base_lr = the LR centre frame, planar fp32 [3][bh][bw]
     const float* base_lr; int bh, bw; float base_step;
+    // Multi-map launches (refvsr_resblock24_chain_batch): batch > 1 maps of one geometry share the launch and the weight fill; the
+    // flat tile index t = b * tpm + (tile of map b), map b reads bsrc[b] and writes bout[b].  batch <= 1: src / out above.
+    int batch, tpm;
+    const unsigned char* bsrc[REFVSR_MAX_MAPS]; unsigned char* bout[REFVSR_MAX_MAPS];
 };
 
 // lane l: a[l] + a[l ^ 32]   (v_mov, v_permlane32_swap, v_add per register).  The two results are taken out of the builtin's
@@ -273,13 +277,20 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
     }
     uint4 xv[KCH];
     // tile origin (top-left pixel of the x tile) may lie outside the frame: only in-frame chunks are dereferenced
-    auto x_fetch = [&](const int t) {
+    auto x_fetch = [&](const int tf) {
+        int t = tf;
+        const unsigned char* srcp = p.src;
+        if (p.batch > 1) {                                       // flat tile index -> (map, tile of the map); uniform
+            const int bm = (int)((unsigned)tf / (unsigned)p.tpm);
+            t = tf - bm * p.tpm;
+            srcp = p.bsrc[bm];
+        }
         const int tyi = t / p.tiles_x;
         const int ty0 = tyi * RB_TH, tx0 = (t - tyi * p.tiles_x) * RB_TW;
         const bool interior = ty0 >= 2 && ty0 + RB_TH + 2 <= p.h && tx0 >= 2 && tx0 + RB_TW + 2 <= p.w;
         const long long org = ((long long)(ty0 - 2) * p.w + (tx0 - 2)) * RB_PXB;
         if (interior) {
-            const unsigned char* b = p.src + org;
+            const unsigned char* b = srcp + org;
 #pragma unroll
             for (int k = 0; k < KCH; ++k) xv[k] = *reinterpret_cast<const uint4*>(b + xg[k]);
         } else {
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
                 const int iy = ty0 - 2 + r, ix = tx0 - 2 + px;
                 const bool ok = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
                 const unsigned off = (unsigned)((min(max(iy, 0), p.h - 1) * p.w + min(max(ix, 0), p.w - 1)) * RB_PXB + ((i - r * RB_RCH) - px * 3) * 16);
-                uint4 v = *reinterpret_cast<const uint4*>(p.src + off);          // clamped address, masked value (32-bit offsets: host check)
+                uint4 v = *reinterpret_cast<const uint4*>(srcp + off);           // clamped address, masked value (32-bit offsets: host check)
                 const unsigned keep = ok ? 0xffffffffu : 0u;
                 v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
                 xv[k] = v;
@@ -345,8 +356,15 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
     for (int iter = 0; tl < k_hi; ++tl, ++iter) {
         const bool stamp = PROBE && iter == p.probe_iter;
         const bool has_next = tl + 1 < k_hi;
-        const int tyi = tl / p.tiles_x;
-        const int ty0 = tyi * RB_TH, tx0 = (tl - tyi * p.tiles_x) * RB_TW;
+        int tm = tl;
+        unsigned char* outp = p.out;
+        if (p.batch > 1) {
+            const int bm = (int)((unsigned)tl / (unsigned)p.tpm);
+            tm = tl - bm * p.tpm;
+            outp = p.bout[bm];
+        }
+        const int tyi = tm / p.tiles_x;
+        const int ty0 = tyi * RB_TH, tx0 = (tm - tyi * p.tiles_x) * RB_TW;
         const bool interior = ty0 >= 2 && ty0 + RB_TH + 2 <= p.h && tx0 >= 2 && tx0 + RB_TW + 2 <= p.w;
 
         // ---------------- phase 1: acc = b1 + conv1(x) on the halo region -------------------------------------------------
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
             // clamp( conv_last + bias + clamp01(bicubic(lr_centre)), 0, 1 ) -> planar fp32: after the fold lane (0, n) holds the
             // three channel sums of pixel n, lane (q, n), q < 3, takes channel q and evaluates ITS channel's bicubic sample
             const size_t plane_o = (size_t)p.h * p.w, plane_b = (size_t)p.bh * p.bw;
-            float* op = reinterpret_cast<float*>(p.out);
+            float* op = reinterpret_cast<float*>(outp);
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
                 const f32x4 y = c0[t];
@@ -447,7 +465,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
                 }
             }
         } else if constexpr (STORE == 0) {
-            unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
+            unsigned char* ob = outp + ((long long)ty0 * p.w + tx0) * RB_PXB;
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
                 const f32x4 m = rb_fold_halves(c1[t]);
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
             }
         } else {
             static_assert(T2 % 2 == 0, "the two pixel groups of an output row live in one wave");
-            unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * RB_PXB;
+            unsigned char* ob = outp + ((long long)ty0 * p.w + tx0) * RB_PXB;
             const int gsel = q & 1;                                  // this lane stores a pixel of the left (0) | right (1) group
 #pragma unroll
             for (int tp = 0; tp < T2 / 2; ++tp) {
@@ -527,7 +545,8 @@ template <bool RELU, int NWV, bool PROBE = false, int TH = 8, int STORE = 0, int
 static int launch_rb24(RB24Args& a, hipStream_t st) {
     constexpr int RB_LDS = rb_lds(TH);
     a.tiles_x = rv_cdiv(a.w, RB_TW);
-    a.n_tiles = a.tiles_x * rv_cdiv(a.h, TH);
+    a.tpm = a.tiles_x * rv_cdiv(a.h, TH);
+    a.n_tiles = a.tpm * (a.batch > 1 ? a.batch : 1);
     static bool attr_done[RV_MAX_DEVICES] = {};
     static int occ_dev[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
@@ -548,36 +567,52 @@ static int launch_rb24(RB24Args& a, hipStream_t st) {
     return 0;
 }
 
-// n fused blocks x <- x + conv2(act(conv1 x)) on a 24-channel fp16 HWC map; block i's weights are the blob at
-// blobs + i * blob_stride (refvsr_amd/packing.py:pack_resblock24).  n launches on the caller's stream, intermediates ping-pong
-// between scratch0 / scratch1 (blocks cannot run in place: neighbouring tiles read the input halo).
-extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride,
-                                       float act_slope, void* scratch0, void* scratch1, void* out, void* stream) {
-    RV_CHECK(src && out && blobs && h > 0 && w > 0 && n >= 1, "resblock24_chain: bad args");
+// n fused blocks x <- x + conv2(act(conv1 x)) on `batch` 24-channel fp16 HWC maps of one geometry (batch = 1: the plain chain); block
+// i's weights are the blob at blobs + i * blob_stride (refvsr_amd/packing.py:pack_resblock24).  n launches on the caller's stream, each
+// over ALL maps (one weight fill per workgroup, batch x the tiles: an LR launch of RefVSR_small is one 8 x 32 tile per workgroup --
+// 4 100 of its 13 000 cycles are the 43 KB fill -- two maps per launch are two tiles per fill); intermediates ping-pong between
+// scratch0 / scratch1 ([batch] maps each, contiguous; blocks cannot run in place: neighbouring tiles read the input halo).
+static int rb24_chain_impl(const void* const* src, int batch, int h, int w, int n, const void* blobs, size_t blob_stride,
+                           float act_slope, void* scratch0, void* scratch1, void* const* out, void* stream) {
+    RV_CHECK(src && out && blobs && h > 0 && w > 0 && n >= 1 && batch >= 1 && batch <= REFVSR_MAX_MAPS, "resblock24_chain: bad args");
     RV_CHECK(blob_stride >= (size_t)RB_BLOB && blob_stride % 16 == 0 && ((uintptr_t)blobs & 15) == 0,
              "resblock24_chain: blobs must be 16-byte aligned, stride >= %d", RB_BLOB);
     RV_CHECK(act_slope >= 0.f && act_slope <= 1.f, "resblock24_chain: activation slope must lie in [0, 1]");
     RV_CHECK(n == 1 || scratch0, "resblock24_chain: n >= 2 needs scratch0");
     RV_CHECK(n <= 2 || scratch1, "resblock24_chain: n >= 3 needs scratch1");
-    RV_CHECK(src != out && scratch0 != out && scratch1 != out && (n < 2 || scratch0 != src) && (n < 3 || scratch1 != src) &&
-             (n < 3 || scratch0 != scratch1), "resblock24_chain: buffers must be distinct");
+    const size_t mapb = (size_t)h * w * RB_PXB;
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(src[b] && out[b], "resblock24_chain: null map pointer (map %d)", b);
+        for (int c = 0; c < batch; ++c) {
+            const unsigned char* s0 = scratch0 ? (const unsigned char*)scratch0 + c * mapb : nullptr;
+            const unsigned char* s1 = scratch1 ? (const unsigned char*)scratch1 + c * mapb : nullptr;
+            RV_CHECK(src[b] != out[c] && s0 != out[b] && s1 != out[b] && (n < 2 || s0 != src[b]) && (n < 3 || s1 != src[b]) &&
+                     (c == b || out[b] != out[c]), "resblock24_chain: buffers must be distinct");
+        }
+    }
+    RV_CHECK(n < 3 || scratch0 != scratch1, "resblock24_chain: buffers must be distinct");
     RV_CHECK((long long)h * w * RB_PXB < (1ll << 31), "resblock24_chain: map too large for 32-bit offsets");
     RV_CHECK(refvsr_init() == 0, "init failed");
     RB24Args a;
     memset(&a, 0, sizeof(a));
-    a.h = h; a.w = w; a.act_slope = act_slope;
+    a.h = h; a.w = w; a.act_slope = act_slope; a.batch = batch;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned char* cur = (const unsigned char*)src;
+    const unsigned char* cur[REFVSR_MAX_MAPS];
+    for (int b = 0; b < batch; ++b) cur[b] = (const unsigned char*)src[b];
     for (int i = 0; i < n; ++i) {
-        unsigned char* dst = (unsigned char*)((i == n - 1) ? out : ((i & 1) ? scratch1 : scratch0));
-        a.src = cur; a.out = dst; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
+        unsigned char* sc = (unsigned char*)((i & 1) ? scratch1 : scratch0);
+        for (int b = 0; b < batch; ++b) {
+            a.bsrc[b] = cur[b];
+            a.bout[b] = (i == n - 1) ? (unsigned char*)out[b] : sc + b * mapb;
+        }
+        a.src = a.bsrc[0]; a.out = a.bout[0]; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
         int rc;
         a.probe = g_rb_probe; a.probe_iter = g_rb_probe_iter;
         // 16 x 32 tiles on sixteen waves (one workgroup per CU: half the weight fill per CU, 10 % less halo work in conv1, 17 % less
         // tile staging) pay on maps of many tiles per workgroup -- 540 x 960: 27.3 -> 26.3 us, 1080 x 1920: 100.1 -> 95.9 us; at
         // 270 x 480 (one tile per workgroup either way) the two shapes are equal (9.3 vs 9.4 us: the fill is latency, not bandwidth,
         // and sixteen waves wait longer at the barriers), below that the 8 x 32 tiles fill more CUs (135 x 240: 6.2 vs 8.2 us)
-        const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8);
+        const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8) * batch;
         const int waves = g_rb24_waves ? g_rb24_waves : (nt8 >= 4 * rv_num_cus() ? 16 : 8);
         if (g_rb_probe && act_slope == 0.f && waves == 8) rc = launch_rb24<true, 8, true>(a, st);          // tools/probe_resblock24.py
         else if (g_rb_probe && act_slope == 0.f && waves == 16) rc = launch_rb24<true, 16, true, 16>(a, st);
@@ -590,9 +625,20 @@ extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, con
         else rc = act_slope == 0.f ? RB24_PICK(true) : RB24_PICK(false);
 #undef RB24_PICK
         if (rc) return rc;
-        cur = dst;
+        for (int b = 0; b < batch; ++b) cur[b] = a.bout[b];
     }
     return 0;
+}
+
+extern "C" int refvsr_resblock24_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride,
+                                       float act_slope, void* scratch0, void* scratch1, void* out, void* stream) {
+    RV_CHECK(src && out, "resblock24_chain: bad args");
+    return rb24_chain_impl(&src, 1, h, w, n, blobs, blob_stride, act_slope, scratch0, scratch1, &out, stream);
+}
+
+extern "C" int refvsr_resblock24_chain_batch(const void* const* src, int batch, int h, int w, int n, const void* blobs, size_t blob_stride,
+                                             float act_slope, void* scratch0, void* scratch1, void* const* out, void* stream) {
+    return rb24_chain_impl(src, batch, h, w, n, blobs, blob_stride, act_slope, scratch0, scratch1, out, stream);
 }
 
 // The last two convs of the upsampler in ONE launch (RefVSR.py:91-92,116-118,288,297, mid_channels = 24):

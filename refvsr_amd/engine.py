@@ -457,10 +457,17 @@ class Engine(object):
         """Install a context another rank prepared: its maps are views into `buf` (kept alive by the context), the frame copy, its
         8-channel HWC form and the SPyNet pyramid are made here (current stream)."""
         assert self.cache and buf.dtype == torch.uint8 and buf.numel() == self.context_nbytes(spec)
-        assert self._ctx(fid) is None, 'context %r exists already' % (fid,)
-        fr = FrameCtx(lr, ref)
+        # A window that merely CONTAINS the frame (positions before its centre) leaves an unprepared FrameCtx in the id cache
+        # (_frames): e.g. frame_num = 5 and a block starting one frame before a reset frame -- that context is filled in place,
+        # like prepare_context does (ADVICE r4).  Only a context that is already PREPARED is a protocol error.
+        fr = self._ctx(fid)
+        assert fr is None or fr.conf is None, 'context %r exists already (prepared)' % (fid,)
+        pinned = fr is None
+        if fr is None:
+            fr = FrameCtx(lr, ref)
         with torch.cuda.device(lr.device), ops.on_stream(torch.cuda.current_stream(lr.device)):
-            fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
+            if fr.lr8 is None:
+                fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
             self.pyramid(fr)
         o = 0
         for k, shape, dtype in spec:
@@ -469,7 +476,8 @@ class Engine(object):
                 n *= d
             setattr(fr, k, buf[o:o + n].view(dtype).view(shape))
             o += (n + 15) // 16 * 16
-        self.ctx_pinned[fid] = fr
+        if pinned:
+            self.ctx_pinned[fid] = fr
         return fr
 
     # ------------------------------------------------------------------ building blocks
@@ -484,6 +492,10 @@ class Engine(object):
         z = self._zero_maps.get(key)
         if z is None:
             if len(self._zero_maps) > 12:
+                # kernels queued on the internal streams may still be reading the maps that are dropped here (they carry no
+                # record_stream): the device is drained first, then the allocator may reuse them (reached only by a
+                # process that walks through more than twelve geometries)
+                torch.cuda.synchronize(dev)
                 self._zero_maps.clear()
             z = self._zero_maps[key] = torch.zeros(shape, dtype=dtype, device=dev)
             torch.cuda.current_stream(dev).synchronize()
@@ -1078,6 +1090,267 @@ class Engine(object):
                 v.record_stream(caller)
         self._inflight.append(done)
         return out, vis
+
+    # ------------------------------------------------------------------ frame groups: multi-map launches (opt-in extension)
+    # The backward branches of CONSECUTIVE output frames are independent chains over identical weights (each window restarts its
+    # backward branch from zeros, RefVSR.py:211-238): step j of the B chains of a group of B consecutive windows runs as ONE launch
+    # per layer over B maps (refvsr_*_batch, ABI 11) -- at 270 x 480 a launch is one 8 x 32 tile per workgroup, a group of four is
+    # four tiles per weight fill and per launch (resblock24: 9.9 -> 7.4 us per map, profiles/r05_multimap_microbench.txt).  Only the
+    # forward-branch step (which carries the state from frame to frame) stays one frame per launch.  Results are bit-identical to
+    # B forward() calls (tests/test_gpu_e2e.py::test_frame_groups_are_bit_identical).
+    def group_ok(self):
+        """The multi-map launch list exists for the mid_channels = 24 family on its default kernels."""
+        return bool(self.C == 24 and self.fuse_resblocks and self.rb24 and self.fuse_conf and self.warp_up2 and not self.fuse_warp and
+                    ops.CONV24 and self.cache and self.overlap and not bool(self.cfg.EVAL.is_gradio) and
+                    ops.conf_alpha_ok(self.cw('conf_fusion.1.0')) and ops.conf_alpha_ok(self.cw('conf_fusion2.1.0')))
+
+    def _block_chain_b(self, xs, pairs, act):
+        """_block_chain over B maps (lists in, list out): one multi-map launch per block."""
+        chains = self.W.chains
+        key = ('rb24',) + tuple(id(c1) for c1, _ in pairs)
+        ch = chains.get(key)
+        if ch is None:
+            ch = chains[key] = ops.Resblock24Chain(pairs, xs[0].device)
+        if self.chain_events is None:
+            return list(ops.resblock24_chain_b(ch, xs, act))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = list(ops.resblock24_chain_b(ch, xs, act))
+        e1.record()
+        self.chain_events.append((e0, e1, len(pairs), xs[0].shape[0], xs[0].shape[1], len(xs)))
+        return out
+
+    def res_list_b(self, xs, name, n):
+        pairs = [(self.cw('%s.RBs.%d.conv1' % (name, i)), self.cw('%s.RBs.%d.conv2' % (name, i))) for i in range(n)]
+        ys = self._block_chain_b(xs, pairs, 0.2)
+        return list(ops.conv_b(self.cw(name + '.conv_tail'), ys, ress=xs))
+
+    def resblocks_b(self, lr8s, feats, name, resume=None):
+        pairs = [(self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i)))
+                 for i in range(self.nb)]
+        if resume is not None:
+            n, xs = resume
+            return self._block_chain_b(xs, pairs[n:], 0.0) if n < self.nb else xs
+        xs = list(ops.conv_b(self.cw(name + '.main.0'), lr8s, feats, act=0.1))
+        return self._block_chain_b(xs, pairs, 0.0)
+
+    def rap_b(self, fs, conf_props, feats, feat_ups):
+        """rap() of B independent (frame, carried maps) tuples as multi-map launches (the fused-confidence launch list)."""
+        R = self.W.raw
+        confs = [f.conf for f in fs]
+        alpha, conf_next = ops.conf_alpha_b(conf_props, confs, 1, *R['conf_fusion.0.0'], self.cw('conf_fusion.1.0'), want_max=True)
+        t = ops.conv_b(self.cw('feat_fusion.0.0'), feats, [f.aligned for f in fs], act=0.2)
+        feat = list(ops.conv_b(self.cw('feat_fusion.1.0'), list(t), act=0.2, muls=list(alpha), ress=feats))     # :131
+        feat = self.res_list_b(feat, 'feat_decoder', 8)
+        up1 = ops.conv_b(self.cw('upsample1.upsample_conv'), feat)                                                # :138
+        feat_up = list(ops.conv_b(self.cw('feat_fusion2_1.0.0'), feat_ups, list(up1), act=0.2))
+        alpha2 = ops.conf_alpha_b(conf_props, confs, 2, *R['conf_fusion2.0.0'], self.cw('conf_fusion2.1.0'))      # :140-142
+        t = ops.conv_b(self.cw('feat_fusion2.0.0'), feat_up, [f.aligned_up for f in fs], act=0.2)
+        feat_up = list(ops.conv_b(self.cw('feat_fusion2.1.0'), list(t), act=0.2, muls=list(alpha2), ress=feat_up))   # :143
+        feat_up = self.res_list_b(feat_up, 'feat_decoder2', 4)
+        return feat, feat_up, list(conf_next)
+
+    def _prop_step_b(self, fs, branch, feats, feat_ups, confs, fls):
+        """_prop_step for B independent chains (lists of B maps / frames / flows; fls None: the first step of the branches)."""
+        if fls is None:
+            n = self.bw_head_blocks if branch == 'backward_resblocks' else -1
+            if n >= 0:
+                heads = []
+                for f, z in zip(fs, feats):
+                    if f.bw_head is None or f.bw_head[0] != n:            # (a frame prepared by a first-frame call has no head yet)
+                        f.bw_head = (n, self.resblocks(f.lr8, z, branch, stop=n))
+                    heads.append(f.bw_head[1])
+                xs = self.resblocks_b(None, None, branch, resume=(n, heads))
+            else:
+                xs = self.resblocks_b([f.lr8 for f in fs], feats, branch)
+            return self.rap_b(fs, confs, xs, feat_ups)
+        confs = list(ops.warp_planar_b(confs, fls))
+        xs = self.resblocks_b([f.lr8 for f in fs], list(ops.warp_nhwc16_b(feats, fls)), branch)
+        return self.rap_b(fs, confs, xs, list(ops.warp_nhwc16_up2_b(feat_ups, fls)))
+
+    def _frames_group(self, wins):
+        """_frames (id-keyed form) for the B windows of a group: the cache keeps the union of their frames."""
+        keep = set()
+        for _, _, ids in wins:
+            keep.update(ids)
+        lr0 = wins[0][0]
+        if self.id_cache and next(iter(self.id_cache.values())).lr.shape != lr0.shape[1:]:
+            self.id_cache, self.flow_cache = {}, {}
+        out = []
+        for lrs, refs, ids in wins:
+            assert len(ids) == lrs.shape[0]
+            frames = []
+            for i, fid in enumerate(ids):
+                fr = self.id_cache.get(fid)
+                if fr is None:
+                    fr = self.ctx_pinned.pop(fid, None)
+                    if fr is None:
+                        fr = FrameCtx(lrs[i], refs[i])
+                    self.id_cache[fid] = fr
+                frames.append(fr)
+            out.append(frames)
+        self.id_cache = {k: v for k, v in self.id_cache.items() if k in keep}
+        live = set(f.uid for fr in out for f in fr)
+        self.flow_cache = {k2: v for k2, v in self.flow_cache.items() if k2[0] in live and k2[1] in live}
+        self.prev_window = out[-1]
+        return out
+
+    @torch.no_grad()
+    def forward_group(self, wins, is_first_frame=False, input_ready=None):
+        """B consecutive windows of this stream in one call: wins = [(lrs [t,3,h,w], refs, frame_ids)] in stream order, every window
+        as forward(lrs, refs, is_first, frame_ids=ids) would get it (is_first_frame applies to wins[0]).  Returns [result planar
+        [3,s h,s w]] per window -- bit-identical to the B forward() calls.  Steady-state runs of >= 2 windows execute as a group
+        (multi-map launches on the internal streams: needs set_pipelined(True)); windows that restart the forward branch (first
+        frame, reset_branch roll-over, no carried state) and engines without the multi-map launch list run one forward() each.
+        input_ready: as in forward() (None | 'materialised' | event | stream), for all windows of the call."""
+        outs = [None] * len(wins)
+        i = 0
+        with torch.cuda.device(wins[0][0].device):
+            while i < len(wins):
+                # the longest run of steady windows from i on (the iteration counter advances by one per window)
+                j = i
+                if self.group_ok() and self.pipelined and self.fw_feat is not None and not (i == 0 and is_first_frame):
+                    while (j < len(wins) and j - i < ops.hip.MAX_MAPS and
+                           (self.max_frame_itr_num is None or self.frame_itr_num + (j - i) != self.max_frame_itr_num)):
+                        j += 1
+                if j - i >= 2:
+                    res = self._forward_group_pipelined(wins[i:j], input_ready)
+                    outs[i:j] = res
+                    i = j
+                else:
+                    lrs, refs, ids = wins[i]
+                    outs[i] = self.forward(lrs, refs, bool(is_first_frame) and i == 0, frame_ids=ids, input_ready=input_ready)[0]
+                    i += 1
+        return outs
+
+    def _forward_group_pipelined(self, wins, input_ready):
+        B = len(wins)
+        t, _, h, w = wins[0][0].shape
+        ctr, dev = t // 2, wins[0][0].device
+        for lrs, refs, _ in wins:
+            self._check_window(lrs, refs)
+            assert tuple(lrs.shape) == (t, 3, h, w)
+        assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
+        caller = torch.cuda.current_stream()
+        M0, M1, F_, P = self._pipe_streams(dev)
+        M = M0
+        self._pipe_calls += 1
+        self._await_fw_up(self.fw_feat_up)
+        while len(self._inflight) >= max(1, self.pipe_depth - 1):          # (a group in flight holds B calls' worth of intermediates)
+            self._inflight.popleft().synchronize()
+        streams = []
+        for st in (M0, M1, F_, P):
+            if all(st is not s_ for s_ in streams):
+                streams.append(st)
+        if input_ready is None:
+            input_ready = torch.cuda.Event()
+            input_ready.record(caller)
+        if not isinstance(input_ready, str):
+            for st in streams:
+                if isinstance(input_ready, torch.cuda.Stream):
+                    st.wait_stream(input_ready)
+                else:
+                    st.wait_event(input_ready)
+        elif input_ready != 'materialised':
+            raise ValueError("input_ready must be None, 'materialised', a torch.cuda.Event or a torch.cuda.Stream")
+        for lrs, refs, _ in wins:
+            for st in streams:
+                lrs.record_stream(st)
+                refs.record_stream(st)
+        sev = self.stream_events
+        mark = (lambda st: None) if sev is None else _timed_event
+        tev = {'n': B}
+        share = (M0, M1, F_, P)
+
+        def publish(f):
+            for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                for st in share:
+                    x.record_stream(st)
+        # ---- P: everything that is a function of single frames / frame pairs, for all windows of the group
+        with ops.on_stream(P):
+            tev['P0'] = mark(P)
+            n_ctx = next(_uid)
+            frs = self._frames_group(wins)
+            for fr in frs:
+                for f in fr:
+                    if f.uid > n_ctx:
+                        for st in share:
+                            f.lr.record_stream(st)
+                            f.ref.record_stream(st)
+            zf = self._zeros((h, w, self._state_cs()), torch.float16, dev)
+            for fr in frs:
+                for i in range(ctr, t):
+                    f = fr[i]
+                    if f.conf is None:
+                        self.pyramid(f)
+                        self.prepare_frame(f)
+                        if i == t - 1 and self.bw_head_blocks >= 0:
+                            f.bw_head = (self.bw_head_blocks, self.resblocks(f.lr8, zf, 'backward_resblocks', stop=self.bw_head_blocks))
+                            for st in share:
+                                f.bw_head[1].record_stream(st)
+                        publish(f)
+                        f.ready = torch.cuda.Event()
+                        f.ready.record()
+                    else:
+                        if f.pyr is None:
+                            self.pyramid(f)
+                        if f.ready is None:          # prepared on M by a first-frame call: make it safe on the other streams too
+                            publish(f)
+            need = []
+            for fr in frs:
+                need += [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
+            self.flows(need, share)
+            tev['P1'] = mark(P)
+        # ---- F: the forward-branch steps, one frame after the other (the carried state)
+        fws, ev_fw = [], []
+        with ops.on_stream(F_):
+            tev['F0'] = mark(F_)
+            for fr in frs:
+                for f in (fr[ctr], fr[ctr + 1]):
+                    if f.ready is not None:
+                        F_.wait_event(f.ready)
+                for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
+                    x.record_stream(F_)
+                fw = self._forward_branch(fr, (lambda a, b, fr=fr: self.flow(fr[a], fr[b], share)), t, h, w, False)
+                for x in fw:
+                    x.record_stream(M0)
+                    x.record_stream(M1)
+                e = torch.cuda.Event(enable_timing=sev is not None)
+                e.record()
+                fws.append(fw)
+                ev_fw.append(e)
+            tev['F1'] = ev_fw[-1]
+        # ---- M: the B backward branches step by step as multi-map launches, then the upsamplers
+        outs = []
+        with ops.on_stream(M):
+            tev['M0'] = mark(M)
+            cs_ = self._state_cs()
+            feats = [self._zeros((h, w, cs_), torch.float16, dev)] * B
+            feat_ups = [self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)] * B
+            confs = [self._zeros((1, h, w), torch.float32, dev)] * B
+            for i in range(t - 1, ctr - 1, -1):
+                fs = [fr[i] for fr in frs]
+                for f in fs:
+                    if f.ready is not None:
+                        M.wait_event(f.ready)
+                fls = None
+                if i < t - 1:
+                    fls = [self.flow(fr[i], fr[i + 1], share) for fr in frs]         # cached by P above: waits on its event
+                feats, feat_ups, confs = self._prop_step_b(fs, 'backward_resblocks', feats, feat_ups, confs, fls)
+            for b, fr in enumerate(frs):
+                M.wait_event(ev_fw[b])
+                outs.append(self.compute_up(feat_ups[b], fws[b][1], confs[b], fws[b][2], fr[ctr].lr))
+        self.frame_itr_num += B
+        done = torch.cuda.Event(enable_timing=sev is not None)
+        done.record(M)
+        if sev is not None:
+            tev['M1'] = done
+            sev.append(tev)
+        caller.wait_event(done)
+        for o in outs:
+            o.record_stream(caller)
+        self._inflight.append(done)
+        return outs
 
     def _side_stream(self, dev, k=0):
         if self._side is None or self._side[0].device != dev:

@@ -165,6 +165,25 @@ class Network(nn.Module):
             outs['eval_vis'] = ev
         return outs
 
+    def forward_group(self, lrs, refs, frame_ids, is_first_frame=False, input_ready=None):
+        """B CONSECUTIVE windows of one stream in one call (extension; see Engine.forward_group): lrs, refs [B,t,3,h,w] -- window b
+        is what the b-th of B consecutive forward() calls would get as its n = 1 input -- frame_ids: B lists of t ids.  Returns
+        OrderedDict{'result': tuple of B tensors [1,3,sh,sw]}, bit-identical to the B calls; the backward branches and the
+        upsamplers' inputs of the B frames run as multi-map launches, the forward-branch steps frame by frame."""
+        hip.lib()
+        if not lrs.is_cuda:
+            raise RuntimeError('refvsr_amd.Network runs on the GPU only (got a %s tensor); there is no CPU path' % lrs.device)
+        for t_ in (lrs, refs):
+            if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.dim() != 5:
+                raise RuntimeError('forward_group needs contiguous float32 [B,t,3,h,w] inputs (got %s, contiguous=%s)' % (t_.dtype, t_.is_contiguous()))
+        assert len(frame_ids) == lrs.shape[0] and lrs.shape == refs.shape
+        eng = self.ensure_engines(1, lrs.device)[0]
+        wins = [(lrs[b], refs[b], [(0, f) for f in frame_ids[b]]) for b in range(lrs.shape[0])]
+        res = eng.forward_group(wins, bool(is_first_frame), input_ready)
+        outs = collections.OrderedDict()
+        outs['result'] = tuple(r.unsqueeze(0) for r in res)
+        return outs
+
     # ---- two-phase forward for the multi-GPU wavefront (refvsr_amd/shard.py:run_wavefront; not in the reference) ----
     def phase_a(self, lrs, refs, frame_ids=None, first_hint=False):
         """State-independent part of forward() (preparation + backward branch) for lrs, refs [n,t,3,h,w]."""
@@ -244,3 +263,7 @@ class SRNet(nn.Module):
         """frame_ids, input_ready (optional extensions, not in the reference): one id per window frame / when the inputs are
         final -- see Engine.forward and Engine.set_pipelined."""
         return self.Network.forward(x, ref, is_first_frame, is_log=is_log, is_train=is_train, frame_ids=frame_ids, input_ready=input_ready)
+
+    def forward_group(self, x, ref, frame_ids, is_first_frame=False, input_ready=None):
+        """B consecutive windows of one stream in one call (extension, not in the reference): see Network.forward_group."""
+        return self.Network.forward_group(x, ref, frame_ids, is_first_frame=is_first_frame, input_ready=input_ready)

@@ -82,7 +82,8 @@ CONV24 = not env_flag('REFVSR_NO_CONV24')      # A/B knob: the generic conv kern
 
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'hi_only', 'desc', 'odtype', 'raw', 'blob24')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'hi_only', 'desc', 'odtype', 'raw', 'blob24',
+                 'no_fused_warp')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
@@ -90,6 +91,7 @@ class ConvWeights(object):
         self.cout, self.ksteps, self.mt, self.ksize = pk['cout'], pk['ksteps'], pk['mt'], pk['ksize']
         self.cpads, self.shuffle, self.f32 = pk['cpads'], pk['shuffle'], bool(pk.get('f32', False))
         self.hi_only = bool(pk.get('hi_only', False))      # plain fp16 weights (descriptor weight mode 2)
+        self.no_fused_warp = False                         # set once the library has answered REFVSR_ERR_UNSUPPORTED for warp=
         # launch descriptor with the per-weight fields filled once (the C side copies it at every call)
         d = self.desc = hip.RefvsrConv()
         d.wpack, d.bias = self.wpack.data_ptr(), self.bias.data_ptr()
@@ -205,10 +207,15 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         out = torch.empty((ho, wo, co), dtype=cw.odtype, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16, co
     d.out = out.data_ptr()
-    rc = hip.lib().refvsr_conv_mfma(C.byref(d), _stream())
-    if rc != 0 and warp is not None:
+    if warp is not None and getattr(cw, 'no_fused_warp', False):
+        rc = hip.ERR_UNSUPPORTED                     # decided once per packed conv: no failed launch attempt per call
+    else:
+        rc = hip.lib().refvsr_conv_mfma(C.byref(d), _stream())
+    if rc == hip.ERR_UNSUPPORTED and warp is not None:
         # no fused-warp kernel for this shape (e.g. the sixteen-wave layout of the C = 48 convs): the stand-alone warp kernel +
-        # the plain conv give the same result bit for bit (a refused launch must not be a hard error)
+        # the plain conv give the same result bit for bit.  ONLY the library's "unsupported" code takes this path: a
+        # genuine argument or launch error stays an error
+        cw.no_fused_warp = True
         warped = warp_nhwc16(src0 if wk == 0 else src1, flow)
         return conv(cw, warped if wk == 0 else src0, src1 if wk == 0 else warped, stride=stride, pad=pad, act=act, mul=mul, res=res,
                     post=post, planar_out=planar_out, res_planar=res_planar, add_const=add_const, clamp=clamp)
@@ -768,6 +775,136 @@ def aligned_sample(x, affine, ks):
     hip.check(hip.lib().refvsr_aligned_sample(_ptr(x), h, w, ks, x.shape[2], _ptr(affine), _ptr(out), _stream()),
               'aligned_sample')
     return out
+
+
+# ---- multi-map launches (ABI 11): B maps of one geometry behind one launch per layer ---------------------------------------
+# Inputs are LISTS of B tensors (slices of a batched tensor or separately allocated per-frame maps); outputs are ONE tensor with a
+# leading batch axis whose slices out[b] are the maps.  Map b of every call == the single-map op on map b, bit for bit.
+def _parr(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def multimap_ok(B):
+    return 2 <= B <= hip.MAX_MAPS
+
+
+def conv_b(cw, src0s, src1s=None, act=1.0, muls=None, ress=None, post=1.0):
+    """refvsr_conv24_batch / refvsr_conv_shuffle2_batch: conv() over B maps (24 output channels, 3x3, or the C = 24 pixel-shuffle
+    conv).  Shapes without a multi-map kernel run map by map (same results)."""
+    B = len(src0s)
+    h, w, c0 = src0s[0].shape
+    c1 = src1s[0].shape[2] if src1s is not None else 0
+    for l_ in (src0s, src1s, muls, ress):
+        if l_ is not None:
+            assert len(l_) == B
+            for t_ in l_:
+                _nhwc(t_)
+                assert tuple(t_.shape[:2]) == (h, w)
+    dev = src0s[0].device
+    if (multimap_ok(B) and cw.shuffle and cw.blob24 is not None and c0 == 24 and src1s is None and muls is None and ress is None and
+            0.0 <= act <= 1.0 and post == 1.0 and h * w * cw.cout * 2 < 2 ** 31):
+        out = torch.empty((B, 2 * h, 2 * w, c0), dtype=torch.float16, device=dev)
+        hip.check(hip.lib().refvsr_conv_shuffle2_batch(_parr(src0s), B, c0, h, w, _ptr(cw.blob24), act, _parr(list(out)), _stream()),
+                  'conv_shuffle2_batch')
+        return out
+    if (multimap_ok(B) and cw.blob24 is not None and not cw.shuffle and cw.cout == 24 and 0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and
+            [c0] + ([c1] if src1s is not None else []) == list(cw.cpads) and hip.lib().refvsr_conv24_supported(c0, c1) and
+            (muls is None or muls[0].shape[2] == 24) and (ress is None or ress[0].shape[2] == 24) and h * w * max(24, c0, c1) * 2 < 2 ** 31):
+        out = torch.empty((B, h, w, 24), dtype=torch.float16, device=dev)
+        hip.check(hip.lib().refvsr_conv24_batch(_parr(src0s), c0, _parr(src1s) if src1s is not None else None, c1, B, h, w, _ptr(cw.blob24),
+                                                act, _parr(muls) if muls is not None else None, _parr(ress) if ress is not None else None,
+                                                post, _parr(list(out)), _stream()), 'conv24_batch')
+        return out
+    return torch.stack([conv(cw, src0s[b], None if src1s is None else src1s[b], act=act, mul=None if muls is None else muls[b],
+                             res=None if ress is None else ress[b], post=post) for b in range(B)], 0)
+
+
+def resblock24_chain_b(chain, xs, act):
+    """refvsr_resblock24_chain_batch: chain.n fused 24-channel blocks over B maps, one launch per block."""
+    B = len(xs)
+    for t_ in xs:
+        _nhwc(t_)
+        assert tuple(t_.shape) == tuple(xs[0].shape) and t_.shape[2] == 24
+    if not multimap_ok(B):
+        return torch.stack([resblock24_chain(chain, x, act) for x in xs], 0)
+    h, w, _ = xs[0].shape
+    dev = xs[0].device
+    out = torch.empty((B, h, w, 24), dtype=torch.float16, device=dev)
+    s0 = torch.empty_like(out) if chain.n >= 2 else None
+    s1 = torch.empty_like(out) if chain.n >= 3 else None
+    hip.check(hip.lib().refvsr_resblock24_chain_batch(_parr(xs), B, h, w, chain.n, _ptr(chain.blobs), chain.stride, act, _ptr(s0), _ptr(s1),
+                                                      _parr(list(out)), _stream()), 'resblock24_chain_batch')
+    return out
+
+
+def conf_alpha_b(conf_as, conf_bs, up, w0, b0, cw, slope0=0.2, slope1=0.2, want_max=False):
+    """refvsr_conf_alpha_batch: conf_alpha() over B pairs of confidence maps (24 output channels)."""
+    B = len(conf_as)
+    assert len(conf_bs) == B
+    if not (multimap_ok(B) and cw.cout == 24):
+        r = [conf_alpha(conf_as[b], conf_bs[b], up, w0, b0, cw, slope0, slope1, want_max) for b in range(B)]
+        if want_max:
+            return torch.stack([a for a, _ in r], 0), torch.stack([m for _, m in r], 0)
+        return torch.stack(r, 0)
+    for t_ in list(conf_as) + list(conf_bs):
+        _planar(t_, 1)
+        assert t_.shape == conf_as[0].shape
+    assert cw.blob24 is not None and cw.cpads == [16]
+    h, w = conf_as[0].shape[1:]
+    dev = conf_as[0].device
+    alpha = torch.empty((B, up * h, up * w, 24), dtype=torch.float16, device=dev)
+    cmax = torch.empty((B, 1, h, w), dtype=torch.float32, device=dev) if want_max else None
+    hip.check(hip.lib().refvsr_conf_alpha_batch(_parr(conf_as), _parr(conf_bs), B, h, w, up, _ptr(w0), _ptr(b0), slope0, _ptr(cw.blob24), 24,
+                                                slope1, _parr(list(alpha)), _parr(list(cmax)) if want_max else None, _stream()),
+              'conf_alpha_batch')
+    return (alpha, cmax) if want_max else alpha
+
+
+def _warp_b(fn, name, xs, flows, out, dims):
+    hip.check(fn(_parr(xs), len(xs), *dims[0], _parr(flows), *dims[1], _parr(list(out)), _stream()), name)
+    return out
+
+
+def warp_nhwc16_b(xs, flows):
+    B = len(xs)
+    if not multimap_ok(B):
+        return torch.stack([warp_nhwc16(x, f) for x, f in zip(xs, flows)], 0)
+    for x, f in zip(xs, flows):
+        _nhwc(x)
+        _planar(f, 2)
+        assert x.shape == xs[0].shape and f.shape == flows[0].shape
+    hin, win, cs = xs[0].shape
+    hf, wf = flows[0].shape[1:]
+    out = torch.empty((B, hf, wf, cs), dtype=torch.float16, device=xs[0].device)
+    return _warp_b(hip.lib().refvsr_warp_nhwc16_batch, 'warp_nhwc16_batch', xs, flows, out, ((hin, win, cs), (hf, wf)))
+
+
+def warp_nhwc16_up2_b(xs, flows_lr):
+    B = len(xs)
+    if not multimap_ok(B):
+        return torch.stack([warp_nhwc16_up2(x, f) for x, f in zip(xs, flows_lr)], 0)
+    for x, f in zip(xs, flows_lr):
+        _nhwc(x)
+        _planar(f, 2)
+        assert x.shape == xs[0].shape and f.shape == flows_lr[0].shape
+    hin, win, cs = xs[0].shape
+    hl, wl = flows_lr[0].shape[1:]
+    out = torch.empty((B, 2 * hl, 2 * wl, cs), dtype=torch.float16, device=xs[0].device)
+    return _warp_b(hip.lib().refvsr_warp_nhwc16_up2_batch, 'warp_nhwc16_up2_batch', xs, flows_lr, out, ((hin, win, cs), (hl, wl)))
+
+
+def warp_planar_b(xs, flows):
+    B = len(xs)
+    if not multimap_ok(B):
+        return torch.stack([warp_planar(x, f) for x, f in zip(xs, flows)], 0)
+    for x, f in zip(xs, flows):
+        _planar(x)
+        _planar(f, 2)
+        assert x.shape == xs[0].shape and f.shape == flows[0].shape
+    c, hin, win = xs[0].shape
+    hf, wf = flows[0].shape[1:]
+    out = torch.empty((B, c, hf, wf), dtype=torch.float32, device=xs[0].device)
+    return _warp_b(hip.lib().refvsr_warp_planar_batch, 'warp_planar_batch', xs, flows, out, ((c, hin, win), (hf, wf)))
 
 
 # ---- RefVSR_IR / EDVR-M pieces (csrc/edvr.hip) -------------------------------------------------------------------------

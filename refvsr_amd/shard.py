@@ -602,6 +602,8 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
     for a, b, r in blocks:
         for f in range(a, b):
             owner_of[f] = r
+    if hasattr(executor, 'begin_run'):
+        executor.begin_run()                                       # (two-lane executors: the lanes wait for the caller's stream)
     lane_a = getattr(executor, 'lane_a', _NullCtx)
     lane_b = getattr(executor, 'lane_b', _NullCtx)
     mark = getattr(executor, 'mark', lambda what, f: None)          # record "what of frame f is enqueued up to here"
@@ -757,10 +759,17 @@ class EngineExecutor(object):
     def _streams(self):
         if self._lanes is None:
             self._lanes = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            self.begin_run()
+        return self._lanes
+
+    def begin_run(self):
+        """Start of every run_wavefront on this executor: the lanes wait for the caller's stream as it stands -- whatever produced
+        the (device-resident) windows / the weights there, also for the SECOND run on one executor (sync() orders the
+        caller after the lanes, not the lanes after the caller)."""
+        if self._lanes is not None:
             cur = torch.cuda.current_stream(self.dev)
             for s_ in self._lanes:
-                s_.wait_stream(cur)                         # whatever produced the windows / the weights on the caller's stream
-        return self._lanes
+                s_.wait_stream(cur)
 
     def comm_lane(self):
         """An otherwise idle stream to post context receives from: a receive posted from lane a would first wait for everything

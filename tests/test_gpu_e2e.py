@@ -982,3 +982,55 @@ def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, 
         net4.Network.reset()
         for f in range(nfr):
             assert torch.equal(net5(wl[f], wr[f], f == 0)['result'], net4(wl[f], wr[f], f == 0)['result']), 'frame %d differs (fused tail)' % f
+
+
+@pytest.mark.parametrize('gsize', [2, 3, 4])
+def test_frame_groups_are_bit_identical(dev, gsize):
+    """forward_group (round 5: the backward branches of B consecutive windows as multi-map launches, ABI 11) against one forward()
+    per frame on the default sequential engine: every output frame bit for bit over a 14-frame clip with reset_branch = 5 (groups
+    that contain a roll-over are split: the restart frame runs alone), clip-edge windows that repeat frames, a first frame inside
+    the call, all three ways of saying when the inputs are final, and a second clip on the same module."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 14, 5
+    lr, rf, _ = make_clip(nfr, 64, 96, seed=17)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    wl = torch.stack([lr[w] for w in wins], 0).contiguous()          # [nfr, t, 3, h, w]
+    wr = torch.stack([rf[w] for w in wins], 0).contiguous()
+    torch.cuda.synchronize()
+    ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=5, save_sample=False)
+    want = [ref_net(wl[f][None], wr[f][None], f == 0)['result'].clone() for f in range(nfr)]
+    side = torch.cuda.Stream(device=dev)
+    for ready in ('materialised', None, 'event'):
+        net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=5, save_sample=False)
+        net.Network.set_pipelined(True)
+        assert net.Network.ensure_engines(1, dev)[0].group_ok()
+        for clip in range(2):
+            outs = []
+            f = 0
+            while f < nfr:
+                n = min(gsize, nfr - f)
+                ids = [[(clip, i) for i in wins[f + b]] for b in range(n)]
+                if ready == 'event':
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        xl, xr = wl[f:f + n].clone(), wr[f:f + n].clone()
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    res = net.forward_group(xl, xr, ids, is_first_frame=(f == 0), input_ready=ev)['result']
+                    xl.record_stream(torch.cuda.current_stream())
+                    xr.record_stream(torch.cuda.current_stream())
+                else:
+                    res = net.forward_group(wl[f:f + n], wr[f:f + n], ids, is_first_frame=(f == 0), input_ready=ready)['result']
+                outs += list(res)
+                f += n
+            torch.cuda.synchronize()
+            assert len(outs) == nfr
+            for f in range(nfr):
+                assert outs[f].shape == want[f].shape and torch.equal(outs[f], want[f]), \
+                    'group frame %d differs (group size %d, input_ready %s, clip %d)' % (f, gsize, ready, clip)
+    # a module that is not in pipelined mode runs the windows one by one: same stream
+    net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=5, save_sample=False)
+    res = net.forward_group(wl[0:3], wr[0:3], [wins[0], wins[1], wins[2]], is_first_frame=True)['result']
+    for f in range(3):
+        assert torch.equal(res[f], want[f])

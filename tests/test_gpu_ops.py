@@ -1280,3 +1280,78 @@ def test_conv1x1_f32_map(dev, cin, size):
     e_new, e_old = maxdiff(got.double(), want) / scale, maxdiff(old.double(), want) / scale
     report('conv1x1_f32 %d->16 %dx%d' % (cin, h, w), rel_vs_f64=e_new, generic_rel_vs_f64=e_old)
     assert got.shape == (16, h, w) and e_new < 2e-6 and e_old < 2e-6
+
+
+# ---- multi-map launches (ABI 11) ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B', [2, 3, 4])
+@pytest.mark.parametrize('h,w', [(8, 32), (19, 45), (64, 96), (270, 480)])
+def test_multimap_launches_equal_the_single_map_launches(dev, B, h, w):
+    """refvsr_*_batch: map b of a multi-map launch == the single-map launch on map b, bit for bit -- the fused 24-channel block
+    chain (n = 1, 2, 3: all scratch configurations; ReLU and leaky), every conv24 input shape with every epilogue operand (the
+    operands are separately allocated maps, as the per-frame cached maps of the engine are), the pixel-shuffle conv, both
+    confidence fusions with the max by-product, the three warps.  Sizes: smaller than a tile, partial tiles, one tile per
+    workgroup x B (270 x 480: the case the launches exist for)."""
+    from refvsr_amd import ops
+    g = torch.Generator().manual_seed(1000 * B + 10 * h + w)
+    rn = lambda c, hh=h, ww=w: nhwc(torch.randn(c, hh, ww, generator=g), dev)
+    # fused block chain
+    for n, act in ((1, 0.0), (2, 0.2), (3, 0.0)):
+        raw = [((torch.randn(24, 24, 3, 3, generator=g) * 0.07, torch.randn(24, generator=g) * 0.1),
+                (torch.randn(24, 24, 3, 3, generator=g) * 0.07, torch.randn(24, generator=g) * 0.1)) for _ in range(n)]
+        ch = ops.Resblock24Chain(raw, dev)
+        xs = [rn(24) for _ in range(B)]
+        got = ops.resblock24_chain_b(ch, xs, act)
+        assert got.shape == (B, h, w, 24)
+        for b in range(B):
+            assert torch.equal(got[b], ops.resblock24_chain(ch, xs[b], act)), ('rb24', n, b)
+    # conv24: every input shape x epilogue operands
+    for cins, act, post, use_mul, use_res in (([24], 0.2, 1.0, True, True), ([16], 0.2, 1.0, False, False), ([8, 24], 0.1, 1.0, False, False),
+                                              ([24, 24], 0.2, 0.2, False, True), ([24], 1.0, 1.0, False, True)):
+        cw = _rand_conv_weights(24, cins, 3 + len(cins) + cins[0], dev)
+        assert cw.blob24 is not None
+        s0 = [rn(cins[0]) for _ in range(B)]
+        s1 = [rn(cins[1]) for _ in range(B)] if len(cins) > 1 else None
+        muls = [nhwc(torch.rand(24, h, w, generator=g), dev) for _ in range(B)] if use_mul else None
+        ress = [rn(24) for _ in range(B)] if use_res else None
+        got = ops.conv_b(cw, s0, s1, act=act, muls=muls, ress=ress, post=post)
+        assert got.shape == (B, h, w, 24)
+        for b in range(B):
+            want = ops.conv(cw, s0[b], None if s1 is None else s1[b], act=act, mul=None if muls is None else muls[b],
+                            res=None if ress is None else ress[b], post=post)
+            assert torch.equal(got[b], want), ('conv24', cins, b)
+    # pixel-shuffle conv (upsample1)
+    gq = torch.Generator().manual_seed(77)
+    from refvsr_amd.packing import pack_conv
+    cws = ops.ConvWeights(pack_conv(torch.randn(96, 24, 3, 3, generator=gq) * 0.07, torch.randn(96, generator=gq) * 0.1, [24], True), dev)
+    assert cws.blob24 is not None and cws.shuffle
+    xs = [rn(24) for _ in range(B)]
+    got = ops.conv_b(cws, xs)
+    assert got.shape == (B, 2 * h, 2 * w, 24)
+    for b in range(B):
+        assert torch.equal(got[b], ops.conv(cws, xs[b])), ('shuffle', b)
+    # confidence fusions
+    w0 = (torch.randn(16, 2, 3, 3, generator=g) * 0.4).to(dev)
+    b0 = (torch.randn(16, generator=g) * 0.1).to(dev)
+    cwa = _rand_conv_weights(24, [16], 31, dev)
+    cas = [torch.rand(1, h, w, generator=g).to(dev) for _ in range(B)]
+    cbs = [(torch.rand(1, h, w, generator=g) * 1.2 - 0.1).to(dev) for _ in range(B)]
+    got, gmax = ops.conf_alpha_b(cas, cbs, 1, w0, b0, cwa, want_max=True)
+    got2 = ops.conf_alpha_b(cas, cbs, 2, w0, b0, cwa)
+    for b in range(B):
+        a1, m1 = ops.conf_alpha(cas[b], cbs[b], 1, w0, b0, cwa, want_max=True)
+        assert torch.equal(got[b], a1) and torch.equal(gmax[b], m1), ('conf1', b)
+        assert torch.equal(got2[b], ops.conf_alpha(cas[b], cbs[b], 2, w0, b0, cwa)), ('conf2', b)
+    # warps
+    fls = [(torch.randn(2, h, w, generator=g) * 3).to(dev) for _ in range(B)]
+    xs = [rn(24) for _ in range(B)]
+    xu = [rn(24, 2 * h, 2 * w) for _ in range(B)]
+    got = ops.warp_nhwc16_b(xs, fls)
+    gup = ops.warp_nhwc16_up2_b(xu, fls)
+    gq_ = ops.warp_nhwc16_up2_b(xs, fls)                      # the :254 quirk: an LR-size map sampled on the 2x grid
+    gpl = ops.warp_planar_b(cas, fls)
+    for b in range(B):
+        assert torch.equal(got[b], ops.warp_nhwc16(xs[b], fls[b])), ('warp', b)
+        assert torch.equal(gup[b], ops.warp_nhwc16_up2(xu[b], fls[b])), ('warp_up2', b)
+        assert torch.equal(gq_[b], ops.warp_nhwc16_up2(xs[b], fls[b])), ('warp_up2 quirk', b)
+        assert torch.equal(gpl[b], ops.warp_planar(cas[b], fls[b])), ('warp_planar', b)
+    report('multimap B=%d %dx%d' % (B, h, w), equal=1)

@@ -389,11 +389,65 @@ def gen_full_mfid(nframes=2, stride=8):
     save('e2e_full_F_270x480_t5', **arrs)
 
 
+def gen_full_hd(h=1080, w=1920, nframes=2, stride=32, t=3):
+    """BASELINE configs[4] at its stated size: config_RefVSR_MFID_8K (C = 48, 30 blocks, flag_HD_in: matching on nearest x0.5 +
+    VGG19[0:7] features, aa1 scale 4 + align, aa2 scale 8 + align; configs/config_RefVSR_MFID_8K.py, RefVSR_/attention.py:65-67,93-98,
+    RefVSR.py:39-40) on a 1080 x 1920 -> 4320 x 7680 synthetic clip, t = 3 (frame_num is a CLI value), random weights: one first-frame
+    call + one steady call.  Stored: PSNR scalars vs the synthetic GT, two 128 x 128 crops at output resolution, a strided sub-sample
+    of the result, and the centre frame's index map + (strided) confidence map.  The 8K result is 398 MB per frame -- never stored.
+    Takes about 1 h on 8 cores and 40-50 GB of RSS (the reference materialises the 32 400 x 129 600 fp32 score matrix and several
+    48-channel 8K maps)."""
+    from refvsr_amd.synth import make_clip, window_indices
+    import time
+    tag = 'e2e_full_HD_%dx%d_t%d' % (h, w, t)
+    clip_n = nframes + t // 2
+    lr, rf, gt = make_clip(clip_n, h, w, seed=0)
+    gt = gt[:nframes].clone()
+    s = 4
+    crops = [(int(1.1 * h), int(1.05 * w)), (int(2.6 * h), int(2.9 * w))]
+    arrs = dict(nframes=np.int64(nframes), clip_frames=np.int64(clip_n), stride=np.int64(stride), crops=np.asarray(crops, np.int64),
+                t=np.int64(t), h=np.int64(h), w=np.int64(w),
+                lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
+    print('== full-size HD (config_RefVSR_MFID_8K) %dx%d t=%d, %d frames, random weights ==' % (h, w, t, nframes), flush=True)
+    net, cfg, mine, sd = ref_net('config_RefVSR_MFID_8K', t, save_sample=False)
+    matches = []
+    hook = net.Network.feature_match.register_forward_hook(lambda m, i, o: matches.append((o[0].clone(), o[1].clone())))
+    with torch.no_grad():
+        for f in range(nframes):
+            wi = window_indices(f, clip_n, t)
+            del matches[:]
+            t0 = time.time()
+            res = net(lr[wi][None], rf[wi][None], f == 0, is_log=False, is_train=False)['result']
+            assert tuple(res.shape) == (1, 3, s * h, s * w)
+            p = float(10 * torch.log10(1 / torch.mean((res - gt[f][None]) ** 2)))
+            print('  frame %d: %.1f s, PSNR vs GT %.6f dB' % (f, time.time() - t0, p), flush=True)
+            arrs['psnr_%d' % f] = np.float64(p)
+            for ci, (y0, x0) in enumerate(crops):
+                arrs['crop%d_%d' % (ci, f)] = res[0, :, y0:y0 + 128, x0:x0 + 128].clone()
+            arrs['sub_%d' % f] = res[0, :, ::stride, ::stride].clone()
+            # feature_match runs for window positions range_start..t-1: the centre frame is call ctr - range_start
+            conf, idx = matches[t // 2 if f == 0 else 0]
+            arrs['conf_%d' % f] = conf[0, 0, ::4, ::4].clone()          # (bicubic x4 of the matching grid's map, attention.py:96-98)
+            arrs['idx_%d' % f] = idx[0].to(torch.int32).clone()
+            del res
+    hook.remove()
+    save(tag, **arrs)
+
+
 def main():
     if '--full-mfid' in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         gen_full_mfid()
+        return
+    if '--full-hd' in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        if '--hd-size' in sys.argv:                       # e.g. --hd-size 540x960 (the fall-back when 62 GB do not hold 1080p)
+            hh, ww = sys.argv[sys.argv.index('--hd-size') + 1].split('x')
+            gen_full_hd(int(hh), int(ww))
+        else:
+            gen_full_hd()
         return
     if '--spec' in sys.argv:
         gen_spec()
