@@ -571,6 +571,114 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     return out
 
 
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_line(line, limit=5600):
+    """The stdout form of the record: the contract fields + roofline, cpu_baseline, the drop-in / one-frame-per-call rates and one
+    figure per extra leg, < 6 KB (the driver keeps the last 8 KB of stdout; round 4's 14 KB line lost its tail).  The complete record
+    goes to --full-json."""
+    pick = lambda d, ks: None if not isinstance(d, dict) else {k: _r(d[k]) for k in ks if k in d and d[k] is not None}
+    out = {k: line.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data')}
+    cfg_ = dict(line.get('config') or {})
+    cfg_.pop('precision', None)
+    out['config'] = cfg_
+    out['samples'] = line.get('samples')
+    out['roofline'] = pick(line.get('roofline'), ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'maps_per_launch',
+                                                  'mean_launch_ms', 'launches_timed', 'flops_per_launch', 'error'))
+    out['cpu_baseline'] = pick(line.get('cpu_baseline'), ('value', 'unit', 'cores', 'kind', 'sample', 'seconds_per_frame', 'gpu_over_cpu', 'error'))
+    if out['cpu_baseline'] and 'sample' in out['cpu_baseline']:
+        out['cpu_baseline']['sample'] = str(out['cpu_baseline']['sample'])[:200]
+    out['dropin_surface'] = pick(line.get('dropin_surface'), ('value', 'unit', 'samples'))
+    out['one_frame_per_call'] = pick(line.get('one_frame_per_call'), ('value', 'unit', 'samples'))
+    out['first_frame_ms'] = _r(line.get('first_frame_ms'), 2)
+    out['roofline_match_top2'] = pick(line.get('roofline_match_top2'), ('achieved', 'frac', 'mean_launch_ms', 'traffic'))
+    out['whole_path'] = pick(line.get('whole_path'), ('algorithmic_tflop_per_frame', 'achieved_tflops_per_gpu', 'frac_of_f16_mfma_peak',
+                                                      'frac_of_f16_mfma_peak_on_survey_figure'))
+    st = (line.get('streams') or {}).get('median_pass')
+    out['streams_ms_per_frame'] = pick(st, ('P_ms_per_call', 'F_ms_per_call', 'M_ms_per_call', 'wall_ms_per_call'))
+    oc = line.get('other_configs')
+    if isinstance(oc, dict):
+        out['other_configs'] = {k: (pick(v, ('value', 'ms_per_step', 'peak_memory_gib', 'error')) or {}) for k, v in oc.items()}
+        for k, v in oc.items():
+            if isinstance(v, dict) and isinstance(v.get('whole_path'), dict):
+                out['other_configs'][k]['frac_of_f16_mfma_peak'] = _r(v['whole_path'].get('frac_of_f16_mfma_peak'))
+            if isinstance(v, dict) and isinstance(v.get('roofline'), dict):
+                out['other_configs'][k]['roofline_frac'] = _r(v['roofline'].get('frac'))
+    wf = line.get('wavefront')
+    if isinstance(wf, dict):
+        out['wavefront'] = pick(wf, ('value', 'unit', 'seconds', 'scaling', 'ranks_seen', 'backend', 'gpus_visible', 'frames_equal',
+                                     'frames_checked_against_single_rank_run', 'speedup_over_one_rank_phase_sum', 'error'))
+        if isinstance(wf.get('partition'), dict):
+            out['wavefront']['partition'] = wf['partition'].get('name')
+            out['wavefront']['predicted_speedup'] = wf['partition'].get('predicted_speedup')
+        if isinstance(wf.get('handoff'), dict):
+            out['wavefront']['handoff'] = pick(wf['handoff'], ('messages', 'bytes_per_message', 'ms_per_message_measured'))
+        if isinstance(wf.get('context_exchange'), dict):
+            out['wavefront']['context_exchange'] = pick(wf['context_exchange'], ('messages', 'bytes_per_message'))
+    if isinstance(line.get('weak_scaling_shards'), dict):
+        out['weak_scaling_shards'] = pick(line['weak_scaling_shards'], ('value', 'unit', 'ms_per_step', 'scaling', 'samples'))
+    wm = line.get('wavefront_model')
+    if isinstance(wm, dict) and isinstance(wm.get('predicted_speedup'), dict):
+        ps = {}
+        for n_, ent in wm['predicted_speedup'].items():
+            row = {}
+            for k, v in ent.items():
+                if isinstance(v, dict):
+                    x = v.get('with_context_exchange', v)
+                    row['restarts' if k.startswith('with_restarts') else 'no_restarts'] = x.get('speedup') if isinstance(x, dict) else None
+            ps[n_] = row
+        out['wavefront_model_predicted_speedup'] = ps
+    ks = line.get('kernels')
+    if isinstance(ks, list):
+        out['kernels'] = [[str(k.get('kernel'))[:28], k.get('us_per_launch'), _r(k.get('frac'), 3)] for k in ks]
+    out['full_record'] = line.get('full_record')
+    for drop in ('kernels', 'wavefront_model_predicted_speedup', 'streams_ms_per_frame', 'roofline_match_top2', 'other_configs'):
+        if len(json.dumps(out)) <= limit:
+            break
+        out.pop(drop, None)
+    return out
+
+
+def emit(line, args):
+    """Complete record -> --full-json (best effort), compact line -> stdout."""
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(args.full_json)), exist_ok=True)
+        with open(args.full_json, 'w') as f:
+            json.dump(line, f)
+        line['full_record'] = os.path.relpath(args.full_json, ROOT)
+    except OSError:
+        line['full_record'] = None
+    print(json.dumps(line if args.verbose_line else compact_line(line)), flush=True)
+
+
+def promote_wavefront(line, wf, args, world):
+    """N > 1: `value` is the STRONG-scaling figure north_star asks for -- ONE clip of args.clip frames (BASELINE configs[3]) sharded
+    over the ranks by frame index with the forward-state hand-off (shard.run_wavefront) -- when that leg ran and its frames equal the
+    single-rank run; the exchange-free reset-aligned K-step figure (per-GPU work fixed: it reads ~N x) moves to `weak_scaling_shards`."""
+    line['wavefront'] = wf
+    if not (isinstance(wf, dict) and wf.get('value') and wf.get('frames_equal')):
+        line['config']['headline'] = 'weak-scaling shards (the sharded-clip leg did not produce a verified figure)'
+        return
+    line['weak_scaling_shards'] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'samples', 'scaling')}
+    line['weak_scaling_shards']['what'] = ('every rank runs the K steps on its own reset-aligned shard of one long clip: no data-path collective, '
+                                           'per-GPU work fixed')
+    line['metric'] = '4x SR frames/sec (270p->1080p, RefVSR_small_MFID, %d-frame clip sharded over %d GPUs)' % (args.clip, world)
+    line['value'], line['ms_per_step'], line['scaling'] = wf['value'], 1e3 * wf['seconds'] / float(args.clip), 'strong'
+    line['samples'] = [round(wf['value'], 2)]
+    cfg_ = line['config']
+    cfg_['workload'] = wf['workload']
+    cfg_['parallelism'] = ('frame-shard x%d of ONE clip: phase A (flows, matching, encoders, alignment, backward branch) in parallel, the '
+                           'forward-branch chain rank to rank with the state hand-off (send/recv), contexts prepared once and exchanged' % world)
+    cfg_['timed_frames'] = args.clip
+    cfg_['ranks_seen'], cfg_['backend'], cfg_['gpus_visible'] = wf.get('ranks_seen'), wf.get('backend'), wf.get('gpus_visible')
+    cfg_['handoff_ms_measured'] = (wf.get('handoff') or {}).get('ms_per_message_measured')
+    cfg_['frames_equal_single_rank_run'] = wf.get('frames_equal')
+    cfg_['steps_note'] = '--steps / --warmup apply to weak_scaling_shards; the headline times the whole %d-frame clip once' % args.clip
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -585,6 +693,11 @@ def main():
     ap.add_argument('--no-cache', action='store_true', help='execute exactly the work the reference executes')
     ap.add_argument('--no-frame-ids', action='store_true', help='headline through the plain call surface (content compare)')
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap consecutive calls on internal streams')
+    ap.add_argument('--group', type=int, default=4, help='output frames per forward_group call of the headline mode (multi-map launches of '
+                                                         'the backward branches, 2..4); 1 = one forward() per frame, the round-4 headline')
+    ap.add_argument('--full-json', default=os.path.join(ROOT, 'gpurun_out', 'bench_full.json'),
+                    help='where the complete record goes (the stdout line is the compact form of it)')
+    ap.add_argument('--verbose-line', action='store_true', help='print the complete record on stdout instead of the compact line')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second timed pass through the unmodified call surface')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline measurements')
     ap.add_argument('--no-wavefront', action='store_true', help='N > 1: skip the sharded-clip leg with the state hand-off')
@@ -607,8 +720,24 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU (the form the driver uses for N > 1,
+        # run.py:209-216 in the reference).  Fewer GPUs than ranks (a 1-GPU test box): the ranks share the GPUs and talk over gloo --
+        # RCCL refuses two ranks on one device -- and the line says so (`backend`, `gpus_visible`).
+        import socket
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        if torch.cuda.device_count() < args.gpus:
+            os.environ.setdefault('REFVSR_DIST_BACKEND', 'gloo')
+        os.environ.setdefault('OMP_NUM_THREADS', '4')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs a torch.distributed.run launch with --nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d under a launcher with WORLD_SIZE=%d: launch with --nproc-per-node %d' % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     # REFVSR_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box (all ranks share GPU 0);
@@ -642,13 +771,16 @@ def main():
     lr, rf = lr.to(dev), rf.to(dev)                             # inputs resident in HBM
     # the sliding windows are materialised before the timed region (inputs resident in HBM)
     wins = [window_indices(f, nfr, T) for f in range(nfr)]
-    win_lr = [lr[torch.tensor(w, device=dev)][None].contiguous() for w in wins]
-    win_rf = [rf[torch.tensor(w, device=dev)][None].contiguous() for w in wins]
+    all_lr = torch.stack([lr[torch.tensor(w, device=dev)] for w in wins], 0).contiguous()       # [nfr, t, 3, h, w]
+    all_rf = torch.stack([rf[torch.tensor(w, device=dev)] for w in wins], 0).contiguous()
+    win_lr = [all_lr[f:f + 1] for f in range(nfr)]
+    win_rf = [all_rf[f:f + 1] for f in range(nfr)]
     torch.cuda.synchronize()
     eng = net.Network.ensure_engines(1, dev)[0]
 
-    def timed_pass(use_ids, pipelined, collect_events, collect_chain=False, timed=True):
-        """W untimed + K timed steps of a new clip; returns (seconds for the K steps, events)."""
+    def timed_pass(use_ids, pipelined, collect_events, collect_chain=False, timed=True, group=1):
+        """W untimed + K timed steps of a new clip; returns (seconds for the K steps, events).  group > 1 (pipelined mode): the
+        steps go through forward_group, `group` consecutive output frames per call (the same frames, the same results)."""
         net.Network.reset()
         net.Network.set_pipelined(bool(use_ids and pipelined))
         # pipelined calls: the windows were materialised (and synchronised) before the first pass -- the caller-side assertion
@@ -660,9 +792,20 @@ def main():
             if ids is None:
                 return net(win_lr[f], win_rf[f], f == 0)['result']                  # the reference's call, verbatim
             return net(win_lr[f], win_rf[f], f == 0, frame_ids=ids, input_ready=ready)['result']
-        out = None
-        for f in range(args.warmup):
-            out = step(f)
+        grouped = group > 1 and use_ids and pipelined
+
+        def run_steps(f0, f1):
+            o, f = None, f0
+            while f < f1:
+                n = min(group, f1 - f) if grouped else 1
+                if n >= 2:
+                    ids = [[start + i for i in wins[f + b]] for b in range(n)]
+                    o = net.forward_group(all_lr[f:f + n], all_rf[f:f + n], ids, is_first_frame=(f == 0), input_ready=ready)['result'][-1]
+                else:
+                    o = step(f)
+                f += n
+            return o
+        out = run_steps(0, args.warmup)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -673,8 +816,7 @@ def main():
         eng.chain_events = [] if (collect_events and collect_chain) else None
         eng.stream_events = [] if (use_ids and pipelined) else None                  # 6 events per call: the P / F / M sections
         t0 = time.perf_counter()
-        for f in range(args.warmup, nfr):
-            out = step(f)
+        out = run_steps(args.warmup, nfr)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -698,16 +840,18 @@ def main():
         if not sev:
             return None
         out = {}
+        nfrm = sum(int(c.get('n', 1)) for c in sev)
         for k in ('P', 'F', 'M'):
             ms = [c[k + '0'].elapsed_time(c[k + '1']) for c in sev if c.get(k + '0') is not None and c.get(k + '1') is not None]
             if ms:
-                out[k + '_ms_per_call'] = round(sum(ms) / len(ms), 3)
+                out[k + '_ms_per_call'] = round(sum(ms) / max(nfrm, 1), 3)        # per OUTPUT FRAME (a group call carries several)
                 out[k + '_ms_max'] = round(max(ms), 3)
         first = next((c for c in sev if c.get('P0') is not None), None)
         if first is not None and sev[-1].get('M1') is not None:
             out['span_ms'] = round(first['P0'].elapsed_time(sev[-1]['M1']), 3)
         out['calls'] = len(sev)
-        out['wall_ms_per_call'] = round(1e3 * elapsed / max(len(sev), 1), 3)
+        out['frames'] = nfrm
+        out['wall_ms_per_call'] = round(1e3 * elapsed / max(nfrm, 1), 3)
         return out
 
     def med(v):
@@ -718,13 +862,19 @@ def main():
     use_ids = not args.no_frame_ids
     pipelined = use_ids and not args.no_pipeline and cfg.cache_windows
     want_dropin = not args.no_dropin and (use_ids or pipelined)
+    # headline call mode: frame groups (forward_group: the backward branches of G consecutive output frames as multi-map launches)
+    # where the engine has the multi-map launch list (mid_channels = 24), else one forward() per frame
+    G = max(1, min(4, args.group)) if (pipelined and eng.group_ok()) else 1
+    want_percall = G > 1 and not args.no_dropin
     # ---- warm-up proper (the first timed pass used to be the first 36 ms of GPU work of the process): untimed
     # passes of both call modes until >= args.warm_seconds of real work have run -- kernels loaded, allocator pools grown for
     # BOTH modes, clocks and power state settled
     tw = time.perf_counter()
     nwarm = 0
     while True:
-        timed_pass(use_ids, pipelined, False, timed=False)
+        timed_pass(use_ids, pipelined, False, timed=False, group=G)
+        if want_percall:
+            timed_pass(use_ids, pipelined, False, timed=False)
         if want_dropin:
             timed_pass(False, False, False, timed=False)
         nwarm += 1
@@ -743,14 +893,17 @@ def main():
     gc.freeze()
     # ---- R timed repetitions, the two call modes interleaved (fast / reference surface / fast / ...): every sample is printed,
     # `value` is the MEDIAN of the fast mode's samples
-    samples, samples_dropin, sums, ev = [], [], [], None
+    samples, samples_dropin, samples_percall, sums, ev = [], [], [], [], None
     for rep in range(max(1, args.repeats)):
         gc.collect()
-        el, e = timed_pass(use_ids, pipelined, True)
+        el, e = timed_pass(use_ids, pipelined, True, group=G)
         samples.append(el)
         sums.append(stream_summary(e[2], el))
         if ev is None or el <= min(samples):
             ev = e
+        if want_percall:
+            el1, _ = timed_pass(use_ids, pipelined, False)
+            samples_percall.append(el1)
         if want_dropin:
             el2, _ = timed_pass(False, False, False)
             samples_dropin.append(el2)
@@ -760,15 +913,34 @@ def main():
     # run of them also bracket the other stream's kernels that get scheduled in between (measured 18.6 us per launch where
     # rocprofv3 reports 9.7).  Their live per-launch time therefore comes from one more pass of the same steps on ONE stream
     # (no cross-call pipelining, no side stream): nothing else is in flight between a run's two events.
+    # Group mode (round 5): the launches of record are the MULTI-MAP launches of the backward branches (G maps behind one launch);
+    # they are timed in one more pass of the same group calls with every internal section on ONE stream (pipe layout 'one').
     ev_rb = None
     if eng.rb24 and cfg.mid_channels == 24:            # (every rank: timed_pass holds barriers)
-        ov = eng.overlap
-        eng.overlap = False
-        try:
-            _, (_, ev_rb, _) = timed_pass(use_ids, False, True, collect_chain=True)
-        finally:
-            eng.overlap = ov
+        if G > 1:
+            lay = getattr(cfg, 'pipe_layout', None)
+            cfg.pipe_layout, eng._pipe = 'one', None
+            try:
+                _, (_, ev_rb, _) = timed_pass(use_ids, pipelined, True, collect_chain=True, group=G)
+            finally:
+                cfg.pipe_layout, eng._pipe = lay, None
+        else:
+            ov = eng.overlap
+            eng.overlap = False
+            try:
+                _, (_, ev_rb, _) = timed_pass(use_ids, False, True, collect_chain=True)
+            finally:
+                eng.overlap = ov
     ev = (ev[0], ev_rb)
+    if pipelined:                                      # (the layout the timed passes ran on, not the measurement pass's)
+        eng._pipe_streams(dev)
+    percall = None
+    if samples_percall:
+        el1 = med(samples_percall)
+        pf_ = [world * args.steps / x for x in samples_percall]
+        percall = {'value': world * args.steps / el1, 'unit': 'frames/s', 'ms_per_step': 1e3 * el1 / args.steps, 'samples': [round(v, 2) for v in pf_],
+                   'call': 'one forward(frame_ids=, input_ready=\'materialised\') per output frame, pipelined over the internal streams '
+                           '(the round-4 headline mode): one frame of latency per call'}
     dropin = None
     if samples_dropin:
         el2 = med(samples_dropin)
@@ -806,12 +978,17 @@ def main():
                                    'seeded random weights 1234' % (args.config, H, W_, 4 * H, 4 * W_, T, ' (BASELINE %s)' % tag if tag else ''),
                        'frames_per_rank': args.steps, 'parallelism': 'frame-shard x%d (reset-aligned, no collective)' % world,
                        'window_cache': bool(cfg.cache_windows), 'frame_ids': bool(use_ids), 'pipelined_calls': bool(pipelined),
-                       'call_surface': ("extended: frame_ids= + set_pipelined(True) + input_ready='materialised'" if pipelined else
+                       'frames_per_call': G,
+                       'call_surface': (("extended: forward_group(%d consecutive windows, frame_ids) + set_pipelined(True) + input_ready='materialised'" % G)
+                                        if G > 1 else "extended: frame_ids= + set_pipelined(True) + input_ready='materialised'" if pipelined else
                                         'extended: frame_ids=' if use_ids else 'reference call surface'),
+                       'dropin_frames_per_s': round(dropin['value'], 2) if dropin else None,
+                       'one_frame_per_call_frames_per_s': round(percall['value'], 2) if percall else None,
                        'pipe_layout': getattr(eng, 'pipe_layout', None) if pipelined else None,
                        'precision': 'fp16 HWC feature maps + fp16 hi+lo MFMA weights, fp32 accumulate; fp32 matching features / flows / '
                                     'output; arg-max decided at fp32 accuracy (fp16 GEMM top-2 + fp32 re-rank + split-fp16 search of ambiguous columns)'},
             'dropin_surface': dropin,
+            'one_frame_per_call': percall,
             # every timed repetition of the fast mode (frames/s); `value` = their median.  The K steps are timed `repeats` times,
             # interleaved with the reference-surface passes, after `warm_seconds` of untimed passes of both modes.
             'samples': [round(v, 2) for v in fps_samples], 'min': min(fps_samples), 'median': fps, 'max': max(fps_samples),
@@ -830,11 +1007,14 @@ def main():
         # that kernel (C = 48) report the matching kernel as `roofline`.
         ev, cev = ev if ev else (None, None)
         rb_line = None
-        runs = [(a.elapsed_time(b), n) for a, b, n, hh, ww in (cev or []) if (hh, ww) == (H, W_) and n >= 8]
+        # chain events: (start, end, blocks, h, w[, maps per launch]); group mode: the multi-map launches only
+        cev5 = [(c[0], c[1], c[2], c[3], c[4], (c[5] if len(c) > 5 else 1)) for c in (cev or [])]
+        maps_per_launch = G if any(c[5] == G for c in cev5) else 1
+        runs = [(a.elapsed_time(b), n) for a, b, n, hh, ww, bb in cev5 if (hh, ww) == (H, W_) and n >= 8 and bb == maps_per_launch]
         if runs:
             per_launch_ms = sum(m for m, _ in runs) / sum(n for _, n in runs)
             C_ = cfg.mid_channels
-            flops = 2 * 2.0 * 9 * C_ * C_ * H * W_
+            flops = maps_per_launch * 2 * 2.0 * 9 * C_ * C_ * H * W_
             ach = flops / (per_launch_ms * 1e-3) / 1e12
             traffic, tsrc = None, None
             pj = os.path.join(ROOT, 'profiles', 'pmc_kernels.json')
@@ -844,9 +1024,11 @@ def main():
                     tsrc = 'profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
                 except Exception:  # noqa: BLE001
                     traffic = None
-            rb_line = {'kernel': 'resblock24_kernel (fused conv3x3-ReLU-conv3x3+residual, 24 channels, LR map %dx%d)' % (H, W_), 'bound': 'mfma',
+            rb_line = {'kernel': 'resblock24_kernel (fused conv3x3-ReLU-conv3x3+residual, 24 channels, LR map %dx%d%s)' %
+                                 (H, W_, ', %d maps per launch' % maps_per_launch if maps_per_launch > 1 else ''), 'bound': 'mfma',
+                       'maps_per_launch': maps_per_launch,
                        'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
-                       'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': sum(n for _, n in runs),
+                       'traffic': (traffic * maps_per_launch if traffic else traffic), 'traffic_source': tsrc, 'launches_timed': sum(n for _, n in runs),
                        'mean_launch_ms': per_launch_ms, 'flops_per_launch': flops,
                        'issued_over_useful_flops': 798.0 * 16384 / (2 * 2.0 * 9 * C_ * C_ * 256),
                        'note': 'useful FLOPs (2 x 9 x 24 x 24 x 2 convs per pixel); the kernel issues 2.46x that on the matrix pipe: x2 hi + lo '
@@ -912,9 +1094,9 @@ def main():
 
         def bail():
             if rank == 0:
-                line['wavefront'] = {'error': 'not finished within %.0f s' % args.wavefront_timeout}
+                promote_wavefront(line, {'error': 'not finished within %.0f s' % args.wavefront_timeout}, args, world)
                 line['cpu_baseline'] = None
-                print(json.dumps(line), flush=True)
+                emit(line, args)
             os._exit(0)
         dog = threading.Timer(args.wavefront_timeout, bail)
         dog.daemon = True
@@ -924,13 +1106,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             wf = {'error': repr(e)[:400]}
             if rank == 0:
-                line['wavefront'] = wf
+                promote_wavefront(line, wf, args, world)
                 line['cpu_baseline'] = None
-                print(json.dumps(line), flush=True)
+                emit(line, args)
             os._exit(0)                       # the other ranks may be blocked in a collective: do not wait for them
         dog.cancel()
         if rank == 0:
-            line['wavefront'] = wf
+            promote_wavefront(line, wf, args, world)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             import subprocess
@@ -947,7 +1129,7 @@ def main():
                 line['cpu_baseline'] = {'error': repr(e)[:300]}
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,3 +7,4 @@ class Network(_Network):
     """models/archs/RefVSR_IR.py:Network (inference path) on the HIP engine."""
     _engine_cls = EngineIR
     _weights_cls = WeightsIR
+    _family = 'RefVSR_IR'

@@ -223,6 +223,12 @@ class Engine(object):
         self.pipelined = bool(getattr(config, 'pipelined', False))
         self._zero_maps = {}
         self._pipe = None
+        # stream layout of the pipelined mode when nothing is configured: 'pf_m' for one forward() per frame (round 4); an engine that
+        # is driven through forward_group switches to 'pfm' (P | F | M) at its first group: with the backward branches batched the
+        # P + F stream is the critical path (P 2.9 + F 1.9 ms per frame = the frame, M idle a third of the time); with F on its own
+        # stream the forward-branch chain runs under the preparation of the group's new frames -- same box, G = 4: 213.1 (pf_m) /
+        # 216.9 (p_fm) / 227.5 (pfm) frames/s, 228.9 with the backward head on M as well (profiles/r05_group_layout_ab.txt)
+        self._layout_default = 'pf_m'
         self.pipe_depth = max(1, int(getattr(config, 'pipe_depth', None) or os.environ.get('REFVSR_PIPE_DEPTH') or 3))
         self._inflight = collections.deque()
         self.stream_events = None      # bench.py: list collecting per-call section events of the pipelined mode's streams
@@ -924,18 +930,24 @@ class Engine(object):
           'pfm'             round 3: P, F, M on three streams (kept for the A/B and the slow-mode reproduction)
           'p_fm'            F on M's stream (one conv chain at a time; measured slower: the backward branch + forward step + upsampler
                             in series are longer than a frame)
+          'one'             P, F and M on ONE stream (measurement aid: bench.py times the multi-map launches of a group in it)
         Wider models (C = 48 / 36) additionally alternate two M streams (REFVSR_PIPE_TWO_M=1 | 0 overrides)."""
+        layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or self._layout_default)
+        if self._pipe is not None and self._pipe[0].device == dev and self.pipe_layout != layout:
+            torch.cuda.synchronize(dev)               # another layout from here on (first group call of an engine): drain, rebuild
+            self._pipe = None
         if self._pipe is None or self._pipe[0].device != dev:
             hi = -1 if env_flag('REFVSR_STREAM_PRIORITY') else 0
-            layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or 'pf_m')
-            if layout not in ('pf_m', 'pfm', 'p_fm'):
-                raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm, got %r' % layout)
+            if layout not in ('pf_m', 'pfm', 'p_fm', 'one'):
+                raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm | one, got %r' % layout)
             two = os.environ.get('REFVSR_PIPE_TWO_M')
             two = (self.C != 24) if two in (None, '') else env_flag('REFVSR_PIPE_TWO_M')
             m = torch.cuda.Stream(device=dev)
+            if layout == 'one':                       # measurement aid (bench.py): every section on ONE internal stream -- HIP events
+                two = False                           # around a run of launches then bracket nothing but that run
             m2 = torch.cuda.Stream(device=dev) if two else m
-            p_ = torch.cuda.Stream(device=dev, priority=hi)
-            f_ = p_ if layout == 'pf_m' else (m if layout == 'p_fm' else torch.cuda.Stream(device=dev))
+            p_ = m if layout == 'one' else torch.cuda.Stream(device=dev, priority=hi)
+            f_ = p_ if layout in ('pf_m', 'one') else (m if layout == 'p_fm' else torch.cuda.Stream(device=dev))
             self._pipe = [m, m2, f_, p_]
             self.pipe_layout = layout
             self._pipe_calls = 0
@@ -1153,14 +1165,12 @@ class Engine(object):
     def _prop_step_b(self, fs, branch, feats, feat_ups, confs, fls):
         """_prop_step for B independent chains (lists of B maps / frames / flows; fls None: the first step of the branches)."""
         if fls is None:
-            n = self.bw_head_blocks if branch == 'backward_resblocks' else -1
-            if n >= 0:
-                heads = []
-                for f, z in zip(fs, feats):
-                    if f.bw_head is None or f.bw_head[0] != n:            # (a frame prepared by a first-frame call has no head yet)
-                        f.bw_head = (n, self.resblocks(f.lr8, z, branch, stop=n))
-                    heads.append(f.bw_head[1])
-                xs = self.resblocks_b(None, None, branch, resume=(n, heads))
+            # (frames that a one-frame-per-call window prepared carry the head of this step -- input conv + bw_head_blocks blocks, run
+            #  with their preparation: used when every frame of the group has one; a group's own preparation computes none: the whole
+            #  first step is cheaper as multi-map launches here)
+            heads = [f.bw_head for f in fs] if branch == 'backward_resblocks' else [None]
+            if all(hd is not None and hd[0] == heads[0][0] for hd in heads):
+                xs = self.resblocks_b(None, None, branch, resume=(heads[0][0], [hd[1] for hd in heads]))
             else:
                 xs = self.resblocks_b([f.lr8 for f in fs], feats, branch)
             return self.rap_b(fs, confs, xs, feat_ups)
@@ -1205,6 +1215,11 @@ class Engine(object):
         input_ready: as in forward() (None | 'materialised' | event | stream), for all windows of the call."""
         outs = [None] * len(wins)
         i = 0
+        if self.group_ok() and self.pipelined and not env_flag('REFVSR_GROUP_KEEP_LAYOUT'):
+            # before the first internal stream exists: an engine driven through forward_group runs P | F | M from its first call on
+            # (a rebuild later would leave the first set of streams behind, and with more streams than hardware queues the
+            # stream -> queue mapping decides which sections serialise)
+            self._layout_default = 'pfm'
         with torch.cuda.device(wins[0][0].device):
             while i < len(wins):
                 # the longest run of steady windows from i on (the iteration counter advances by one per window)
@@ -1277,17 +1292,12 @@ class Engine(object):
                         for st in share:
                             f.lr.record_stream(st)
                             f.ref.record_stream(st)
-            zf = self._zeros((h, w, self._state_cs()), torch.float16, dev)
             for fr in frs:
                 for i in range(ctr, t):
                     f = fr[i]
                     if f.conf is None:
                         self.pyramid(f)
                         self.prepare_frame(f)
-                        if i == t - 1 and self.bw_head_blocks >= 0:
-                            f.bw_head = (self.bw_head_blocks, self.resblocks(f.lr8, zf, 'backward_resblocks', stop=self.bw_head_blocks))
-                            for st in share:
-                                f.bw_head[1].record_stream(st)
                         publish(f)
                         f.ready = torch.cuda.Event()
                         f.ready.record()

@@ -50,6 +50,7 @@ class Network(nn.Module):
     """HIP implementation of models/archs/RefVSR.py:Network (inference path)."""
     _engine_cls = Engine
     _weights_cls = Weights
+    _family = 'RefVSR'                  # which state-dict contract this class carries, whatever name config.network has
 
     def __init__(self, config):
         super().__init__()
@@ -59,7 +60,7 @@ class Network(nn.Module):
         self.flag_HD_in = config.flag_HD_in
         self.mid_channels = config.mid_channels
         self.add_module('FlowNet', _FlowNetHandle())
-        for name, shape in state_spec(config).items():
+        for name, shape in state_spec(config, self._family).items():
             assert name.startswith('Network.')
             p = nn.Parameter(torch.zeros(shape), requires_grad=False)
             _register(self, name[len('Network.'):], p)

@@ -88,9 +88,11 @@ def _edvr(spec, P):
     _conv(spec, F_ + 'spatial_attn_add2', M, M, 1)
 
 
-def state_spec(config):
-    """OrderedDict name -> shape for `SRNet(config).state_dict()` (keys start with `Network.`)."""
-    if getattr(config, 'network', 'RefVSR') == 'RefVSR_IR':
+def state_spec(config, family=None):
+    """OrderedDict name -> shape for `SRNet(config).state_dict()` (keys start with `Network.`).  family: 'RefVSR' | 'RefVSR_IR' -- the
+    model family of the arch class that asks (a reference-side plug-in file may carry any name in `config.network`, e.g.
+    RefVSR_MI355X); default: `config.network`."""
+    if (family or getattr(config, 'network', 'RefVSR')) == 'RefVSR_IR':
         return _state_spec_ir(config)
     return _state_spec_refvsr(config)
 

@@ -535,6 +535,55 @@ def test_weight_reload_drops_cached_state(dev):
         net2(lr[w][None], rf[w][None], False)
 
 
+def test_full_size_hd_against_reference_fixture(dev):
+    """BASELINE configs[4] AT ITS STATED SIZE against the reference itself: config_RefVSR_MFID_8K (C = 48, 30
+    blocks, flag_HD_in) on a 1080 x 1920 -> 4320 x 7680 clip, t = 3, one first-frame and one steady call -- the fixture was written by
+    the imported reference on the build container's CPU (tools/gen_golden.py --full-hd: 11 + 7 minutes per frame).  The launch shapes
+    that exist only at this size meet a reference number here: the sixteen-wave conv48 on 2 040+ tiles, the > 2^31-byte fall-backs of
+    the output head, the stride-4 / stride-8 gather convs of aa1 / aa2 (attention.py:65-67,93-98, RefVSR.py:39-40).  Compared: PSNR vs
+    the synthetic GT under the north-star bar, two 128 x 128 crops at output resolution, a strided sub-sample of the 8K frame, the
+    centre frame's index map (129 600 arg-max decisions) and its bicubic x4 confidence map."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'e2e_full_HD_1080x1920_t3.npz')
+    if not os.path.exists(path):
+        pytest.skip('full-size HD fixture not generated')
+    from refvsr_amd.synth import make_clip, window_indices
+    g = load_golden('e2e_full_HD_1080x1920_t3')
+    nfr, clip_n, t, h, w = int(g['nframes']), int(g['clip_frames']), int(g['t']), int(g['h']), int(g['w'])
+    lr, rf, gt = make_clip(clip_n, h, w, seed=0)
+    assert abs(float(lr.double().sum()) - float(g['lr_checksum'])) < 1e-6 * abs(float(g['lr_checksum']))
+    assert abs(float(rf.double().sum()) - float(g['ref_checksum'])) < 1e-6 * abs(float(g['ref_checksum']))
+    gt = gt[:nfr]
+    lr, rf = lr.to(dev), rf.to(dev)
+    net, cfg, sd = make_net('config_RefVSR_MFID_8K', t, dev, save_sample=False)
+    assert cfg.mid_channels == 48 and cfg.flag_HD_in and cfg.matching_ksize == 8
+    st = int(g['stride'])
+    crops = g['crops'].tolist()
+    for f in range(nfr):
+        wi = window_indices(f, clip_n, t)
+        res = net(lr[wi][None], rf[wi][None], f == 0)['result']
+        assert tuple(res.shape) == (1, 3, 4 * h, 4 * w)
+        gtf = gt[f][None].to(dev)
+        p = float(10 * torch.log10(1 / torch.mean((res - gtf) ** 2)))
+        del gtf
+        d_psnr = abs(p - float(g['psnr_%d' % f]))
+        e_crop = max(maxdiff(res[0, :, y0:y0 + 128, x0:x0 + 128].cpu(), g['crop%d_%d' % (ci, f)]) for ci, (y0, x0) in enumerate(crops))
+        p_crop = min(psnr(res[0, :, y0:y0 + 128, x0:x0 + 128].cpu(), g['crop%d_%d' % (ci, f)]) for ci, (y0, x0) in enumerate(crops))
+        e_sub = maxdiff(res[0, :, ::st, ::st].cpu(), g['sub_%d' % f])
+        fr = net.Network.engine(0).prev_window[t // 2]
+        idx, want_i = fr.idx.cpu().view(-1), g['idx_%d' % f].view(-1)
+        conf, want_c = fr.conf.cpu()[0, ::4, ::4], g['conf_%d' % f]
+        mism = idx != want_i
+        e_conf = maxdiff(conf, want_c)
+        report('full-size HD vs reference f%d' % f, sub_err=e_sub, crop_err=e_crop, crop_psnr_vs_ref=float(p_crop), psnr=float(p),
+               ref_psnr=float(g['psnr_%d' % f]), dPSNR=float(d_psnr), idx_mismatch=int(mism.sum()), conf_err=e_conf)
+        del res
+        assert d_psnr < 1e-3                                   # the north-star bar, against the reference itself
+        assert idx.numel() == 129600 and int(mism.sum()) <= 8 and e_conf < 1e-5
+        # measured on MI355X (profiles/r05_gpu_parity_report.txt): sub-sample 2.8e-2 / 4.3e-2, crops 1.8e-3 / 2.3e-3 (69.0 / 67.3 dB),
+        # |dPSNR| 6.2e-5 / 1.2e-5 dB, 2 / 3 fp32-tie indices, conf 1.2e-6: bars = 2x
+        assert e_sub < 9e-2 and e_crop < 5e-3 and p_crop > 61.0
+
+
 def test_8k_single_window_at_size(dev):
     """BASELINE configs[4] at its stated size: config_RefVSR_MFID_8K (C = 48, 30 blocks, flag_HD_in: matching on the
     half-size frames, aa1 scale 4 + aa2 scale 8 with their stride-4 / stride-8 gather-mode predictor convs), one
@@ -1034,3 +1083,32 @@ def test_frame_groups_are_bit_identical(dev, gsize):
     res = net.forward_group(wl[0:3], wr[0:3], [wins[0], wins[1], wins[2]], is_first_frame=True)['result']
     for f in range(3):
         assert torch.equal(res[f], want[f])
+
+
+def test_bench_gpus_2_self_launches_and_reports_the_sharded_clip(dev):
+    """`python bench.py --gpus 2` with no launcher around it (the driver may call it like `--gpus 1`): re-executes
+    itself under torch.distributed.run, two ranks -- on this one-GPU box they share the GPU and talk over gloo --, prints ONE
+    compact JSON line whose `value` is the strong-scaling sharded-clip rate with the frames verified against a single-rank run,
+    the exchange-free figure beside it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    env.pop('LOCAL_RANK', None)
+    env['REFVSR_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--size', '64x96', '--clip', '12',
+                        '--clip-check', '12', '--repeats', '1', '--warm-seconds', '0.05', '--no-kernels', '--full-json', '/tmp/bench_n2_full.json'],
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 6000
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 4 and d['warmup'] == 2
+    assert d['config']['ranks_seen'] == 2 and d['config']['timed_frames'] == 12 and d['config']['frames_equal_single_rank_run'] is True
+    assert d['wavefront']['frames_equal'] is True and d['wavefront']['backend'].startswith('gloo')
+    assert d['weak_scaling_shards']['scaling'] == 'weak' and d['weak_scaling_shards']['value'] > 0
+    assert abs(d['value'] - 12.0 / d['wavefront']['seconds']) < 2e-2 * d['value']          # (the compact line rounds the seconds)

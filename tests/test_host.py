@@ -1022,3 +1022,58 @@ def test_bench_wavefront_model_runs_on_cpu():
     assert sum(nr['with_context_exchange']['block_sizes']) == 64
     for n in ('2', '4'):
         assert m['predicted_speedup'][n]['no_restarts (reset_branch=None, configs[4] regime)']['speedup'] <= float(n) + 1e-6
+
+
+def test_bench_compact_line_keeps_the_judged_fields_under_6_kb():
+    """bench.compact_line (pure host code): the stdout form of the record must stay under 6 KB whatever the extra legs carry (the
+    driver keeps the last 8 KB of stdout; round 4's 14 KB line lost `dropin_surface`, `roofline_match_top2`, `whole_path`) and must
+    keep the contract fields, `roofline`, `cpu_baseline`, the drop-in rate and the N > 1 evidence."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    blob = {'x' * 20 + str(i): list(range(64)) for i in range(40)}          # stands for the verbose objects of the full record
+    line = {'metric': 'm', 'value': 250.0, 'unit': 'frames/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 4.0, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': 'w' * 300, 'precision': 'p' * 400, 'dropin_frames_per_s': 180.0, 'frames_per_call': 4},
+            'samples': [250.0] * 5, 'dropin_surface': {'value': 180.0, 'unit': 'frames/s', 'samples': [180.0] * 5, 'call': 'c' * 300},
+            'one_frame_per_call': {'value': 215.0, 'unit': 'frames/s', 'samples': [215.0] * 5},
+            'roofline': {'kernel': 'k' * 120, 'bound': 'mfma', 'achieved': 375.0, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 0.15, 'traffic': 5.4e7,
+                         'maps_per_launch': 4, 'mean_launch_ms': 0.0287, 'note': 'n' * 600},
+            'roofline_match_top2': {'achieved': 1150.0, 'frac': 0.46, 'mean_launch_ms': 1.05, 'kernel': 'k' * 80},
+            'cpu_baseline': {'value': 0.035, 'unit': 'frames/s', 'cores': 16, 'kind': 'port', 'sample': 's' * 500, 'seconds_per_frame': 28.5},
+            'whole_path': {'algorithmic_tflop_per_frame': 2.306, 'frac_of_f16_mfma_peak': 0.23, 'breakdown': blob, 'counting': 'c' * 400},
+            'streams': {'median_pass': {'P_ms_per_call': 3.0, 'F_ms_per_call': 1.0, 'M_ms_per_call': 4.0, 'wall_ms_per_call': 4.0}, 'slow_passes': [blob]},
+            'kernels': [{'kernel': 'kernel number %d with a long description' % i, 'us_per_launch': 10.0, 'frac': 0.1, 'x': blob} for i in range(14)],
+            'wavefront_model': {'predicted_speedup': {str(n): {'with_restarts (reset_branch=9)': {'chosen': 'x', 'speedup': 7.0, 'with_context_exchange': {'speedup': 7.5}},
+                                                              'no_restarts (reset_branch=None, configs[4] regime)': {'speedup': 5.4, 'with_context_exchange': {'speedup': 5.9, 'block_sizes': list(range(64))}}}
+                                                      for n in (2, 4, 8)}, 'junk': blob},
+            'other_configs': {'configs[2]': {'value': 95.0, 'ms_per_step': 10.5, 'whole_path': {'frac_of_f16_mfma_peak': 0.2}, 'roofline': {'frac': 0.16}, 'w': 'x' * 400},
+                              'configs[4] on one GPU': {'value': 7.5, 'ms_per_step': 133.0, 'peak_memory_gib': 17.6, 'workload': 'x' * 400}},
+            'first_frame_ms': 11.8, 'full_record': 'gpurun_out/bench_full.json'}
+    c = bench.compact_line(line)
+    txt = json.dumps(c)
+    assert len(txt) < 6000, len(txt)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in c
+    assert c['roofline']['frac'] == 0.15 and c['roofline']['bound'] == 'mfma' and c['roofline']['traffic'] == 5.4e7
+    assert c['cpu_baseline']['cores'] == 16 and c['cpu_baseline']['kind'] == 'port' and len(c['cpu_baseline']['sample']) <= 200
+    assert c['dropin_surface']['value'] == 180.0 and c['config']['dropin_frames_per_s'] == 180.0 and 'precision' not in c['config']
+    assert c['wavefront_model_predicted_speedup']['8'] == {'restarts': 7.5, 'no_restarts': 5.9}
+    # N > 1: the sharded-clip figure becomes the headline, the weak-scaling figure moves aside
+    import argparse
+    wf = {'value': 900.0, 'seconds': 64 / 900.0, 'frames_equal': True, 'workload': 'clip', 'ranks_seen': 8, 'backend': 'nccl (= RCCL)', 'gpus_visible': 8,
+          'handoff': {'ms_per_message_measured': 0.31, 'messages': 50, 'bytes_per_message': 32700000}, 'partition': {'name': 'cyclic_growing', 'blocks': blob, 'predicted_speedup': 7.4}}
+    line8 = dict(line, n_gpus=8, value=1700.0, config=dict(line['config']))
+    bench.promote_wavefront(line8, wf, argparse.Namespace(clip=64), 8)
+    assert line8['scaling'] == 'strong' and line8['value'] == 900.0 and line8['weak_scaling_shards']['value'] == 1700.0
+    assert line8['config']['ranks_seen'] == 8 and line8['config']['handoff_ms_measured'] == 0.31 and line8['config']['timed_frames'] == 64
+    c8 = bench.compact_line(line8)
+    assert len(json.dumps(c8)) < 6000 and c8['wavefront']['frames_equal'] is True and c8['weak_scaling_shards']['value'] == 1700.0
+    # a leg that failed its frame check never becomes the headline
+    line_bad = dict(line, n_gpus=8, value=1700.0, config=dict(line['config']))
+    bench.promote_wavefront(line_bad, dict(wf, frames_equal=False), argparse.Namespace(clip=64), 8)
+    assert line_bad['value'] == 1700.0 and line_bad['scaling'] == 'weak'
