@@ -1020,7 +1020,10 @@ def main():
             pj = os.path.join(ROOT, 'profiles', 'pmc_kernels.json')
             if os.path.exists(pj) and (H, W_) == (270, 480):
                 try:
-                    traffic = json.load(open(pj)).get('traffic_bytes_per_launch', {}).get('resblock LR')
+                    tj = json.load(open(pj)).get('traffic_bytes_per_launch', {})
+                    traffic = tj.get('resblock LR x%d maps' % maps_per_launch) if maps_per_launch > 1 else tj.get('resblock LR')
+                    if traffic is None and maps_per_launch > 1 and tj.get('resblock LR'):
+                        traffic = tj['resblock LR'] * maps_per_launch
                     tsrc = 'profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
                 except Exception:  # noqa: BLE001
                     traffic = None
@@ -1028,7 +1031,7 @@ def main():
                                  (H, W_, ', %d maps per launch' % maps_per_launch if maps_per_launch > 1 else ''), 'bound': 'mfma',
                        'maps_per_launch': maps_per_launch,
                        'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
-                       'traffic': (traffic * maps_per_launch if traffic else traffic), 'traffic_source': tsrc, 'launches_timed': sum(n for _, n in runs),
+                       'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': sum(n for _, n in runs),
                        'mean_launch_ms': per_launch_ms, 'flops_per_launch': flops,
                        'issued_over_useful_flops': 798.0 * 16384 / (2 * 2.0 * 9 * C_ * C_ * 256),
                        'note': 'useful FLOPs (2 x 9 x 24 x 24 x 2 convs per pixel); the kernel issues 2.46x that on the matrix pipe: x2 hi + lo '

@@ -36,7 +36,9 @@ extern "C" {
                                   11: multi-map launches (REFVSR_MAX_MAPS maps of one geometry behind one launch and one weight fill):
                                       refvsr_resblock24_chain_batch, refvsr_conv24_batch, refvsr_conv_shuffle2_batch,
                                       refvsr_conf_alpha_batch, refvsr_warp_nhwc16_batch, refvsr_warp_nhwc16_up2_batch,
-                                      refvsr_warp_planar_batch */
+                                      refvsr_warp_planar_batch; RefvsrConv.warp_* (ABI 6: the inter-frame warp fused into a conv's tile
+                                      staging) REMOVED: bit-identical to warp + conv but measured slower in every configuration
+                                      (169 vs 176 frames/s, profiles/r03_fused_warp_ab.txt) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -81,26 +83,14 @@ typedef struct RefvsrConv {
                                              contribution to the end-to-end error budget is measured in DESIGN.md section 2 */
     float add_const;                   /* PLANAR32: constant added after the residual                 */
     float clamp_lo, clamp_hi;          /* PLANAR32: clamp when clamp_lo < clamp_hi                    */
-    /* Fused inter-frame warp (ABI 6): when warp_flow != NULL, source `warp_src` (0 = src0, 1 = src1) is NOT read directly:
-     * the conv consumes warp(src, flow) -- models/utils.py:35-43, the bilinear zero-padded sampling of refvsr_warp_nhwc16 --
-     * evaluated while the input tile is staged (same fp32 blend, same fp16 rounding as the stand-alone kernel: results are
-     * bit-identical to warp + conv).  warp_flow: planar fp32 [2][h_in][w_in] (the conv's input grid); the warped source
-     * map has warp_h x warp_w pixels (it may differ from the grid: RefVSR.py:254 resamples the LR state on the 2x grid).
-     * Supported by the resident 3x3 kernels with fp16 HWC output (the two call sites: ResidualBlocksWithInputConv's input conv,
-     * RefVSR.py:218,227-228 / 253,258-259, and feat_fusion2_1, :220,254,259-260 via :138-139); other shapes are refused. */
-    const float* warp_flow; int warp_src; int warp_h, warp_w;
     /* Batch (ABI 10): batch > 1 runs the same conv over `batch` images in ONE launch (blockIdx.y = image); image b reads
      * src0 + b * bs_src0 (src1 + b * bs_src1) and writes out + b * bs_out, res_planar + b * bs_res_planar (byte strides).
-     * mul / res / warp_flow must be NULL then.  batch = 0 or 1: a single image (strides ignored).  Used for the two SPyNet
+     * mul / res must be NULL then.  batch = 0 or 1: a single image (strides ignored).  Used for the two SPyNet
      * flows a frame needs (SPyNet.py:49-104 is called per pair by the reference; same weights, same shapes): the coarse
      * pyramid levels are launches of 2-36 workgroups, two images per launch fill twice the CUs for the same latency. */
     int batch; size_t bs_src0, bs_src1, bs_out, bs_res_planar;
 } RefvsrConv;
 
-/* Return codes: 0 = ok, 1 = bad arguments, 2 = HIP runtime error, REFVSR_ERR_UNSUPPORTED = valid arguments, but no kernel of this
- * library covers the shape (refvsr_conv_mfma with warp_flow on a shape without a fused-warp kernel: the caller runs
- * refvsr_warp_nhwc16 + the plain conv instead, bit-identical).  Only this code licenses a fallback. */
-#define REFVSR_ERR_UNSUPPORTED 3
 int refvsr_conv_mfma(const RefvsrConv* d, void* stream);
 /* Tuning / test knob (no reference counterpart): upper bound on the workgroups one single-chunk conv launches; each
  * workgroup walks the remaining pixel tiles.  0 = automatic (occupancy x CUs).  Results do not depend on it. */
@@ -111,17 +101,13 @@ int refvsr_set_conv_workgroup_cap(int cap);
 int refvsr_kslot(int ty, int tx, int cg, int ksize, int ncg);
 int refvsr_ksteps(int ksize, int ncg);
 
-/* Fused residual block  out = post( x + conv2( act( conv1(x) ) ) ),  3x3, C -> C, stride 1 (one launch; the
- * intermediate map lives in LDS): ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97) and ResBlock
- * (RefVSR_/common.py:25-39).  w1/w2: fp16 hi+lo packed weights of the two convs, b1/b2 packed biases.
- * refvsr_resblock_fits(c) tells whether the fused kernel supports c channels (LDS budget). */
-int refvsr_resblock_fits(int c);
-int refvsr_resblock_mfma(const void* src, int c, int h, int w, const void* w1, const float* b1,
-                         const void* w2, const float* b2, int ksteps, float act_slope, float post_slope,
-                         void* out, void* stream);
-/* The same fused block on a smaller footprint (4 waves, 8 x 32 tile, both weight sets + one activation tile in LDS,
- * the intermediate map overwrites the input tile): two workgroups per CU, so one's epilogue runs under the other's
- * MFMAs.  Bit-identical to refvsr_resblock_mfma.  Slopes must lie in [0, 1]. */
+/* Fused residual block  out = post( x + conv2( act( conv1(x) ) ) ),  3x3, C -> C, stride 1, in ONE launch (the intermediate map
+ * lives in LDS): ResidualBlockNoBN (mmedit sr_backbone_utils.py:42-97) and ResBlock (RefVSR_/common.py:25-39).  w1 / w2: fp16 hi + lo
+ * packed weights of the two convs, b1 / b2 packed biases.  Runtime-generic kernel for C in {8, 16, 24, 32} (refvsr_resblock_lean_fits):
+ * 8 waves on an 8 x 32 tile, both weight sets + one activation tile in LDS (the intermediate map overwrites the input tile): two
+ * workgroups per CU, so one's epilogue runs under the other's MFMAs.  Same arithmetic as two refvsr_conv_mfma launches up to fp32 summation order.  Slopes must
+ * lie in [0, 1].  (Round 1's 16 x 32-tile kernel, refvsr_resblock_mfma, was the reference of the bit-identity tests until round 4 and
+ * is gone: every shape it ran is covered by this kernel and by refvsr_resblock24_chain.) */
 int refvsr_resblock_lean_fits(int c);
 /* n fused blocks behind one call (n launches, intermediates ping-pong between scratch0 / scratch1: each [h][w][c] fp16,
  * scratch0 needed for n >= 2, scratch1 for n >= 3; src, scratch*, out pairwise distinct).  w1 / b1 / w2 / b2: host arrays of
@@ -174,8 +160,8 @@ int refvsr_set_resblock24_waves(int waves);
 int refvsr_resblock48_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
                             void* scratch0, void* scratch1, void* out, void* stream);
 /* Tuning knob: how the 24-channel kernel stores its output tile.  0: 8-byte stores (one per lane and pixel group); 1: 16-byte
- * stores after a v_permlane16_swap exchange between neighbouring lane rows (half the store instructions); 2: the same as
- * write-through (sc1) stores.  Results do not depend on it (bit-identical). */
+ * stores after a v_permlane16_swap exchange between neighbouring lane rows (half the store instructions; default).  Results do not
+ * depend on it (bit-identical). */
 int refvsr_set_resblock24_store(int mode);
 /* 3x3 stride-1 pad-1 convolutions with 24 output channels on fp16 HWC maps, compile-time specialised like the block above
  * (csrc/conv24.hip): the ResList tails (RefVSR_/common.py:80-82), feat_fusion / conf_fusion / fusion_UP convs (RefVSR.py:47-62,87),
@@ -265,7 +251,7 @@ int refvsr_conv_shuffle2(const void* src, int c, int h, int w, const void* blobs
 /* refvsr_conv_shuffle2 over `batch` maps (ABI 11, c = 24): src / out host arrays of `batch` device pointers. */
 int refvsr_conv_shuffle2_batch(const void* const* src, int batch, int c, int h, int w, const void* blobs, float act_slope,
                                void* const* out, void* stream);
-/* Debug knob (no reference counterpart): when buf != NULL every workgroup of refvsr_resblock_mfma records 8 s_memtime
+/* Debug knob (no reference counterpart): when buf != NULL every workgroup of the PROBE instantiations of the fused-block kernels records s_memtime
  * stamps (entry, loads issued, loads landed, conv1 K loop, conv1 epilogue, barrier, conv2 K loop, stores issued) of its
  * iter-th tile at buf[12 * workgroup + i] (uint64; [8], [9] = 100 MHz s_memrealtime at entry / exit, [10] = s_memtime at exit) -- tools/probe_resblock.py.  NULL switches it off (default). */
 int refvsr_set_probe(void* buf, int iter);

@@ -46,18 +46,6 @@ static inline int rv_device() {
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= RV_MAX_DEVICES) d = 0;
     return d;
 }
-// A/B knob REFVSR_WAVE_PRIO=1 (read once per process): the second-dispatched half of a workgroup's waves raises its priority once
-// (s_setprio 1) before the tile loop of the fused ResBlock / conv24 kernels -- the younger waves are the arbitration losers of
-// every segment (MI355X_MICROARCH.md, "Static priority for the younger half").  Results do not depend on it.
-static inline int rv_wave_prio() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("REFVSR_WAVE_PRIO");
-        v = (e && e[0] && e[0] != '0') ? 1 : 0;
-    }
-    return v;
-}
-
 static inline int rv_num_cus() {
     static int n_cu[RV_MAX_DEVICES] = {};
     const int d = rv_device();

@@ -43,7 +43,6 @@ struct C24Args {
     const unsigned char* blob; const unsigned char* mul; const unsigned char* res;
     int h, w, tiles_x, n_tiles, grid;
     float act_slope, post_slope;
-    int prio;                                    // REFVSR_WAVE_PRIO (common.h:rv_wave_prio): the younger half of the waves at priority 1
     // CONF variants (refvsr_conf_alpha): the 16-channel input map is not read, it is COMPUTED while the tile is staged
     const float* conf_a; const float* conf_b;    // the two planar fp32 confidence maps [ch][cw]
     const float* cw0; const float* cb0;          // first conv of the pair: fp32 weights [16][2][3][3], bias [16]
@@ -280,7 +279,6 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
     };
     int tl, k_hi;
     rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
-    if (p.prio && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
     if constexpr (CONF == 0) { if (tl < k_hi) x_fetch(tl); }
     __builtin_amdgcn_sched_barrier(0);                               // weights and first tile in flight before the rest of the set-up
 
@@ -549,7 +547,6 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     int cap = (rv_num_cus() * occ_dev[dev] / NZ) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    a.prio = rv_wave_prio();
     hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF, MM>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;

@@ -67,8 +67,6 @@ struct ConvArgs {
     int prefetch;                    // resident kernels: 1 = next tile prefetched into registers during the K loop
     int grid;                        // gridDim.x (resident kernels: rv_tile_range)
     int ring;                        // streamed kernels: LDS ring slots of CONV_CH K-steps each (2..4)
-    const float* warp_flow;          // WARP kernels: flow on the conv's input grid; the warped source has warp_h x warp_w pixels
-    int warp_h, warp_w;
     int batch;                       // images per launch (blockIdx.y); byte strides between the images of each map
     unsigned long long bs_src0, bs_src1, bs_out, bs_res_planar;
 };
@@ -82,11 +80,10 @@ struct ConvArgs {
 // RefVSR_MFID(_8K): 84 KB resident, or a 65 KB two-source tile next to the streamed chunk -- a 4-wave workgroup leaves a
 // SIMD with a single wave and nothing to interleave: those launches use 16 waves on a 16 x 32 tile (resident, where it fits)
 // or 8 waves on the same 8 x 32 tile (two pixel groups per wave).
-// WARP (resident fp16 kernels): 0 = plain sources; 1 | 2 = source 0 | 1 is warp(source, p.warp_flow), evaluated while the tile is
-// staged (models/utils.py:35-43; the arithmetic of resample.hip:warp_nhwc16_kernel, so warp + conv == this kernel bit for bit).
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0, bool HI1 = false>
+// (Rounds 3-4 carried a WARP variant here -- the inter-frame warp evaluated while the tile is staged, bit-identical to warp + conv:
+// measured slower in every configuration, 169 vs 176 frames/s, profiles/r03_fused_warp_ab.txt -- removed in round 5.)
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, bool HI1 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_mfma_kernel(ConvArgs p) {
-    static_assert(WARP == 0 || (RESIDENT && !F32), "the fused warp lives in the resident fp16 kernels' tile staging");
     constexpr int NT = NW * 64;                      // threads per workgroup
     static_assert(!(GATHER && RESIDENT), "gather mode streams its weights");
     static_assert(EPI == 0 || (RESIDENT && !F32), "the lean epilogue is built for the resident fp16 kernels");
@@ -443,13 +440,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
                 const int iy = iy0 + (e & 31), ix = ix0 + ((e >> 5) & 127);   // registers that live across the K loop
                 if (e >= 0 && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) {
                     const bool s1 = (e >> 19) & 1;
-                    if (WARP != 0 && s1 == (WARP == 2)) {             // this chunk = one channel group of warp(source, flow)(iy, ix)
-                        const WarpCoord wc = warp_coord(p.warp_flow, p.h_in, p.w_in, p.warp_h, p.warp_w, iy, ix);
-                        v = warp_group16(s1 ? p.src1 : p.src0, s1 ? p.pixb1 : p.pixb0, p.warp_h, p.warp_w, wc, ((e >> 12) & 127) * 16);
-                    } else {
-                        const int off = ((e & 31) * p.w_in + ((e >> 5) & 127)) * (s1 ? p.pixb1 : p.pixb0) + ((e >> 12) & 127) * 16;
-                        v = *reinterpret_cast<const uint4*>((s1 ? b1 : b0) + off);
-                    }
+                    const int off = ((e & 31) * p.w_in + ((e >> 5) & 127)) * (s1 ? p.pixb1 : p.pixb0) + ((e >> 12) & 127) * 16;
+                    v = *reinterpret_cast<const uint4*>((s1 ? b1 : b0) + off);
                 }
                 xv[k] = v;
             }
@@ -721,13 +713,13 @@ extern "C" int refvsr_ksteps(int ksize, int ncg) { return rv_ksteps(ksize, ncg);
 
 // RESIDENT kernels launch only as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 for
 // the XCD banding) and walk the tiles; the others launch one workgroup per tile.
-template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, int WARP = 0, bool HI1 = false>
+template <int MT, int TILES, bool F32, bool GATHER, bool RESIDENT, int EPI = 0, int NW = 4, bool HI1 = false>
 static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
     // per device: the dynamic-LDS attribute and the occupancy table (a process may drive several GPUs)
     static bool attr_done[RV_MAX_DEVICES] = {};
     const int dev = rv_device();
     if (!attr_done[dev]) {
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>),
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, HI1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
@@ -740,7 +732,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         for (int i = 0; i < 4; ++i)
             if (occ_lds[dev][i] == lds && occ_val[dev][i] > 0) occ = occ_val[dev][i];
         if (occ == 0) {
-            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>, NW * 64, lds));
+            RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, HI1>, NW * 64, lds));
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
@@ -750,7 +742,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
         if (gx > cap) gx = cap;
     }
     a.grid = gx;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, WARP, HI1>), dim3(gx, a.batch > 1 ? a.batch : 1, nz), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, TILES, F32, GATHER, RESIDENT, EPI, NW, HI1>), dim3(gx, a.batch > 1 ? a.batch : 1, nz), dim3(NW * 64), lds, st, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -796,19 +788,12 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
     a.mul = (const unsigned char*)d->mul; a.mul_c = d->mul_c;
     a.res = (const unsigned char*)d->res; a.res_c = d->res_c;
     a.out_mode = d->out_mode; a.out = d->out; a.out_c = d->out_c;
-    a.warp_flow = d->warp_flow; a.warp_h = d->warp_h; a.warp_w = d->warp_w;
-    if (d->warp_flow) {
-        RV_CHECK(d->warp_src == 0 || d->warp_src == 1, "conv: warp_src must be 0 or 1");
-        RV_CHECK(d->warp_src == 0 || d->src1, "conv: warp_src = 1 needs a second source");
-        RV_CHECK(d->warp_h > 1 && d->warp_w > 1 && d->h_in > 1 && d->w_in > 1, "conv: warp needs maps of at least 2 x 2 pixels");
-        RV_CHECK(!f32 && d->stride == 1 && d->ksize == 3, "conv: the fused warp is built for the 3x3 stride-1 fp16 convs");
-    }
     a.res_planar = d->res_planar; a.add_const = d->add_const;
     a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
     RV_CHECK(d->batch >= 0 && d->batch <= 65535, "conv: batch out of range (%d)", d->batch);
     a.batch = d->batch > 1 ? d->batch : 1;
     if (a.batch > 1) {
-        RV_CHECK(!d->mul && !d->res && !d->warp_flow, "conv: batch > 1 takes no mul / res / warp operands");
+        RV_CHECK(!d->mul && !d->res, "conv: batch > 1 takes no mul / res operands");
         RV_CHECK(d->bs_src0 % 16 == 0 && d->bs_src1 % 16 == 0 && d->bs_out % 8 == 0 && d->bs_res_planar % 4 == 0, "conv: batch strides must keep the maps aligned");
         RV_CHECK(d->bs_src0 > 0 && d->bs_out > 0 && (!d->src1 || d->bs_src1 > 0) && (!d->res_planar || d->bs_res_planar > 0), "conv: batch strides missing");
         a.bs_src0 = d->bs_src0; a.bs_src1 = d->bs_src1; a.bs_out = d->bs_out; a.bs_res_planar = d->bs_res_planar;
@@ -919,14 +904,14 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         return launch_conv<3, 4, false, true, false>(a, nz, lds, st);
     }
     if (hi1) {                                     // SPyNet's streamed 7x7 convs (Engine.flow): half the weight stream, half the MFMAs
-        RV_CHECK(!a.gather && !d->warp_flow && MT <= 2, "conv: single-fp16 weights are built for the streamed stride-1 convs (MT=%d)", MT);
+        RV_CHECK(!a.gather && MT <= 2, "conv: single-fp16 weights are built for the streamed stride-1 convs (MT=%d)", MT);
         const bool nw8h = tiles == 4 && !no_nw8 && (one_wg || n_tiles8 <= 2048);
-        if (nw8h) return MT == 1 ? launch_conv<1, 2, false, false, false, 0, 8, 0, true>(a, nz, lds, st)
-                                 : launch_conv<2, 2, false, false, false, 0, 8, 0, true>(a, nz, lds, st);
-        if (tiles == 4) return MT == 1 ? launch_conv<1, 4, false, false, false, 0, 4, 0, true>(a, nz, lds, st)
-                                       : launch_conv<2, 4, false, false, false, 0, 4, 0, true>(a, nz, lds, st);
-        return MT == 1 ? launch_conv<1, 2, false, false, false, 0, 4, 0, true>(a, nz, lds, st)
-                       : launch_conv<2, 2, false, false, false, 0, 4, 0, true>(a, nz, lds, st);
+        if (nw8h) return MT == 1 ? launch_conv<1, 2, false, false, false, 0, 8, true>(a, nz, lds, st)
+                                 : launch_conv<2, 2, false, false, false, 0, 8, true>(a, nz, lds, st);
+        if (tiles == 4) return MT == 1 ? launch_conv<1, 4, false, false, false, 0, 4, true>(a, nz, lds, st)
+                                       : launch_conv<2, 4, false, false, false, 0, 4, true>(a, nz, lds, st);
+        return MT == 1 ? launch_conv<1, 2, false, false, false, 0, 4, true>(a, nz, lds, st)
+                       : launch_conv<2, 2, false, false, false, 0, 4, true>(a, nz, lds, st);
     }
     // lean epilogue: fp16 HWC output, slopes in [0, 1], maps addressable with 32-bit element offsets, tile coordinates in
     // the packed chunk descriptor's range
@@ -942,19 +927,6 @@ extern "C" int refvsr_conv_mfma(const RefvsrConv* d, void* stream) {
         if (lean) return launch_conv<M, T, false, false, true, 1>(a, nz, lds, st);                        \
         return resident ? launch_conv<M, T, false, false, true>(a, nz, lds, st)                           \
                         : launch_conv<M, T, false, false, false>(a, nz, lds, st);                         \
-    }
-    if (d->warp_flow) {                            // RefVSR.py:218,253 / 220,254,259: 8+24 -> 24 and 24+24 -> 24 (16 output rows x 2)
-        if (!(lean && MT == 2 && !w16)) {          // rc 3 = REFVSR_ERR_UNSUPPORTED: the caller may run warp + conv instead (same results)
-            refvsr_set_error("conv: no fused-warp kernel for this shape (MT=%d tiles=%d lean=%d)", MT, tiles, (int)lean);
-            return REFVSR_ERR_UNSUPPORTED;
-        }
-#define RV_WARP_CASE(T, NW_)                                                                              \
-        return d->warp_src == 0 ? launch_conv<2, T, false, false, true, 1, NW_, 1>(a, nz, lds, st)        \
-                                : launch_conv<2, T, false, false, true, 1, NW_, 2>(a, nz, lds, st);
-        if (nw8) { RV_WARP_CASE(2, 8) }
-        if (tiles == 2) { RV_WARP_CASE(2, 4) }
-        RV_WARP_CASE(4, 4)
-#undef RV_WARP_CASE
     }
     if (w16) {
         if (MT == 3) return lean ? launch_conv<3, 2, false, false, true, 1, 16>(a, nz, lds, st) : launch_conv<3, 2, false, false, true, 0, 16>(a, nz, lds, st);

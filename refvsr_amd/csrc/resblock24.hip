@@ -62,7 +62,6 @@ struct RB24Args {
     float act_slope;
     unsigned long long* probe;           // PROBE kernels: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
     int probe_iter;                      // which tile iteration of the workgroup is stamped
-    int prio;                            // REFVSR_WAVE_PRIO (common.h:rv_wave_prio): the younger half of the waves at priority 1
     // HEAD kernels (refvsr_conv_hr_last): `out` is planar fp32 [3][h][w]; base_lr = the LR centre frame, planar fp32 [3][bh][bw]
     const float* base_lr; int bh, bw; float base_step;
     // Multi-map launches (refvsr_resblock24_chain_batch): batch > 1 maps of one geometry share the launch and the weight fill; the
@@ -207,12 +206,9 @@ __device__ __forceinline__ uint2 rb_pack(const f32x4 y) {
 // STORE: how the output tile leaves the workgroup.  0 (round 3): 8-byte stores, lane (q, pixel) writes its own four channels.
 // 1: 16-byte stores -- the lanes q and q ^ 1 exchange halves with v_permlane16_swap so that a lane holds EIGHT consecutive
 // channels of one pixel (of the wave's left 16-pixel group for even q, of the right one for odd q): half the store instructions
-// (the store phase is issue bound: 8 waves x 6 stores of 8 bytes per tile).  2: the same as write-through stores (sc1): the tile is
-// on its way to memory while the workgroup is still running instead of being written back by the end-of-kernel release (every
-// workgroup of an LR launch ends at about the same time; the next launch reads the map through the fabric anyway).
-// Measured (profiles/r04_resblock_microbench.txt, us per block 0 / 1 / 2): LR 9.17 / 9.19 / 9.47, 2x 28.73 / 27.80 / 29.68, HR 103.3 /
-// 102.2 / 107.6; in the frame 199.2 / 199.5 / 197.1 frames/s (profiles/r04_knobs_ab.txt) -> 1 is the default: the stores were not what
-// an LR launch waits for, and write-through stores are slower than letting the L2 write the tile back.
+// (the store phase is issue bound: 8 waves x 6 stores of 8 bytes per tile).  Measured (profiles/r04_resblock_microbench.txt, us per
+// block 0 / 1): LR 9.17 / 9.19, 2x 28.73 / 27.80, HR 103.3 / 102.2 -> 1 is the default.  (Round 4 also carried the same stores as
+// write-through `sc1` stores: slower everywhere -- 9.47 / 29.68 / 107.6 us, 197.1 vs 199.5 frames/s -- removed in round 5.)
 // HEAD = 1 (refvsr_conv_hr_last, round 4): not a residual block but the last two convs of the upsampler, conv_hr (24 -> 24,
 // LeakyReLU 0.1) and conv_last (24 -> 3) + the bicubic base + the clamps (RefVSR.py:91-92,116-118,288,297), on this kernel's
 // two-conv skeleton: conv1 = conv_hr, the intermediate tile stays in LDS (the 100 MB HR map between the two convs never exists),
@@ -322,7 +318,6 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
 
     int tl, k_hi;
     rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
-    if (p.prio && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
     if (tl < k_hi) x_fetch(tl);
     __builtin_amdgcn_sched_barrier(0);                           // weights and first tile in flight before the rest of the set-up
     RB_STAMP(1);
@@ -507,13 +502,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
                 }
                 unsigned char* d = ob + (unsigned)(tp * rowb_g) + (unsigned)(oy0 * rowb_g + (gsel * 16 + lp) * RB_PXB);
                 if (ok) {
-                    if constexpr (STORE == 2) {
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d + (q >> 1) * 16), "v"(lo) : "memory");
-                        if (q < 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d + 32), "v"(hi) : "memory");
-                    } else {
-                        *reinterpret_cast<u32x4*>(d + (q >> 1) * 16) = lo;
-                        if (q < 2) *reinterpret_cast<u32x4*>(d + 32) = hi;
-                    }
+                    *reinterpret_cast<u32x4*>(d + (q >> 1) * 16) = lo;
+                    if (q < 2) *reinterpret_cast<u32x4*>(d + 32) = hi;
                 }
             }
         }
@@ -525,12 +515,12 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
 #undef RB_STAMP
 }
 
-extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
+extern unsigned long long* g_rb_probe;             // runtime.hip: refvsr_set_probe
 extern int g_rb_probe_iter;
 
-static int g_rb24_store = REFVSR_RB24_STORE_DEFAULT;   // A/B knob (refvsr_set_resblock24_store): 0 | 1 | 2, see the kernel's STORE parameter
+static int g_rb24_store = REFVSR_RB24_STORE_DEFAULT;   // A/B knob (refvsr_set_resblock24_store): 0 | 1, see the kernel's STORE parameter
 extern "C" int refvsr_set_resblock24_store(int mode) {
-    if (mode < 0 || mode > 2) return 1;
+    if (mode < 0 || mode > 1) return 1;
     g_rb24_store = mode;
     return 0;
 }
@@ -561,7 +551,6 @@ static int launch_rb24(RB24Args& a, hipStream_t st) {
     int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    a.prio = rv_wave_prio();
     hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH, STORE, HEAD>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;
@@ -618,10 +607,8 @@ static int rb24_chain_impl(const void* const* src, int batch, int h, int w, int 
         else if (g_rb_probe && act_slope == 0.f && waves == 16) rc = launch_rb24<true, 16, true, 16>(a, st);
         else if (waves == 4) rc = act_slope == 0.f ? launch_rb24<true, 4>(a, st) : launch_rb24<false, 4>(a, st);
 #define RB24_PICK(R_)                                                                                                              \
-        (waves == 16 ? (g_rb24_store == 2 ? launch_rb24<R_, 16, false, 16, 2>(a, st) : g_rb24_store == 1 ? launch_rb24<R_, 16, false, 16, 1>(a, st) \
-                                                                                                        : launch_rb24<R_, 16, false, 16, 0>(a, st))  \
-                     : (g_rb24_store == 2 ? launch_rb24<R_, 8, false, 8, 2>(a, st) : g_rb24_store == 1 ? launch_rb24<R_, 8, false, 8, 1>(a, st)      \
-                                                                                                       : launch_rb24<R_, 8, false, 8, 0>(a, st)))
+        (waves == 16 ? (g_rb24_store == 1 ? launch_rb24<R_, 16, false, 16, 1>(a, st) : launch_rb24<R_, 16, false, 16, 0>(a, st)) \
+                     : (g_rb24_store == 1 ? launch_rb24<R_, 8, false, 8, 1>(a, st) : launch_rb24<R_, 8, false, 8, 0>(a, st)))
         else rc = act_slope == 0.f ? RB24_PICK(true) : RB24_PICK(false);
 #undef RB24_PICK
         if (rc) return rc;

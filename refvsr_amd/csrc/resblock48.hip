@@ -66,7 +66,6 @@ struct RB48Args {
     float act_slope;
     unsigned long long* probe;           // PROBE kernel: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
     int probe_iter;                      // which tile iteration of the workgroup is stamped
-    int prio;                            // REFVSR_WAVE_PRIO (common.h:rv_wave_prio): the younger half of the waves at priority 1
 };
 
 // K loop of one conv: T pixel groups of this wave; fragments at LDS offset 0, B windows at pb[t] + pd[pattern] + immediate.
@@ -209,7 +208,6 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     int tl, k_hi;
     rv_tile_range(p.n_tiles, p.grid, tl, k_hi);
-    if (p.prio && wave >= R48_NWV / 2) __builtin_amdgcn_s_setprio(1);
     if (tl < k_hi) x_fetch(tl);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -358,7 +356,7 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #undef R48_STAMP
 }
 
-extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
+extern unsigned long long* g_rb_probe;             // runtime.hip: refvsr_set_probe
 extern int g_rb_probe_iter;
 
 template <bool RELU, bool PROBE = false>
@@ -374,7 +372,6 @@ static int launch_rb48(RB48Args& a, hipStream_t st) {
     int cap = rv_num_cus() & ~7;                                     // one 135 KB workgroup per CU
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
-    a.prio = rv_wave_prio();
     hipLaunchKernelGGL((resblock48_kernel<RELU, PROBE>), dim3(a.grid), dim3(R48_NT), R48_LDS, st, a);
     RV_LAUNCH_CHECK();
     return 0;

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV / 
 #undef RL_STAMP
 }
 
-extern unsigned long long* g_rb_probe;             // resblock_mfma.hip: refvsr_set_probe
+extern unsigned long long* g_rb_probe;             // runtime.hip: refvsr_set_probe
 extern int g_rb_probe_iter;
 
 static size_t rl_lds_bytes(int c) {

@@ -28,3 +28,13 @@ extern "C" int refvsr_init(void) {
     state = 1;
     return 0;
 }
+
+// Debug knob shared by the fused-block kernels (resblock_lean.hip, resblock24.hip, resblock48.hip): when set, their PROBE
+// instantiations record s_memtime stamps per workgroup (tools/probe_resblock24.py, tools/probe_resblock48.py).
+unsigned long long* g_rb_probe = nullptr;
+int g_rb_probe_iter = 0;
+extern "C" int refvsr_set_probe(void* buf, int iter) {
+    g_rb_probe = (unsigned long long*)buf;
+    g_rb_probe_iter = iter;
+    return 0;
+}

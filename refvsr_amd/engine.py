@@ -188,12 +188,6 @@ class Engine(object):
         self.rb48 = (bool(getattr(config, 'fuse_resblocks', True)) and not env_flag('REFVSR_NO_FUSE')
                      and not env_flag('REFVSR_NO_RB48'))                 # A/B knob: C = 48 blocks as two refvsr_conv48 launches (round 3)
         self.rb48_max_pixels = int(os.environ.get('REFVSR_RB48_MAX_PIXELS', str(540 * 960)))
-        # inter-frame warp fused into its consumer's tile staging (RefvsrConv.warp_*; conv kernels with 16-row pairs:
-        # mid_channels = 24 / 32).  Bit-identical to warp + conv (tests/test_gpu_ops.py), but OPT-IN: measured on MI355X it is
-        # slower (169.3 vs 176.4 frames/s, profiles/r03_fused_warp_ab.txt) -- the gather makes the tile staging a chain of
-        # dependent memory round trips (flow -> 4 taps per 16-byte group) that the register prefetch can no longer issue ahead
-        # of the K loop: 114 us for the fused 2x conv against 28 + 18 us for conv + stand-alone warp (3.0 TB/s gather kernel).
-        self.fuse_warp = self.C in (24, 32) and bool(getattr(config, 'fuse_warp', env_flag('REFVSR_FUSE_WARP')))
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
         # pipelined mode: the backward branch restarts from zeros at the window's LAST frame (RefVSR.py:211-214), so the first
@@ -215,8 +209,6 @@ class Engine(object):
         self.map1x1 = not env_flag('REFVSR_NO_MAP1X1')
         self.spynet_batch = not env_flag('REFVSR_NO_SPYNET_BATCH')   # A/B knob: one SPyNet pass per flow, as in round 3
         self.overlap = bool(getattr(config, 'overlap_streams', True)) and not env_flag('REFVSR_NO_OVERLAP')
-        # encoders-under-matching overlap measured neutral (+0..1 %, profiles/): kept behind an opt-in switch
-        self.overlap_prepare = env_flag('REFVSR_OVERLAP_PREPARE')
         self._side = None
         # pipelined mode (opt-in, see forward()): internal streams M (backward branch + upsampler), F (forward branch),
         # P (per-frame preparation + flows); the caller's stream only receives the result
@@ -563,9 +555,8 @@ class Engine(object):
         y = self._block_chain(x, pairs, 0.2)
         return ops.conv(self.cw(name + '.conv_tail'), y, res=x)
 
-    def resblocks(self, lr8, feat, name, flow=None, stop=None, resume=None):
-        """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources.  flow: the propagated
-        features are consumed as warp(feat, flow) (RefVSR.py:218,253,258), sampled inside the input conv's tile staging.
+    def resblocks(self, lr8, feat, name, stop=None, resume=None):
+        """ResidualBlocksWithInputConv (RefVSR.py:327-360); torch.cat([lr, feat]) fused as two sources.
         stop = n: only the input conv and the first n blocks (returns the intermediate map); resume = (n, map): the blocks from n
         on -- the two halves of one call, for running them on different streams (same launches, same results)."""
         pairs = [(self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i)))
@@ -573,7 +564,7 @@ class Engine(object):
         if resume is not None:
             n, x = resume
             return self._block_chain(x, pairs[n:], 0.0) if n < self.nb else x
-        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1, warp=None if flow is None else (1, flow))
+        x = ops.conv(self.cw(name + '.main.0'), lr8, feat, act=0.1)
         if stop is not None:
             return self._block_chain(x, pairs[:stop], 0.0) if stop > 0 else x
         return self._block_chain(x, pairs, 0.0)
@@ -762,22 +753,9 @@ class Engine(object):
             raise RuntimeError('a window needs a per-frame context that was neither prepared ahead nor imported (strict mode)')
         h, w = fr.lr.shape[1:]
         fr.lr8 = ops.pack_nhwc16(fr.lr, 8)
-        # the reference encoders do not depend on the matching: with stream overlap they run on a second side
-        # stream underneath the (MFMA-bound, 1 workgroup / CU) matching kernel
-        main = torch.cuda.current_stream()
-        par = self.overlap and self.overlap_prepare
-        if par:
-            side = self._side_stream(fr.lr.device, 1)
-            side.wait_stream(main)
-            with ops.on_stream(side):
-                ref_feat, ref_feat_down = self._ref_encoders(fr)
+        # (running the reference encoders on a side stream underneath the matching kernel measured neutral, +0..1 %: removed in round 5)
         fr.conf, fr.idx, (gh, gw) = self.feature_match(fr)
-        if par:
-            main.wait_stream(side)
-            ref_feat.record_stream(main)
-            ref_feat_down.record_stream(main)
-        else:
-            ref_feat, ref_feat_down = self._ref_encoders(fr)
+        ref_feat, ref_feat_down = self._ref_encoders(fr)
         s1, s2 = self.ks // 2, self.ks
         # aa1 (RefVSR.py:127, attention.py:142-157): gather of LR/2 reference features; with a patch > 1 px (HD)
         # also the affine AlignedConv2d, queried by bicubic x0.5 of the LR frame (RefVSR.py:125)
@@ -792,9 +770,8 @@ class Engine(object):
         rgb2 = ops.block_gather_rgb(fr.ref, fr.idx, gh, gw, s2)                          # attention.py:152-154
         fr.aligned_up = self.aligned_conv(feats2, fr.lr, rgb2, 'aa2.align', s2)
 
-    def rap(self, fr, conf_prop, feat, feat_up, flow_up=None):
-        """AA_AF_conf_prop (RefVSR.py:123-149).  flow_up: the propagated 2x features are consumed as warp(feat_up, flow_up)
-        (RefVSR.py:220,254,259), sampled inside feat_fusion2_1's tile staging (their only consumer, :138-139)."""
+    def rap(self, fr, conf_prop, feat, feat_up):
+        """AA_AF_conf_prop (RefVSR.py:123-149)."""
         R = self.W.raw
         fused = self.fuse_conf and ops.conf_alpha_ok(self.cw('conf_fusion.1.0')) and ops.conf_alpha_ok(self.cw('conf_fusion2.1.0'))
         if fused:
@@ -808,7 +785,7 @@ class Engine(object):
         feat = ops.conv(self.cw('feat_fusion.1.0'), t, act=0.2, mul=alpha, res=feat)     # :131
         feat = self.res_list(feat, 'feat_decoder', 8)
         up1 = ops.conv(self.cw('upsample1.upsample_conv'), feat)                         # :138 (pixel shuffle fused)
-        feat_up = ops.conv(self.cw('feat_fusion2_1.0.0'), feat_up, up1, act=0.2, warp=None if flow_up is None else (0, flow_up))
+        feat_up = ops.conv(self.cw('feat_fusion2_1.0.0'), feat_up, up1, act=0.2)
         if fused:
             alpha2 = ops.conf_alpha(conf_prop, fr.conf, 2, *R['conf_fusion2.0.0'], self.cw('conf_fusion2.1.0'))   # :140-142
         else:
@@ -931,22 +908,21 @@ class Engine(object):
           'p_fm'            F on M's stream (one conv chain at a time; measured slower: the backward branch + forward step + upsampler
                             in series are longer than a frame)
           'one'             P, F and M on ONE stream (measurement aid: bench.py times the multi-map launches of a group in it)
-        Wider models (C = 48 / 36) additionally alternate two M streams (REFVSR_PIPE_TWO_M=1 | 0 overrides)."""
+        Wider models (C = 48 / 36) additionally alternate two M streams (for mid_channels = 24 two M streams measured equal to one,
+        209.5 / 210.2 vs 209.1 / 209.6 frames/s, profiles/r04_two_m_and_mfid_layout_ab.txt: no switch)."""
         layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or self._layout_default)
         if self._pipe is not None and self._pipe[0].device == dev and self.pipe_layout != layout:
             torch.cuda.synchronize(dev)               # another layout from here on (first group call of an engine): drain, rebuild
             self._pipe = None
         if self._pipe is None or self._pipe[0].device != dev:
-            hi = -1 if env_flag('REFVSR_STREAM_PRIORITY') else 0
             if layout not in ('pf_m', 'pfm', 'p_fm', 'one'):
                 raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm | one, got %r' % layout)
-            two = os.environ.get('REFVSR_PIPE_TWO_M')
-            two = (self.C != 24) if two in (None, '') else env_flag('REFVSR_PIPE_TWO_M')
+            two = self.C != 24
             m = torch.cuda.Stream(device=dev)
             if layout == 'one':                       # measurement aid (bench.py): every section on ONE internal stream -- HIP events
                 two = False                           # around a run of launches then bracket nothing but that run
             m2 = torch.cuda.Stream(device=dev) if two else m
-            p_ = m if layout == 'one' else torch.cuda.Stream(device=dev, priority=hi)
+            p_ = m if layout == 'one' else torch.cuda.Stream(device=dev)
             f_ = p_ if layout in ('pf_m', 'one') else (m if layout == 'p_fm' else torch.cuda.Stream(device=dev))
             self._pipe = [m, m2, f_, p_]
             self.pipe_layout = layout
@@ -1112,7 +1088,7 @@ class Engine(object):
     # B forward() calls (tests/test_gpu_e2e.py::test_frame_groups_are_bit_identical).
     def group_ok(self):
         """The multi-map launch list exists for the mid_channels = 24 family on its default kernels."""
-        return bool(self.C == 24 and self.fuse_resblocks and self.rb24 and self.fuse_conf and self.warp_up2 and not self.fuse_warp and
+        return bool(self.C == 24 and self.fuse_resblocks and self.rb24 and self.fuse_conf and self.warp_up2 and
                     ops.CONV24 and self.cache and self.overlap and not bool(self.cfg.EVAL.is_gradio) and
                     ops.conf_alpha_ok(self.cw('conf_fusion.1.0')) and ops.conf_alpha_ok(self.cw('conf_fusion2.1.0')))
 
@@ -1215,10 +1191,10 @@ class Engine(object):
         input_ready: as in forward() (None | 'materialised' | event | stream), for all windows of the call."""
         outs = [None] * len(wins)
         i = 0
-        if self.group_ok() and self.pipelined and not env_flag('REFVSR_GROUP_KEEP_LAYOUT'):
+        if self.group_ok() and self.pipelined:
             # before the first internal stream exists: an engine driven through forward_group runs P | F | M from its first call on
             # (a rebuild later would leave the first set of streams behind, and with more streams than hardware queues the
-            # stream -> queue mapping decides which sections serialise)
+            # stream -> queue mapping decides which sections serialise); REFVSR_PIPE_LAYOUT / config.pipe_layout override it
             self._layout_default = 'pfm'
         with torch.cuda.device(wins[0][0].device):
             while i < len(wins):
@@ -1369,9 +1345,7 @@ class Engine(object):
 
     def _prop_step(self, f, branch, feat, feat_up, conf, fl, up_from_lr=False):
         """One propagation step (RefVSR.py:216-230 backward, :251-277 forward): warp the carried maps with `fl` (None: first
-        step of a branch, nothing to warp), ResidualBlocksWithInputConv, AA_AF_conf_prop.  The two feature warps run inside
-        their consumers' tile staging (ops.conv warp=) unless self.fuse_warp is off; the 1-channel confidence map keeps its
-        own kernel.  up_from_lr: the 2x state is warp(warp(feat, fl), flow_up2(fl)) -- the reference's :254 quirk."""
+        step of a branch, nothing to warp), ResidualBlocksWithInputConv, AA_AF_conf_prop.  up_from_lr: the 2x state is warp(warp(feat, fl), flow_up2(fl)) -- the reference's :254 quirk."""
         if fl is None:
             if branch == 'backward_resblocks' and f.bw_head is not None:
                 feat = self.resblocks(f.lr8, feat, branch, resume=f.bw_head)      # its head ran with the frame's preparation
@@ -1379,15 +1353,6 @@ class Engine(object):
                 feat = self.resblocks(f.lr8, feat, branch)
             return self.rap(f, conf, feat, feat_up)
         conf = ops.warp_planar(conf, fl)
-        if self.fuse_warp:
-            fl2 = ops.flow_up2(fl)
-            if up_from_lr:
-                feat = ops.warp_nhwc16(feat, fl)          # needed as a map: it is warped a second time onto the 2x grid
-                x = self.resblocks(f.lr8, feat, branch)
-                return self.rap(f, conf, x, feat, flow_up=fl2)
-            x = self.resblocks(f.lr8, feat, branch, flow=fl)
-            self._await_fw_up(feat_up)
-            return self.rap(f, conf, x, feat_up, flow_up=fl2)
         # the 2x state is warped by flow_up2(fl): evaluated inside the warp kernel (no 2x flow map) unless REFVSR_NO_WARP_UP2=1
         warp2 = ops.warp_nhwc16_up2 if self.warp_up2 else (lambda m, fl_: ops.warp_nhwc16(m, ops.flow_up2(fl_)))
         if up_from_lr:

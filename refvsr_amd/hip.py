@@ -14,7 +14,6 @@ RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
 ABI_VERSION = 11
 MAX_MAPS = 4
-ERR_UNSUPPORTED = 3
 RESBLOCK24_BLOB_BYTES = 43264
 RESBLOCK48_BLOB_BYTES = 172544
 
@@ -38,7 +37,6 @@ class RefvsrConv(C.Structure):
         ('res_planar', C.c_void_p),
         ('f32', C.c_int),
         ('add_const', C.c_float), ('clamp_lo', C.c_float), ('clamp_hi', C.c_float),
-        ('warp_flow', C.c_void_p), ('warp_src', C.c_int), ('warp_h', C.c_int), ('warp_w', C.c_int),
         ('batch', C.c_int), ('bs_src0', C.c_size_t), ('bs_src1', C.c_size_t), ('bs_out', C.c_size_t), ('bs_res_planar', C.c_size_t),
     ]
 
@@ -52,8 +50,6 @@ SIGNATURES = {
     'refvsr_set_conv_workgroup_cap': [_I],
     'refvsr_kslot': [_I, _I, _I, _I, _I],        # returns the slot, not a status
     'refvsr_ksteps': [_I, _I],                   # returns the K-step count
-    'refvsr_resblock_fits': [_I],
-    'refvsr_resblock_mfma': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P],
     'refvsr_set_probe': [_P, _I],
     'refvsr_resblock_lean_fits': [_I],
     'refvsr_set_resblock_waves': [_I],

@@ -82,8 +82,7 @@ CONV24 = not env_flag('REFVSR_NO_CONV24')      # A/B knob: the generic conv kern
 
 class ConvWeights(object):
     """Packed weights of one conv on the device (see packing.pack_conv)."""
-    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'hi_only', 'desc', 'odtype', 'raw', 'blob24',
-                 'no_fused_warp')
+    __slots__ = ('wpack', 'bias', 'cout', 'ksteps', 'mt', 'ksize', 'cpads', 'shuffle', 'f32', 'hi_only', 'desc', 'odtype', 'raw', 'blob24')
 
     def __init__(self, pk, device):
         self.wpack = pk['wpack'].to(device).contiguous()
@@ -91,7 +90,6 @@ class ConvWeights(object):
         self.cout, self.ksteps, self.mt, self.ksize = pk['cout'], pk['ksteps'], pk['mt'], pk['ksize']
         self.cpads, self.shuffle, self.f32 = pk['cpads'], pk['shuffle'], bool(pk.get('f32', False))
         self.hi_only = bool(pk.get('hi_only', False))      # plain fp16 weights (descriptor weight mode 2)
-        self.no_fused_warp = False                         # set once the library has answered REFVSR_ERR_UNSUPPORTED for warp=
         # launch descriptor with the per-weight fields filled once (the C side copies it at every call)
         d = self.desc = hip.RefvsrConv()
         d.wpack, d.bias = self.wpack.data_ptr(), self.bias.data_ptr()
@@ -113,45 +111,35 @@ class ConvWeights(object):
 
 
 def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, post=1.0,
-         planar_out=False, res_planar=None, add_const=0.0, clamp=None, warp=None, batch=None):
+         planar_out=False, res_planar=None, add_const=0.0, clamp=None, batch=None):
     """refvsr_conv_mfma.  Returns nhwc16 [ho,wo,cout] (or [2ho,2wo,cout/4] for pixel-shuffle weights),
     or planar fp32 [cout,ho,wo] when planar_out.  For f32-packed weights all maps are fp32 HWC.
-    warp = (k, flow): source k (0 | 1) is consumed as warp_nhwc16(source_k, flow) -- sampled while the conv stages its input
-    tile, no intermediate map (bit-identical to the two launches); flow planar fp32 [2,h,w] defines the conv's input grid,
-    source k may have another size (RefVSR.py:254: the LR state on the 2x grid).
     batch = B: src0 is a contiguous batch [B,h,w,c] (res_planar [B,cout,h,w]) of images sharing the weights: ONE launch
     (RefvsrConv.batch), output [B,...]; image b == conv of image b alone, bit for bit."""
     if batch is not None:
         return _conv_batch(cw, src0, int(batch), stride, pad, act, post, planar_out, res_planar, add_const, clamp,
-                           src1, mul, res, warp)
+                           src1, mul, res)
     f32 = cw.f32
     _nhwc(src0, f32)
     if src1 is not None:
         _nhwc(src1, f32)
     c0 = src0.shape[2]
     c1 = src1.shape[2] if src1 is not None else 0
-    if warp is not None:
-        wk, flow = warp
-        _planar(flow, 2)
-        h, w = flow.shape[1:]
-        other = src1 if wk == 0 else src0
-        assert wk in (0, 1) and (wk == 0 or src1 is not None) and (other is None or tuple(other.shape[:2]) == (h, w))
-    else:
-        h, w = src0.shape[:2]
-        assert src1 is None or src1.shape[:2] == src0.shape[:2]
+    h, w = src0.shape[:2]
+    assert src1 is None or src1.shape[:2] == src0.shape[:2]
     assert [c0] + ([c1] if src1 is not None else []) == list(cw.cpads), \
         'conv input channels %s do not match packed weights %s' % ([c0, c1], cw.cpads)
     k = cw.ksize
     if pad is None:
         pad = k // 2
     co_ = cw.cout
-    if (cw.shuffle and cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
+    if (cw.shuffle and cw.blob24 is not None and stride == 1 and pad == 1 and not planar_out and res_planar is None and
             src1 is None and mul is None and res is None and 0.0 <= act <= 1.0 and post == 1.0 and h * w * co_ * 2 < 2 ** 31):
         # C -> 4 C conv + pixel shuffle on the compile-time-specialised kernel (csrc/conv24.hip, SHUF variant)
         out = torch.empty((2 * h, 2 * w, c0), dtype=torch.float16, device=src0.device)
         hip.check(hip.lib().refvsr_conv_shuffle2(_ptr(src0), c0, h, w, _ptr(cw.blob24), act, _ptr(out), _stream()), 'conv_shuffle2')
         return out
-    if (cw.blob24 is not None and not cw.shuffle and stride == 1 and pad == 1 and not planar_out and warp is None and res_planar is None and
+    if (cw.blob24 is not None and not cw.shuffle and stride == 1 and pad == 1 and not planar_out and res_planar is None and
             0.0 <= act <= 1.0 and 0.0 <= post <= 1.0 and (mul is None or mul.shape[2] == co_) and (res is None or res.shape[2] == co_) and
             h * w * max(co_, c0, c1) * 2 < 2 ** 31):         # (32-bit element offsets in the specialised kernels: 8K HR maps go generic)
         # compile-time-specialised kernel (24 | 32 | 48 output channels, 3x3): csrc/conv24.hip
@@ -183,11 +171,6 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
     else:
         d.res, d.res_c = None, 0
     d.res_planar, d.add_const, d.clamp_lo, d.clamp_hi = None, 0.0, 0.0, 0.0
-    if warp is not None:
-        wsrc = src0 if wk == 0 else src1
-        d.warp_flow, d.warp_src, d.warp_h, d.warp_w = flow.data_ptr(), wk, wsrc.shape[0], wsrc.shape[1]
-    else:
-        d.warp_flow, d.warp_src, d.warp_h, d.warp_w = None, 0, 0, 0
     if planar_out:
         out = torch.empty((cw.cout, ho, wo), dtype=torch.float32, device=src0.device)
         d.out_mode, d.out_c = OUT_PLANAR32, 0
@@ -207,24 +190,13 @@ def conv(cw, src0, src1=None, stride=1, pad=None, act=1.0, mul=None, res=None, p
         out = torch.empty((ho, wo, co), dtype=cw.odtype, device=src0.device)
         d.out_mode, d.out_c = OUT_NHWC16, co
     d.out = out.data_ptr()
-    if warp is not None and getattr(cw, 'no_fused_warp', False):
-        rc = hip.ERR_UNSUPPORTED                     # decided once per packed conv: no failed launch attempt per call
-    else:
-        rc = hip.lib().refvsr_conv_mfma(C.byref(d), _stream())
-    if rc == hip.ERR_UNSUPPORTED and warp is not None:
-        # no fused-warp kernel for this shape (e.g. the sixteen-wave layout of the C = 48 convs): the stand-alone warp kernel +
-        # the plain conv give the same result bit for bit.  ONLY the library's "unsupported" code takes this path: a
-        # genuine argument or launch error stays an error
-        cw.no_fused_warp = True
-        warped = warp_nhwc16(src0 if wk == 0 else src1, flow)
-        return conv(cw, warped if wk == 0 else src0, src1 if wk == 0 else warped, stride=stride, pad=pad, act=act, mul=mul, res=res,
-                    post=post, planar_out=planar_out, res_planar=res_planar, add_const=add_const, clamp=clamp)
+    rc = hip.lib().refvsr_conv_mfma(C.byref(d), _stream())
     hip.check(rc, 'conv_mfma')
     return out
 
 
-def _conv_batch(cw, src0, B, stride, pad, act, post, planar_out, res_planar, add_const, clamp, src1, mul, res, warp):
-    assert src1 is None and mul is None and res is None and warp is None and not cw.shuffle, 'batched conv: single source, no mul / res / warp'
+def _conv_batch(cw, src0, B, stride, pad, act, post, planar_out, res_planar, add_const, clamp, src1, mul, res):
+    assert src1 is None and mul is None and res is None and not cw.shuffle, 'batched conv: single source, no mul / res'
     assert src0.dim() == 4 and src0.shape[0] == B and src0.is_contiguous() and B >= 1
     f32 = cw.f32
     _nhwc(src0[0], f32)
@@ -242,7 +214,6 @@ def _conv_batch(cw, src0, B, stride, pad, act, post, planar_out, res_planar, add
     d.act_slope, d.post_slope = act, post
     d.mul, d.mul_c, d.res, d.res_c = None, 0, None, 0
     d.res_planar, d.add_const, d.clamp_lo, d.clamp_hi = None, 0.0, 0.0, 0.0
-    d.warp_flow, d.warp_src, d.warp_h, d.warp_w = None, 0, 0, 0
     esz = 4 if f32 else 2
     d.bs_res_planar = 0
     if planar_out:
@@ -271,16 +242,12 @@ def _conv_batch(cw, src0, B, stride, pad, act, post, planar_out, res_planar, add
     return out
 
 
-# Two kernels implement the fused block with identical results: 'lean' (4 waves, 8x32 tile, 77 KB LDS at C = 24, two
-# workgroups per CU -- resblock_lean.hip) and 'wide' (8 waves, 16x32 tile, one 154 KB workgroup per CU -- resblock_mfma.hip).
-RESBLOCK_KERNEL = os.environ.get('REFVSR_RESBLOCK', 'lean')
 _WAVES_SET = False
 
 
 def resblock_fits(c):
-    if RESBLOCK_KERNEL == 'lean' and hip.lib().refvsr_resblock_lean_fits(int(c)):
-        return True
-    return bool(hip.lib().refvsr_resblock_fits(int(c)))
+    """Channel counts of the runtime-generic fused block (resblock_lean.hip: C in {8, 16, 24, 32})."""
+    return bool(hip.lib().refvsr_resblock_lean_fits(int(c)))
 
 
 def _apply_resblock_knobs():
@@ -291,21 +258,16 @@ def _apply_resblock_knobs():
             hip.check(hip.lib().refvsr_set_resblock_waves(int(os.environ['REFVSR_RESBLOCK_WAVES'])), 'set_resblock_waves')
 
 
-def resblock(cw1, cw2, x, act, post=1.0, kernel=None):
-    """refvsr_resblock_lean / refvsr_resblock_mfma: post(x + conv2(act(conv1(x)))) in one launch (3x3, C->C)."""
+def resblock(cw1, cw2, x, act, post=1.0):
+    """refvsr_resblock_lean: post(x + conv2(act(conv1(x)))) in one launch (3x3, C->C)."""
     _nhwc(x)
     h, w, c = x.shape
     assert cw1.cpads == [c] and cw2.cpads == [c] and cw1.cout == c and cw2.cout == c and cw1.ksize == 3
     assert not cw1.f32 and not cw1.shuffle and cw1.wpack.shape[0] == 1
     out = torch.empty_like(x)
-    kernel = kernel or RESBLOCK_KERNEL
     _apply_resblock_knobs()
-    if kernel == 'lean' and hip.lib().refvsr_resblock_lean_fits(c):
-        hip.check(hip.lib().refvsr_resblock_lean(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
-                                                 _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_lean')
-    else:
-        hip.check(hip.lib().refvsr_resblock_mfma(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
-                                                 _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_mfma')
+    hip.check(hip.lib().refvsr_resblock_lean(_ptr(x), c, h, w, _ptr(cw1.wpack), _ptr(cw1.bias), _ptr(cw2.wpack),
+                                             _ptr(cw2.bias), cw1.ksteps, act, post, _ptr(out), _stream()), 'resblock_lean')
     return out
 
 
@@ -327,7 +289,7 @@ class ResblockChain(object):
 
 def resblock_chain(chain, x, act, post=1.0):
     """refvsr_resblock_chain: chain.n fused blocks behind ONE library call (same launches and results as chain.n calls of
-    resblock(); two scratch maps instead of n - 1 intermediates).  Lean kernel only (resblock_fits_lean)."""
+    resblock(); two scratch maps instead of n - 1 intermediates).  """
     _nhwc(x)
     h, w, c = x.shape
     assert c == chain.c
@@ -366,7 +328,7 @@ def resblock24_chain(chain, x, act):
         _RB24_WAVES_SET = True
         if os.environ.get('REFVSR_RESBLOCK24_WAVES'):
             hip.check(hip.lib().refvsr_set_resblock24_waves(int(os.environ['REFVSR_RESBLOCK24_WAVES'])), 'set_resblock24_waves')
-        if os.environ.get('REFVSR_RB24_STORE'):           # A/B knob of the output store path (0 | 1 | 2, refvsr_set_resblock24_store)
+        if os.environ.get('REFVSR_RB24_STORE'):           # A/B knob of the output store path (0 | 1, refvsr_set_resblock24_store)
             hip.check(hip.lib().refvsr_set_resblock24_store(int(os.environ['REFVSR_RB24_STORE'])), 'set_resblock24_store')
     _nhwc(x)
     h, w, c = x.shape
@@ -410,7 +372,7 @@ def resblock48_chain(chain, x, act):
 
 def resblock_chain_ok(c):
     _apply_resblock_knobs()
-    return RESBLOCK_KERNEL == 'lean' and bool(hip.lib().refvsr_resblock_lean_fits(int(c)))
+    return bool(hip.lib().refvsr_resblock_lean_fits(int(c)))
 
 
 def conv_direct(x, w, b, stride=1, pad=None, act=1.0, nhwc16_out=False):

@@ -104,11 +104,11 @@ def test_argument_validation_precedes_device_work(libpath):
     d.cout, d.out_mode, d.res = 24, 1, p                                      # pixel shuffle with a residual
     expect(h.refvsr_conv_mfma(ctypes.byref(d), None), 'pixel-shuffle output constraints')
 
-    assert h.refvsr_resblock_fits(24) == 1 and h.refvsr_resblock_fits(16) == 1
-    assert h.refvsr_resblock_fits(48) == 0 and h.refvsr_resblock_fits(20) == 0
-    expect(h.refvsr_resblock_mfma(p, 24, 8, 8, p, p, p, p, 7, 0.0, 1.0, p, None), 'in-place operation is not supported')
+    assert h.refvsr_resblock_lean_fits(24) == 1 and h.refvsr_resblock_lean_fits(16) == 1
+    assert h.refvsr_resblock_lean_fits(48) == 0 and h.refvsr_resblock_lean_fits(20) == 0
+    expect(h.refvsr_resblock_lean(p, 24, 8, 8, p, p, p, p, 7, 0.0, 1.0, p, None), 'in-place')
     q = ctypes.cast(ctypes.addressof(buf) + 2048, P)
-    expect(h.refvsr_resblock_mfma(p, 48, 8, 8, p, p, p, p, 14, 0.0, 1.0, q, None), 'channel count 48 not supported')
+    expect(h.refvsr_resblock_lean(p, 48, 8, 8, p, p, p, p, 14, 0.0, 1.0, q, None), '48')
 
     expect(h.refvsr_pack_nhwc16(p, 3, 8, 8, q, 12, None), 'pack_nhwc16: bad args')
     expect(h.refvsr_resize(p, 3, 8, 8, q, 16, 16, 7, 0.0, 1.0, None, None, None, 0, 0, 0, None), 'resize: bad mode 7')

@@ -932,39 +932,6 @@ def test_refvsr_ir_state_handoff_roundtrip(dev):
     assert torch.equal(want, call(b, 2, False)) and torch.equal(want, call(c, 2, False))
 
 
-def test_fused_warp_engine_matches_default(dev):
-    """config.fuse_warp = True (the propagated features are warped inside their consumer convs' tile staging instead of by
-    refvsr_warp_nhwc16; north-star 'bilinear warp as a fused gather', opt-in because it measures slower) against the default
-    engine over a first frame and three steady calls, including the forward branch's LR-state-on-the-2x-grid warp
-    (RefVSR.py:254) that the first call exercises.  With the generic conv kernel on both sides the two engines agree bit for bit
-    (the op-level guarantee of test_conv_fused_warp_is_bit_identical carried through the whole network); with the specialised
-    conv24 kernel serving the unfused input convs the fp32 summation order differs: fp16 ulps."""
-    from refvsr_amd import SRNet, get_config, make_state_dict, ops
-    from refvsr_amd.synth import make_clip, window_indices
-    lr, rf, _ = make_clip(4, 48, 64, seed=11)
-
-    def run(fuse):
-        cfg = get_config('p', 'm', 'config_RefVSR_small_L1')
-        cfg.frame_num = 5
-        cfg.fuse_warp = fuse
-        net = SRNet(cfg).to(dev).eval()
-        net.load_state_dict(make_state_dict(cfg, 1234))
-        assert net.Network.ensure_engines(1, dev)[0].fuse_warp == fuse
-        return [net(lr[window_indices(f, 4, 5)][None].to(dev), rf[window_indices(f, 4, 5)][None].to(dev), f == 0)['result'].clone()
-                for f in range(4)]
-    plain, fused = run(False), run(True)
-    for a, b in zip(plain, fused):
-        assert maxdiff(a, b) < 2e-2 and psnr(a.cpu(), b.cpu()) > 60.0
-    c24 = ops.CONV24
-    ops.CONV24 = False                                   # packed without conv24 blobs: the generic kernel everywhere
-    try:
-        plain, fused = run(False), run(True)
-    finally:
-        ops.CONV24 = c24
-    for a, b in zip(plain, fused):
-        assert torch.equal(a, b)
-
-
 def cfg_name_is_small(name):
     return 'small' in name
 

@@ -416,14 +416,9 @@ def test_resblock_fused(dev, C, h, w, act):
     # both workgroup shapes of the lean kernel (8 waves / 4 waves) agree bit for bit
     if ops.hip.lib().refvsr_resblock_lean_fits(C):
         ops.hip.lib().refvsr_set_resblock_waves(4)
-        four = ops.resblock(c1, c2, xin, act=act, kernel='lean')
+        four = ops.resblock(c1, c2, xin, act=act)
         ops.hip.lib().refvsr_set_resblock_waves(8)
-        assert torch.equal(four, ops.resblock(c1, c2, xin, act=act, kernel='lean')), 'lean 4 waves != 8 waves'
-    # the two fused kernels (8x32-tile 'lean', 8-wave 16x32-tile 'wide') agree bit for bit
-    if ops.hip.lib().refvsr_resblock_fits(C) and ops.hip.lib().refvsr_resblock_lean_fits(C):
-        for post in (1.0, 0.2):
-            assert torch.equal(ops.resblock(c1, c2, xin, act=act, post=post, kernel='lean'),
-                               ops.resblock(c1, c2, xin, act=act, post=post, kernel='wide')), 'lean != wide'
+        assert torch.equal(four, ops.resblock(c1, c2, xin, act=act)), 'lean 4 waves != 8 waves'
 
 
 @pytest.mark.parametrize('n', [1, 2, 3, 5, 8])
@@ -443,7 +438,7 @@ def test_resblock_chain_call(dev, n):
     x0 = x.clone()
     want = x
     for c1, c2 in pairs:
-        want = ops.resblock(c1, c2, want, act=0.2, kernel='lean')
+        want = ops.resblock(c1, c2, want, act=0.2)
     assert ops.resblock_chain_ok(C)
     got = ops.resblock_chain(ops.ResblockChain(pairs), x, 0.2)
     assert torch.equal(got, want) and torch.equal(x, x0)
@@ -490,7 +485,7 @@ def test_resblock24_chain(dev, h, w, act, n):
     for ((w1, b1), (w2, b2)), (c1, c2) in zip(raw, pairs):
         t = F.leaky_relu(F.conv2d(want[None], w1, b1, padding=1), act).half().float()
         want = (want + F.conv2d(t, w2, b2, padding=1)[0]).half().float()
-        lean = ops.resblock(c1, c2, lean, act=act, kernel='lean')
+        lean = ops.resblock(c1, c2, lean, act=act)
     e, d = rel(planar(got), want), maxdiff(planar(got), planar(lean))
     report('resblock24 %dx%d act%.1f n%d' % (h, w, act, n), rel=e, vs_lean=d)
     assert e < 1e-3 * n
@@ -596,36 +591,6 @@ def test_warp_vs_golden(dev):
     got = ops.warp_planar(x.to(dev), z.to(dev)).cpu()
     assert maxdiff(got, orc.warp(x[None], z[None])[0]) < 2e-5
     assert maxdiff(got, x) > 1e-2
-
-
-@pytest.mark.parametrize('cins,wk,h,w,src_hw', [([8, 24], 1, 45, 83, None), ([24, 24], 0, 54, 96, None), ([24, 24], 0, 54, 96, (27, 48)),
-                                                ([8, 24], 1, 270, 480, None), ([24, 24], 0, 540, 960, (270, 480)), ([8, 24], 1, 1080, 1920, None),
-                                                ([24, 24], 1, 16, 20, None)])
-def test_conv_fused_warp_is_bit_identical(dev, cins, wk, h, w, src_hw):
-    """warp fused into the consumer (RefvsrConv.warp_*: the propagated features are sampled while the conv stages its input tile,
-    models/utils.py:35-43 inside RefVSR.py:218,227-228 / 220,254,259-260) == refvsr_warp_nhwc16 followed by the plain conv, bit
-    for bit -- every kernel variant the engine can select (8 waves, 4 waves on 4 x 32 and on 8 x 32 tiles), both source slots,
-    a source map of another size than the grid (the LR state on the 2x grid, RefVSR.py:254), flows that leave the frame."""
-    from refvsr_amd import ops
-    from refvsr_amd.packing import pack_conv
-    g = torch.Generator().manual_seed(h + w + wk)
-    cin = sum(cins)
-    wt = torch.randn(24, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
-    b = torch.randn(24, generator=g) * 0.1
-    cw = ops.ConvWeights(pack_conv(wt, b, cins), dev)
-    sh, sw = src_hw or (h, w)
-    srcs = [nhwc(torch.randn(c, h, w, generator=g), dev) for c in cins]
-    srcs[wk] = nhwc(torch.randn(cins[wk], sh, sw, generator=g), dev)
-    flow = (torch.randn(2, h, w, generator=g) * 3.0)
-    flow[:, :2, :] += 40.0                                   # samples far outside the frame: zero padding
-    flow = flow.to(dev)
-    fused = ops.conv(cw, srcs[0], srcs[1], act=0.1, warp=(wk, flow))
-    plain = list(srcs)
-    plain[wk] = ops.warp_nhwc16(srcs[wk], flow)
-    cw.blob24 = None                                         # the same (generic) conv kernel on both sides: the statement is about the warp
-    two = ops.conv(cw, plain[0], plain[1], act=0.1)
-    assert fused.shape == two.shape and torch.equal(fused, two)
-    assert float(two.float().abs().max()) > 0.1
 
 
 def test_spynet_level_input(dev):
@@ -1071,8 +1036,8 @@ def test_batched_conv_and_spynet_level_input_equal_the_single_launches(dev):
 
 @pytest.mark.parametrize('h,w', [(19, 45), (64, 96), (135, 240)])
 def test_resblock24_store_modes_are_bit_identical(dev, h, w):
-    """refvsr_set_resblock24_store: 16-byte stores after the v_permlane16_swap exchange (1) and their write-through form (2)
-    write exactly the bytes of the 8-byte stores (0) -- border tiles, partial tiles, ReLU and leaky blocks, 8- and 16-wave shapes."""
+    """refvsr_set_resblock24_store: the 16-byte stores after the v_permlane16_swap exchange (1, the default) write exactly the
+    bytes of the 8-byte stores (0) -- border tiles, partial tiles, ReLU and leaky blocks, 8- and 16-wave shapes."""
     from refvsr_amd import hip, ops
     g = torch.Generator().manual_seed(h + w)
     raw = []
@@ -1089,13 +1054,13 @@ def test_resblock24_store_modes_are_bit_identical(dev, h, w):
             for act in (0.0, 0.2):
                 lib.refvsr_set_resblock24_store(0)
                 want = ops.resblock24_chain(ch, x, act)
-                for mode in (1, 2):
+                for mode in (1,):
                     lib.refvsr_set_resblock24_store(mode)
                     got = ops.resblock24_chain(ch, x, act)
                     assert torch.equal(got, want), 'store mode %d, %d waves, act %.1f: %d elements differ' % (mode, waves, act, int((got != want).sum()))
     finally:
         lib.refvsr_set_resblock24_waves(0)
-        assert lib.refvsr_set_resblock24_store(7) != 0                      # rejected, mode unchanged
+        assert lib.refvsr_set_resblock24_store(2) != 0                      # (round 4's write-through mode is gone) rejected, mode unchanged
         lib.refvsr_set_resblock24_store(int(os.environ.get('REFVSR_RB24_STORE', str(RB24_STORE_DEFAULT))))
 
 

@@ -113,9 +113,6 @@ def bench_conv():
         us_t = timeit(lambda: ops.conv(c2, ops.conv(c1, x, act=0.0), res=x))
         fl = 2 * 2.0 * h * w * C * C * 9
         emit('resblock %-5s fused %7.1f us (%6.1f TFLOP/s useful)   two launches %7.1f us' % (name, us_f, fl / us_f / 1e6, us_t))
-        us_l = timeit(lambda: ops.resblock(c1, c2, x, act=0.0, kernel='lean'))
-        us_w = timeit(lambda: ops.resblock(c1, c2, x, act=0.0, kernel='wide'))
-        emit('resblock %-5s lean %7.1f us   wide %7.1f us' % (name, us_l, us_w))
     # launch floor: smallest possible conv
     wt = torch.randn(24, 24, 3, 3) * 0.1
     cw = ops.ConvWeights(pack_conv(wt, torch.zeros(24), [24]), dev)

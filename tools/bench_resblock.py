@@ -53,8 +53,7 @@ def main():
                           ('rb24 16 waves 16x32', lambda: (lib.refvsr_set_resblock24_waves(16), ops.resblock24_chain(ch24, x, 0.0))),
                           ('rb24 default', lambda: (lib.refvsr_set_resblock24_waves(0), ops.resblock24_chain(ch24, x, 0.0))),
                           ('rb24 8 waves lrelu', lambda: (lib.refvsr_set_resblock24_waves(8), ops.resblock24_chain(ch24, x, 0.2))),
-                          ('rb24 default, 16 B stores', lambda: (lib.refvsr_set_resblock24_waves(0), lib.refvsr_set_resblock24_store(1), ops.resblock24_chain(ch24, x, 0.0), lib.refvsr_set_resblock24_store(0))),
-                          ('rb24 default, 16 B sc1', lambda: (lib.refvsr_set_resblock24_waves(0), lib.refvsr_set_resblock24_store(2), ops.resblock24_chain(ch24, x, 0.0), lib.refvsr_set_resblock24_store(0)))):
+                          ('rb24 default, 16 B stores', lambda: (lib.refvsr_set_resblock24_waves(0), lib.refvsr_set_resblock24_store(1), ops.resblock24_chain(ch24, x, 0.0), lib.refvsr_set_resblock24_store(0)))):
             us = timeit(fn, iters) / n
             res.append((label, us))
             print('resblock %-14s %-26s %8.2f us/block  %7.1f TFLOP/s useful  %5.1f %% of 2.5 PF' %

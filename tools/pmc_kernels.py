@@ -16,7 +16,7 @@ from refvsr_amd.engine import Engine, Weights  # noqa: E402
 
 dev = torch.device('cuda:0')
 GROUPS = ['resblock LR', 'resblock 2x', 'conv HR', 'conv shuffle 2x', 'warp LR', 'warp 2x', 'gather 2x', 'aligned_sample 2x',
-          'bicubic x4', 'match_top2', 'warp up2 2x', 'conf_alpha LR', 'conf_alpha 2x']
+          'bicubic x4', 'match_top2', 'warp up2 2x', 'conf_alpha LR', 'conf_alpha 2x', 'resblock LR x4 maps', 'resblock LR x2 maps']
 REPS = 4
 
 
@@ -28,6 +28,7 @@ def main():
     g = torch.Generator().manual_seed(3)
     rnd16 = lambda hh, ww, c: ops.pack_nhwc16(torch.randn(c, hh, ww, generator=g).to(dev))
     x_lr, x_2x, x_hr = rnd16(h, w, C), rnd16(2 * h, 2 * w, C), rnd16(4 * h, 4 * w, C)
+    xs4 = [rnd16(h, w, C) for _ in range(4)]
     flow = (torch.randn(2, h, w, generator=g) * 2).to(dev)
     flow2 = ops.flow_up2(flow)
     idx = torch.randint(0, (h // 2) * (w // 2), (h * w,), generator=g, dtype=torch.int32).to(dev)
@@ -57,6 +58,9 @@ def main():
         'warp up2 2x': lambda: ops.warp_nhwc16_up2(x_2x, flow),
         'conf_alpha LR': lambda: ops.conf_alpha(ca, cb, 1, w0, b0, cwa, want_max=True),
         'conf_alpha 2x': lambda: ops.conf_alpha(ca, cb, 2, w0, b0, cwa),
+        # round 5: the multi-map launches of a frame group (four / two maps behind one launch, refvsr_resblock24_chain_batch)
+        'resblock LR x4 maps': lambda: eng._block_chain_b(xs4, [(c1, c2)], 0.0),
+        'resblock LR x2 maps': lambda: eng._block_chain_b(xs4[:2], [(c1, c2)], 0.0),
     }
     torch.cuda.synchronize()
     for gi, name in enumerate(GROUPS):

@@ -30,7 +30,7 @@ def main():
             torch.cuda.synchronize()
         lib.refvsr_set_resblock24_waves(8)
         for _ in range(6):
-            ops.resblock(pair[0], pair[1], x, act=0.0, kernel='lean')
+            ops.resblock(pair[0], pair[1], x, act=0.0)
         torch.cuda.synchronize()
     print('done')
 
