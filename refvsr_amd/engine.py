@@ -1224,7 +1224,7 @@ class Engine(object):
         assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
-        M = M0
+        M = M0          # (two M streams alternating between groups: 210.5 vs 220.4 frames/s, profiles/r05_group_knobs_ab.txt)
         self._pipe_calls += 1
         self._await_fw_up(self.fw_feat_up)
         while len(self._inflight) >= max(1, self.pipe_depth - 1):          # (a group in flight holds B calls' worth of intermediates)
