@@ -434,11 +434,45 @@ def gen_full_hd(h=1080, w=1920, nframes=2, stride=32, t=3):
     save(tag, **arrs)
 
 
+def gen_full_long(nframes=12):
+    """The north-star bar itself -- |PSNR(build, GT) - PSNR(reference, GT)| < 1e-3 dB -- over a LONGER full-size stream than the two
+    frames of e2e_full_S_270x480_t5 (VERDICT r4 weak 1 iii): config_RefVSR_small_MFID (BASELINE configs[3]'s model: reset_branch = 9, so
+    the 12 frames cross a restart of the forward branch), 270 x 480 -> 1080 x 1920, t = 5, random AND 'plausible' weights.  Stored per
+    frame: the PSNR scalar and one 64 x 64 crop at output resolution (the fixture stays small).  ~1.5 min per frame and variant."""
+    from refvsr_amd.synth import make_clip, window_indices
+    import time
+    lr, rf, gt = make_clip(nframes, 270, 480, seed=0)
+    arrs = dict(nframes=np.int64(nframes), crop=np.asarray([520, 930], np.int64),
+                lr_checksum=np.float64(lr.double().sum().item()), ref_checksum=np.float64(rf.double().sum().item()))
+    for variant in (None, 'plausible'):
+        tag = '' if variant is None else 'p_'
+        print('== full-size small_MFID 270x480 t=5, %d frames, weights: %s ==' % (nframes, variant or 'random'), flush=True)
+        net, cfg, mine, sd = ref_net('config_RefVSR_small_MFID', 5, save_sample=False)
+        assert cfg.reset_branch == 9
+        if variant:
+            net.load_state_dict(wts.make_state_dict(mine, SEED_W, variant=variant), strict=True)
+        with torch.no_grad():
+            for f in range(nframes):
+                w = window_indices(f, nframes, 5)
+                t0 = time.time()
+                res = net(lr[w][None], rf[w][None], f == 0, is_log=False, is_train=False)['result']
+                p = float(10 * torch.log10(1 / torch.mean((res - gt[f][None]) ** 2)))
+                print('  frame %d: %.1f s, PSNR vs GT %.6f dB' % (f, time.time() - t0, p), flush=True)
+                arrs[tag + 'psnr_%d' % f] = np.float64(p)
+                arrs[tag + 'crop_%d' % f] = res[0, :, 520:584, 930:994].clone()
+    save('e2e_full_S_270x480_t5_long', **arrs)
+
+
 def main():
     if '--full-mfid' in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         gen_full_mfid()
+        return
+    if '--full-long' in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        gen_full_long()
         return
     if '--full-hd' in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
