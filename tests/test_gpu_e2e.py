@@ -1079,3 +1079,71 @@ def test_bench_gpus_2_self_launches_and_reports_the_sharded_clip(dev):
     assert d['wavefront']['frames_equal'] is True and d['wavefront']['backend'].startswith('gloo')
     assert d['weak_scaling_shards']['scaling'] == 'weak' and d['weak_scaling_shards']['value'] > 0
     assert abs(d['value'] - 12.0 / d['wavefront']['seconds']) < 2e-2 * d['value']          # (the compact line rounds the seconds)
+
+
+def _exchange_t5_worker(rank, world, port, q):
+    """Two ranks, 12 frames, frame_num = 5, reset_branch = 7, balanced shards (0,6) (6,12): rank 1's block starts ONE frame before
+    the reset frame -- its first window (ids 4..8) leaves unprepared contexts of frames 4, 5 in the id cache, and the plan then hands
+    it the contexts of 5 and 6 for the hinted reset window of frame 7 (import_context used to assert here)."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from refvsr_amd import shard
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 12, 5
+    lr, rf, _ = make_clip(nfr, 32, 48, seed=5)
+    get = lambda f: (lr[window_indices(f, nfr, t)], rf[window_indices(f, nfr, t)])
+    dev = torch.device('cuda:0')
+    net, cfg, sd = make_net('config_RefVSR_small_MFID', t, dev, reset=7, save_sample=False)
+    ex = shard.EngineExecutor(net, dev, 32, 48, nfr, t, keep_on_device=False)
+    parts = shard.partition(nfr, world)
+    assert parts[1][0] == 7 - 1, parts
+    imported = []
+    orig = ex.eng.import_context
+    ex.eng.import_context = lambda lr_, ref_, fid, buf, spec: (imported.append((fid, ex.eng._ctx(fid) is not None)), orig(lr_, ref_, fid, buf, spec))[1]
+    res = shard.run_wavefront(ex, get, nfr, t, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=parts, exchange_contexts=True)
+    q.put((rank, {f: v.clone().numpy() for f, v in res.items()}, imported))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_context_exchange_block_start_before_a_reset_frame(dev):
+    """run_wavefront(exchange_contexts=True) with frame_num = 5 and a block that starts at k * reset_branch - 1:
+    the importing rank already holds an UNPREPARED context of a frame it is sent -- import_context fills it in place -- and the stream
+    equals the sequential run bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from refvsr_amd.synth import make_clip, window_indices
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_t5_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, imported = {}, {}
+    try:
+        for _ in range(2):
+            r, res, imp = q.get(timeout=300)
+            got.update({f: torch.from_numpy(v) for f, v in res.items()})
+            imported[r] = imp
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+    # the case the finding describes did occur: rank 1 was sent a context whose (unprepared) FrameCtx it already held
+    assert any(held for _, held in imported[1]), imported
+    nfr, t = 12, 5
+    lr, rf, _ = make_clip(nfr, 32, 48, seed=5)
+    net, cfg, sd = make_net('config_RefVSR_small_MFID', t, dev, reset=7, save_sample=False)
+    for f in range(nfr):
+        w = window_indices(f, nfr, t)
+        want = net(lr[w][None].to(dev), rf[w][None].to(dev), f == 0)['result'][0].cpu()
+        assert torch.equal(got[f], want), 'frame %d differs from the sequential run' % f
