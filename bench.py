@@ -742,7 +742,7 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     # REFVSR_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box (all ranks share GPU 0);
     # the real multi-GPU run uses nccl (= RCCL), one rank per GPU.
-    backend = os.environ.get('REFVSR_DIST_BACKEND', 'nccl')
+    backend = os.environ.get('REFVSR_DIST_BACKEND') or ('gloo' if world > torch.cuda.device_count() else 'nccl')
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
