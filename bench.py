@@ -3,45 +3,38 @@
 the drop-in SRNet surface on the HIP path.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # re-launches itself under torch.distributed.run, or (the driver's form):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one forward call = one output frame.  Inputs (the synthetic LR / Ref clip, every sliding window) are
-resident in HBM before the timed region.  Workload (default): BASELINE configs[1] -- RefVSR_small_L1, 270x480 ->
-1080x1920, frame_num = 5; `--config config_RefVSR_MFID` is configs[2], `--config config_RefVSR_MFID_8K --size 1080x1920`
-configs[4] on one GPU.  With N > 1 every rank runs K steps on its own reset-aligned shard of one long clip
-(exchange-free partition, refvsr_amd/shard.py): per-GPU work fixed ("weak"), no data-path collective; the timed region is
-bracketed by barrier + synchronize and the MAX over ranks is reported.
+One "step" = one output frame.  Inputs (the synthetic LR / Ref clip, every sliding window) are resident in HBM before the
+timed region.  Workload (default, N = 1): BASELINE configs[1] -- RefVSR_small_L1, 270x480 -> 1080x1920, frame_num = 5;
+`--config config_RefVSR_MFID` is configs[2], `--config config_RefVSR_MFID_8K --size 1080x1920` configs[4] on one GPU.
+N > 1: `value` is the STRONG-scaling figure -- ONE 64-frame clip of config_RefVSR_small_MFID (configs[3]) sharded by frame index
+over the ranks with the forward-state hand-off and the context exchange over RCCL send/recv (refvsr_amd/shard.py:run_wavefront),
+barrier + synchronize on both sides, max over ranks, frames verified against a single-rank run; the exchange-free figure (every
+rank K steps on its own reset-aligned shard, per-GPU work fixed) sits beside it as `weak_scaling_shards`.
 
-What the JSON line carries beside the contract fields:
-  value              -- the build's fastest supported call mode: windows named by frame ids (`frame_ids=`) and calls
-                        pipelined over the engine's internal streams (`set_pipelined`) -- two documented EXTENSIONS of
-                        the reference's call surface (what the build's own eval harness, refvsr_amd/evalrun.py, uses)
+The stdout line is the COMPACT form of the record (< 6 KB: the driver keeps 8 KB); the complete record goes to --full-json.
+What the line carries beside the contract fields:
+  value              -- the build's fastest supported call mode: FRAME GROUPS (`forward_group`: --group consecutive output frames per
+                        call, named by frame ids, on the engine's internal streams, inputs 'materialised') -- documented EXTENSIONS of
+                        the reference's call surface, bit-identical to it; the backward branches of a group run as multi-map launches
+  one_frame_per_call -- the same K steps with one `forward(frame_ids=)` per frame (round 4's headline mode)
   dropin_surface     -- the same K steps through the UNMODIFIED reference call surface (`net(x, ref, is_first_frame)`,
                         frames recognised by content, no pipelining): what run.py / eval.py get with the 3-line plug-in
-  roofline           -- the TIME-dominant kernel (the fused 24-channel ResBlock, ~30 % of the device time in 156 launches per
-                        frame, MFMA-bound): useful FLOPs per LR launch / mean launch duration from HIP events recorded around
-                        every run of blocks in a second, single-stream pass over the same frames (inside the pipelined region the
-                        launches of other streams sit between the events); configurations whose blocks do not run on that
-                        kernel (C = 48 / 36) report the matching kernel here
-  roofline_match_top2 -- the fused matching GEMM + arg-max (one launch per frame, ~16 % of the device time): algorithmic FLOPs per
-                        launch / mean duration from HIP events around every launch inside the timed region
-  wavefront_model    -- (N = 1) phase A / B1 / B2 times of one restart unit of BASELINE configs[3], host-synchronised per phase,
-                        one per-frame context prepared alone, a cold window with and without its contexts, and the makespan
-                        model's predicted speed-up at 2 / 4 / 8 ranks per partition, with and without the context exchange
-                        (refvsr_amd/shard.py)
-  kernels            -- device time per launch (HIP events around back-to-back launches queued behind a long kernel, so
-                        the host launch rate does not enter) of the time-dominant conv kernels (MFMA and HBM fractions)
-                        and of the HBM-bound warp / gather / sampler / resize kernels (GB/s of algorithmic bytes against
-                        8 TB/s; `traffic` = PMC FETCH_SIZE x2 + WRITE_SIZE per launch from profiles/pmc_kernels.json)
-  whole_path         -- algorithmic TFLOP per output frame (refvsr_amd/flops.py, config-aware) x frames/s against the
-                        dense fp16 MFMA peak
-  wavefront (N > 1)  -- BASELINE configs[3]: a 64-frame clip of config_RefVSR_small_MFID (reset_branch = 9) sharded over
-                        the N ranks by frame index with the forward-state hand-off over RCCL send/recv and the per-frame
-                        contexts prepared once and exchanged (shard.run_wavefront(exchange_contexts=True);
-                        --no-wavefront-exchange for the A/B); per-frame checksums are compared with a single-rank run
+  roofline           -- the TIME-dominant kernel (the fused 24-channel ResBlock, a third of the device time, MFMA-bound): useful FLOPs
+                        per launch / mean launch duration from HIP events around every run of blocks in one more pass of the same calls
+                        with every internal section on ONE stream; in group mode the launches of record are the multi-map launches
+                        (`maps_per_launch`); `traffic` = HBM bytes per launch from the PMC passes (profiles/pmc_kernels.json);
+                        configurations whose blocks do not run on that kernel (C = 48 / 36) report the matching kernel here
+  roofline_match_top2 -- the fused matching GEMM + arg-max (one launch per frame): algorithmic FLOPs per launch / mean duration from HIP
+                        events around every launch inside the timed region
   cpu_baseline       -- the CPU oracle (a port of the reference's algorithm; the reference itself cannot travel) timed on
                         this host: ONE full steady-state forward as the reference executes it, nothing sampled
+  whole_path, streams_ms_per_frame, other_configs (configs[2], configs[4] on one GPU), kernels (per-kernel rates, stand-alone),
+  wavefront_model_predicted_speedup (N = 1) / wavefront (N > 1: the measured sharded-clip leg) -- one figure each; details in the
+  full record
 """
 import argparse
 import json
@@ -665,7 +658,8 @@ def promote_wavefront(line, wf, args, world):
     line['weak_scaling_shards'] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'samples', 'scaling')}
     line['weak_scaling_shards']['what'] = ('every rank runs the K steps on its own reset-aligned shard of one long clip: no data-path collective, '
                                            'per-GPU work fixed')
-    line['metric'] = '4x SR frames/sec (270p->1080p, RefVSR_small_MFID, %d-frame clip sharded over %d GPUs)' % (args.clip, world)
+    hh = int(args.size.lower().split('x')[0])
+    line['metric'] = '4x SR frames/sec (%dp->%dp, RefVSR_small_MFID, %d-frame clip sharded over %d GPUs)' % (hh, 4 * hh, args.clip, world)
     line['value'], line['ms_per_step'], line['scaling'] = wf['value'], 1e3 * wf['seconds'] / float(args.clip), 'strong'
     line['samples'] = [round(wf['value'], 2)]
     cfg_ = line['config']

@@ -1338,10 +1338,11 @@ class Engine(object):
         self._inflight.append(done)
         return outs
 
-    def _side_stream(self, dev, k=0):
-        if self._side is None or self._side[0].device != dev:
-            self._side = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        return self._side[k]
+    def _side_stream(self, dev):
+        """The one side stream of the sequential path (the forward-branch step under the new frame's preparation)."""
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def _prop_step(self, f, branch, feat, feat_up, conf, fl, up_from_lr=False):
         """One propagation step (RefVSR.py:216-230 backward, :251-277 forward): warp the carried maps with `fl` (None: first

@@ -1068,12 +1068,12 @@ def test_bench_compact_line_keeps_the_judged_fields_under_6_kb():
     wf = {'value': 900.0, 'seconds': 64 / 900.0, 'frames_equal': True, 'workload': 'clip', 'ranks_seen': 8, 'backend': 'nccl (= RCCL)', 'gpus_visible': 8,
           'handoff': {'ms_per_message_measured': 0.31, 'messages': 50, 'bytes_per_message': 32700000}, 'partition': {'name': 'cyclic_growing', 'blocks': blob, 'predicted_speedup': 7.4}}
     line8 = dict(line, n_gpus=8, value=1700.0, config=dict(line['config']))
-    bench.promote_wavefront(line8, wf, argparse.Namespace(clip=64), 8)
+    bench.promote_wavefront(line8, wf, argparse.Namespace(clip=64, size='270x480'), 8)
     assert line8['scaling'] == 'strong' and line8['value'] == 900.0 and line8['weak_scaling_shards']['value'] == 1700.0
     assert line8['config']['ranks_seen'] == 8 and line8['config']['handoff_ms_measured'] == 0.31 and line8['config']['timed_frames'] == 64
     c8 = bench.compact_line(line8)
     assert len(json.dumps(c8)) < 6000 and c8['wavefront']['frames_equal'] is True and c8['weak_scaling_shards']['value'] == 1700.0
     # a leg that failed its frame check never becomes the headline
     line_bad = dict(line, n_gpus=8, value=1700.0, config=dict(line['config']))
-    bench.promote_wavefront(line_bad, dict(wf, frames_equal=False), argparse.Namespace(clip=64), 8)
+    bench.promote_wavefront(line_bad, dict(wf, frames_equal=False), argparse.Namespace(clip=64, size='270x480'), 8)
     assert line_bad['value'] == 1700.0 and line_bad['scaling'] == 'weak'
