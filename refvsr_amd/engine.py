@@ -1338,6 +1338,155 @@ class Engine(object):
         self._inflight.append(done)
         return outs
 
+    # ------------------------------------------------------------------ n > 1: the samples of a batch as multi-map launches (round 5)
+    # The n samples of a call (lrs [n,t,3,h,w], RefVSR.py:151) are n independent streams over identical weights: in steady state the
+    # forward-branch step AND the backward branches of all samples run as multi-map launches (one launch per layer over n maps); only the
+    # per-frame preparation stays per sample.  Same streams, events and hazards as a frame group; results equal one forward() per sample,
+    # bit for bit (tests/test_gpu_e2e.py::test_batch_samples_as_multimap_launches).
+    @staticmethod
+    @torch.no_grad()
+    def forward_multi(engines, lrs, refs, is_first_frame, frame_ids, input_ready=None):
+        """engines: one Engine per sample (sharing one Weights); lrs, refs [n,t,3,h,w]; frame_ids: per-sample id lists.  Returns the n
+        results.  Calls that restart a forward branch (first frame, reset_branch roll-over -- the samples' counters run in lock-step),
+        more than REFVSR_MAX_MAPS samples and engines without the multi-map launch list run one forward() per sample."""
+        n = len(engines)
+        lead = engines[0]
+        if lead.group_ok() and lead.pipelined:
+            for e in engines:                       # P | F | M from the first stream on, like an engine driven through forward_group
+                e._layout_default = 'pfm'
+        steady = (not is_first_frame and 2 <= n <= ops.hip.MAX_MAPS and lead.group_ok() and
+                  all(e.pipelined and e.fw_feat is not None and e.W is lead.W and
+                      (e.max_frame_itr_num is None or e.frame_itr_num != e.max_frame_itr_num) and
+                      tuple(e.fw_feat.shape[:2]) == tuple(lrs.shape[3:]) for e in engines))
+        for e in engines[1:]:                       # one set of internal streams for all samples: the lead's
+            e._layout_default, e._pipe, e._inflight = lead._layout_default, lead._pipe, lead._inflight
+            if lead._pipe is not None:
+                e.pipe_layout, e._pipe_calls = lead.pipe_layout, lead._pipe_calls
+        if not steady:
+            outs = []
+            for b, e in enumerate(engines):
+                outs.append(e.forward(lrs[b], refs[b], bool(is_first_frame), frame_ids=frame_ids[b], input_ready=input_ready)[0])
+                for e2 in engines:                  # (the lead may just have created the streams)
+                    if e2 is not e:
+                        e2._pipe, e2._inflight = e._pipe, e._inflight
+                        if e._pipe is not None:
+                            e2.pipe_layout, e2._pipe_calls = e.pipe_layout, e._pipe_calls
+            return outs
+        with torch.cuda.device(lrs.device):
+            return lead._forward_multi_pipelined(engines, lrs, refs, frame_ids, input_ready)
+
+    def _forward_multi_pipelined(self, engines, lrs, refs, frame_ids, input_ready):
+        n, t, _, h, w = lrs.shape
+        ctr, dev = t // 2, lrs.device
+        for b in range(n):
+            self._check_window(lrs[b], refs[b])
+        caller = torch.cuda.current_stream()
+        M0, M1, F_, P = self._pipe_streams(dev)
+        M = M0
+        self._pipe_calls += 1
+        for e in engines:
+            e._pipe, e.pipe_layout, e._pipe_calls = self._pipe, self.pipe_layout, self._pipe_calls
+            e._await_fw_up(e.fw_feat_up)
+        while len(self._inflight) >= self.pipe_depth:
+            self._inflight.popleft().synchronize()
+        streams = []
+        for st in (M0, M1, F_, P):
+            if all(st is not s_ for s_ in streams):
+                streams.append(st)
+        if input_ready is None:
+            input_ready = torch.cuda.Event()
+            input_ready.record(caller)
+        if not isinstance(input_ready, str):
+            for st in streams:
+                if isinstance(input_ready, torch.cuda.Stream):
+                    st.wait_stream(input_ready)
+                else:
+                    st.wait_event(input_ready)
+        elif input_ready != 'materialised':
+            raise ValueError("input_ready must be None, 'materialised', a torch.cuda.Event or a torch.cuda.Stream")
+        for st in streams:
+            lrs.record_stream(st)
+            refs.record_stream(st)
+        share = (M0, M1, F_, P)
+
+        def publish(f):
+            for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                for st in share:
+                    x.record_stream(st)
+        # ---- P: per-sample preparation of the new frames and flows
+        frs = []
+        with ops.on_stream(P):
+            for b, e in enumerate(engines):
+                n_ctx = next(_uid)
+                fr = e._frames(lrs[b], refs[b], frame_ids[b])
+                frs.append(fr)
+                for f in fr:
+                    if f.uid > n_ctx:
+                        for st in share:
+                            f.lr.record_stream(st)
+                            f.ref.record_stream(st)
+                for i in range(ctr, t):
+                    f = fr[i]
+                    if f.conf is None:
+                        e.pyramid(f)
+                        e.prepare_frame(f)
+                        publish(f)
+                        f.ready = torch.cuda.Event()
+                        f.ready.record()
+                    else:
+                        if f.pyr is None:
+                            e.pyramid(f)
+                        if f.ready is None:
+                            publish(f)
+                e.flows([(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])], share)
+        # ---- F: the forward-branch step of all samples as multi-map launches
+        with ops.on_stream(F_):
+            for e, fr in zip(engines, frs):
+                for f in (fr[ctr], fr[ctr + 1]):
+                    if f.ready is not None:
+                        F_.wait_event(f.ready)
+                for x in (e.fw_feat, e.fw_feat_up, e.fw_conf, e.fw_flow):
+                    x.record_stream(F_)
+            fw_feat, fw_up, fw_conf = self._prop_step_b([fr[ctr] for fr in frs], 'forward_resblocks', [e.fw_feat for e in engines],
+                                                        [e.fw_feat_up for e in engines], [e.fw_conf for e in engines],
+                                                        [e.fw_flow for e in engines])
+            for b, (e, fr) in enumerate(zip(engines, frs)):                               # RefVSR.py:279-283
+                e.fw_feat, e.fw_feat_up, e.fw_conf = fw_feat[b], fw_up[b], fw_conf[b]
+                e.fw_flow = e.flow(fr[ctr + 1], fr[ctr], share)
+            for x in list(fw_up) + list(fw_conf):
+                x.record_stream(M0)
+                x.record_stream(M1)
+            ev_fw = torch.cuda.Event()
+            ev_fw.record()
+        # ---- M: the backward branches of all samples step by step as multi-map launches, then the upsamplers
+        outs = []
+        with ops.on_stream(M):
+            cs_ = self._state_cs()
+            feats = [self._zeros((h, w, cs_), torch.float16, dev)] * n
+            feat_ups = [self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)] * n
+            confs = [self._zeros((1, h, w), torch.float32, dev)] * n
+            for i in range(t - 1, ctr - 1, -1):
+                fs = [fr[i] for fr in frs]
+                for f in fs:
+                    if f.ready is not None:
+                        M.wait_event(f.ready)
+                fls = None
+                if i < t - 1:
+                    fls = [e.flow(fr[i], fr[i + 1], share) for e, fr in zip(engines, frs)]
+                feats, feat_ups, confs = self._prop_step_b(fs, 'backward_resblocks', feats, feat_ups, confs, fls)
+            M.wait_event(ev_fw)
+            for b, fr in enumerate(frs):
+                outs.append(self.compute_up(feat_ups[b], fw_up[b], confs[b], fw_conf[b], fr[ctr].lr))
+        for e in engines:
+            e.frame_itr_num += 1
+        done = torch.cuda.Event()
+        done.record(M)
+        caller.wait_event(done)
+        for o in outs:
+            o.record_stream(caller)
+        self._inflight.append(done)
+        return outs
+
     def _side_stream(self, dev):
         """The one side stream of the sequential path (the forward-branch step under the new frame's preparation)."""
         if self._side is None or self._side.device != dev:

@@ -146,6 +146,15 @@ class Network(nn.Module):
         want_vis = bool(is_log and self.config.save_sample)
         results, vis_all = [], []
         dbg_all = []
+        if (n > 1 and frame_ids is not None and not is_log and
+                all(e.takes_pipelined_path(frame_ids, False) and e.group_ok() for e in self._engines[:n])):
+            # round 5: the n samples are n independent streams over identical weights -- in steady state their forward-branch steps and
+            # backward branches run as multi-map launches (Engine.forward_multi); same results as the loop below, bit for bit
+            res = self._engine_cls.forward_multi(self._engines[:n], lrs, refs, bool(is_first_frame),
+                                                 [[(b, f) for f in frame_ids] for b in range(n)], input_ready)
+            outs = collections.OrderedDict()
+            outs['result'] = torch.stack(res, 0)
+            return outs
         for b in range(n):
             out, vis = self._engines[b].forward(lrs[b], refs[b], bool(is_first_frame), want_vis,
                                                 None if frame_ids is None else [(b, f) for f in frame_ids], want_log=bool(is_log),

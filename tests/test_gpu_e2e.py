@@ -1219,3 +1219,33 @@ def test_frame_groups_other_configurations(dev, name, t, size, scale, reset):
     torch.cuda.synchronize()
     for f in range(nfr):
         assert torch.equal(outs[f], want[f]), '%s: group frame %d differs' % (name, f)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4])
+def test_batch_samples_as_multimap_launches(dev, n):
+    """n > 1 (lrs [n,t,3,h,w], RefVSR.py:151) with frame ids on a pipelined module: the n samples' forward-branch steps and backward
+    branches run as multi-map launches (Engine.forward_multi) -- every sample's stream must equal its own one-sample sequential run bit
+    for bit, over a reset_branch roll-over (the restart call runs one forward() per sample) and a second clip."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 9, 5
+    clips = [make_clip(nfr, 64, 96, seed=31 + b) for b in range(n)]
+    lr = torch.stack([c[0] for c in clips], 0).to(dev)                    # [n, nfr, 3, h, w]
+    rf = torch.stack([c[1] for c in clips], 0).to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    want = []
+    for b in range(n):
+        ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+        want.append([ref_net(lr[b, wins[f]][None].contiguous(), rf[b, wins[f]][None].contiguous(), f == 0)['result'][0].clone() for f in range(nfr)])
+    net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    net.Network.set_pipelined(True)
+    for clip in range(2):
+        outs = []
+        for f in range(nfr):
+            x = lr[:, wins[f]].contiguous()
+            r = rf[:, wins[f]].contiguous()
+            outs.append(net(x, r, f == 0, frame_ids=[(clip, i) for i in wins[f]])['result'])
+        torch.cuda.synchronize()
+        for f in range(nfr):
+            assert outs[f].shape[0] == n
+            for b in range(n):
+                assert torch.equal(outs[f][b], want[b][f]), 'sample %d frame %d differs (n = %d, clip %d)' % (b, f, n, clip)
