@@ -330,7 +330,7 @@ int refvsr_warp_planar_batch(const float* const* x, int batch, int c, int hin, i
  * planar fp32 [2][h][w].  ref/supp: planar fp32 [3][h][w]; flow_prev: planar [2][h/2][w/2]. */
 int refvsr_spynet_level_input(const float* ref, const float* supp, const float* flow_prev, int h, int w,
                               void* out8, float* flow_up, void* stream);
-/* The same for `batch` (1..4) independent (ref, supp) pairs of one pyramid level in one launch: ref / supp are host arrays of
+/* The same for `batch` (1..8; 4 until ABI 10) independent (ref, supp) pairs of one pyramid level in one launch: ref / supp are host arrays of
  * `batch` device pointers; flow_prev [batch][2][h/2][w/2] (or NULL), out8 [batch][h][w][8], flow_up [batch][2][h][w] are
  * contiguous batches.  Image b == refvsr_spynet_level_input of pair b, bit for bit. */
 int refvsr_spynet_level_input_batch(const float* const* ref, const float* const* supp, int batch, const float* flow_prev,

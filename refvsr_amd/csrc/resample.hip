@@ -397,8 +397,9 @@ extern "C" int refvsr_warp_planar(const float* x, int c, int hin, int win, const
 // ------------------------------------------------------------------------------------------------
 // SPyNet level input: x2 align_corners flow upsample (*2) + border-clamped flow_warp + concat
 // ------------------------------------------------------------------------------------------------
-struct SpyLevelArgs {                   // up to 4 independent (ref, supp) pairs of one pyramid level per launch (blockIdx.z)
-    const float* ref[4]; const float* supp[4];
+#define SPY_MAX_PAIRS 8
+struct SpyLevelArgs {                   // up to 8 independent (ref, supp) pairs of one pyramid level per launch (blockIdx.z)
+    const float* ref[SPY_MAX_PAIRS]; const float* supp[SPY_MAX_PAIRS];
     const float* flow_prev;             // [batch][2][h/2][w/2] or NULL
     f16* out8; float* flow_up;          // [batch][h][w][8], [batch][2][h][w]
     int h, w;
@@ -410,8 +411,10 @@ __global__ void spynet_level_input_kernel(SpyLevelArgs a) {
     const int h = a.h, w = a.w;
     if (x >= w) return;
     const int bi = blockIdx.z;
-    const float* __restrict__ ref = bi == 0 ? a.ref[0] : bi == 1 ? a.ref[1] : bi == 2 ? a.ref[2] : a.ref[3];
-    const float* __restrict__ supp = bi == 0 ? a.supp[0] : bi == 1 ? a.supp[1] : bi == 2 ? a.supp[2] : a.supp[3];
+#define SPY_SEL(t) (bi == 0 ? (t)[0] : bi == 1 ? (t)[1] : bi == 2 ? (t)[2] : bi == 3 ? (t)[3] : bi == 4 ? (t)[4] : bi == 5 ? (t)[5] : bi == 6 ? (t)[6] : (t)[7])
+    const float* __restrict__ ref = SPY_SEL(a.ref);
+    const float* __restrict__ supp = SPY_SEL(a.supp);
+#undef SPY_SEL
     const float* __restrict__ flow_prev = a.flow_prev ? a.flow_prev + (size_t)bi * 2 * (h / 2) * (w / 2) : nullptr;
     f16* __restrict__ out8 = a.out8 + (size_t)bi * h * w * 8;
     float* __restrict__ flow_up = a.flow_up + (size_t)bi * 2 * h * w;
@@ -461,7 +464,7 @@ __global__ void spynet_level_input_kernel(SpyLevelArgs a) {
 
 extern "C" int refvsr_spynet_level_input_batch(const float* const* ref, const float* const* supp, int batch, const float* flow_prev,
                                                int h, int w, void* out8, float* flow_up, void* stream) {
-    RV_CHECK(ref && supp && out8 && flow_up && h > 0 && w > 0 && batch >= 1 && batch <= 4, "spynet_level_input: bad args");
+    RV_CHECK(ref && supp && out8 && flow_up && h > 0 && w > 0 && batch >= 1 && batch <= SPY_MAX_PAIRS, "spynet_level_input: bad args");
     RV_CHECK(flow_prev == nullptr || (h % 2 == 0 && w % 2 == 0), "spynet_level_input: odd level size");
     SpyLevelArgs a;
     memset(&a, 0, sizeof(a));

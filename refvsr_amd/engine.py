@@ -627,8 +627,8 @@ class Engine(object):
             if (a.uid, b.uid) not in self.flow_cache and all((a.uid, b.uid) != (x.uid, y.uid) for x, y in todo):
                 todo.append((a, b))
         if len(todo) >= 2 and self.spynet_batch:
-            for i0 in range(0, len(todo), 4):
-                chunk = todo[i0:i0 + 4]
+            for i0 in range(0, len(todo), 8):         # (a frame group of four asks for eight flows: ONE pass -- the coarse levels are
+                chunk = todo[i0:i0 + 8]               #  launches of 2-36 workgroups per image; 222.5 vs 220.6 frames/s with two passes of four)
                 if len(chunk) >= 2:
                     self._flow_batch(chunk, share)
         return [self.flow(a, b, share) for a, b in pairs]

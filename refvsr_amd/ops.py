@@ -604,7 +604,7 @@ def spynet_level_input_batch(refs, supps, flow_prev):
     """refvsr_spynet_level_input_batch: B independent (ref, supp) pairs of one pyramid level in one launch.  refs / supps:
     lists of B planar fp32 [3,h,w] tensors; flow_prev [B,2,h/2,w/2] or None.  Returns (x [B,h,w,8] fp16, flow_up [B,2,h,w])."""
     B = len(refs)
-    assert 1 <= B <= 4 and len(supps) == B
+    assert 1 <= B <= 8 and len(supps) == B
     for t_ in list(refs) + list(supps):
         _planar(t_, 3)
     h, w = refs[0].shape[1:]

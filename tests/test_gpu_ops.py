@@ -1024,14 +1024,15 @@ def test_batched_conv_and_spynet_level_input_equal_the_single_launches(dev):
     got = ops.conv(cw, torch.stack(xs, 0).contiguous(), planar_out=True, res_planar=torch.stack(rp, 0).contiguous(), batch=2)
     for b in range(2):
         assert torch.equal(got[b], ops.conv(cw, xs[b], planar_out=True, res_planar=rp[b]))
-    refs = [torch.rand(3, 20, 36, generator=g).to(dev) for _ in range(2)]
-    sups = [torch.rand(3, 20, 36, generator=g).to(dev) for _ in range(2)]
-    fp = (torch.randn(2, 2, 10, 18, generator=g) * 2).to(dev)
-    for flow_prev in (None, fp):
-        x8, fup = ops.spynet_level_input_batch(refs, sups, flow_prev)
-        for b in range(2):
-            x1, f1 = ops.spynet_level_input(refs[b], sups[b], None if flow_prev is None else flow_prev[b].contiguous())
-            assert torch.equal(x8[b], x1) and torch.equal(fup[b], f1)
+    for nb in (2, 8):                                      # (eight pairs per launch since ABI 11: the flows of a frame group)
+        refs = [torch.rand(3, 20, 36, generator=g).to(dev) for _ in range(nb)]
+        sups = [torch.rand(3, 20, 36, generator=g).to(dev) for _ in range(nb)]
+        fp = (torch.randn(nb, 2, 10, 18, generator=g) * 2).to(dev)
+        for flow_prev in (None, fp):
+            x8, fup = ops.spynet_level_input_batch(refs, sups, flow_prev)
+            for b in range(nb):
+                x1, f1 = ops.spynet_level_input(refs[b], sups[b], None if flow_prev is None else flow_prev[b].contiguous())
+                assert torch.equal(x8[b], x1) and torch.equal(fup[b], f1)
 
 
 @pytest.mark.parametrize('h,w', [(19, 45), (64, 96), (135, 240)])
