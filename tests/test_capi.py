@@ -118,3 +118,37 @@ def test_argument_validation_precedes_device_work(libpath):
     expect(h.refvsr_block_gather_nhwc16(p, 8, 8, 20, q, 4, 4, 2, q, None), 'block_gather')
     flags = (ctypes.c_void_p * 1)(p)
     expect(h.refvsr_buffers_equal(flags, flags, 1, 24, q, None), 'multiple of 16 bytes')
+
+
+def test_multimap_entry_points_validate_before_device_work(libpath):
+    """The ABI 11 entry points (host arrays of per-map device pointers): batch bounds, null table entries, shape support and aliasing are
+    rejected with a message before anything touches the device."""
+    from refvsr_amd import hip
+    h = hip.lib()
+    P = ctypes.c_void_p
+    buf = (ctypes.c_char * 65536)()
+    at = lambda off: ctypes.cast(ctypes.addressof(buf) + off, P)
+    arr = lambda *ps: (P * len(ps))(*[p.value for p in ps])
+
+    def expect(rc, text):
+        assert rc != 0 and text in h.refvsr_last_error().decode(), h.refvsr_last_error()
+
+    assert hip.MAX_MAPS == 4
+    s2, o2 = arr(at(0), at(4096)), arr(at(8192), at(12288))
+    five = arr(at(0), at(64), at(128), at(192), at(256))
+    expect(h.refvsr_resblock24_chain_batch(five, 5, 8, 8, 1, at(1024), 43264, 0.0, None, None, five, None), 'resblock24_chain: bad args')
+    expect(h.refvsr_resblock24_chain_batch(s2, 2, 8, 8, 2, at(1024), 43264, 0.0, None, None, o2, None), 'n >= 2 needs scratch0')
+    expect(h.refvsr_resblock24_chain_batch(s2, 2, 8, 8, 1, at(1024), 43264, 0.0, None, None, s2, None), 'buffers must be distinct')
+    expect(h.refvsr_resblock24_chain_batch(arr(at(0), P(0)), 2, 8, 8, 1, at(1024), 43264, 0.0, None, None, o2, None), 'null map pointer (map 1)')
+    expect(h.refvsr_conv24_batch(s2, 24, None, 0, 5, 8, 8, at(1024), 1.0, None, None, 1.0, o2, None), '1..4 maps per launch')
+    expect(h.refvsr_conv24_batch(s2, 20, None, 0, 2, 8, 8, at(1024), 1.0, None, None, 1.0, o2, None), 'input channels not supported')
+    expect(h.refvsr_conv24_batch(s2, 24, None, 24, 2, 8, 8, at(1024), 1.0, None, None, 1.0, o2, None), 'src1 / c1 mismatch')
+    expect(h.refvsr_conv24_batch(s2, 24, None, 0, 2, 8, 8, at(1024), 1.0, None, None, 1.0, s2, None), 'in-place operation is not supported')
+    expect(h.refvsr_conv_shuffle2_batch(s2, 2, 48, 8, 8, at(1024), 1.0, o2, None), '48 channels not supported (24)')
+    expect(h.refvsr_conf_alpha_batch(s2, s2, 2, 8, 8, 3, at(1024), at(2048), 0.2, at(3072), 24, 0.2, o2, None, None), 'up must be 1 or 2')
+    expect(h.refvsr_conf_alpha_batch(s2, s2, 2, 8, 8, 2, at(1024), at(2048), 0.2, at(3072), 24, 0.2, o2, o2, None), 'max by-product exists at up = 1 only')
+    expect(h.refvsr_conf_alpha_batch(s2, s2, 2, 8, 8, 1, at(1024), at(2048), 0.2, at(3072), 48, 0.2, o2, None, None), '48 output channels not supported (24)')
+    expect(h.refvsr_warp_nhwc16_batch(s2, 2, 8, 8, 20, s2, 8, 8, o2, None), 'warp_nhwc16: bad args')
+    expect(h.refvsr_warp_nhwc16_up2_batch(five, 5, 8, 8, 24, five, 8, 8, five, None), '(map, flow) pairs per launch')
+    expect(h.refvsr_warp_planar_batch(arr(at(0), P(0)), 2, 1, 8, 8, s2, 8, 8, o2, None), 'null pointer (pair 1)')
+
