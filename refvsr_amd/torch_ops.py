@@ -17,6 +17,8 @@ dispatcher's per-call cost (5-10 us) would put the host back on the critical pat
 Op set (argument conventions of ops.py: `planar` = float32 [C,H,W], `nhwc16` = float16 [H,W,Cs]):
   conv_mfma(wpack, bias, meta, src0, src1?, mul?, res?, res_planar?, stride, act, post, out_mode, add_const, clamp_lo, clamp_hi)
   resblock(w1, b1, w2, b2, ksteps, x, act, post)        fused ResidualBlockNoBN / ResBlock
+  resblock24_chain_batch(blobs, xs[], act) / conv24_batch(blob, src0[], src1[], mul[], res[], act, post; [] = absent) / warp_batch(xs[], flows[])
+                                                         multi-map launches (ABI 11): B maps per launch, one [B, ...] output
   match_argmax(lr_feat, ref_feat) -> (conf, idx)         FeatureMatching GEMM + exact arg-max (attention.py:72-91)
   warp(x_nhwc16, flow) / warp_planar(x, flow)            models/utils.py:35-43
   spynet_level_input(ref, supp, flow_prev?) -> (x8, flow_up)
@@ -136,6 +138,44 @@ def register():
     def _(blobs, x, act):
         return torch.empty_like(x)
 
+    # ---- multi-map launches (ABI 11): B maps of one geometry behind one launch per layer.  Tensor[] in, one [B, ...] tensor out.
+    @op('resblock24_chain_batch')
+    def resblock24_chain_batch(blobs: torch.Tensor, xs: List[torch.Tensor], act: float) -> torch.Tensor:
+        class _Ch(object):
+            pass
+        ch = _Ch()
+        ch.n, ch.blobs, ch.stride = blobs.shape[0], blobs, blobs.shape[1]
+        return ops.resblock24_chain_b(ch, list(xs), act)
+
+    @resblock24_chain_batch.register_fake
+    def _(blobs, xs, act):
+        return xs[0].new_empty((len(xs),) + tuple(xs[0].shape))
+
+    @op('conv24_batch')
+    def conv24_batch(blob: torch.Tensor, src0: List[torch.Tensor], src1: List[torch.Tensor], mul: List[torch.Tensor],
+                     res: List[torch.Tensor], act: float, post: float) -> torch.Tensor:
+        # (an EMPTY list = operand absent: the dispatcher's schema language has no optional tensor list)
+        B = len(src0)
+        h, w, c0 = src0[0].shape
+        c1 = src1[0].shape[2] if len(src1) else 0
+        out = torch.empty((B, h, w, 24), dtype=torch.float16, device=src0[0].device)
+        pa = lambda l_: ops._parr(list(l_)) if len(l_) else None
+        hip.check(hip.lib().refvsr_conv24_batch(pa(src0), c0, pa(src1), c1, B, h, w, ops._ptr(blob), act, pa(mul), pa(res), post,
+                                                ops._parr(list(out)), ops._stream()), 'conv24_batch')
+        return out
+
+    @conv24_batch.register_fake
+    def _(blob, src0, src1, mul, res, act, post):
+        return src0[0].new_empty((len(src0), src0[0].shape[0], src0[0].shape[1], 24), dtype=torch.float16)
+
+    @op('warp_batch')
+    def warp_batch(xs: List[torch.Tensor], flows: List[torch.Tensor]) -> torch.Tensor:
+        return ops.warp_nhwc16_b(list(xs), list(flows))
+
+    @warp_batch.register_fake
+    def _(xs, flows):
+        return xs[0].new_empty((len(xs), flows[0].shape[1], flows[0].shape[2], xs[0].shape[2]))
+
     @op('match_argmax')
     def match_argmax(lr_feat: torch.Tensor, ref_feat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         lr_rows, inv_lr, lr_lo = ops.match_patches(lr_feat, hip.MATCH_COLBLOCK, want_lo=True)
@@ -224,7 +264,7 @@ def register():
         return x.new_empty((c, x.shape[0], x.shape[1]), dtype=torch.float32)
 
 
-OP_NAMES = ('conv_mfma', 'conv24', 'resblock', 'resblock24_chain', 'match_argmax', 'warp', 'warp_planar', 'spynet_level_input', 'block_gather',
+OP_NAMES = ('conv_mfma', 'conv24', 'resblock', 'resblock24_chain', 'resblock24_chain_batch', 'conv24_batch', 'warp_batch', 'match_argmax', 'warp', 'warp_planar', 'spynet_level_input', 'block_gather',
             'block_gather_rgb', 'aligned_sample', 'resize', 'pack_nhwc16', 'unpack_nhwc16')
 
 register()

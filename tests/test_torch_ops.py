@@ -48,6 +48,11 @@ def test_fake_tensor_shape_inference():
         assert torch.ops.refvsr.resize(torch.empty((3, 20, 30), device=dev), 80, 120, 0, 0.25, 0.25, True).shape == (3, 80, 120)
         x8, fu = torch.ops.refvsr.spynet_level_input(torch.empty((3, 32, 32), device=dev), torch.empty((3, 32, 32), device=dev), None)
         assert x8.shape == (32, 32, 8) and x8.dtype == torch.float16 and fu.shape == (2, 32, 32)
+        y = torch.ops.refvsr.resblock24_chain_batch(torch.empty((3, 43264), dtype=torch.uint8, device=dev), [x, x, x], 0.0)
+        assert y.shape == (3, 20, 30, 24) and y.dtype == torch.float16                                # multi-map launches: [B, ...] out
+        y = torch.ops.refvsr.conv24_batch(w, [x, x], [x, x], [], [x, x], 0.2, 1.0)
+        assert y.shape == (2, 20, 30, 24) and y.dtype == torch.float16
+        assert torch.ops.refvsr.warp_batch([x, x], [fl, fl]).shape == (2, 40, 60, 24)
         assert torch.ops.refvsr.pack_nhwc16(torch.empty((3, 20, 30), device=dev), 8).shape == (20, 30, 8)
         assert torch.ops.refvsr.unpack_nhwc16(x, 24).shape == (24, 20, 30)
 
@@ -83,6 +88,18 @@ def test_torch_library_ops_match_direct_calls():
     assert torch.equal(R.resblock(c1.wpack, c1.bias, c2.wpack, c2.bias, c1.ksteps, x, 0.0, 1.0), ops.resblock(c1, c2, x, act=0.0))
     fl = (torch.randn(2, h, w, generator=g) * 2).to(dev)
     assert torch.equal(R.warp(x, fl), ops.warp_nhwc16(x, fl))
+    # multi-map launches through the dispatcher: map b == the single-map op on map b
+    x2 = ops.pack_nhwc16(torch.randn(C, h, w, generator=g).to(dev))
+    fl2 = (torch.randn(2, h, w, generator=g) * 2).to(dev)
+    yb = R.resblock24_chain_batch(ch.blobs, [x, x2], 0.0)
+    assert yb.shape == (2, h, w, C) and torch.equal(yb[0], ops.resblock24_chain(ch, x, 0.0)) and torch.equal(yb[1], ops.resblock24_chain(ch, x2, 0.0))
+    yb = R.conv24_batch(c1.blob24, [x, x2], [], [], [x2, x], 0.2, 1.0)
+    assert torch.equal(yb[0], ops.conv(c1, x, act=0.2, res=x2)) and torch.equal(yb[1], ops.conv(c1, x2, act=0.2, res=x))
+    yb = R.warp_batch([x, x2], [fl, fl2])
+    assert torch.equal(yb[0], ops.warp_nhwc16(x, fl)) and torch.equal(yb[1], ops.warp_nhwc16(x2, fl2))
+    torch.library.opcheck(R.resblock24_chain_batch, (ch.blobs, [x, x2], 0.0), test_utils=('test_schema', 'test_faketensor'))
+    torch.library.opcheck(R.conv24_batch, (c1.blob24, [x, x2], [], [], [x2, x], 0.2, 1.0), test_utils=('test_schema', 'test_faketensor'))
+    torch.library.opcheck(R.warp_batch, ([x, x2], [fl, fl2]), test_utils=('test_schema', 'test_faketensor'))
     lr_f, ref_f = torch.randn(16, h, w, generator=g).to(dev), torch.randn(16, h // 2, w // 2, generator=g).to(dev)
     conf, idx = R.match_argmax(lr_f, ref_f)
     lr_rows, inv_lr, l_lo = ops.match_patches(lr_f, 512, want_lo=True)
