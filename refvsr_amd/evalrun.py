@@ -146,58 +146,90 @@ def evaluate(config, net=None, log=print):
     ds = ClipSet(config)
     dev = next(net.parameters()).device
     res = {'psnr': [], 'ssim': [], 'seconds': [], 'frames': 0}
-    clip_p, clip_s, clip_t, clip_n, first_line = 0.0, 0.0, 0.0, 0, True
+    # --frame_group G (extension, default 1 = the reference's loop): G consecutive windows of a clip per network call
+    # (SRNet.forward_group: the backward branches of the G frames as multi-map launches; results bit-identical); the per-frame time in
+    # the score lines is then the group's time / G
+    G = max(1, int(getattr(E, 'frame_group', 1) or 1))
+    if G > 1:
+        net.Network.set_pipelined(True)
+    st = {'clip_p': 0.0, 'clip_s': 0.0, 'clip_t': 0.0, 'clip_n': 0, 'first_line': True, 'prev': None}
+
+    def emit(it, out, lr_c, dt):
+        out_cpu = out[0].float().cpu()
+        p = s = 0.0
+        if not getattr(E, 'qualitative_only', False):
+            gt = it['HR_UW']
+            p = psnr(out_cpu, gt)
+            cmp_out = out_cpu
+            if config.flag_HD_in:          # eval_qual_quan.py:86-87: SSIM against the LR-size GT
+                cmp_out = F.interpolate(out_cpu[None], scale_factor=1.0 / config.scale, mode='bicubic',
+                                        align_corners=False)[0]
+            if cmp_out.shape == gt.shape:
+                s = ssim(cmp_out, gt)
+        line = '[EVAL {}|{}|{}][{}/{}][{}/{}] {} PSNR: {:.5f} SSIM: {:.5f} ({:.5f}sec)'.format(
+            config.mode, E.data, it['video_name'], it['video_idx'] + 1, it['video_len'], it['frame_idx'] + 1,
+            it['frame_len'], it['frame_name'], p, s, dt)
+        log(line)
+        with open(score_path, 'w' if st['first_line'] else 'a') as fh:
+            fh.write(line + '\n')
+        st['first_line'] = False
+        if not getattr(E, 'quantitative_only', False):
+            stem = it['frame_name'].split('.')[0]
+            for fmt in ('png', 'jpg'):
+                base = os.path.join(out_root, fmt)
+                write_frame(os.path.join(base, 'input', it['video_name'], '%s.%s' % (stem, fmt)), lr_c)
+                write_frame(os.path.join(base, 'output', it['video_name'], '%s.%s' % (stem, fmt)), out_cpu)
+        st['clip_p'] += p
+        st['clip_s'] += s
+        st['clip_t'] += dt
+        st['clip_n'] += 1
+        st['prev'] = it
+        res['psnr'].append(p)
+        res['ssim'].append(s)
+        res['seconds'].append(dt)
+        res['frames'] += 1
+
+    def flush(pending):
+        if not pending:
+            return
+        t0 = time.time()
+        lrs = torch.stack([it['LR_UW'] for it in pending], 0).to(dev).float().contiguous()
+        rfs = torch.stack([it['LR_REF_W'] for it in pending], 0).to(dev).float().contiguous()
+        outs = net.forward_group(lrs, rfs, [it['frame_ids'] for it in pending])['result']
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / len(pending)
+        c = lrs.shape[1] // 2
+        for b, it in enumerate(pending):
+            emit(it, outs[b], lrs[b, c], dt)
+        del pending[:]
+
     with torch.no_grad():
+        pending = []
         for i in range(len(ds)):
             it = ds[i]
             if it.get('is_continue'):
                 continue
-            if it['is_first'] and clip_n:
-                _clip_summary(config, score_path, prev, clip_p, clip_s, clip_t, clip_n, log)
-                clip_p = clip_s = clip_t = 0.0
-                clip_n = 0
             if it['is_first']:
+                flush(pending)
+                if st['clip_n']:
+                    _clip_summary(config, score_path, st['prev'], st['clip_p'], st['clip_s'], st['clip_t'], st['clip_n'], log)
+                    st['clip_p'] = st['clip_s'] = st['clip_t'] = 0.0
+                    st['clip_n'] = 0
                 net.Network.reset()
+            use_ids = getattr(E, 'use_frame_ids', True) and 'frame_ids' in it
+            if G > 1 and use_ids and not it['is_first']:
+                pending.append(it)
+                if len(pending) == G:
+                    flush(pending)
+                continue
             t0 = time.time()
             lr, rf = it['LR_UW'][None].to(dev), it['LR_REF_W'][None].to(dev)
-            kw = {'frame_ids': it['frame_ids']} if getattr(E, 'use_frame_ids', True) and 'frame_ids' in it else {}
+            kw = {'frame_ids': it['frame_ids']} if use_ids else {}
             out = net(lr, rf, it['is_first'], is_log=False, is_train=False, **kw)['result']
             torch.cuda.synchronize()
-            dt = time.time() - t0
-            out_cpu = out[0].float().cpu()
-            p = s = 0.0
-            if not getattr(E, 'qualitative_only', False):
-                gt = it['HR_UW']
-                p = psnr(out_cpu, gt)
-                cmp_out = out_cpu
-                if config.flag_HD_in:          # eval_qual_quan.py:86-87: SSIM against the LR-size GT
-                    cmp_out = F.interpolate(out_cpu[None], scale_factor=1.0 / config.scale, mode='bicubic',
-                                            align_corners=False)[0]
-                if cmp_out.shape == gt.shape:
-                    s = ssim(cmp_out, gt)
-            line = '[EVAL {}|{}|{}][{}/{}][{}/{}] {} PSNR: {:.5f} SSIM: {:.5f} ({:.5f}sec)'.format(
-                config.mode, E.data, it['video_name'], it['video_idx'] + 1, it['video_len'], it['frame_idx'] + 1,
-                it['frame_len'], it['frame_name'], p, s, dt)
-            log(line)
-            with open(score_path, 'w' if first_line else 'a') as fh:
-                fh.write(line + '\n')
-            first_line = False
-            if not getattr(E, 'quantitative_only', False):
-                stem = it['frame_name'].split('.')[0]
-                c = lr.shape[1] // 2
-                for fmt in ('png', 'jpg'):
-                    base = os.path.join(out_root, fmt)
-                    write_frame(os.path.join(base, 'input', it['video_name'], '%s.%s' % (stem, fmt)), lr[0, c])
-                    write_frame(os.path.join(base, 'output', it['video_name'], '%s.%s' % (stem, fmt)), out_cpu)
-            clip_p += p
-            clip_s += s
-            clip_t += dt
-            clip_n += 1
-            prev = it
-            res['psnr'].append(p)
-            res['ssim'].append(s)
-            res['seconds'].append(dt)
-            res['frames'] += 1
+            emit(it, out, lr[0, lr.shape[1] // 2], time.time() - t0)
+        flush(pending)
+    clip_p, clip_s, clip_t, clip_n, prev = st['clip_p'], st['clip_s'], st['clip_t'], st['clip_n'], st['prev']
     if clip_n:
         _clip_summary(config, score_path, prev, clip_p, clip_s, clip_t, clip_n, log)
     n = max(res['frames'], 1)
@@ -239,6 +271,8 @@ def build_config(argv=None):
     ap.add_argument('-frame_num', '--frame_num', type=int, default=None)
     ap.add_argument('-vid_name', '--vid_name', nargs='+', default=None)
     ap.add_argument('-ss', '--save_sample', action='store_true')
+    ap.add_argument('--frame_group', type=int, default=1, help='extension: consecutive frames of a clip per network call (1 = the reference loop; 4 = '
+                                                                'multi-map launches of the backward branches, same results)')
     args, _ = ap.parse_known_args(argv)
     cfg = get_config(args.project, args.mode, args.config, args.data)
     if args.network:
@@ -251,6 +285,7 @@ def build_config(argv=None):
     E.qualitative_only, E.quantitative_only = args.qualitative_only, args.quantitative_only
     E.is_gradio, E.vid_name = args.is_gradio, args.vid_name
     E.eval_mode, E.test_set, E.data = args.eval_mode, args.test_set, args.data
+    E.frame_group = args.frame_group
     cfg.save_sample = args.save_sample
     cfg.device = 'cpu' if args.cpu else 'cuda'
     cfg.cuda = not args.cpu

@@ -18,6 +18,14 @@ def dataset(tmp_path_factory):
     return root
 
 
+@pytest.fixture(scope='module')
+def dataset_long(tmp_path_factory):
+    import make_synth_dataset
+    root = str(tmp_path_factory.mktemp('ds_long'))
+    make_synth_dataset.make(root, clips=2, frames=7, h=32, w=48)
+    return root
+
+
 def _cfg(root, out, extra=()):
     from refvsr_amd import evalrun
     return evalrun.build_config(['--config', 'config_RefVSR_small_L1', '--mode', 'unit', '--data_offset', root,
@@ -92,3 +100,26 @@ def test_cli_end_to_end_on_gpu(dataset, tmp_path):
     assert abs(evalrun.psnr(want, it['HR_UW']) - res['psnr'][0]) < 1e-3
     back = evalrun.read_frame(png)
     assert float((back - want).abs().max()) < 2.0 / 255 + 5e-3          # 8-bit truncation + fp16 path
+
+
+@pytest.mark.gpu
+def test_cli_frame_groups_equal_the_reference_loop(dataset_long, tmp_path):
+    """`--frame_group 4`: the CLI hands the network four consecutive windows of a clip per call (SRNet.forward_group) -- PSNR / SSIM
+    of every frame, the score-file structure and the written PNGs equal the one-frame-per-call loop's."""
+    from refvsr_amd import evalrun, get_config, make_state_dict
+    sd = make_state_dict(get_config('p', 'm', 'config_RefVSR_small_L1'), 1234)
+    ck = str(tmp_path / 'RefVSR_small_L1.pytorch')
+    torch.save({'module.' + k: v for k, v in sd.items()}, ck)
+    res = {}
+    for g in (1, 4):
+        cfg = _cfg(dataset_long, str(tmp_path / ('out%d' % g)), ['--ckpt_abs_name', ck, '--frame_group', str(g)])
+        res[g] = evalrun.evaluate(cfg, log=lambda *_: None)
+    assert res[1]['frames'] == res[4]['frames'] == 14
+    assert res[1]['psnr'] == res[4]['psnr'] and res[1]['ssim'] == res[4]['ssim']
+    l1, l4 = (open(res[g]['score_file']).read().splitlines() for g in (1, 4))
+    strip = lambda ln: ln.split(' (')[0]                      # everything but the per-frame seconds
+    assert [strip(a) for a in l1] == [strip(b) for b in l4]
+    for clip, frame in (('0001', '0000'), ('0001', '0005'), ('0002', '0006')):
+        a = evalrun.read_frame(os.path.join(res[1]['output_root'], 'png', 'output', clip, frame + '.png'))
+        b = evalrun.read_frame(os.path.join(res[4]['output_root'], 'png', 'output', clip, frame + '.png'))
+        assert torch.equal(a, b)
