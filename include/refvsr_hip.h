@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 11  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 12  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
@@ -38,7 +38,8 @@ extern "C" {
                                       refvsr_conf_alpha_batch, refvsr_warp_nhwc16_batch, refvsr_warp_nhwc16_up2_batch,
                                       refvsr_warp_planar_batch; RefvsrConv.warp_* (ABI 6: the inter-frame warp fused into a conv's tile
                                       staging) REMOVED: bit-identical to warp + conv but measured slower in every configuration
-                                      (169 vs 176 frames/s, profiles/r03_fused_warp_ab.txt) */
+                                      (169 vs 176 frames/s, profiles/r03_fused_warp_ab.txt);
+                                  12: refvsr_resblock48_chain_batch (the multi-map form of the 48-channel block) */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
@@ -159,6 +160,13 @@ int refvsr_set_resblock24_waves(int waves);
 #define REFVSR_RESBLOCK48_BLOB_BYTES 172544
 int refvsr_resblock48_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
                             void* scratch0, void* scratch1, void* out, void* stream);
+/* refvsr_resblock48_chain over `batch` <= REFVSR_MAX_MAPS maps of one geometry (ABI 12; the backward branches of consecutive output
+ * frames of the mid_channels = 48 models, like refvsr_resblock24_chain_batch): ONE launch per block over all maps -- the launch's fixed
+ * cost, the first 86 KB weight fill and the tail are shared (the two weight sets still swap per tile).  src / out: host arrays of
+ * batch device pointers ([h][w][48] fp16 each), scratch0 / scratch1: [batch][h][w][48] contiguous.  Map b == the single-map call on
+ * map b, bit for bit. */
+int refvsr_resblock48_chain_batch(const void* const* src, int batch, int h, int w, int n, const void* blobs, size_t blob_stride,
+                                  float act_slope, void* scratch0, void* scratch1, void* const* out, void* stream);
 /* Tuning knob: how the 24-channel kernel stores its output tile.  0: 8-byte stores (one per lane and pixel group); 1: 16-byte
  * stores after a v_permlane16_swap exchange between neighbouring lane rows (half the store instructions; default).  Results do not
  * depend on it (bit-identical). */

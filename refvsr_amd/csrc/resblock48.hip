@@ -66,6 +66,11 @@ struct RB48Args {
     float act_slope;
     unsigned long long* probe;           // PROBE kernel: per-workgroup s_memtime stamps (refvsr_set_probe), 12 per workgroup
     int probe_iter;                      // which tile iteration of the workgroup is stamped
+    // Multi-map launches (refvsr_resblock48_chain_batch): batch > 1 maps of one geometry share the launch -- its fixed cost, the first
+    // weight fill and the tail; the two weight sets still swap per tile.  Flat tile index t = b * tpm + (tile of map b), map b reads
+    // bsrc[b] and writes bout[b].  batch <= 1: src / out above.
+    int batch, tpm;
+    const unsigned char* bsrc[REFVSR_MAX_MAPS]; unsigned char* bout[REFVSR_MAX_MAPS];
 };
 
 // K loop of one conv: T pixel groups of this wave; fragments at LDS offset 0, B windows at pb[t] + pd[pattern] + immediate.
@@ -159,14 +164,21 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     //      VGPRs a wave has at two waves per SIMD, and the kernel spilled
     const int rowb_g = p.w * R48_GPX;
     uint4 xv[R48_KCH];
-    auto x_fetch = [&](const int t) {
+    auto x_fetch = [&](const int tf) {
+        int t = tf;
+        const unsigned char* srcp = p.src;
+        if (p.batch > 1) {                                           // flat tile index -> (map, tile of the map); uniform
+            const int bm = (int)((unsigned)tf / (unsigned)p.tpm);
+            t = tf - bm * p.tpm;
+            srcp = p.bsrc[bm];
+        }
         const int tyi = t / p.tiles_x;
         const int ty0 = tyi * R48_TH, tx0 = (t - tyi * p.tiles_x) * R48_TW;
         const bool interior = ty0 >= 2 && ty0 + R48_TH + 2 <= p.h && tx0 >= 2 && tx0 + R48_TW + 2 <= p.w;
         int tide = tid;
         asm volatile("" : "+v"(tide));
         if (interior) {
-            const unsigned char* b = p.src + ((long long)(ty0 - 2) * p.w + (tx0 - 2)) * R48_GPX;
+            const unsigned char* b = srcp + ((long long)(ty0 - 2) * p.w + (tx0 - 2)) * R48_GPX;
 #pragma unroll
             for (int k = 0; k < R48_KCH; ++k) {
                 const int i = min(tide + k * R48_NT, R48_NCH - 1);
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const int iy = ty0 - 2 + r, ix = tx0 - 2 + c;
                 const bool ok = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
                 const unsigned off = (unsigned)((min(max(iy, 0), p.h - 1) * p.w + min(max(ix, 0), p.w - 1)) * R48_GPX + cg * 16);
-                uint4 v = *reinterpret_cast<const uint4*>(p.src + off);          // clamped address, masked value (32-bit offsets: host check)
+                uint4 v = *reinterpret_cast<const uint4*>(srcp + off);           // clamped address, masked value (32-bit offsets: host check)
                 const unsigned keep = ok ? 0xffffffffu : 0u;
                 v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
                 xv[k] = v;
@@ -252,8 +264,15 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const bool has_next = tl + 1 < k_hi;
         const bool stamp = PROBE && iter == p.probe_iter;
         if (stamp) R48_STAMP(1);
-        const int tyi = tl / p.tiles_x;
-        const int ty0 = tyi * R48_TH, tx0 = (tl - tyi * p.tiles_x) * R48_TW;
+        int tm = tl;
+        unsigned char* outp = p.out;
+        if (p.batch > 1) {
+            const int bm = (int)((unsigned)tl / (unsigned)p.tpm);
+            tm = tl - bm * p.tpm;
+            outp = p.bout[bm];
+        }
+        const int tyi = tm / p.tiles_x;
+        const int ty0 = tyi * R48_TH, tx0 = (tm - tyi * p.tiles_x) * R48_TW;
         const bool interior = ty0 >= 2 && ty0 + R48_TH + 2 <= p.h && tx0 >= 2 && tx0 + R48_TW + 2 <= p.w;
 
         // ---------------- phase 1: acc = b1 + conv1(x) on the halo region ----------------------------------------------------------
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(R48_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             R48_STAMP(8);
         }
         {
-            unsigned char* ob = p.out + ((long long)ty0 * p.w + tx0) * R48_GPX;
+            unsigned char* ob = outp + ((long long)ty0 * p.w + tx0) * R48_GPX;
 #pragma unroll
             for (int t = 0; t < R48_T2; ++t) {
                 bool ok = true;
@@ -368,7 +387,8 @@ static int launch_rb48(RB48Args& a, hipStream_t st) {
         attr_done[dev] = true;
     }
     a.tiles_x = rv_cdiv(a.w, R48_TW);
-    a.n_tiles = a.tiles_x * rv_cdiv(a.h, R48_TH);
+    a.tpm = a.tiles_x * rv_cdiv(a.h, R48_TH);
+    a.n_tiles = a.tpm * (a.batch > 1 ? a.batch : 1);
     int cap = rv_num_cus() & ~7;                                     // one 135 KB workgroup per CU
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
@@ -377,34 +397,59 @@ static int launch_rb48(RB48Args& a, hipStream_t st) {
     return 0;
 }
 
-// n fused blocks x <- x + conv2(act(conv1 x)) on a 48-channel fp16 HWC map; block i's parameters are the blob at
-// blobs + i * blob_stride (refvsr_amd/packing.py:pack_resblock48).  n launches on the caller's stream, intermediates ping-pong
-// between scratch0 / scratch1 like refvsr_resblock24_chain.
-extern "C" int refvsr_resblock48_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
-                                       void* scratch0, void* scratch1, void* out, void* stream) {
-    RV_CHECK(src && out && blobs && h > 0 && w > 0 && n >= 1, "resblock48_chain: bad args");
+// n fused blocks x <- x + conv2(act(conv1 x)) on `batch` 48-channel fp16 HWC maps of one geometry (batch = 1: the plain chain); block i's
+// parameters are the blob at blobs + i * blob_stride (refvsr_amd/packing.py:pack_resblock48).  n launches on the caller's stream, each over
+// ALL maps; intermediates ping-pong between scratch0 / scratch1 ([batch] maps each, contiguous) like refvsr_resblock24_chain.
+static int rb48_chain_impl(const void* const* src, int batch, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
+                           void* scratch0, void* scratch1, void* const* out, void* stream) {
+    RV_CHECK(src && out && blobs && h > 0 && w > 0 && n >= 1 && batch >= 1 && batch <= REFVSR_MAX_MAPS, "resblock48_chain: bad args");
     RV_CHECK(blob_stride >= (size_t)R48_BLOB && blob_stride % 16 == 0 && ((uintptr_t)blobs & 15) == 0,
              "resblock48_chain: blobs must be 16-byte aligned, stride >= %d", R48_BLOB);
     RV_CHECK(act_slope >= 0.f && act_slope <= 1.f, "resblock48_chain: activation slope must lie in [0, 1]");
     RV_CHECK(n == 1 || scratch0, "resblock48_chain: n >= 2 needs scratch0");
     RV_CHECK(n <= 2 || scratch1, "resblock48_chain: n >= 3 needs scratch1");
-    RV_CHECK(src != out && scratch0 != out && scratch1 != out && (n < 2 || scratch0 != src) && (n < 3 || scratch1 != src) &&
-             (n < 3 || scratch0 != scratch1), "resblock48_chain: buffers must be distinct");
+    const size_t mapb = (size_t)h * w * R48_GPX;
+    for (int b = 0; b < batch; ++b) {
+        RV_CHECK(src[b] && out[b], "resblock48_chain: null map pointer (map %d)", b);
+        for (int c = 0; c < batch; ++c) {
+            const unsigned char* s0 = scratch0 ? (const unsigned char*)scratch0 + c * mapb : nullptr;
+            const unsigned char* s1 = scratch1 ? (const unsigned char*)scratch1 + c * mapb : nullptr;
+            RV_CHECK(src[b] != out[c] && s0 != out[b] && s1 != out[b] && (n < 2 || s0 != src[b]) && (n < 3 || s1 != src[b]) &&
+                     (c == b || out[b] != out[c]), "resblock48_chain: buffers must be distinct");
+        }
+    }
+    RV_CHECK(n < 3 || scratch0 != scratch1, "resblock48_chain: buffers must be distinct");
     RV_CHECK((long long)h * w * R48_GPX < (1ll << 31), "resblock48_chain: map too large for 32-bit offsets");
     RV_CHECK(refvsr_init() == 0, "init failed");
     RB48Args a;
     memset(&a, 0, sizeof(a));
-    a.h = h; a.w = w; a.act_slope = act_slope;
+    a.h = h; a.w = w; a.act_slope = act_slope; a.batch = batch;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned char* cur = (const unsigned char*)src;
+    const unsigned char* cur[REFVSR_MAX_MAPS];
+    for (int b = 0; b < batch; ++b) cur[b] = (const unsigned char*)src[b];
     for (int i = 0; i < n; ++i) {
-        unsigned char* dst = (unsigned char*)((i == n - 1) ? out : ((i & 1) ? scratch1 : scratch0));
-        a.src = cur; a.out = dst; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
+        unsigned char* sc = (unsigned char*)((i & 1) ? scratch1 : scratch0);
+        for (int b = 0; b < batch; ++b) {
+            a.bsrc[b] = cur[b];
+            a.bout[b] = (i == n - 1) ? (unsigned char*)out[b] : sc + b * mapb;
+        }
+        a.src = a.bsrc[0]; a.out = a.bout[0]; a.blob = (const unsigned char*)blobs + (size_t)i * blob_stride;
         a.probe = g_rb_probe; a.probe_iter = g_rb_probe_iter;
         const int rc = (g_rb_probe && act_slope == 0.f) ? launch_rb48<true, true>(a, st)       // tools/probe_resblock48.py
                        : act_slope == 0.f ? launch_rb48<true>(a, st) : launch_rb48<false>(a, st);
         if (rc) return rc;
-        cur = dst;
+        for (int b = 0; b < batch; ++b) cur[b] = a.bout[b];
     }
     return 0;
+}
+
+extern "C" int refvsr_resblock48_chain(const void* src, int h, int w, int n, const void* blobs, size_t blob_stride, float act_slope,
+                                       void* scratch0, void* scratch1, void* out, void* stream) {
+    RV_CHECK(src && out, "resblock48_chain: bad args");
+    return rb48_chain_impl(&src, 1, h, w, n, blobs, blob_stride, act_slope, scratch0, scratch1, &out, stream);
+}
+
+extern "C" int refvsr_resblock48_chain_batch(const void* const* src, int batch, int h, int w, int n, const void* blobs, size_t blob_stride,
+                                             float act_slope, void* scratch0, void* scratch1, void* const* out, void* stream) {
+    return rb48_chain_impl(src, batch, h, w, n, blobs, blob_stride, act_slope, scratch0, scratch1, out, stream);
 }

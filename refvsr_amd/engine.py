@@ -188,6 +188,7 @@ class Engine(object):
         self.rb48 = (bool(getattr(config, 'fuse_resblocks', True)) and not env_flag('REFVSR_NO_FUSE')
                      and not env_flag('REFVSR_NO_RB48'))                 # A/B knob: C = 48 blocks as two refvsr_conv48 launches (round 3)
         self.rb48_max_pixels = int(os.environ.get('REFVSR_RB48_MAX_PIXELS', str(540 * 960)))
+        self.rb48_multimap = not env_flag('REFVSR_NO_RB48_MULTIMAP')      # A/B knob: frame groups of C = 48 run their blocks map by map
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
         # pipelined mode: the backward branch restarts from zeros at the window's LAST frame (RefVSR.py:211-214), so the first
@@ -1087,23 +1088,36 @@ class Engine(object):
     # forward-branch step (which carries the state from frame to frame) stays one frame per launch.  Results are bit-identical to
     # B forward() calls (tests/test_gpu_e2e.py::test_frame_groups_are_bit_identical).
     def group_ok(self):
-        """The multi-map launch list exists for the mid_channels = 24 family on its default kernels."""
-        return bool(self.C == 24 and self.fuse_resblocks and self.rb24 and self.fuse_conf and self.warp_up2 and
+        """Frame groups run on the default kernels of the mid_channels = 24 family (every launch of the backward branches multi-map)
+        and of the mid_channels = 48 family (multi-map warps; its blocks and convs have no multi-map kernels and run map by map inside
+        the group's schedule -- same results)."""
+        return bool(((self.C == 24 and self.rb24 and self.fuse_resblocks) or (self.C == 48 and self.rb48)) and self.fuse_conf and self.warp_up2 and
                     ops.CONV24 and self.cache and self.overlap and not bool(self.cfg.EVAL.is_gradio) and
                     ops.conf_alpha_ok(self.cw('conf_fusion.1.0')) and ops.conf_alpha_ok(self.cw('conf_fusion2.1.0')))
 
     def _block_chain_b(self, xs, pairs, act):
-        """_block_chain over B maps (lists in, list out): one multi-map launch per block."""
+        """_block_chain over B maps (lists in, list out): one multi-map launch per block (the 24- and 48-channel fused blocks; anything
+        else map by map)."""
+        if (self.rb48 and xs[0].shape[2] == 48 and pairs[0][0].raw is not None and 0.0 <= act <= 1.0 and
+                xs[0].shape[0] * xs[0].shape[1] <= self.rb48_max_pixels and self.rb48_multimap):
+            chains = self.W.chains
+            key = ('rb48',) + tuple(id(c1) for c1, _ in pairs)
+            ch = chains.get(key)
+            if ch is None:
+                ch = chains[key] = ops.Resblock48Chain(pairs, xs[0].device)
+            return list(ops.resblock48_chain_b(ch, xs, act, stack=False))
+        if not (self.rb24 and xs[0].shape[2] == 24 and pairs[0][0].raw is not None):
+            return [self._block_chain(x, pairs, act) for x in xs]
         chains = self.W.chains
         key = ('rb24',) + tuple(id(c1) for c1, _ in pairs)
         ch = chains.get(key)
         if ch is None:
             ch = chains[key] = ops.Resblock24Chain(pairs, xs[0].device)
         if self.chain_events is None:
-            return list(ops.resblock24_chain_b(ch, xs, act))
+            return list(ops.resblock24_chain_b(ch, xs, act, stack=False))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = list(ops.resblock24_chain_b(ch, xs, act))
+        out = list(ops.resblock24_chain_b(ch, xs, act, stack=False))
         e1.record()
         self.chain_events.append((e0, e1, len(pairs), xs[0].shape[0], xs[0].shape[1], len(xs)))
         return out
@@ -1111,7 +1125,7 @@ class Engine(object):
     def res_list_b(self, xs, name, n):
         pairs = [(self.cw('%s.RBs.%d.conv1' % (name, i)), self.cw('%s.RBs.%d.conv2' % (name, i))) for i in range(n)]
         ys = self._block_chain_b(xs, pairs, 0.2)
-        return list(ops.conv_b(self.cw(name + '.conv_tail'), ys, ress=xs))
+        return list(ops.conv_b(self.cw(name + '.conv_tail'), ys, ress=xs, stack=False))
 
     def resblocks_b(self, lr8s, feats, name, resume=None):
         pairs = [(self.cw('%s.main.2.%d.conv1' % (name, i)), self.cw('%s.main.2.%d.conv2' % (name, i)))
@@ -1119,22 +1133,22 @@ class Engine(object):
         if resume is not None:
             n, xs = resume
             return self._block_chain_b(xs, pairs[n:], 0.0) if n < self.nb else xs
-        xs = list(ops.conv_b(self.cw(name + '.main.0'), lr8s, feats, act=0.1))
+        xs = list(ops.conv_b(self.cw(name + '.main.0'), lr8s, feats, act=0.1, stack=False))
         return self._block_chain_b(xs, pairs, 0.0)
 
     def rap_b(self, fs, conf_props, feats, feat_ups):
         """rap() of B independent (frame, carried maps) tuples as multi-map launches (the fused-confidence launch list)."""
         R = self.W.raw
         confs = [f.conf for f in fs]
-        alpha, conf_next = ops.conf_alpha_b(conf_props, confs, 1, *R['conf_fusion.0.0'], self.cw('conf_fusion.1.0'), want_max=True)
-        t = ops.conv_b(self.cw('feat_fusion.0.0'), feats, [f.aligned for f in fs], act=0.2)
-        feat = list(ops.conv_b(self.cw('feat_fusion.1.0'), list(t), act=0.2, muls=list(alpha), ress=feats))     # :131
+        alpha, conf_next = ops.conf_alpha_b(conf_props, confs, 1, *R['conf_fusion.0.0'], self.cw('conf_fusion.1.0'), want_max=True, stack=False)
+        t = ops.conv_b(self.cw('feat_fusion.0.0'), feats, [f.aligned for f in fs], act=0.2, stack=False)
+        feat = list(ops.conv_b(self.cw('feat_fusion.1.0'), list(t), act=0.2, muls=list(alpha), ress=feats, stack=False))     # :131
         feat = self.res_list_b(feat, 'feat_decoder', 8)
-        up1 = ops.conv_b(self.cw('upsample1.upsample_conv'), feat)                                                # :138
-        feat_up = list(ops.conv_b(self.cw('feat_fusion2_1.0.0'), feat_ups, list(up1), act=0.2))
-        alpha2 = ops.conf_alpha_b(conf_props, confs, 2, *R['conf_fusion2.0.0'], self.cw('conf_fusion2.1.0'))      # :140-142
-        t = ops.conv_b(self.cw('feat_fusion2.0.0'), feat_up, [f.aligned_up for f in fs], act=0.2)
-        feat_up = list(ops.conv_b(self.cw('feat_fusion2.1.0'), list(t), act=0.2, muls=list(alpha2), ress=feat_up))   # :143
+        up1 = ops.conv_b(self.cw('upsample1.upsample_conv'), feat, stack=False)                                                # :138
+        feat_up = list(ops.conv_b(self.cw('feat_fusion2_1.0.0'), feat_ups, list(up1), act=0.2, stack=False))
+        alpha2 = ops.conf_alpha_b(conf_props, confs, 2, *R['conf_fusion2.0.0'], self.cw('conf_fusion2.1.0'), stack=False)      # :140-142
+        t = ops.conv_b(self.cw('feat_fusion2.0.0'), feat_up, [f.aligned_up for f in fs], act=0.2, stack=False)
+        feat_up = list(ops.conv_b(self.cw('feat_fusion2.1.0'), list(t), act=0.2, muls=list(alpha2), ress=feat_up, stack=False))   # :143
         feat_up = self.res_list_b(feat_up, 'feat_decoder2', 4)
         return feat, feat_up, list(conf_next)
 
@@ -1150,9 +1164,9 @@ class Engine(object):
             else:
                 xs = self.resblocks_b([f.lr8 for f in fs], feats, branch)
             return self.rap_b(fs, confs, xs, feat_ups)
-        confs = list(ops.warp_planar_b(confs, fls))
-        xs = self.resblocks_b([f.lr8 for f in fs], list(ops.warp_nhwc16_b(feats, fls)), branch)
-        return self.rap_b(fs, confs, xs, list(ops.warp_nhwc16_up2_b(feat_ups, fls)))
+        confs = list(ops.warp_planar_b(confs, fls, stack=False))
+        xs = self.resblocks_b([f.lr8 for f in fs], list(ops.warp_nhwc16_b(feats, fls, stack=False)), branch)
+        return self.rap_b(fs, confs, xs, list(ops.warp_nhwc16_up2_b(feat_ups, fls, stack=False)))
 
     def _frames_group(self, wins):
         """_frames (id-keyed form) for the B windows of a group: the cache keeps the union of their frames."""

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_MAPS = 4
 RESBLOCK24_BLOB_BYTES = 43264
 RESBLOCK48_BLOB_BYTES = 172544
@@ -95,6 +95,7 @@ SIGNATURES = {
     'refvsr_spynet_level_input_batch': [_P, _P, _I, _P, _I, _I, _P, _P, _P],
     # multi-map launches (ABI 11): host arrays of `batch` device pointers
     'refvsr_resblock24_chain_batch': [_P, _I, _I, _I, _I, _P, _Z, _F, _P, _P, _P, _P],
+    'refvsr_resblock48_chain_batch': [_P, _I, _I, _I, _I, _P, _Z, _F, _P, _P, _P, _P],      # ABI 12
     'refvsr_conv24_batch': [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _P, _F, _P, _P],
     'refvsr_conv_shuffle2_batch': [_P, _I, _I, _I, _I, _P, _F, _P, _P],
     'refvsr_conf_alpha_batch': [_P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _F, _P, _P, _P],

@@ -750,9 +750,15 @@ def multimap_ok(B):
     return 2 <= B <= hip.MAX_MAPS
 
 
-def conv_b(cw, src0s, src1s=None, act=1.0, muls=None, ress=None, post=1.0):
+def _maps(ts, stack):
+    """Result of a map-by-map fallback: one [B, ...] tensor like the multi-map launches return (stack: one more copy per map), or
+    the list of the B maps as they are (the engine only ever indexes / iterates the result)."""
+    return torch.stack(ts, 0) if stack else list(ts)
+
+
+def conv_b(cw, src0s, src1s=None, act=1.0, muls=None, ress=None, post=1.0, stack=True):
     """refvsr_conv24_batch / refvsr_conv_shuffle2_batch: conv() over B maps (24 output channels, 3x3, or the C = 24 pixel-shuffle
-    conv).  Shapes without a multi-map kernel run map by map (same results)."""
+    conv).  Shapes without a multi-map kernel run map by map (same results; stack=False: returned as a list, no copy)."""
     B = len(src0s)
     h, w, c0 = src0s[0].shape
     c1 = src1s[0].shape[2] if src1s is not None else 0
@@ -777,18 +783,18 @@ def conv_b(cw, src0s, src1s=None, act=1.0, muls=None, ress=None, post=1.0):
                                                 act, _parr(muls) if muls is not None else None, _parr(ress) if ress is not None else None,
                                                 post, _parr(list(out)), _stream()), 'conv24_batch')
         return out
-    return torch.stack([conv(cw, src0s[b], None if src1s is None else src1s[b], act=act, mul=None if muls is None else muls[b],
-                             res=None if ress is None else ress[b], post=post) for b in range(B)], 0)
+    return _maps([conv(cw, src0s[b], None if src1s is None else src1s[b], act=act, mul=None if muls is None else muls[b],
+                       res=None if ress is None else ress[b], post=post) for b in range(B)], stack)
 
 
-def resblock24_chain_b(chain, xs, act):
+def resblock24_chain_b(chain, xs, act, stack=True):
     """refvsr_resblock24_chain_batch: chain.n fused 24-channel blocks over B maps, one launch per block."""
     B = len(xs)
     for t_ in xs:
         _nhwc(t_)
         assert tuple(t_.shape) == tuple(xs[0].shape) and t_.shape[2] == 24
     if not multimap_ok(B):
-        return torch.stack([resblock24_chain(chain, x, act) for x in xs], 0)
+        return _maps([resblock24_chain(chain, x, act) for x in xs], stack)
     h, w, _ = xs[0].shape
     dev = xs[0].device
     out = torch.empty((B, h, w, 24), dtype=torch.float16, device=dev)
@@ -799,15 +805,32 @@ def resblock24_chain_b(chain, xs, act):
     return out
 
 
-def conf_alpha_b(conf_as, conf_bs, up, w0, b0, cw, slope0=0.2, slope1=0.2, want_max=False):
+def resblock48_chain_b(chain, xs, act, stack=True):
+    """refvsr_resblock48_chain_batch (ABI 12): chain.n fused 48-channel blocks over B maps, one launch per block."""
+    B = len(xs)
+    for t_ in xs:
+        _nhwc(t_)
+        assert tuple(t_.shape) == tuple(xs[0].shape) and t_.shape[2] == 48
+    if not multimap_ok(B):
+        return _maps([resblock48_chain(chain, x, act) for x in xs], stack)
+    h, w, _ = xs[0].shape
+    out = torch.empty((B, h, w, 48), dtype=torch.float16, device=xs[0].device)
+    s0 = torch.empty_like(out) if chain.n >= 2 else None
+    s1 = torch.empty_like(out) if chain.n >= 3 else None
+    hip.check(hip.lib().refvsr_resblock48_chain_batch(_parr(xs), B, h, w, chain.n, _ptr(chain.blobs), chain.stride, act, _ptr(s0), _ptr(s1),
+                                                      _parr(list(out)), _stream()), 'resblock48_chain_batch')
+    return out
+
+
+def conf_alpha_b(conf_as, conf_bs, up, w0, b0, cw, slope0=0.2, slope1=0.2, want_max=False, stack=True):
     """refvsr_conf_alpha_batch: conf_alpha() over B pairs of confidence maps (24 output channels)."""
     B = len(conf_as)
     assert len(conf_bs) == B
     if not (multimap_ok(B) and cw.cout == 24):
         r = [conf_alpha(conf_as[b], conf_bs[b], up, w0, b0, cw, slope0, slope1, want_max) for b in range(B)]
         if want_max:
-            return torch.stack([a for a, _ in r], 0), torch.stack([m for _, m in r], 0)
-        return torch.stack(r, 0)
+            return _maps([a for a, _ in r], stack), _maps([m for _, m in r], stack)
+        return _maps(r, stack)
     for t_ in list(conf_as) + list(conf_bs):
         _planar(t_, 1)
         assert t_.shape == conf_as[0].shape
@@ -827,10 +850,10 @@ def _warp_b(fn, name, xs, flows, out, dims):
     return out
 
 
-def warp_nhwc16_b(xs, flows):
+def warp_nhwc16_b(xs, flows, stack=True):
     B = len(xs)
     if not multimap_ok(B):
-        return torch.stack([warp_nhwc16(x, f) for x, f in zip(xs, flows)], 0)
+        return _maps([warp_nhwc16(x, f) for x, f in zip(xs, flows)], stack)
     for x, f in zip(xs, flows):
         _nhwc(x)
         _planar(f, 2)
@@ -841,10 +864,10 @@ def warp_nhwc16_b(xs, flows):
     return _warp_b(hip.lib().refvsr_warp_nhwc16_batch, 'warp_nhwc16_batch', xs, flows, out, ((hin, win, cs), (hf, wf)))
 
 
-def warp_nhwc16_up2_b(xs, flows_lr):
+def warp_nhwc16_up2_b(xs, flows_lr, stack=True):
     B = len(xs)
     if not multimap_ok(B):
-        return torch.stack([warp_nhwc16_up2(x, f) for x, f in zip(xs, flows_lr)], 0)
+        return _maps([warp_nhwc16_up2(x, f) for x, f in zip(xs, flows_lr)], stack)
     for x, f in zip(xs, flows_lr):
         _nhwc(x)
         _planar(f, 2)
@@ -855,10 +878,10 @@ def warp_nhwc16_up2_b(xs, flows_lr):
     return _warp_b(hip.lib().refvsr_warp_nhwc16_up2_batch, 'warp_nhwc16_up2_batch', xs, flows_lr, out, ((hin, win, cs), (hl, wl)))
 
 
-def warp_planar_b(xs, flows):
+def warp_planar_b(xs, flows, stack=True):
     B = len(xs)
     if not multimap_ok(B):
-        return torch.stack([warp_planar(x, f) for x, f in zip(xs, flows)], 0)
+        return _maps([warp_planar(x, f) for x, f in zip(xs, flows)], stack)
     for x, f in zip(xs, flows):
         _planar(x)
         _planar(f, 2)

@@ -140,6 +140,10 @@ def test_multimap_entry_points_validate_before_device_work(libpath):
     expect(h.refvsr_resblock24_chain_batch(s2, 2, 8, 8, 2, at(1024), 43264, 0.0, None, None, o2, None), 'n >= 2 needs scratch0')
     expect(h.refvsr_resblock24_chain_batch(s2, 2, 8, 8, 1, at(1024), 43264, 0.0, None, None, s2, None), 'buffers must be distinct')
     expect(h.refvsr_resblock24_chain_batch(arr(at(0), P(0)), 2, 8, 8, 1, at(1024), 43264, 0.0, None, None, o2, None), 'null map pointer (map 1)')
+    expect(h.refvsr_resblock48_chain_batch(five, 5, 8, 8, 1, at(1024), 172544, 0.0, None, None, five, None), 'resblock48_chain: bad args')
+    expect(h.refvsr_resblock48_chain_batch(s2, 2, 8, 8, 3, at(1024), 172544, 0.0, at(16384), None, o2, None), 'n >= 3 needs scratch1')
+    expect(h.refvsr_resblock48_chain_batch(s2, 2, 8, 8, 1, at(1024), 172544, 0.0, None, None, arr(at(8192), at(8192)), None), 'buffers must be distinct')
+    expect(h.refvsr_resblock48_chain_batch(s2, 2, 8, 8, 1, at(1024), 1024, 0.0, None, None, o2, None), 'stride >= 172544')
     expect(h.refvsr_conv24_batch(s2, 24, None, 0, 5, 8, 8, at(1024), 1.0, None, None, 1.0, o2, None), '1..4 maps per launch')
     expect(h.refvsr_conv24_batch(s2, 20, None, 0, 2, 8, 8, at(1024), 1.0, None, None, 1.0, o2, None), 'input channels not supported')
     expect(h.refvsr_conv24_batch(s2, 24, None, 24, 2, 8, 8, at(1024), 1.0, None, None, 1.0, o2, None), 'src1 / c1 mismatch')

@@ -1270,6 +1270,16 @@ def test_multimap_launches_equal_the_single_map_launches(dev, B, h, w):
         assert got.shape == (B, h, w, 24)
         for b in range(B):
             assert torch.equal(got[b], ops.resblock24_chain(ch, xs[b], act)), ('rb24', n, b)
+    # the 48-channel fused block chain (ABI 12)
+    for n, act in ((1, 0.0), (2, 0.2), (3, 0.0)):
+        raw = [((torch.randn(48, 48, 3, 3, generator=g) * 0.05, torch.randn(48, generator=g) * 0.1),
+                (torch.randn(48, 48, 3, 3, generator=g) * 0.05, torch.randn(48, generator=g) * 0.1)) for _ in range(n)]
+        ch = ops.Resblock48Chain(raw, dev)
+        xs = [rn(48) for _ in range(B)]
+        got = ops.resblock48_chain_b(ch, xs, act)
+        assert got.shape == (B, h, w, 48)
+        for b in range(B):
+            assert torch.equal(got[b], ops.resblock48_chain(ch, xs[b], act)), ('rb48', n, b)
     # conv24: every input shape x epilogue operands
     for cins, act, post, use_mul, use_res in (([24], 0.2, 1.0, True, True), ([16], 0.2, 1.0, False, False), ([8, 24], 0.1, 1.0, False, False),
                                               ([24, 24], 0.2, 0.2, False, True), ([24], 1.0, 1.0, False, True)):

@@ -1053,6 +1053,7 @@ def test_bench_compact_line_keeps_the_judged_fields_under_6_kb():
                                                       for n in (2, 4, 8)}, 'junk': blob},
             'other_configs': {'configs[2]': {'value': 95.0, 'ms_per_step': 10.5, 'whole_path': {'frac_of_f16_mfma_peak': 0.2}, 'roofline': {'frac': 0.16}, 'w': 'x' * 400},
                               'configs[4] on one GPU': {'value': 7.5, 'ms_per_step': 133.0, 'peak_memory_gib': 17.6, 'workload': 'x' * 400}},
+            'pcie_inclusive': {'value': 200.0, 'unit': 'frames/s', 'samples': [200.0] * 3, 'h2d_mb_per_frame': 15.55, 'd2h_mb_per_frame': 24.88, 'note': 'n' * 300},
             'first_frame_ms': 11.8, 'full_record': 'gpurun_out/bench_full.json'}
     c = bench.compact_line(line)
     txt = json.dumps(c)
@@ -1062,6 +1063,7 @@ def test_bench_compact_line_keeps_the_judged_fields_under_6_kb():
     assert c['roofline']['frac'] == 0.15 and c['roofline']['bound'] == 'mfma' and c['roofline']['traffic'] == 5.4e7
     assert c['cpu_baseline']['cores'] == 16 and c['cpu_baseline']['kind'] == 'port' and len(c['cpu_baseline']['sample']) <= 200
     assert c['dropin_surface']['value'] == 180.0 and c['config']['dropin_frames_per_s'] == 180.0 and 'precision' not in c['config']
+    assert c['pcie_inclusive']['value'] == 200.0 and 'note' not in c['pcie_inclusive']
     assert c['wavefront_model_predicted_speedup']['8'] == {'restarts': 7.5, 'no_restarts': 5.9}
     # N > 1: the sharded-clip figure becomes the headline, the weak-scaling figure moves aside
     import argparse

@@ -39,7 +39,7 @@ def main():
     ch = ops.Resblock24Chain(raw, dev)
     iters = int(os.environ.get('RB_ITERS', '10'))
     sizes = [('LR 270x480', 270, 480), ('LR/2 135x240', 135, 240), ('2x 540x960', 540, 960)]
-    for name, h, w in sizes:
+    for name, h, w in ([] if os.environ.get('RB48_ONLY', '0') == '1' else sizes):
         fl = 2.0 * h * w * C * C * 9 * 2
         for B in (1, 2, 3, 4):
             xs = [ops.pack_nhwc16(torch.randn(C, h, w, generator=g).to(dev)) for _ in range(B)]
@@ -47,6 +47,23 @@ def main():
             us = timeit(fn, iters) / n
             print('multimap resblock24 %-13s B=%d  %7.2f us/launch  %6.2f us/map  %6.1f TFLOP/s useful  %5.1f %% of 2.5 PF' %
                   (name, B, us, us / B, fl * B / us / 1e6, fl * B / us / 1e6 / 25.0), flush=True)
+    if os.environ.get('RB48', '1') != '0':            # the 48-channel block (ABI 12): launch cost + first fill + tail shared, sets swap per tile
+        C48, n48 = 48, 12
+        raw = []
+        for _ in range(n48):
+            ws = [torch.randn(C48, C48, 3, 3, generator=g) / (C48 * 9) ** 0.5 * 0.5 for _ in range(2)]
+            raw.append(((ws[0], torch.zeros(C48)), (ws[1], torch.zeros(C48))))
+        ch48 = ops.Resblock48Chain(raw, dev)
+        for name, h, w in sizes:
+            fl = 2.0 * h * w * C48 * C48 * 9 * 2
+            for B in (1, 2, 3, 4):
+                xs = [ops.pack_nhwc16(torch.randn(C48, h, w, generator=g).to(dev)) for _ in range(B)]
+                fn = (lambda: ops.resblock48_chain(ch48, xs[0], 0.0)) if B == 1 else (lambda: ops.resblock48_chain_b(ch48, xs, 0.0))
+                us = timeit(fn, iters) / n48
+                print('multimap resblock48 %-13s B=%d  %7.2f us/launch  %6.2f us/map  %6.1f TFLOP/s useful  %5.1f %% of 2.5 PF' %
+                      (name, B, us, us / B, fl * B / us / 1e6, fl * B / us / 1e6 / 25.0), flush=True)
+    if os.environ.get('RB48_ONLY', '0') == '1':
+        return
     gq = torch.Generator().manual_seed(1)
     shapes = [('24->24', [24], False), ('8+24->24', [8, 24], False), ('24+24->24', [24, 24], False), ('24->96 shuffle', [24], True)]
     for name, h, w in sizes[:1] + sizes[2:]:
