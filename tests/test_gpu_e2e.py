@@ -1223,11 +1223,13 @@ def test_frame_groups_other_configurations(dev, name, t, size, scale, reset):
         assert torch.equal(outs[f], want[f]), '%s: group frame %d differs' % (name, f)
 
 
-@pytest.mark.parametrize('n', [2, 3, 4])
-def test_batch_samples_as_multimap_launches(dev, n):
+@pytest.mark.parametrize('n,name', [(2, 'config_RefVSR_small_L1'), (3, 'config_RefVSR_small_L1'), (4, 'config_RefVSR_small_L1'),
+                                    (2, 'config_RefVSR_MFID')])
+def test_batch_samples_as_multimap_launches(dev, n, name):
     """n > 1 (lrs [n,t,3,h,w], RefVSR.py:151) with frame ids on a pipelined module: the n samples' forward-branch steps and backward
     branches run as multi-map launches (Engine.forward_multi) -- every sample's stream must equal its own one-sample sequential run bit
-    for bit, over a reset_branch roll-over (the restart call runs one forward() per sample) and a second clip."""
+    for bit, over a reset_branch roll-over (the restart call runs one forward() per sample) and a second clip; mid_channels = 24 and 48
+    (the 48-channel blocks through refvsr_resblock48_chain_batch)."""
     from refvsr_amd.synth import make_clip, window_indices
     nfr, t = 9, 5
     clips = [make_clip(nfr, 64, 96, seed=31 + b) for b in range(n)]
@@ -1236,9 +1238,9 @@ def test_batch_samples_as_multimap_launches(dev, n):
     wins = [window_indices(f, nfr, t) for f in range(nfr)]
     want = []
     for b in range(n):
-        ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+        ref_net, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
         want.append([ref_net(lr[b, wins[f]][None].contiguous(), rf[b, wins[f]][None].contiguous(), f == 0)['result'][0].clone() for f in range(nfr)])
-    net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
+    net, _, _ = make_net(name, t, dev, reset=4, save_sample=False)
     net.Network.set_pipelined(True)
     for clip in range(2):
         outs = []
