@@ -158,3 +158,48 @@ def test_refvsr_ir_stream():
             assert maxdiff(outs['vis'][k], g['vis_%s_%d' % (k, f)]) < 1e-4, (f, k)
         assert maxdiff(o.forward_feat_prop_prev, g['state_feat_%d' % f].float()) < 2e-3      # stored as fp16
         assert maxdiff(o.forward_flow_prev, g['state_flow_%d' % f]) < TOL
+
+
+def test_ir_oracle_deformable_conv_against_independent_formulations():
+    """The modulated deformable convolution inside the IR fixture is the oracle's own restatement of mmcv's compiled op (absent from this
+    image: the op stays "parity-unpinned" against mmcv itself).  What CAN be pinned here: (1) its bilinear sampler against torch's
+    F.grid_sample(bilinear, zeros, align_corners=True) -- the same definition as mmcv's dmcn_im2col_bilinear: a sample is 0 outside
+    (-1, H) x (-1, W), corner pixels outside the map contribute 0 -- on coordinates that leave the map on every side; (2) the whole
+    ModulatedDCNPack against plain convolutions where the op degenerates to one: zero offsets (0.5 x conv: sigmoid(0) masks) and
+    integer offsets (the conv of the shifted, zero-filled map)."""
+    import torch.nn.functional as F
+    from oracle import refvsr_ir_oracle as iro
+    g = torch.Generator().manual_seed(7)
+    n, c, H, W = 2, 8, 13, 17
+    x = torch.randn(n, c, H, W, generator=g, dtype=torch.float64)
+    py = torch.rand(n, 1, H, W, generator=g, dtype=torch.float64) * (H + 6) - 3.0          # [-3, H + 3): leaves the map on every side
+    px = torch.rand(n, 1, H, W, generator=g, dtype=torch.float64) * (W + 6) - 3.0
+    py[0, 0, 0, :4] = torch.tensor([-1.0, 0.0, H - 1.0, float(H)], dtype=torch.float64)    # the boundaries themselves
+    px[0, 0, 0, :4] = torch.tensor([-1.0, W - 1.0, float(W), 0.0], dtype=torch.float64)
+    got = iro.deform_sample(x, py, px)
+    grid = torch.stack([2.0 * px[:, 0] / (W - 1) - 1.0, 2.0 * py[:, 0] / (H - 1) - 1.0], -1)
+    want = F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    assert maxdiff(got, want) < 1e-12
+    # the pack: zero conv_offset -> every tap at its integer position with mask 0.5
+    M = 16
+    xs = torch.randn(1, M, 9, 11, generator=g)
+    extra = torch.randn(1, M, 9, 11, generator=g)
+    Wt = {'d.weight': torch.randn(M, M, 3, 3, generator=g) / 12.0, 'd.bias': torch.randn(M, generator=g) * 0.1,
+          'd.conv_offset.weight': torch.zeros(216, M, 3, 3), 'd.conv_offset.bias': torch.zeros(216)}
+    want0 = 0.5 * F.conv2d(xs, Wt['d.weight'], None, padding=1) + Wt['d.bias'].view(1, -1, 1, 1)
+    assert maxdiff(iro.dcn_pack(xs, extra, Wt, 'd'), want0) < 1e-5
+    # integer offsets (dy, dx) for every tap and group, mask logits 0: 0.5 x the conv of the map shifted by (dy, dx), zero filled
+    dy, dx = 2, -3
+    bias = torch.zeros(216)
+    bias[0:144:2] = float(dy)               # channel g*18 + 2k: row offset, + 1: column offset
+    bias[1:144:2] = float(dx)
+    Wt['d.conv_offset.bias'] = bias
+    sh = torch.zeros_like(xs)
+    sh[:, :, max(0, -dy):xs.shape[2] - max(0, dy), max(0, -dx):xs.shape[3] - max(0, dx)] = \
+        xs[:, :, max(0, dy):xs.shape[2] - max(0, -dy), max(0, dx):xs.shape[3] - max(0, -dx)]
+    # tap k of output pixel (y, x) reads x[y + ky - 1 + dy, x + kx - 1 + dx] (0 outside the map) = the zero-padded conv of the shifted map,
+    # except where the SHIFTED map's zero fill and the conv's zero padding disagree with "0 outside the original map": they agree everywhere
+    want1 = 0.5 * F.conv2d(sh, Wt['d.weight'], None, padding=1) + Wt['d.bias'].view(1, -1, 1, 1)
+    got1 = iro.dcn_pack(xs, extra, Wt, 'd')
+    # rows / columns whose 3x3 window reaches shifted-in data beyond the padding ring differ by construction; compare the interior
+    assert maxdiff(got1[:, :, 3:-3, 4:-4], want1[:, :, 3:-3, 4:-4]) < 1e-5
