@@ -932,6 +932,8 @@ def main():
     # headline call mode: frame groups (forward_group: the backward branches of G consecutive output frames as multi-map launches)
     # where the engine has the multi-map launch list (mid_channels = 24), else one forward() per frame
     G = max(1, min(4, args.group)) if (pipelined and eng.group_ok()) else 1
+    if H * W_ > 4 * 270 * 480 and '--group' not in sys.argv:
+        G = 1                                       # (1080p -> 8K: four frames' 8K intermediates; one frame per call unless asked for)
     want_percall = G > 1 and not args.no_dropin
     # ---- warm-up proper (the first timed pass used to be the first 36 ms of GPU work of the process): untimed
     # passes of both call modes until >= args.warm_seconds of real work have run -- kernels loaded, allocator pools grown for
