@@ -774,6 +774,7 @@ def main():
     ap.add_argument('--no-wavefront-exchange', action='store_true', help='N > 1: every rank prepares all contexts its windows need (round-4 call 1 schedule)')
     ap.add_argument('--wavefront-partition', default=None, help='N > 1 A/B: balanced | growing | hybrid | cyclicK | cyclic_growing (default: shard.choose_partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gc-freeze', action='store_true', help='A/B: leave the collector\'s old generations unfrozen (what a plain eval loop runs with)')
     ap.add_argument('--match-margin', type=float, default=None, help='A/B knob: margin of the exact-search flagging (0 = top-2 re-rank only)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-timeout', type=float, default=300.0)
@@ -959,7 +960,8 @@ def main():
     # goes to the permanent generation, the young generations are collected between the passes
     import gc
     gc.collect()
-    gc.freeze()
+    if not args.no_gc_freeze:
+        gc.freeze()
     # ---- R timed repetitions, the two call modes interleaved (fast / reference surface / fast / ...): every sample is printed,
     # `value` is the MEDIAN of the fast mode's samples
     samples, samples_dropin, samples_percall, sums, ev = [], [], [], [], None

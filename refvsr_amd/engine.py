@@ -67,9 +67,9 @@ class Weights(object):
         C = self.C
         g = lambda n: (sd['Network.' + n + '.weight'], sd['Network.' + n + '.bias'])
 
-        def mf(name, srcs, shuffle=False):
+        def mf(name, srcs, shuffle=False, mt=None):
             w, b = g(name)
-            self.conv[name] = ops.ConvWeights(pack_conv(w, b, srcs, shuffle), device)
+            self.conv[name] = ops.ConvWeights(pack_conv(w, b, srcs, shuffle, mt=mt), device)
 
         def dr(name):
             w, b = g(name)
@@ -110,17 +110,23 @@ class Weights(object):
             self.raw[fe + 'map64.0'] = tuple(t.detach().to(device, torch.float32).contiguous() for t in
                                              (g(fe + 'map64.0')[0].reshape(16, 64), g(fe + 'map64.0')[1]))
 
-        def aligned(prefix):
+        def aligned(prefix, stride):
             mf(prefix + '.conv1.0', [3])
             mf(prefix + '.conv1.2.conv1', [32])
             mf(prefix + '.conv1.2.conv2', [32])
-            mf(prefix + '.p_conv.0', [32, 32])
+            # the strided 5x5 predictor conv (alignment.py:20: 64 -> 32, stride = the patch size): with 32 output channels per workgroup
+            # its staged input tile + a weight ring exceeds the LDS and the generic kernel runs in gather mode (B fragments from global
+            # memory inside the K loop); at stride 2 sixteen output channels per workgroup (mt = 1) fit the 4 x 32 tile mode: 116.6 ->
+            # 94.9 us at 540 x 960, bit-identical (profiles/r05_pconv_mt1_ab.txt; at stride 4 no tile fits either way and mt = 1 only
+            # doubles the gathers: 196 vs 421 us at 1080 x 1920).  REFVSR_PCONV_MT = 1 | 2 forces one packing (A/B knob)
+            mt_p = int(os.environ.get('REFVSR_PCONV_MT', '1' if stride == 2 else '2'))
+            mf(prefix + '.p_conv.0', [32, 32], mt=mt_p)
             mf(prefix + '.p_conv.2.conv1', [32])
             mf(prefix + '.p_conv.2.conv2', [32])
             mf(prefix + '.p_conv.4', [32])
-        aligned('aa2.align')
+        aligned('aa2.align', config.matching_ksize)
         if config.matching_ksize // 2 > 1:     # RefVSR.py:39 -- aa1 aligns only when its patch is larger than 1 px
-            aligned('aa1.align')
+            aligned('aa1.align', config.matching_ksize // 2)
 
         def reslist(name, n):
             for i in range(n):

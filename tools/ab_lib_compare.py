@@ -25,16 +25,22 @@ def load(path):
 
 
 def us(fn, iters=20):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    import gc
+    gc.collect()
+    gc.disable()                         # a gen-2 collection inside the timed loop stalls the host for tens of ms: the GPU
+    try:                                 # idles and the events report milliseconds per launch (seen twice in round 5)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    finally:
+        gc.enable()
 
 
 def main():

@@ -15,18 +15,24 @@ dev = torch.device('cuda:0')
 
 
 def timeit(fn, iters):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    blocker = torch.randn(8192, 8192, device=dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    _ = blocker @ blocker
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    import gc
+    gc.collect()
+    gc.disable()                         # a gen-2 collection inside the timed loop stalls the host for tens of ms: the GPU
+    try:                                 # idles and the events report milliseconds per launch (seen twice in round 5)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        blocker = torch.randn(8192, 8192, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _ = blocker @ blocker
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    finally:
+        gc.enable()
 
 
 def main():
