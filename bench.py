@@ -228,10 +228,10 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
     torch.cuda.synchronize()
     N = net.Network
     eng = N.ensure_engines(1, dev)[0]
-    # call modes: one forward() per frame, and -- where the engine has the group schedule and the maps are small enough for four
-    # frames' intermediates (the 1080p -> 8K config keeps one frame per call) -- frame groups of four; `value` = the faster one
+    # call modes: one forward() per frame, and -- for mid_channels = 24 models, where the groups pay (neutral at C = 48, whose
+    # streams stay on round 4's layout) -- frame groups of four; `value` = the faster one
     # (groups first: an engine driven through forward_group lays its streams out as P | F | M before the first one exists)
-    modes = ([4] if (eng.group_ok() and h * w <= 4 * 270 * 480) else []) + [1]
+    modes = ([4] if (eng.group_ok() and cfg.mid_channels == 24 and h * w <= 4 * 270 * 480) else []) + [1]
     all_lr = torch.cat(win_lr, 0) if 4 in modes else None
     all_rf = torch.cat(win_rf, 0) if 4 in modes else None
     by_mode = {}

@@ -194,6 +194,7 @@ class Engine(object):
         self.rb48 = (bool(getattr(config, 'fuse_resblocks', True)) and not env_flag('REFVSR_NO_FUSE')
                      and not env_flag('REFVSR_NO_RB48'))                 # A/B knob: C = 48 blocks as two refvsr_conv48 launches (round 3)
         self.rb48_max_pixels = int(os.environ.get('REFVSR_RB48_MAX_PIXELS', str(540 * 960)))
+        self.pipe_restart = not env_flag('REFVSR_SERIAL_RESTART')         # A/B knob: roll-over restarts of a pipelined stream drain it and run on M (round 4)
         self.rb48_multimap = not env_flag('REFVSR_NO_RB48_MULTIMAP')      # A/B knob: frame groups of C = 48 run their blocks map by map
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
@@ -227,7 +228,7 @@ class Engine(object):
         # P + F stream is the critical path (P 2.9 + F 1.9 ms per frame = the frame, M idle a third of the time); with F on its own
         # stream the forward-branch chain runs under the preparation of the group's new frames -- same box, G = 4: 213.1 (pf_m) /
         # 216.9 (p_fm) / 227.5 (pfm) frames/s, 228.9 with the backward head on M as well (profiles/r05_group_layout_ab.txt)
-        self._layout_default = 'pf_m'
+        self._layout_default = None               # None: by model (see _pipe_streams); forward_group / forward_multi set 'pfm'
         self.pipe_depth = max(1, int(getattr(config, 'pipe_depth', None) or os.environ.get('REFVSR_PIPE_DEPTH') or 3))
         self._inflight = collections.deque()
         self.stream_events = None      # bench.py: list collecting per-call section events of the pipelined mode's streams
@@ -917,7 +918,12 @@ class Engine(object):
           'one'             P, F and M on ONE stream (measurement aid: bench.py times the multi-map launches of a group in it)
         Wider models (C = 48 / 36) additionally alternate two M streams (for mid_channels = 24 two M streams measured equal to one,
         209.5 / 210.2 vs 209.1 / 209.6 frames/s, profiles/r04_two_m_and_mfid_layout_ab.txt: no switch)."""
-        layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or self._layout_default)
+        # default: P | F | M for the mid_channels = 24 models (what their frame groups run on: an engine whose FIRST pipelined call is a
+        # single forward() -- a caller that sends the first window alone -- must not lay its streams out differently and rebuild them at
+        # the first group: the idle first set of streams changes the stream -> hardware-queue mapping, 212 vs 231 frames/s,
+        # profiles/r05_group_cut_ab.txt); P + F | M for the wider models (round 4's layout, two alternating M streams)
+        layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or self._layout_default or
+                     ('pfm' if (self.C == 24 and self.group_ok()) else 'pf_m'))
         if self._pipe is not None and self._pipe[0].device == dev and self.pipe_layout != layout:
             torch.cuda.synchronize(dev)               # another layout from here on (first group call of an engine): drain, rebuild
             self._pipe = None
@@ -957,7 +963,14 @@ class Engine(object):
         # (profiles/r04_stream_layout_ab.txt: passes of 175 instead of 187 frames/s with unstretched stream sections).
         while len(self._inflight) >= self.pipe_depth:
             self._inflight.popleft().synchronize()
-        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num:
+        # reset_branch roll-over of a RUNNING stream (RefVSR.py:168-170): the call differs from a steady one only in its forward branch --
+        # t // 2 + 1 steps from zeros over the window's first frames instead of one step from the carried state (their contexts and flows
+        # are cached) -- so it stays on the three streams (`restart`): no drain of the calls in flight, no serial pass on M, no refill of the
+        # pipeline behind it (round 5, late: the serial restart cost a group-mode stream a tenth of its rate at reset_branch = 9).  A caller's
+        # first frame, a stream without a state and the gradio mode take the reference order on M as before.
+        restart = bool(not is_first_frame and self.fw_feat is not None and self.max_frame_itr_num is not None and
+                       self.frame_itr_num == self.max_frame_itr_num and not bool(self.cfg.EVAL.is_gradio) and self.pipe_restart)
+        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num and not restart:
             is_first_frame = True
         streams = []
         for st in (M0, M1, F_, P):
@@ -1006,7 +1019,7 @@ class Engine(object):
                         for st in share:
                             f.lr.record_stream(st)
                             f.ref.record_stream(st)
-                for i in range(ctr, t):
+                for i in range(0 if restart else ctr, t):        # (restart: the forward branch walks the first frames too -- cached)
                     f = fr[i]
                     if f.conf is None:
                         self.pyramid(f)
@@ -1029,19 +1042,22 @@ class Engine(object):
                                 for st in share:
                                     x.record_stream(st)
                 # the window's new flows in one batched SPyNet pass: the backward flows and the forward flow of this call
-                self.flows([(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])], share)
+                need = [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
+                if restart:
+                    need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]           # forward flows of the first frames (cached pairs cost nothing)
+                self.flows(need, share)
                 bw_flows = {i: self.flow(fr[i], fr[i + 1], share) for i in range(ctr, t - 1)}
                 tev['P1'] = mark(P)
             # ---- F: forward-branch step (state of the previous call, cached frames)
             with ops.on_stream(F_):
                 tev['F0'] = mark(F_)
-                for f in (fr[ctr], fr[ctr + 1]):
+                for f in (fr[:ctr + 2] if restart else (fr[ctr], fr[ctr + 1])):
                     if f.ready is not None:
                         F_.wait_event(f.ready)
                 for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
                     x.record_stream(F_)
                 flow_f = lambda a, b: self.flow(fr[a], fr[b], share)
-                fw = self._forward_branch(fr, flow_f, t, h, w, False)
+                fw = self._forward_branch(fr, flow_f, t, h, w, restart)
                 for x in fw:
                     x.record_stream(M0)
                     x.record_stream(M1)
@@ -1072,6 +1088,8 @@ class Engine(object):
                     vis['conf_map_prop_backward'] = conf
                     vis['conf_map_prop_forward'] = fw[2]
             del bw_flows
+            if restart:                                                             # RefVSR.py:292-295
+                self.frame_itr_num = 0
             self.frame_itr_num += 1
         done = torch.cuda.Event(enable_timing=sev is not None)
         done.record(M)

@@ -1194,6 +1194,39 @@ def test_context_exchange_block_start_before_a_reset_frame(dev):
         assert torch.equal(got[f], want), 'frame %d differs from the sequential run' % f
 
 
+def test_groups_of_any_cut_after_a_single_first_call(dev):
+    """A caller may cut its forward_group calls anywhere -- here: the first window alone through the plain call, then groups that end at
+    the reset_branch roll-overs (4 + 2 windows, the restart window alone through forward()) -- and gets the frames of one forward() per
+    window on the sequential engine, bit for bit.  The module's FIRST pipelined call is a single forward(): its streams must come up in
+    the group layout (P | F | M) right away (rebuilding them at the first group was worth 8 % of the rate, profiles/r05_group_cut_ab.txt),
+    and the roll-over restarts stay on the three streams (no drain)."""
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t, reset = 23, 5, 7
+    lr, rf, _ = make_clip(nfr, 48, 64, seed=29)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    wl = torch.stack([lr[w] for w in wins], 0).contiguous()
+    wr = torch.stack([rf[w] for w in wins], 0).contiguous()
+    torch.cuda.synchronize()
+    ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=reset, save_sample=False)
+    want = [ref_net(wl[f][None], wr[f][None], f == 0)['result'].clone() for f in range(nfr)]
+    net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=reset, save_sample=False)
+    net.Network.set_pipelined(True)
+    outs = []
+    # reset_branch = 7: windows 0, 7, 14, 21 restart; the six steady windows between two restarts go as 4 + 2
+    for f, n in [(0, 1), (1, 4), (5, 2), (7, 1), (8, 4), (12, 2), (14, 1), (15, 4), (19, 2), (21, 1), (22, 1)]:
+        if n == 1:
+            outs.append(net(wl[f][None], wr[f][None], f == 0, frame_ids=wins[f], input_ready='materialised')['result'])
+        else:
+            outs += list(net.forward_group(wl[f:f + n], wr[f:f + n], [wins[f + b] for b in range(n)], input_ready='materialised')['result'])
+        if f == 0:
+            assert net.Network.engine(0).pipe_layout == 'pfm'
+    torch.cuda.synchronize()
+    assert net.Network.engine(0).pipe_layout == 'pfm' and len(outs) == nfr
+    for f in range(nfr):
+        assert torch.equal(outs[f], want[f]), 'frame %d differs' % f
+
+
 @pytest.mark.parametrize('name,t,size,scale,reset', [('config_RefVSR_small_MFID_8K', 3, (32, 48), 4, 4), ('config_RefVSR_small_L1', 3, (32, 48), 2, 3),
                                                      ('config_RefVSR_small_MFID', 7, (40, 56), 4, 'keep'), ('config_RefVSR_MFID', 5, (32, 48), 4, 4),
                                                      ('config_RefVSR_MFID', 5, (72, 104), 4, 4), ('config_RefVSR_MFID_8K', 3, (64, 96), 4, 3)])
