@@ -1219,13 +1219,23 @@ class Engine(object):
         self.prev_window = out[-1]
         return out
 
+    def _itr_after(self, k):
+        """frame_itr_num as the k-th window from now will find it (the counter restarts at max_frame_itr_num, RefVSR.py:168-170,292-295)."""
+        itr = int(self.frame_itr_num)
+        for _ in range(k):
+            if self.max_frame_itr_num is not None and itr == self.max_frame_itr_num:
+                itr = 0
+            itr += 1
+        return itr
+
     @torch.no_grad()
     def forward_group(self, wins, is_first_frame=False, input_ready=None):
         """B consecutive windows of this stream in one call: wins = [(lrs [t,3,h,w], refs, frame_ids)] in stream order, every window
         as forward(lrs, refs, is_first, frame_ids=ids) would get it (is_first_frame applies to wins[0]).  Returns [result planar
         [3,s h,s w]] per window -- bit-identical to the B forward() calls.  Steady-state runs of >= 2 windows execute as a group
-        (multi-map launches on the internal streams: needs set_pipelined(True)); windows that restart the forward branch (first
-        frame, reset_branch roll-over, no carried state) and engines without the multi-map launch list run one forward() each.
+        (multi-map launches on the internal streams: needs set_pipelined(True); a reset_branch roll-over window stays in its group, only
+        its forward branch is the long one); a caller's first frame, a stream without a carried state and engines without the group
+        schedule run one forward() each.
         input_ready: as in forward() (None | 'materialised' | event | stream), for all windows of the call."""
         outs = [None] * len(wins)
         i = 0
@@ -1239,8 +1249,11 @@ class Engine(object):
                 # the longest run of steady windows from i on (the iteration counter advances by one per window)
                 j = i
                 if self.group_ok() and self.pipelined and self.fw_feat is not None and not (i == 0 and is_first_frame):
+                    # (a roll-over window stays inside the group: only its forward branch is the long one, `restart` in
+                    #  _forward_group_pipelined; with REFVSR_SERIAL_RESTART=1 it ends the run and goes through forward() alone)
                     while (j < len(wins) and j - i < ops.hip.MAX_MAPS and
-                           (self.max_frame_itr_num is None or self.frame_itr_num + (j - i) != self.max_frame_itr_num)):
+                           (self.pipe_restart or self.max_frame_itr_num is None or
+                            self._itr_after(j - i) != self.max_frame_itr_num)):
                         j += 1
                 if j - i >= 2:
                     res = self._forward_group_pipelined(wins[i:j], input_ready)
@@ -1260,6 +1273,9 @@ class Engine(object):
             self._check_window(lrs, refs)
             assert tuple(lrs.shape) == (t, 3, h, w)
         assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
+        # windows of the group at which the forward branch restarts (reset_branch roll-over): their backward branches are chains like the
+        # others', their forward branch is the long one (from zeros over the window's first frames)
+        rst = [bool(self.max_frame_itr_num is not None and self._itr_after(b) == self.max_frame_itr_num) for b in range(B)]
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
         M = M0          # (two M streams alternating between groups: 210.5 vs 220.4 frames/s, profiles/r05_group_knobs_ab.txt)
@@ -1306,8 +1322,8 @@ class Engine(object):
                         for st in share:
                             f.lr.record_stream(st)
                             f.ref.record_stream(st)
-            for fr in frs:
-                for i in range(ctr, t):
+            for b, fr in enumerate(frs):
+                for i in range(0 if rst[b] else ctr, t):          # (a roll-over window's forward branch walks its first frames too: cached)
                     f = fr[i]
                     if f.conf is None:
                         self.pyramid(f)
@@ -1321,21 +1337,23 @@ class Engine(object):
                         if f.ready is None:          # prepared on M by a first-frame call: make it safe on the other streams too
                             publish(f)
             need = []
-            for fr in frs:
+            for b, fr in enumerate(frs):
                 need += [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
+                if rst[b]:
+                    need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]
             self.flows(need, share)
             tev['P1'] = mark(P)
         # ---- F: the forward-branch steps, one frame after the other (the carried state)
         fws, ev_fw = [], []
         with ops.on_stream(F_):
             tev['F0'] = mark(F_)
-            for fr in frs:
-                for f in (fr[ctr], fr[ctr + 1]):
+            for b, fr in enumerate(frs):
+                for f in (fr[:ctr + 2] if rst[b] else (fr[ctr], fr[ctr + 1])):
                     if f.ready is not None:
                         F_.wait_event(f.ready)
                 for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
                     x.record_stream(F_)
-                fw = self._forward_branch(fr, (lambda a, b, fr=fr: self.flow(fr[a], fr[b], share)), t, h, w, False)
+                fw = self._forward_branch(fr, (lambda a, b_, fr=fr: self.flow(fr[a], fr[b_], share)), t, h, w, rst[b])
                 for x in fw:
                     x.record_stream(M0)
                     x.record_stream(M1)
@@ -1364,7 +1382,7 @@ class Engine(object):
             for b, fr in enumerate(frs):
                 M.wait_event(ev_fw[b])
                 outs.append(self.compute_up(feat_ups[b], fws[b][1], confs[b], fws[b][2], fr[ctr].lr))
-        self.frame_itr_num += B
+        self.frame_itr_num = self._itr_after(B)                       # (+ B, through the roll-overs inside the group)
         done = torch.cuda.Event(enable_timing=sev is not None)
         done.record(M)
         if sev is not None:
