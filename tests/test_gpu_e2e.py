@@ -1048,8 +1048,8 @@ def test_round4_fused_launches_do_not_change_the_stream(dev, monkeypatch, name, 
 @pytest.mark.parametrize('gsize', [2, 3, 4])
 def test_frame_groups_are_bit_identical(dev, gsize):
     """forward_group (round 5: the backward branches of B consecutive windows as multi-map launches, ABI 11) against one forward()
-    per frame on the default sequential engine: every output frame bit for bit over a 14-frame clip with reset_branch = 5 (groups
-    that contain a roll-over are split: the restart frame runs alone), clip-edge windows that repeat frames, a first frame inside
+    per frame on the default sequential engine: every output frame bit for bit over a 14-frame clip with reset_branch = 5 (roll-over
+    windows inside the groups: only their forward branch is the long one), clip-edge windows that repeat frames, a first frame inside
     the call, all three ways of saying when the inputs are final, and a second clip on the same module."""
     from refvsr_amd.synth import make_clip, window_indices
     nfr, t = 14, 5
