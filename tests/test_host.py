@@ -1079,3 +1079,27 @@ def test_bench_compact_line_keeps_the_judged_fields_under_6_kb():
     line_bad = dict(line, n_gpus=8, value=1700.0, config=dict(line['config']))
     bench.promote_wavefront(line_bad, dict(wf, frames_equal=False), argparse.Namespace(clip=64, size='270x480'), 8)
     assert line_bad['value'] == 1700.0 and line_bad['scaling'] == 'weak'
+
+
+def test_roll_over_counter_of_a_frame_group():
+    """Engine._itr_after (host arithmetic of the frame groups, round 5): the value of frame_itr_num the k-th window from now will find
+    -- the counter restarts when it reaches reset_branch (RefVSR.py:168-170, 292-295) -- against a window-by-window simulation; the
+    windows of a group that restart the forward branch are exactly those that find the counter at reset_branch."""
+    import types
+    from refvsr_amd.engine import Engine
+    for reset in (None, 1, 2, 3, 5, 9):
+        for start in range(1, (reset or 6) + 1):
+            eng = types.SimpleNamespace(frame_itr_num=start, max_frame_itr_num=reset)
+            itr, found = start, []
+            for k in range(14):
+                found.append(itr)
+                assert Engine._itr_after(eng, k) == itr, (reset, start, k)
+                if reset is not None and itr == reset:          # this window restarts: the counter starts again
+                    itr = 0
+                itr += 1
+            restarts = [k for k, v in enumerate(found) if reset is not None and v == reset]
+            if reset is None:
+                assert restarts == [] and found == list(range(start, start + 14))
+            else:
+                assert all(b - a == reset for a, b in zip(restarts, restarts[1:])), (reset, start, restarts)
+                assert restarts and restarts[0] == reset - start
