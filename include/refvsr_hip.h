@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 12  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 13  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
@@ -39,12 +39,26 @@ extern "C" {
                                       refvsr_warp_planar_batch; RefvsrConv.warp_* (ABI 6: the inter-frame warp fused into a conv's tile
                                       staging) REMOVED: bit-identical to warp + conv but measured slower in every configuration
                                       (169 vs 176 frames/s, profiles/r03_fused_warp_ab.txt);
-                                  12: refvsr_resblock48_chain_batch (the multi-map form of the 48-channel block) */
+                                  12: refvsr_resblock48_chain_batch (the multi-map form of the 48-channel block);
+                                  13: CU partitions: refvsr_stream_create_cu_range / refvsr_stream_set_cu_budget /
+                                      refvsr_stream_destroy / refvsr_num_cus */
 
 int refvsr_abi_version(void);
 const char* refvsr_last_error(void);
 /* One-time per-process setup (raises dynamic-LDS limits).  Called lazily by every entry point. */
 int refvsr_init(void);
+
+/* CU partitions (ABI 13; no reference counterpart -- the reference leaves kernel placement to the CUDA runtime).
+ * The path runs three internal streams (per-frame preparation, forward branch, backward branch: models/archs/RefVSR.py:196-204 is
+ * independent of :211-238 of the previous frames); kernels of two streams only run side by side if both fit a CU, which the
+ * LDS-heavy kernels of this library never do.  A stream created here executes on CUs [first_cu, first_cu + n_cus) only (both
+ * multiples of 8: an equal share of every XCD) and the persistent launchers of this library size their grids for n_cus CUs on it.
+ * refvsr_stream_set_cu_budget overrides the CU count the launchers assume on any stream (0 = forget the stream).
+ * Results never depend on the partition.  refvsr_num_cus returns the CU count of the current device (a value, not a status). */
+int refvsr_num_cus(void);
+int refvsr_stream_create_cu_range(int first_cu, int n_cus, void** stream);
+int refvsr_stream_set_cu_budget(void* stream, int n_cus);
+int refvsr_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on v_mfma_f32_16x16x32_f16, fp32 accumulate).

@@ -57,6 +57,10 @@ static inline int rv_num_cus() {
     return n_cu[d];
 }
 
+// CUs the persistent launchers may count on for a launch on `st`: the budget registered for a CU-masked stream
+// (refvsr_stream_create_cu_range / refvsr_stream_set_cu_budget, runtime.hip), otherwise the whole device.
+int rv_stream_cus(hipStream_t st);
+
 // Persistent tile walk, XCD-aware and balanced.  Workgroup b runs on XCD b % 8 (observed placement, used for speed only):
 // the workgroups of one XCD get consecutive ranks, rank r walks the CONTIGUOUS tile range [r*n/g, (r+1)*n/g), so every
 // workgroup has floor or ceil(n/g) tiles (a strided walk inside fixed eighths of the frame left single workgroups with

@@ -544,7 +544,7 @@ static int launch_c24(C24Args& a, hipStream_t st) {
     a.tiles_x = rv_cdiv(a.w, C24_TW);
     a.tpm = a.tiles_x * rv_cdiv(a.h, TH);
     a.n_tiles = a.tpm * (MM ? a.batch : 1);
-    int cap = (rv_num_cus() * occ_dev[dev] / NZ) & ~7;
+    int cap = (rv_stream_cus(st) * occ_dev[dev] / NZ) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
     hipLaunchKernelGGL((conv24_kernel<COUT, NCG0, NCG1, NWV, TH, WPS, SHUF, CONF, HALF, MM>), dim3(a.grid, NZ), dim3(NWV * 64), LDS, st, a);

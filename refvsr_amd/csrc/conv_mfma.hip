@@ -736,7 +736,7 @@ static int launch_conv(ConvArgs& a, int nz, size_t lds, hipStream_t st) {
             if (occ < 1) occ = 1;
             occ_lds[dev][slot[dev] & 3] = lds; occ_val[dev][slot[dev] & 3] = occ; ++slot[dev];
         }
-        int cap = (rv_num_cus() * occ / (nz * (a.batch > 1 ? a.batch : 1))) & ~7;
+        int cap = (rv_stream_cus(st) * occ / (nz * (a.batch > 1 ? a.batch : 1))) & ~7;
         if (cap < 8) cap = 8;
         if (g_wg_cap > 0) cap = g_wg_cap;                          // refvsr_set_conv_workgroup_cap
         if (gx > cap) gx = cap;

@@ -364,7 +364,7 @@ extern "C" int refvsr_match_exact(const float* lr_feat, int h, int w, const floa
              keys && conf && idx, "match_exact: null pointer");
     RV_CHECK(h >= 2 && w >= 2 && hr >= 2 && wr >= 2, "match_exact: bad sizes");
     // fixed grid, two workgroups per CU (the flagged count lives on the device; the kernel sizes its work items from it)
-    hipLaunchKernelGGL(match_exact_kernel, dim3(2 * rv_num_cus()), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(match_exact_kernel, dim3(2 * rv_stream_cus((hipStream_t)stream)), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)lr_rows, (const f16*)lr_rows_lo, (const f16*)ref_rows, (const f16*)ref_rows_lo, hr * wr,
                        flagged, (unsigned long long*)keys);
     RV_LAUNCH_CHECK();

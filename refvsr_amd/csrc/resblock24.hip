@@ -548,7 +548,7 @@ static int launch_rb24(RB24Args& a, hipStream_t st) {
         occ_dev[dev] = occ < 1 ? 1 : occ;
         attr_done[dev] = true;
     }
-    int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
+    int cap = (rv_stream_cus(st) * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
     hipLaunchKernelGGL((resblock24_kernel<RELU, NWV, PROBE, TH, STORE, HEAD>), dim3(a.grid), dim3(NWV * 64), RB_LDS, st, a);
@@ -602,7 +602,7 @@ static int rb24_chain_impl(const void* const* src, int batch, int h, int w, int 
         // 270 x 480 (one tile per workgroup either way) the two shapes are equal (9.3 vs 9.4 us: the fill is latency, not bandwidth,
         // and sixteen waves wait longer at the barriers), below that the 8 x 32 tiles fill more CUs (135 x 240: 6.2 vs 8.2 us)
         const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8) * batch;
-        const int waves = g_rb24_waves ? g_rb24_waves : (nt8 >= 4 * rv_num_cus() ? 16 : 8);
+        const int waves = g_rb24_waves ? g_rb24_waves : (nt8 >= 4 * rv_stream_cus(st) ? 16 : 8);
         if (g_rb_probe && act_slope == 0.f && waves == 8) rc = launch_rb24<true, 8, true>(a, st);          // tools/probe_resblock24.py
         else if (g_rb_probe && act_slope == 0.f && waves == 16) rc = launch_rb24<true, 16, true, 16>(a, st);
         else if (waves == 4) rc = act_slope == 0.f ? launch_rb24<true, 4>(a, st) : launch_rb24<false, 4>(a, st);
@@ -648,7 +648,7 @@ extern "C" int refvsr_conv_hr_last(const void* src, int h, int w, const void* bl
     a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h;
     hipStream_t st = (hipStream_t)stream;
     const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8);
-    const int waves = g_rb24_waves == 8 || g_rb24_waves == 16 ? g_rb24_waves : (nt8 >= 4 * rv_num_cus() ? 16 : 8);
+    const int waves = g_rb24_waves == 8 || g_rb24_waves == 16 ? g_rb24_waves : (nt8 >= 4 * rv_stream_cus(st) ? 16 : 8);
     return waves == 16 ? launch_rb24<false, 16, false, 16, 0, 1>(a, st) : launch_rb24<false, 8, false, 8, 0, 1>(a, st);
 }
 

@@ -389,7 +389,7 @@ static int launch_rb48(RB48Args& a, hipStream_t st) {
     a.tiles_x = rv_cdiv(a.w, R48_TW);
     a.tpm = a.tiles_x * rv_cdiv(a.h, R48_TH);
     a.n_tiles = a.tpm * (a.batch > 1 ? a.batch : 1);
-    int cap = rv_num_cus() & ~7;                                     // one 135 KB workgroup per CU
+    int cap = rv_stream_cus(st) & ~7;                                     // one 135 KB workgroup per CU
     if (cap < 8) cap = 8;
     a.grid = a.n_tiles < cap ? a.n_tiles : cap;
     hipLaunchKernelGGL((resblock48_kernel<RELU, PROBE>), dim3(a.grid), dim3(R48_NT), R48_LDS, st, a);

@@ -381,7 +381,7 @@ static int launch_lean(ResLeanArgs& a, size_t lds, hipStream_t st) {
         occ_dev[dev] = occ < 1 ? 1 : occ;
         occ_lds[dev] = lds;
     }
-    int cap = (rv_num_cus() * occ_dev[dev]) & ~7;
+    int cap = (rv_stream_cus(st) * occ_dev[dev]) & ~7;
     if (cap < 8) cap = 8;
     const int gx = a.n_tiles < cap ? a.n_tiles : cap;
     a.grid = gx;

@@ -931,6 +931,18 @@ class Engine(object):
             if layout not in ('pf_m', 'pfm', 'p_fm', 'one'):
                 raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm | one, got %r' % layout)
             two = self.C != 24
+            split = str(getattr(self.cfg, 'cu_split', None) or os.environ.get('REFVSR_CU_SPLIT') or '')
+            if split and layout in ('pfm', 'pf_m'):
+                # CU partitions (round 6, ABI 13; measurement knob, off by default -- DESIGN 5 "CU partitions"): 'p,f,m' CUs for the
+                # three streams as disjoint ranges (multiples of 8 = an equal share of every XCD); f = 0 with layout pf_m
+                cp, cf, cm = (int(v) for v in split.split(','))
+                p_ = ops.CuStream(0, cp, dev)
+                f_ = ops.CuStream(cp, cf, dev) if (layout == 'pfm' and cf > 0) else p_
+                m = ops.CuStream(cp + (cf if f_ is not p_ else 0), cm, dev)
+                self._pipe = [m, m, f_, p_]
+                self.pipe_layout = layout
+                self._pipe_calls = 0
+                return self._pipe
             m = torch.cuda.Stream(device=dev)
             if layout == 'one':                       # measurement aid (bench.py): every section on ONE internal stream -- HIP events
                 two = False                           # around a run of launches then bracket nothing but that run

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_MAPS = 4
 RESBLOCK24_BLOB_BYTES = 43264
 RESBLOCK48_BLOB_BYTES = 172544
@@ -46,6 +46,10 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> argtypes; every function returns int (0 = ok) except the two listed in _SPECIAL
 SIGNATURES = {
     'refvsr_init': [],
+    'refvsr_num_cus': [],                        # returns the CU count
+    'refvsr_stream_create_cu_range': [_I, _I, C.POINTER(C.c_void_p)],
+    'refvsr_stream_set_cu_budget': [_P, _I],
+    'refvsr_stream_destroy': [_P],
     'refvsr_conv_mfma': [C.POINTER(RefvsrConv), _P],
     'refvsr_set_conv_workgroup_cap': [_I],
     'refvsr_kslot': [_I, _I, _I, _I, _I],        # returns the slot, not a status

@@ -45,6 +45,27 @@ class on_stream(object):
         return self.ctx.__exit__(*exc)
 
 
+def num_cus():
+    """CU count of the current device as the library sees it."""
+    return int(hip.lib().refvsr_num_cus())
+
+
+class CuStream(torch.cuda.ExternalStream):
+    """A HIP stream restricted to the CUs [first_cu, first_cu + n_cus) (refvsr_stream_create_cu_range: both multiples of 8 = an equal
+    share of every XCD).  The persistent launchers of the library size their grids for n_cus CUs on it.  A torch stream in every other
+    respect (events, wait_stream, record_stream, `with ops.on_stream(s)`).  The HIP stream lives as long as the process: engines keep
+    their streams for their whole life and the allocator may hold record_stream references to it."""
+
+    def __new__(cls, first_cu, n_cus, device=None):
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        out = C.c_void_p(0)
+        with torch.cuda.device(dev):
+            hip.check(hip.lib().refvsr_stream_create_cu_range(int(first_cu), int(n_cus), C.byref(out)), 'stream_create_cu_range')
+        self = super().__new__(cls, out.value, device=dev)
+        self.first_cu, self.n_cus = int(first_cu), int(n_cus)
+        return self
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
