@@ -229,7 +229,7 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
     N = net.Network
     eng = N.ensure_engines(1, dev)[0]
     # call modes: one forward() per frame, and -- for mid_channels = 24 models, where the groups pay (neutral at C = 48, whose
-    # streams stay on round 4's layout) -- frame groups of four; `value` = the faster one
+    # streams stay on round 4's layout) -- frame groups of four; `value` = the first mode of the list (decided before measuring)
     # (groups first: an engine driven through forward_group lays its streams out as P | F | M before the first one exists)
     modes = ([4] if (eng.group_ok() and cfg.mid_channels == 24 and h * w <= 4 * 270 * 480) else []) + [1]
     all_lr = torch.cat(win_lr, 0) if 4 in modes else None
@@ -264,7 +264,7 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
         N.set_pipelined(False)
         fps.sort()
         by_mode[G] = fps
-    best = max(by_mode, key=lambda g_: by_mode[g_][len(by_mode[g_]) // 2])
+    best = modes[0]                                   # fixed a priori: groups where the engine has them and they pay, else per frame
     fps = by_mode[best]
     value = fps[len(fps) // 2]
     del all_lr, all_rf
@@ -297,7 +297,7 @@ def other_config_leg(name, h, w, steps, warmup, dev, repeats=3):
     return res
 
 
-def wavefront_model(per_frame, nfr, reset_branch, t_msg=0.3, head_fraction=0.24):
+def wavefront_model(per_frame, nfr, reset_branch, t_msg=0.3, head_fraction=0.24, one_rank_clip_ms=None, one_rank_wavefront_ms=None):
     """serial_fraction and predicted strong-scaling speedups of shard.run_wavefront from measured per-frame phase times
     (shard.simulate_wavefront: pre-emptive makespan model of the two-lane schedule; t_msg = one 33 MB message over one xGMI link +
     latency, 0.3 ms assumed at N = 1, the measured ring time at N > 1: what a context costs; the hand-off goes in two messages and
@@ -316,22 +316,41 @@ def wavefront_model(per_frame, nfr, reset_branch, t_msg=0.3, head_fraction=0.24)
                                 'what': 'shard.run_wavefront(exchange_contexts=True): every per-frame context (matching, reference encoders, aligned '
                                         'attention) prepared ONCE, by the owner of its frame, and sent to the ranks whose windows need it'},
            'predicted_speedup': {}}
-    sp = lambda n, parts, rb, il=True: round(shard.predicted_speedup(nfr, n, parts, rb, ta, tb1, tb2, th, cold, il)[0], 3)
+    G, ta1 = int(per_frame.get('phase_a_group', 1) or 1), per_frame.get('phase_a_single_ms')
+    gk = dict(group=G, t_a_single=ta1)
+    out['phase_a_group'] = G
+    # Denominators (the speed-ups used to be relative to a rank that walks the clip phase by phase, 153.6 frames/s
+    # where the N = 1 headline was 231.6).  `speedup` = against one rank's phase sum at the SAME per-frame times (the model's own
+    # unit); `speedup_vs_one_rank_fast_path` = against the wall time ONE GPU needs for the same clip through its fastest call mode
+    # (forward_group on three streams; one_rank_clip_ms, measured here) -- the strong-scaling figure a user sees.  The model's ranks
+    # execute one task at a time (no overlap between the lanes), so the second figure is a lower bound of what the model stands for.
+    # With one_rank_wavefront_ms -- the SAME executor measured with one rank (bench.one_rank_wavefront_seconds) -- the figure is
+    # calibrated instead: speedup (the model's, relative to one rank of the same executor) x fast path / one-rank executor time, i.e.
+    # the ranks are assumed to overlap their lanes at N ranks as the one rank measurably does.
+    base_ms = one_rank_wavefront_ms if one_rank_wavefront_ms else nfr * tot
+    out['one_rank'] = {'phase_sum_ms_per_frame': tot, 'phase_sum_clip_ms': nfr * tot, 'fast_path_clip_ms': one_rank_clip_ms,
+                       'fast_path_ms_per_frame': (one_rank_clip_ms / nfr) if one_rank_clip_ms else None,
+                       'executor_clip_ms': one_rank_wavefront_ms,
+                       'lane_overlap_factor (executor / phase sum)': (one_rank_wavefront_ms / (nfr * tot)) if one_rank_wavefront_ms else None,
+                       'vs_fast_path_is': 'speedup x fast_path_clip_ms / %s' % ('executor_clip_ms (measured)' if one_rank_wavefront_ms else 'phase_sum_clip_ms')}
+    vs_fast = lambda s_: None if not one_rank_clip_ms else round(s_ * one_rank_clip_ms / base_ms, 3)
+    sp = lambda n, parts, rb, il=True: round(shard.predicted_speedup(nfr, n, parts, rb, ta, tb1, tb2, th, cold, il, **gk)[0], 3)
     for n in (2, 4, 8):
         bal = shard.partition(nfr, n)
         grow = shard.partition_chain(nfr, n, tb1 / ta if ta > 0 else 0.165)
         ent = {}
         if reset_branch:
-            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, th, cold)
-            ent['with_restarts (reset_branch=%d)' % reset_branch] = {'chosen': nm, 'speedup': round(s_, 3),
+            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, th, cold, **gk)
+            ent['with_restarts (reset_branch=%d)' % reset_branch] = {'chosen': nm, 'speedup': round(s_, 3), 'speedup_vs_one_rank_fast_path': vs_fast(s_),
                                                                     'hybrid_reset_aligned': sp(n, shard.partition_hybrid(nfr, n, reset_branch), reset_branch),
                                                                     'balanced_handoff_at_every_boundary': sp(n, bal, reset_branch)}
         if reset_branch:
-            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, th, cold, exchange=ex)
-            ent['with_restarts (reset_branch=%d)' % reset_branch]['with_context_exchange'] = {'chosen': nm, 'speedup': round(s_, 3)}
-        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, th, cold, exchange=ex)
-        ex_free = {'chosen': nm, 'speedup': round(s_, 3), 'block_sizes': [b_ - a_ for a_, b_, _ in blk]}
-        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, th, cold)
+            blk, s_, nm = shard.choose_partition(nfr, n, reset_branch, ta, tb1, tb2, th, cold, exchange=ex, **gk)
+            ent['with_restarts (reset_branch=%d)' % reset_branch]['with_context_exchange'] = {'chosen': nm, 'speedup': round(s_, 3),
+                                                                                             'speedup_vs_one_rank_fast_path': vs_fast(s_)}
+        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, th, cold, exchange=ex, **gk)
+        ex_free = {'chosen': nm, 'speedup': round(s_, 3), 'speedup_vs_one_rank_fast_path': vs_fast(s_), 'block_sizes': [b_ - a_ for a_, b_, _ in blk]}
+        blk, s_, nm = shard.choose_partition(nfr, n, None, ta, tb1, tb2, th, cold, **gk)
         ent['no_restarts (reset_branch=None, configs[4] regime)'] = {
             'with_context_exchange': ex_free,
             'chosen': nm, 'speedup': round(s_, 3), 'balanced': sp(n, bal, None), 'growing_shards': sp(n, grow, None),
@@ -341,9 +360,18 @@ def wavefront_model(per_frame, nfr, reset_branch, t_msg=0.3, head_fraction=0.24)
     return out
 
 
-def measure_phases(net, cfg, dev, h, w, t=5):
-    """Per-frame phase times of one restart unit (or 9 frames) on this GPU, host-synchronised per phase; first repetition =
-    warm-up.  Also the extra phase-A time of a COLD window in the middle of a clip (a block start of the wavefront partitions)."""
+PHASE_GROUP = 4          # windows per phase-A group of the sharded executor (Engine.phase_a_group: REFVSR_MAX_MAPS)
+
+
+def measure_phases(net, cfg, dev, h, w, t=5, group=PHASE_GROUP):
+    """Per-frame DEVICE time of the three phases of shard.run_wavefront over one restart unit (or 9 frames) on this GPU: phase A of
+    all its frames -- in groups of `group` windows (Engine.phase_a_group: the backward branches as multi-map launches; what the
+    sharded executor runs since round 6) and, for the model's partial groups, window by window --, then the forward-branch chain
+    (B1), then the upsamplers (B2), everything queued on ONE stream with HIP events between the phases: no host synchronisation
+    inside the timed region (round 5 synchronised after every phase of every frame: the launch latency of each phase's first
+    kernels was part of its time), no overlap between the phases (the model adds that: simulate_wavefront's lanes).  First
+    repetition = warm-up.  Also the extra phase-A time of a COLD window in the middle of a clip (a block start of the wavefront
+    partitions)."""
     from refvsr_amd.synth import make_clip, window_indices
     R = cfg.reset_branch or 9
     nfr = R + 4
@@ -352,25 +380,42 @@ def measure_phases(net, cfg, dev, h, w, t=5):
     N = net.Network
     win = lambda f: (lr[torch.tensor(window_indices(f, nfr, t), device=dev)][None].contiguous(),
                      rf[torch.tensor(window_indices(f, nfr, t), device=dev)][None].contiguous(), window_indices(f, nfr, t))
-    acc = [0.0, 0.0, 0.0]
-    for rep in range(2):
+    wins = [win(f) for f in range(R)]
+
+    def unit(G):
+        """One restart unit: A (groups of G) | B1 chain | B2s on the current stream; returns (ms A, ms B1, ms B2)."""
         N.reset()
-        acc = [0.0, 0.0, 0.0]
-        for f in range(R):                                 # frames 0 .. R-1: one restart unit (incl. its first-frame call)
-            x, r, ids = win(f)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            hnd = N.phase_a(x, r, frame_ids=ids, first_hint=(f == 0))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            N.phase_b1(hnd, f == 0)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            N.phase_b2(hnd)
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            acc = [acc[0] + t1 - t0, acc[1] + t2 - t1, acc[2] + t3 - t2]
-    per_frame = {'phase_a_ms': 1e3 * acc[0] / R, 'phase_b1_ms': 1e3 * acc[1] / R, 'phase_b2_ms': 1e3 * acc[2] / R}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        hs = []
+        for f0 in range(0, R, G):
+            fs = list(range(f0, min(f0 + G, R)))
+            if G > 1:
+                hs += N.phase_a_group([wins[f][0][0] for f in fs], [wins[f][1][0] for f in fs], [wins[f][2] for f in fs], [f == 0 for f in fs])
+            else:
+                hs.append(N.phase_a(wins[f0][0], wins[f0][1], frame_ids=wins[f0][2], first_hint=(f0 == 0)))
+        ev[1].record()
+        for f in range(R):
+            N.phase_b1(hs[f], f == 0)
+        ev[2].record()
+        outs = [N.phase_b2(hs[f]) for f in range(R)]
+        ev[3].record()
+        torch.cuda.synchronize()
+        del outs
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+    eng0 = N.ensure_engines(1, dev)[0]
+    G = max(1, int(group)) if eng0.group_ok() else 1
+    for rep in range(2):
+        acc = unit(G)
+    per_frame = {'phase_a_ms': acc[0] / R, 'phase_b1_ms': acc[1] / R, 'phase_b2_ms': acc[2] / R, 'phase_a_group': G,
+                 'how': 'device time (HIP events) of A | B1 | B2 of one restart unit of %d frames queued on one stream, phase A in groups of %d windows' % (R, G)}
+    if G > 1:
+        for rep in range(2):
+            acc1 = unit(1)
+        per_frame['phase_a_single_ms'] = acc1[0] / R
+    else:
+        per_frame['phase_a_single_ms'] = per_frame['phase_a_ms']
     cold = []
     for rep in range(3):                                   # phase A of a mid-clip frame on an empty window cache
         N.reset()
@@ -382,7 +427,7 @@ def measure_phases(net, cfg, dev, h, w, t=5):
         cold.append(1e3 * (time.perf_counter() - t0))
     N.reset()
     # (the first-frame call of the restart unit is in the phase-A mean: compare the cold window with the steady frames only)
-    per_frame['phase_a_cold_extra_ms'] = max(0.0, min(cold[1:]) - per_frame['phase_a_ms'])
+    per_frame['phase_a_cold_extra_ms'] = max(0.0, min(cold[1:]) - per_frame['phase_a_single_ms'])
     # the context exchange of shard.run_wavefront: one per-frame context prepared on its own (Engine.prepare_context), and phase A of
     # the same cold window when its three contexts are there already (prepared / received ahead): what is left of the cold start
     eng = N.ensure_engines(1, dev)[0]
@@ -413,9 +458,95 @@ def exchange_terms(per_frame, ctx_ms=0.3):
     what a cold window costs beyond a steady window's remainder once its contexts are there, t_ctx = one 32 MB message over one
     xGMI link + latency (assumed, like the hand-off)."""
     ta = per_frame['phase_a_ms']
+    ta1 = per_frame.get('phase_a_single_ms') or ta           # (the cold window is measured as ONE window: compare with a lone steady one)
     tp = min(per_frame.get('context_prepare_ms', 0.35 * ta), ta)
     cx = per_frame.get('phase_a_cold_with_contexts_ms')
-    return dict(t_prep=tp, t_ctx=ctx_ms, t_cold_x=max(0.0, cx - (ta - tp)) if cx is not None else 0.1 * ta)
+    return dict(t_prep=tp, t_ctx=ctx_ms, t_cold_x=max(0.0, cx - (ta1 - tp)) if cx is not None else 0.1 * ta)
+
+
+def one_rank_clip_seconds(net, cfg, dev, h, w, nfr, t=5, group=PHASE_GROUP, reps=2):
+    """Wall seconds ONE GPU needs for the whole nfr-frame clip (cold start, every restart) through its fastest call mode -- frame
+    groups of `group` windows on the engine's three streams, inputs resident and materialised: the denominator of every strong-scaling
+    figure of this script.  Best of `reps` after one warm-up run; the module is left reset and un-pipelined."""
+    from refvsr_amd.synth import make_clip, window_indices
+    lr, rf, _ = make_clip(nfr, h, w, seed=0, want_gt=False)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    all_lr = torch.stack([lr[torch.tensor(w_, device=dev)] for w_ in wins], 0).contiguous()
+    all_rf = torch.stack([rf[torch.tensor(w_, device=dev)] for w_ in wins], 0).contiguous()
+    N = net.Network
+    eng = N.ensure_engines(1, dev)[0]
+    G = max(1, int(group)) if eng.group_ok() else 1
+    best = None
+    try:
+        for rep in range(reps + 1):
+            N.reset()
+            N.set_pipelined(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = net(all_lr[0:1], all_rf[0:1], True, frame_ids=wins[0], input_ready='materialised')['result']
+            f = 1
+            while f < nfr:
+                n = min(G, nfr - f)
+                if n >= 2:
+                    o = net.forward_group(all_lr[f:f + n], all_rf[f:f + n], [wins[f + b] for b in range(n)], input_ready='materialised')['result'][-1]
+                else:
+                    o = net(all_lr[f:f + 1], all_rf[f:f + 1], False, frame_ids=wins[f], input_ready='materialised')['result']
+                f += n
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            assert bool(torch.isfinite(o).all())
+            if rep > 0:
+                best = el if best is None else min(best, el)
+    finally:
+        torch.cuda.synchronize()
+        N.set_pipelined(False)
+        N.reset()
+    return best
+
+
+def one_rank_wavefront_seconds(net, cfg, dev, h, w, nfr, t=5, group=PHASE_GROUP, reps=2):
+    """Wall seconds of shard.run_wavefront over the whole clip with ONE rank (a world-1 gloo group made here when the process has
+    none): the sharded executor itself -- phase-A groups on P | M, the B1 chain on its own lane, upsamplers behind the chains -- with
+    no partner to wait for.  Against one_rank_clip_seconds it says what the executor costs over the single-GPU fast path; against
+    the phase sum it gives the overlap of the lanes, which the makespan model (one task at a time per rank) does not have."""
+    import torch.distributed as dist
+    from refvsr_amd import shard
+    from refvsr_amd.synth import make_clip, window_indices
+    made = False
+    if not dist.is_initialized():
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+        made = True
+    try:
+        lr, rf, _ = make_clip(nfr, h, w, seed=0, want_gt=False)
+        lr, rf = lr.to(dev), rf.to(dev)
+        win = {f: (lr[torch.tensor(window_indices(f, nfr, t), device=dev)].contiguous(), rf[torch.tensor(window_indices(f, nfr, t), device=dev)].contiguous())
+               for f in range(nfr)}
+        ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
+        G = max(1, int(group)) if ex.eng.group_ok() else 1
+        best = None
+        for rep in range(reps + 1):
+            net.Network.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, torch.device('cpu'), parts=[(0, nfr)], group=G)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            assert len(res) == nfr and bool(torch.isfinite(res[nfr - 1]).all())
+            del res
+            if rep > 0:
+                best = el if best is None else min(best, el)
+        net.Network.set_pipelined(False)
+        net.Network.reset()
+        return best
+    finally:
+        if made:
+            dist.destroy_process_group()
 
 
 def wavefront_model_single_gpu(args, dev, h, w):
@@ -429,11 +560,23 @@ def wavefront_model_single_gpu(args, dev, h, w):
     net = SRNet(cfg).to(dev).eval()
     net.load_state_dict(make_state_dict(cfg, 1234))
     per_frame = measure_phases(net, cfg, dev, h, w)
-    out = {'workload': '%s %dx%d, frame_num=5, reset_branch=%d: phases of one restart unit (9 frames, host-synchronised per phase) and of a cold '
-                       'mid-clip window on one GPU; prediction for a 64-frame clip (BASELINE configs[3]) under the two-lane schedule of '
-                       'shard.run_wavefront' % (name, h, w, cfg.reset_branch),
-           'phase_ms_per_frame_measured': per_frame}
-    out.update(wavefront_model(per_frame, 64, cfg.reset_branch))
+    clip_s = one_rank_clip_seconds(net, cfg, dev, h, w, 64)
+    out = {'workload': '%s %dx%d, frame_num=5, reset_branch=%d: device time of the phases of one restart unit (9 frames; phase A in groups of %d '
+                       'windows) and of a cold mid-clip window on one GPU; prediction for a 64-frame clip (BASELINE configs[3]) under the two-lane '
+                       'schedule of shard.run_wavefront, also against the wall time this GPU needs for the same clip through forward_group'
+                       % (name, h, w, cfg.reset_branch, per_frame.get('phase_a_group', 1)),
+           'phase_ms_per_frame_measured': per_frame,
+           'one_rank_same_clip': {'seconds': clip_s, 'frames_per_s': 64.0 / clip_s,
+                                  'what': 'the 64-frame clip of configs[3] on ONE GPU, frame groups of 4 on three streams, cold start and the seven restarts included'}}
+    try:
+        wf1 = one_rank_wavefront_seconds(net, cfg, dev, h, w, 64)
+        out['one_rank_wavefront'] = {'seconds': wf1, 'frames_per_s': 64.0 / wf1, 'over_the_fast_path': wf1 / clip_s,
+                                     'what': 'shard.run_wavefront over the same clip with ONE rank: the sharded executor (phase-A groups on P | M, '
+                                             'B1 lane, upsamplers behind the chains) with nobody to wait for'}
+    except Exception as e:  # noqa: BLE001
+        wf1 = None
+        out['one_rank_wavefront'] = {'error': repr(e)[:300]}
+    out.update(wavefront_model(per_frame, 64, cfg.reset_branch, one_rank_clip_ms=1e3 * clip_s, one_rank_wavefront_ms=None if wf1 is None else 1e3 * wf1))
     return out
 
 
@@ -451,10 +594,21 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     net.load_state_dict(make_state_dict(cfg, 1234))
     comm_dev = dev if backend == 'nccl' else torch.device('cpu')
     pf = measure_phases(net, cfg, dev, h, w)
-    keys = ('phase_a_ms', 'phase_b1_ms', 'phase_b2_ms', 'phase_a_cold_extra_ms', 'context_prepare_ms', 'phase_a_cold_with_contexts_ms')
+    keys = ('phase_a_ms', 'phase_b1_ms', 'phase_b2_ms', 'phase_a_cold_extra_ms', 'context_prepare_ms', 'phase_a_cold_with_contexts_ms',
+            'phase_a_single_ms')
     v = torch.tensor([pf[k] for k in keys], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(v, op=dist.ReduceOp.SUM)
     per_frame = {k: float(x) / world for k, x in zip(keys, v.cpu().tolist())}
+    G = per_frame['phase_a_group'] = int(pf.get('phase_a_group', 1))
+    gk = dict(group=G, t_a_single=per_frame['phase_a_single_ms'])
+    # the strong-scaling denominator: the SAME clip on one GPU through its fastest call mode, measured by rank 0 while the others wait
+    # (ranks that share a GPU -- the one-GPU protocol run -- must not measure under each other)
+    clip1 = torch.zeros(1, dtype=torch.float64, device=comm_dev)
+    if rank == 0:
+        clip1[0] = one_rank_clip_seconds(net, cfg, dev, h, w, nfr, t, reps=1)
+    dist.barrier()
+    dist.all_reduce(clip1, op=dist.ReduceOp.SUM)
+    one_rank_s = float(clip1.item())
     ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
     # warm-up of the point-to-point communicators (their first use costs seconds) and the hand-off time itself: the packed state of
     # this model goes round the ring of ranks, timed on every rank -- BEFORE the partition is chosen: the model's message terms
@@ -483,7 +637,7 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     t_chain = t_msg * nb_head / float(nb) + (0.03 if ex.split_handoff else 0.0)      # what the B1 chain waits for per hand-off
     exch = None if args.no_wavefront_exchange else exchange_terms(per_frame, ctx_ms=t_msg)
     blocks, predicted, pname = shard.choose_partition(nfr, world, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                                      per_frame['phase_b2_ms'], t_chain, per_frame['phase_a_cold_extra_ms'], exchange=exch)
+                                                      per_frame['phase_b2_ms'], t_chain, per_frame['phase_a_cold_extra_ms'], exchange=exch, **gk)
     if args.wavefront_partition:                           # A/B: force a partition family
         fam = args.wavefront_partition
         parts = {'balanced': shard.partition(nfr, world), 'growing': shard.partition_chain(nfr, world),
@@ -494,7 +648,7 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
             parts = shard.partition_cyclic(nfr, world, int(fam[6:] or 3))
         blocks, pname = shard.as_blocks(parts), fam
         predicted = shard.predicted_speedup(nfr, world, blocks, cfg.reset_branch, per_frame['phase_a_ms'], per_frame['phase_b1_ms'],
-                                            per_frame['phase_b2_ms'], t_chain, per_frame['phase_a_cold_extra_ms'], True, exch)[0]
+                                            per_frame['phase_b2_ms'], t_chain, per_frame['phase_a_cold_extra_ms'], True, exch, **gk)[0]
     mine = [(a, b) for a, b, r in blocks if r == rank]
     need = sorted(set(i for a, b in mine for f in range(a, b) for i in window_indices(f, nfr, t)))
     clip = {}
@@ -525,7 +679,7 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     t0 = time.perf_counter()
     tim = {}
     res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=blocks, timings=tim,
-                              exchange_contexts=exch is not None)
+                              exchange_contexts=exch is not None, group=G)
     torch.cuda.synchronize()
     dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
@@ -560,14 +714,21 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                'partition_chosen_with': {'message_ms': t_msg, 'handoff_ms_on_the_chain': t_chain, 'split_handoff': bool(ex.split_handoff),
                                          'what': 'context messages priced at the measured ring time of the packed state; a hand-off at its '
                                                  'first message (header + LR state) when it goes in two'},
-               'model': wavefront_model(per_frame, nfr, cfg.reset_branch, t_msg, nb_head / float(nb)),
+               'model': wavefront_model(per_frame, nfr, cfg.reset_branch, t_msg, nb_head / float(nb), one_rank_clip_ms=1e3 * one_rank_s),
+               'phase_a_group': G,
+               'one_rank_same_clip': {'seconds': one_rank_s, 'frames_per_s': nfr / one_rank_s,
+                                      'what': 'the same clip on ONE GPU through forward_group (frame groups of 4, three streams), measured by rank 0 '
+                                              'before the sharded run while the other ranks wait'},
+               'speedup_vs_n1_headline': one_rank_s / float(el.item()),
                'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
                            '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
                'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
                'speedup_over_one_rank_phase_sum': seq_s / float(el.item()),
-               'schedule': 'two lanes per rank (HIP streams): phase A (flows, matching, encoders, alignment, backward branch) of all local '
-                           'frames on lane 1; the B1 chain (forward-branch steps) on lane 2, B1(f) as soon as phase A of frame f is done and '
-                           'the state has arrived, state sent right after a block\'s last B1; B2 (BW/FW fusion + upsampler) afterwards on lane 1',
+               'schedule': 'two lanes per rank (HIP streams): phase A (flows, matching, encoders, alignment, backward branch) of the local '
+                           'frames on lane 1 in groups of %d windows (backward branches as multi-map launches); the B1 chain (forward-branch steps) '
+                           'on lane 2, B1(f) as soon as the group of frame f is done and the state has arrived -- issued between the groups '
+                           'wherever it needs no blocking receive --, state sent right after a block\'s last B1; B2 (BW/FW fusion + upsampler) '
+                           'on lane 1 one group behind its B1' % G,
                'handoff': {'messages': int(msgs[0].item()), 'bytes_per_message': 64 + h * w * (10 * C + 12),
                            'format': ('two messages: [header | fp16 HWC feat | fp32 flow + conf] (%d bytes: the receiver\'s forward-branch step starts '
                                       'on it), then fp16 HWC feat_up as it lies' % nb_head) if ex.split_handoff else
@@ -676,7 +837,10 @@ def compact_line(line, limit=5600):
     wf = line.get('wavefront')
     if isinstance(wf, dict):
         out['wavefront'] = pick(wf, ('value', 'unit', 'seconds', 'scaling', 'ranks_seen', 'backend', 'gpus_visible', 'frames_equal',
-                                     'frames_checked_against_single_rank_run', 'speedup_over_one_rank_phase_sum', 'error'))
+                                     'frames_checked_against_single_rank_run', 'speedup_over_one_rank_phase_sum', 'speedup_vs_n1_headline',
+                                     'phase_a_group', 'error'))
+        if isinstance(wf.get('one_rank_same_clip'), dict):
+            out['wavefront']['one_rank_same_clip_frames_per_s'] = _r(wf['one_rank_same_clip'].get('frames_per_s'))
         if isinstance(wf.get('partition'), dict):
             out['wavefront']['partition'] = wf['partition'].get('name')
             out['wavefront']['predicted_speedup'] = wf['partition'].get('predicted_speedup')
@@ -694,9 +858,18 @@ def compact_line(line, limit=5600):
             for k, v in ent.items():
                 if isinstance(v, dict):
                     x = v.get('with_context_exchange', v)
-                    row['restarts' if k.startswith('with_restarts') else 'no_restarts'] = x.get('speedup') if isinstance(x, dict) else None
+                    key = 'restarts' if k.startswith('with_restarts') else 'no_restarts'
+                    row[key] = x.get('speedup') if isinstance(x, dict) else None
+                    if isinstance(x, dict) and x.get('speedup_vs_one_rank_fast_path') is not None:
+                        row[key + '_vs_n1_fast_path'] = x.get('speedup_vs_one_rank_fast_path')
             ps[n_] = row
         out['wavefront_model_predicted_speedup'] = ps
+        out['wavefront_model_note'] = ('x = against one rank walking the clip phase by phase at the measured per-frame phase times; *_vs_n1_fast_path = '
+                                       'against the wall time ONE GPU needs for the same 64-frame clip through forward_group (%s ms per frame)'
+                                       % _r(((wm.get('one_rank') or {}).get('fast_path_ms_per_frame')), 3))
+        pm = wm.get('phase_ms_per_frame_measured')
+        if isinstance(pm, dict):
+            out['wavefront_phase_ms_per_frame'] = pick(pm, ('phase_a_ms', 'phase_a_single_ms', 'phase_b1_ms', 'phase_b2_ms', 'phase_a_group'))
     ks = line.get('kernels')
     if isinstance(ks, list):
         out['kernels'] = [[str(k.get('kernel'))[:28], k.get('us_per_launch'), _r(k.get('frac'), 3)] for k in ks]
@@ -980,16 +1153,10 @@ def main():
             samples_dropin.append(el2)
     elapsed = med(samples)
     fps_samples = [world * args.steps / x for x in samples]
-    # `value` = the build's fastest supported call mode, measured in THIS run: frame groups, unless the one-frame-per-call mode -- timed
-    # interleaved with them -- is faster on this box (never observed in round 5: 19 boxes, groups + 7 ... + 10 %; the three internal
-    # streams of the group mode share the runtime's four hardware queues with the caller's, a mapping this script does not control).
+    # (round 6, ADVICE r5: the mode is fixed BEFORE the measurement -- frame groups wherever the engine has the multi-map launch list;
+    #  rounds 4-5 reported the faster of the two modes measured, a max-of-medians with a small upward bias.  The other mode's rate stays
+    #  in the line as `one_frame_per_call`.)
     headline_mode = 'frame groups' if G > 1 else 'one frame per call'
-    if samples_percall and med(samples_percall) < elapsed:
-        headline_mode = 'one frame per call (faster than the frame groups in this run: %.1f vs %.1f frames/s)' % (
-            world * args.steps / med(samples_percall), world * args.steps / elapsed)
-        samples, samples_percall = samples_percall, samples
-        elapsed = med(samples)
-        fps_samples = [world * args.steps / x for x in samples]
     # The fused-ResBlock launches are ~10 us each: with the internal streams feeding the GPU concurrently the HIP events around a
     # run of them also bracket the other stream's kernels that get scheduled in between (measured 18.6 us per launch where
     # rocprofv3 reports 9.7).  Their live per-launch time therefore comes from one more pass of the same steps on ONE stream

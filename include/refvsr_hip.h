@@ -44,6 +44,8 @@ extern "C" {
                                       refvsr_stream_destroy / refvsr_num_cus */
 
 int refvsr_abi_version(void);
+/* REFVSR_MAX_MAPS of the built library (a value, not a status): bindings check their own copy against it at load time. */
+int refvsr_max_maps(void);
 const char* refvsr_last_error(void);
 /* One-time per-process setup (raises dynamic-LDS limits).  Called lazily by every entry point. */
 int refvsr_init(void);

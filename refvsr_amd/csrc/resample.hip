@@ -267,6 +267,7 @@ struct WarpArgs {
     const void* x[REFVSR_MAX_MAPS]; const float* flow[REFVSR_MAX_MAPS]; void* out[REFVSR_MAX_MAPS];
     int c, hin, win, cs, hf, wf;         // c: planar channels (warp_planar); cs: channel stride (nhwc16); hf x wf: the flow map (up2: hl x wl)
 };
+static_assert(REFVSR_MAX_MAPS == 4, "WARP_SEL selects among exactly four table entries");
 #define WARP_SEL(tbl, bi) ((bi) == 0 ? (tbl)[0] : (bi) == 1 ? (tbl)[1] : (bi) == 2 ? (tbl)[2] : (tbl)[3])
 
 __global__ void warp_nhwc16_kernel(WarpArgs a) {

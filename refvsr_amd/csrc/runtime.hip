@@ -16,6 +16,7 @@ void refvsr_set_error(const char* fmt, ...) {
 
 extern "C" const char* refvsr_last_error(void) { return g_err; }
 extern "C" int refvsr_abi_version(void) { return REFVSR_ABI_VERSION; }
+extern "C" int refvsr_max_maps(void) { return REFVSR_MAX_MAPS; }
 
 extern "C" int refvsr_init(void) {
     static int state = 0;   // 0 = not done, 1 = ok, 2 = failed

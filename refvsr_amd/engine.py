@@ -922,12 +922,14 @@ class Engine(object):
         # single forward() -- a caller that sends the first window alone -- must not lay its streams out differently and rebuild them at
         # the first group: the idle first set of streams changes the stream -> hardware-queue mapping, 212 vs 231 frames/s,
         # profiles/r05_group_cut_ab.txt); P + F | M for the wider models (round 4's layout, two alternating M streams)
+        # The layout is decided ONCE, when the streams are built (re-deriving it per call cost weight look-ups per launch
+        # list and could rebuild the streams mid-stream); another layout needs an explicit rebuild: `engine._pipe = None` after a
+        # device synchronisation (bench.py's single-stream measurement does that), a new device, or a new engine.
+        if self._pipe is not None and self._pipe[0].device == dev:
+            return self._pipe
         layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or self._layout_default or
                      ('pfm' if (self.C == 24 and self.group_ok()) else 'pf_m'))
-        if self._pipe is not None and self._pipe[0].device == dev and self.pipe_layout != layout:
-            torch.cuda.synchronize(dev)               # another layout from here on (first group call of an engine): drain, rebuild
-            self._pipe = None
-        if self._pipe is None or self._pipe[0].device != dev:
+        if True:
             if layout not in ('pf_m', 'pfm', 'p_fm', 'one'):
                 raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm | one, got %r' % layout)
             two = self.C != 24
@@ -1678,6 +1680,94 @@ class Engine(object):
                 for i in range(1, ctr + 1):
                     flows[(i, i - 1)] = flow(i, i - 1)
         return dict(fr=fr, flows=flows, zero_flow=zero_flow, bw_up=bw_up, conf_bw=conf_bw, t=t, h=h, w=w)
+
+    @torch.no_grad()
+    def phase_a_group(self, wins, first_hints=None, streams=None):
+        """phase_a of B <= REFVSR_MAX_MAPS windows of one clip in ONE pass (round 6): wins = [(lrs [t,3,h,w], refs, frame_ids)] -- any
+        windows of the clip, consecutive or not (a rank's frames of a block-cyclic partition are not): their backward branches are B
+        independent chains over identical weights (RefVSR.py:211-238 restarts from zeros in every window) and run as multi-map launches
+        (_prop_step_b: one launch per layer over B maps, the launch list of a frame group's M section), every flow the B windows ask for
+        comes out of batched SPyNet passes.  Returns the B handles phase_a would return, bit for bit
+        (tests/test_gpu_e2e.py::test_phase_a_group_equals_phase_a); engines without the multi-map launch list run phase_a per window.
+        streams=None: everything on the current stream, like phase_a.
+        streams=(M, consumers): the stream layout of a frame group for the sharded executor -- the per-frame preparation and
+        the flows on the CURRENT stream (the executor's lane a = P), the backward chains on M behind per-frame / per-flow events, so that
+        the next group's preparation runs under this group's chains; every handle carries `ready`, an event on M after which all of
+        the handle is final; `consumers`: the other streams that will read the contexts and flows (the B1 lane), for the allocator."""
+        B = len(wins)
+        hints = [False] * B if first_hints is None else [bool(v) for v in first_hints]
+        if B > ops.hip.MAX_MAPS or not self.group_ok() or (B == 1 and streams is None):
+            return [self.phase_a(lrs, refs, ids, hints[b]) for b, (lrs, refs, ids) in enumerate(wins)]
+        t, h, w = self._check_window(wins[0][0], wins[0][1])
+        for lrs, refs, ids in wins:
+            assert self._check_window(lrs, refs) == (t, h, w) and ids is not None, 'a group needs windows of one geometry, named by frame ids'
+        ctr, dev = t // 2, wins[0][0].device
+        P = torch.cuda.current_stream(dev)
+        M, share = P, None
+        if streams is not None:
+            M = streams[0]
+            share = [P, M] + [st for st in streams[1] if st is not P and st is not M]
+
+        def publish(f):
+            for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
+                for st in share:
+                    x.record_stream(st)
+        with torch.cuda.device(dev), ops.on_stream(P):
+            frs = self._frames_group(wins)
+            need = []
+            for b, fr in enumerate(frs):
+                need += [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
+                if hints[b]:
+                    need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]
+            for b, fr in enumerate(frs):
+                for i in range(0 if hints[b] else ctr, t):
+                    self.prepare_frame(fr[i])
+                    if share is not None and fr[i].ready is None:
+                        # (also contexts prepared / imported ahead on this stream: safe on the other streams from here on)
+                        if fr[i].pyr is None:
+                            self.pyramid(fr[i])
+                        publish(fr[i])
+                        fr[i].ready = torch.cuda.Event()
+                        fr[i].ready.record()
+            fl_all = self.flows(need, share)
+            if share is not None:
+                for fr in frs:                                     # frames a window merely contains: their copies are read by nobody else
+                    for f in fr:
+                        for x in (f.lr, f.ref):
+                            for st in share:
+                                x.record_stream(st)
+                done_p = torch.cuda.Event()
+                done_p.record()
+        with torch.cuda.device(dev), ops.on_stream(M):
+            if share is not None:
+                M.wait_event(done_p)                               # (everything this group reads was produced on P before this point)
+                for fl in fl_all:
+                    fl.record_stream(M)
+            cs_ = self._state_cs()
+            feats = [self._zeros((h, w, cs_), torch.float16, dev)] * B
+            feat_ups = [self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)] * B
+            confs = [self._zeros((1, h, w), torch.float32, dev)] * B
+            if B == 1:
+                fr = frs[0]
+                bw_up, conf_bw = self._backward_branch(fr, (lambda a, b_: self.flow(fr[a], fr[b_], share)), t, h, w)
+                feat_ups, confs = [bw_up], [conf_bw]
+            else:
+                for i in range(t - 1, ctr - 1, -1):
+                    fls = None if i == t - 1 else [self.flow(fr[i], fr[i + 1], share) for fr in frs]
+                    feats, feat_ups, confs = self._prop_step_b([fr[i] for fr in frs], 'backward_resblocks', feats, feat_ups, confs, fls)
+            ready = None
+            if share is not None:
+                ready = torch.cuda.Event()
+                ready.record()
+            out = []
+            for b, fr in enumerate(frs):
+                flows = {(ctr + 1, ctr): self.flow(fr[ctr + 1], fr[ctr], share)}
+                if hints[b]:
+                    for i in range(1, ctr + 1):
+                        flows[(i, i - 1)] = self.flow(fr[i], fr[i - 1], share)
+                out.append(dict(fr=fr, flows=flows, zero_flow=None, bw_up=feat_ups[b], conf_bw=confs[b], t=t, h=h, w=w, ready=ready,
+                                bw_flows=fl_all if share is not None else None))     # (alive until the executor's final synchronisation)
+        return out
 
     @torch.no_grad()
     def phase_b1(self, pa, is_first_frame):

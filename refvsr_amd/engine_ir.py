@@ -87,6 +87,11 @@ class EngineIR(Engine):
         Engine.reset_state(self)
         self.keyframe_idx = None
 
+    def group_ok(self):
+        """Frame groups, phase-A groups and the n > 1 multi-map path are schedules of RefVSR's propagation (Engine._prop_step_b / rap_b):
+        an IR engine never takes them, whatever its mid_channels."""
+        return False
+
     def set_pipelined(self, on=True):
         """Cross-call pipelining (round 4; Engine.set_pipelined's contract): everything that is a function of the window's frames
         only -- matching and alignment of the new frame, its EDVR pyramid features, the flows, the refill features of the key frames

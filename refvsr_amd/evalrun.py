@@ -150,8 +150,9 @@ def evaluate(config, net=None, log=print):
     # (SRNet.forward_group: the backward branches of the G frames as multi-map launches; results bit-identical); the per-frame time in
     # the score lines is then the group's time / G
     G = max(1, int(getattr(E, 'frame_group', 1) or 1))
+    was_pipelined = bool(getattr(config, 'pipelined', False))
     if G > 1:
-        net.Network.set_pipelined(True)
+        net.Network.set_pipelined(True)          # (restored at the end: the caller's plain net(...) calls keep their stream contract)
     st = {'clip_p': 0.0, 'clip_s': 0.0, 'clip_t': 0.0, 'clip_n': 0, 'first_line': True, 'prev': None}
 
     def emit(it, out, lr_c, dt):
@@ -203,6 +204,27 @@ def evaluate(config, net=None, log=print):
             emit(it, outs[b], lrs[b, c], dt)
         del pending[:]
 
+    try:
+        _evaluate_loop(net, ds, dev, E, G, st, emit, flush, config, score_path, log)
+    finally:
+        if G > 1 and not was_pipelined:
+            torch.cuda.synchronize()
+            net.Network.set_pipelined(False)
+    clip_p, clip_s, clip_t, clip_n, prev = st['clip_p'], st['clip_s'], st['clip_t'], st['clip_n'], st['prev']
+    if clip_n:
+        _clip_summary(config, score_path, prev, clip_p, clip_s, clip_t, clip_n, log)
+    n = max(res['frames'], 1)
+    total = '\n[TOTAL {}|{}] PSNR: {:.5f} SSIM: {:.5f} ({:.5f}sec)'.format(
+        ckpt_name, E.data, sum(res['psnr']) / n, sum(res['ssim']) / n, sum(res['seconds']) / n)
+    log(total)
+    with open(score_path, 'a') as fh:
+        fh.write(total + '\n')
+    res['score_file'], res['output_root'] = score_path, out_root
+    return res
+
+
+def _evaluate_loop(net, ds, dev, E, G, st, emit, flush, config, score_path, log):
+    """The per-frame loop of evaluate() (eval_qual_quan.py:39-128)."""
     with torch.no_grad():
         pending = []
         for i in range(len(ds)):
@@ -229,17 +251,6 @@ def evaluate(config, net=None, log=print):
             torch.cuda.synchronize()
             emit(it, out, lr[0, lr.shape[1] // 2], time.time() - t0)
         flush(pending)
-    clip_p, clip_s, clip_t, clip_n, prev = st['clip_p'], st['clip_s'], st['clip_t'], st['clip_n'], st['prev']
-    if clip_n:
-        _clip_summary(config, score_path, prev, clip_p, clip_s, clip_t, clip_n, log)
-    n = max(res['frames'], 1)
-    total = '\n[TOTAL {}|{}] PSNR: {:.5f} SSIM: {:.5f} ({:.5f}sec)'.format(
-        ckpt_name, E.data, sum(res['psnr']) / n, sum(res['ssim']) / n, sum(res['seconds']) / n)
-    log(total)
-    with open(score_path, 'a') as fh:
-        fh.write(total + '\n')
-    res['score_file'], res['output_root'] = score_path, out_root
-    return res
 
 
 def _clip_summary(config, score_path, it, p, s, t, n, log):

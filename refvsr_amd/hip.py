@@ -46,6 +46,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> argtypes; every function returns int (0 = ok) except the two listed in _SPECIAL
 SIGNATURES = {
     'refvsr_init': [],
+    'refvsr_max_maps': [],                       # returns REFVSR_MAX_MAPS
     'refvsr_num_cus': [],                        # returns the CU count
     'refvsr_stream_create_cu_range': [_I, _I, C.POINTER(C.c_void_p)],
     'refvsr_stream_set_cu_budget': [_P, _I],
@@ -146,6 +147,8 @@ def lib():
             fn.restype = res
         if h.refvsr_abi_version() != ABI_VERSION:
             raise RuntimeError('refvsr_amd: ABI mismatch (library %d, binding %d)' % (h.refvsr_abi_version(), ABI_VERSION))
+        if h.refvsr_max_maps() != MAX_MAPS:
+            raise RuntimeError('refvsr_amd: REFVSR_MAX_MAPS mismatch (library %d, binding %d)' % (h.refvsr_max_maps(), MAX_MAPS))
         _lib = h
     return _lib
 

@@ -205,6 +205,18 @@ class Network(nn.Module):
         return [self._engines[b].phase_a(lrs[b], refs[b], None if frame_ids is None else [(b, f) for f in frame_ids],
                                          first_hint) for b in range(lrs.shape[0])]
 
+    def phase_a_group(self, lrs, refs, frame_ids, first_hints=None, streams=None):
+        """phase_a of B windows of ONE clip in one pass (round 6; see Engine.phase_a_group): lrs, refs [B,t,3,h,w], frame_ids B lists of t
+        ids (or sequences of B window tensors [t,3,h,w]).  Returns B handle lists (one per window, each what phase_a returns for an
+        n = 1 call)."""
+        hip.lib()
+        if not lrs[0].is_cuda:
+            raise RuntimeError('refvsr_amd.Network runs on the GPU only (got a %s tensor); there is no CPU path' % lrs[0].device)
+        assert len(lrs) == len(refs) == len(frame_ids)
+        eng = self.ensure_engines(1, lrs[0].device)[0]
+        wins = [(lrs[b].float().contiguous(), refs[b].float().contiguous(), [(0, f) for f in frame_ids[b]]) for b in range(len(lrs))]
+        return [[h] for h in eng.phase_a_group(wins, first_hints, streams)]
+
     def phase_b1(self, handles, is_first_frame):
         """Serial part of phase_b (forward-branch step, carried state); see Engine.phase_b1."""
         for b, h in enumerate(handles):

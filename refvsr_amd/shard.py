@@ -73,10 +73,27 @@ def send_state(state, dst, device, async_op=False):
     assert len(kf) <= MAX_KEYFRAMES
     meta = torch.tensor([float(state['frame_itr_num'])] + [float(d) for k in STATE_KEYS for d in state[k].shape[-2:]] +
                         [float(len(kf))] + kf + [0.0] * (MAX_KEYFRAMES - len(kf)), dtype=torch.float32, device=device)
+    if async_op:
+        # (round 6: the chain may issue a hand-off while lane a still has context messages to send -- a blocking send there can close
+        #  a cycle with a peer that waits for one of them; the work handles keep their buffers alive)
+        bufs = [meta] + [state[k].contiguous().to(device) for k in STATE_KEYS]
+        return _Works([dist.isend(b_, dst) for b_ in bufs], bufs)
     dist.send(meta, dst)
     for k in STATE_KEYS:
         dist.send(state[k].contiguous().to(device), dst)
     return None
+
+
+class _Works(object):
+    """Several isend handles (and the buffers they read) behind one wait()."""
+
+    def __init__(self, works, bufs):
+        self.works, self.bufs = works, bufs
+
+    def wait(self):
+        for w_ in self.works:
+            w_.wait()
+        self.bufs = None
 
 
 def recv_state(src, channels, device, nbytes=None):
@@ -402,8 +419,39 @@ class ContextPlan(object):
         return out
 
 
+def group_lane_ops(program, group):
+    """Phase-A groups (round 6): the lane-a program of a rank -- ('a1', f) ops, with the context exchange also ('prep', i),
+    ('send', i, peer), ('post_recv', i, peer), ('wait_recv', i, peer) -- with runs of up to `group` windows turned into ONE
+    ('ag', (f1, ..., fk)) op: their backward branches are independent chains over identical weights and run as multi-map launches
+    (Engine.phase_a_group), whether the windows are consecutive or not.  Everything that stood between the windows of a group is
+    issued BEFORE the group (a window computes nothing another op waits for: deferring it reorders no message -- every rank still
+    issues its sends and receives in the one global order of ContextPlan.program -- and cannot close a cycle).  group <= 1: unchanged."""
+    if group <= 1:
+        return list(program)
+    out, cur = [], []
+    for op in program:
+        if op[0] == 'a1':
+            cur.append(op[1])
+            if len(cur) == group:
+                out.append(('ag', tuple(cur)))
+                cur = []
+        else:
+            out.append(op)
+    if cur:
+        out.append(('ag', tuple(cur)))
+    return out
+
+
+def group_time(k, group, t_a, t_a_single):
+    """Phase-A time PER FRAME of a group of k windows when a full group of `group` costs t_a per frame and a lone window t_a_single:
+    linear in between (the multi-map launches share one weight fill and one launch among k tiles)."""
+    if group <= 1 or t_a_single is None or k >= group:
+        return t_a
+    return t_a_single - (t_a_single - t_a) * (k - 1) / float(group - 1)
+
+
 def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True, dt=0.01,
-                       exchange=None, frame_num=5):
+                       exchange=None, frame_num=5, group=1, t_a_single=None):
     """Makespan of run_wavefront from per-frame phase times (any time unit): every rank executes ONE task at a time with
     priorities  B1 (its phase A done, the previous frame's B1 done and -- across ranks -- handed over) > phase A (lane-a order)
     > B2, pre-emptively (the kernels of the two streams interleave at ~10 us granularity).
@@ -414,7 +462,10 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
     exchange: None | dict(t_prep, t_ctx, t_cold_x=0, lookahead=1) -- run_wavefront(exchange_contexts=True): every context is
     prepared once, by the owner of its frame (t_prep of the t_a), and sent to the ranks that need it (t_ctx after its preparation
     it is usable there); lane a follows ContextPlan.tasks (in order: a window waiting for an import blocks the lane), a block start
-    costs t_cold_x (the flows of a cold window) instead of t_cold.  Returns the makespan."""
+    costs t_cold_x (the flows of a cold window) instead of t_cold.
+    group > 1 (round 6): lane a runs phase A in groups of up to `group` windows (group_lane_ops: what run_wavefront(group=) executes);
+    t_a is then the per-frame phase-A time INSIDE a full group, t_a_single that of a lone window (group_time), a group is ready when
+    every import of every member is there and all its windows are done at its end.  Returns the makespan."""
     blocks = as_blocks(parts)
     owner, first = {}, set()
     for a, b, r in blocks:
@@ -435,6 +486,23 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
         lane = {r: [(k, x, t_prep if k == 'prep' else (t_a - t_prep) + (t_cold_x if (x in first and x != 0) else 0.0))
                     for k, x in (op[:2] for op in plan.program(r) if op[0] in ('prep', 'a1'))] for r in range(world)}
         imports = plan.imports
+    if group > 1:
+        # the grouped lanes: ('ag', members, sum of the members' times at the group's per-frame rate); everything else unchanged
+        glane = {}
+        for r in range(world):
+            dur = {}
+            for k, x, d in lane[r]:
+                if k == 'a1':
+                    dur[x] = d - t_a if exchange is None else d - (t_a - exchange['t_prep'])      # the window's extras (cold terms)
+            out = []
+            for op in group_lane_ops([(k, x) for k, x, _ in lane[r]], group):
+                if op[0] == 'ag':
+                    per = group_time(len(op[1]), group, t_a, t_a_single) - (0.0 if exchange is None else exchange['t_prep'])
+                    out.append(('ag', op[1], sum(per + dur[f] for f in op[1])))
+                else:
+                    out.append((op[0], op[1], next(d for k, x, d in lane[r] if k == op[0] and x == op[1])))
+            glane[r] = out
+        lane = glane
     rem_lane = {r: [d for _, _, d in lane[r]] for r in range(world)}
     rem_b1 = {f: t_b1 for f in range(nframes)}
     rem_b2 = {f: t_b2 for f in range(nframes)}
@@ -467,14 +535,18 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
             if not ran and nxt_l[r] < len(lane[r]):
                 kind, x, _ = lane[r][nxt_l[r]]
                 ready = True
-                if kind == 'a1':
-                    for i in imports[r].get(x, ()):
+                members = (x,) if kind == 'a1' else (x if kind == 'ag' else ())
+                for f_ in members:
+                    for i in imports[r].get(f_, ()):
                         ready = ready and i in done_prep and t >= done_prep[i] + t_ctx
                 if ready:
                     j = nxt_l[r]
                     rem_lane[r][j] -= dt
                     if rem_lane[r][j] <= 1e-9:
-                        (done_a if kind == 'a1' else done_prep)[x] = t + dt
+                        if kind == 'prep':
+                            done_prep[x] = t + dt
+                        for f_ in members:
+                            done_a[f_] = t + dt
                         nxt_l[r] += 1
                     ran = True
             if not ran and nxt_b2[r] < nxt_b1[r]:
@@ -489,16 +561,19 @@ def simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_h
 
 
 def predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff=0.0, t_cold=0.0, interleaved=True, exchange=None,
-                      frame_num=5, steps_per_frame=2000.0):
+                      frame_num=5, steps_per_frame=2000.0, group=1, t_a_single=None):
     """(speedup over one rank, makespan) of run_wavefront for a partition (per-rank ranges or a block list) from per-frame
-    phase times: simulate_wavefront against nframes * (t_a + t_b1 + t_b2)."""
+    phase times: simulate_wavefront against nframes * (t_a + t_b1 + t_b2) -- one rank walking the clip phase by phase at the same
+    per-frame times (with group > 1: in full groups).  bench.py quotes the makespan against the N = 1 HEADLINE rate as well."""
     dt = max(1e-6, (t_a + t_b1 + t_b2) / steps_per_frame)
-    span = simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, interleaved, dt, exchange, frame_num)
+    span = simulate_wavefront(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, interleaved, dt, exchange, frame_num,
+                              group, t_a_single)
     seq = nframes * (t_a + t_b1 + t_b2)
     return (seq / span if span > 0 else 0.0), span
 
 
-def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.3, t_cold=None, exchange=None, frame_num=5):
+def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.3, t_cold=None, exchange=None, frame_num=5, group=1,
+                     t_a_single=None):
     """The partition run_wavefront should use for these phase times: the best of the reset-aligned hybrid (when the forward
     branch restarts), the balanced and the growing contiguous shards and the block-cyclic partitions with 1..8 frames per
     block, by simulated makespan.  t_cold defaults to 0.85 t_a (two more frames to prepare: ~5.0 of 5.8 ms for RefVSR_small
@@ -524,12 +599,14 @@ def choose_partition(nframes, world, reset_branch, t_a, t_b1, t_b2, t_handoff=0.
     # rank the candidates at a quarter of the time resolution, re-simulate the best three at the full one
     rough = []
     for name, parts in cands:
-        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num, 500.0)
+        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num, 500.0,
+                                  group, t_a_single)
         rough.append((sp, name, parts))
     rough.sort(key=lambda v: -v[0])
     fine = []
     for _, name, parts in rough[:3]:
-        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num)
+        sp, _ = predicted_speedup(nframes, world, parts, reset_branch, t_a, t_b1, t_b2, t_handoff, t_cold, True, exchange, frame_num,
+                                  group=group, t_a_single=t_a_single)
         fine.append((as_blocks(parts), sp, name))
     top = max(v[1] for v in fine)
     # within 1 % of the best: the partition with the fewest blocks (fewest hand-offs and messages: the model's terms for those are
@@ -559,18 +636,18 @@ class _NullCtx(object):
 
 
 def run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
-                  timings=None, exchange_contexts=False):
+                  timings=None, exchange_contexts=False, group=1):
     """See _run_wavefront (this wrapper only makes sure the executor's strict-context mode ends with the run)."""
     try:
         return _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result, parts, timings,
-                              exchange_contexts)
+                              exchange_contexts, group)
     finally:
         if exchange_contexts and hasattr(executor, 'strict_contexts'):
             executor.strict_contexts(False)
 
 
 def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, channels, device, on_result=None, parts=None,
-                   timings=None, exchange_contexts=False):
+                   timings=None, exchange_contexts=False, group=1):
     """Two-phase run of this rank's share of the clip.  parts: per-rank ranges [(start, end)] * world or a block list
     [(start, end, rank), ...] (default: the balanced contiguous partition).
 
@@ -591,6 +668,9 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
     ContextPlan.program(rank): prepare context i (+ isend to its consumers) | receive what window f lacks, then phase A of f (which
     finds every context prepared: a missing one raises, executor.strict_contexts).  Context messages travel in their own process
     group; every rank issues them in increasing frame order.
+    group > 1 (round 6; executors with phase_a_group(windows, frames, hints) -> handles): lane a runs phase A in groups of up to
+    `group` local windows (group_lane_ops) -- their backward branches as multi-map launches; B1(f) then waits for the group that
+    holds f.  Same results, same messages in the same order.
     Results are identical to the sequential run.  Returns {frame: result} for the local frames.  timings (optional dict):
     'issue_a' / 'recv_wait' / 'issue_b1' / 'issue_b2' host seconds, 'handoff_messages' sent, 'blocks' local blocks,
     'context_messages' sent, 'context_wait' host seconds blocked waiting for contexts."""
@@ -606,6 +686,7 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
         executor.begin_run()                                       # (two-lane executors: the lanes wait for the caller's stream)
     lane_a = getattr(executor, 'lane_a', _NullCtx)
     lane_b = getattr(executor, 'lane_b', _NullCtx)
+    lane_c = getattr(executor, 'lane_c', lane_a)                   # the upsamplers' lane (EngineExecutor: M, behind the backward chains)
     mark = getattr(executor, 'mark', lambda what, f: None)          # record "what of frame f is enqueued up to here"
     wait = getattr(executor, 'wait', lambda what, f: None)          # the CURRENT lane waits for that mark
     tim = {'issue_a': 0.0, 'recv_wait': 0.0, 'issue_b1': 0.0, 'issue_b2': 0.0, 'handoff_messages': 0, 'blocks': len(mine),
@@ -613,13 +694,90 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
     t0 = time.perf_counter()
     handles, keep = {}, []
     results, pending = {}, []
+    split = hasattr(executor, 'phase_b1')
+    # the hand-off in two messages (the receiver's step starts on the small one): executors that offer it, with the B1 / B2 split
+    two_msg = split and bool(getattr(executor, 'split_handoff', False))
+    # ---- the chain (B1 / B2 executors).  Round 6: the host no longer issues it after ALL of lane a -- after every window (group) of
+    # lane a, advance(False) issues the forward-branch steps that can go WITHOUT a blocking receive (a block that starts at a restart
+    # or continues a local block: every block of a reset-aligned partition) and, one call later, their upsamplers, so that on shards
+    # of tens of frames lane b and the upsamplers run under lane a instead of behind it (a 32-frame shard: the host needs > 60 ms
+    # to issue its phase A).  Blocks in frame order, as before (the engine carries ONE state); a block that needs a remote state
+    # stops the early issue until lane a is through (a blocking receive in the middle of lane a could close a cycle with the context
+    # messages this rank has not sent yet).  Sends are asynchronous wherever they are issued.
+    chain = [f for a, b in mine for f in range(a, b)]
+    block_of = {f: (a, b) for a, b in mine for f in range(a, b)}
+    cst = {'b1': 0, 'b2': 0, 'first': False}
+    early_chain = split and bool(getattr(executor, 'early_chain', hasattr(executor, 'lane_b')))
+
+    def advance(blocking):
+        b2_upto = len(chain) if blocking else cst['b1']            # upsamplers lag one call: their B1 is long done when lane a gets there
+        t2 = time.perf_counter()
+        while cst['b1'] < len(chain):
+            f = chain[cst['b1']]
+            a, b = block_of[f]
+            if f not in handles:
+                break                                              # its phase A is not issued yet
+            with lane_b():
+                if f == a:
+                    if needs_handoff(a, reset_branch):
+                        if owner_of[a - 1] != rank:
+                            if not blocking:
+                                break
+                            t1 = time.perf_counter()
+                            _import(executor, owner_of[a - 1], channels, device, split=two_msg)
+                            tim['recv_wait'] += time.perf_counter() - t1
+                        cst['first'] = False
+                    else:
+                        cst['first'] = True
+                wait('a', f)
+                handles[f] = executor.phase_b1(handles[f], cst['first'])
+                mark('b1', f)
+                cst['first'] = False
+                nxt_rank = owner_of.get(b)                         # owner of the block that follows in chain order
+                if f == b - 1 and nxt_rank is not None and nxt_rank != rank and needs_handoff(b, reset_branch):
+                    if two_msg:                                    # the next block's chain starts as soon as this one ends
+                        pending.extend(_send_split(executor, nxt_rank, device, keep))
+                    else:
+                        pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
+                    tim['handoff_messages'] += 1
+            cst['b1'] += 1
+        t3 = time.perf_counter()
+        tim['issue_b1'] += t3 - t2
+        if blocking:
+            b2_upto = cst['b1']
+        with lane_c():
+            while cst['b2'] < min(b2_upto, cst['b1']):             # ---- B2: upsamplers, off the chain
+                f = chain[cst['b2']]
+                wait('b1', f)
+                h = handles.pop(f)
+                keep.append(h)                                     # (two lanes: the handle's tensors stay allocated until the
+                out = executor.phase_b2(h)                         #  final synchronisation -- they are read on both streams)
+                results[f] = out
+                if on_result is not None:
+                    on_result(f, out)
+                cst['b2'] += 1
+        tim['issue_b2'] += time.perf_counter() - t3
+
+    group = int(group) if hasattr(executor, 'phase_a_group') else 1
+
+    def run_group(fs, window_of):                                  # one ('ag', frames) op of the grouped lane-a program
+        hs = executor.phase_a_group([window_of(f) for f in fs], list(fs), [window_is_hinted(f, reset_branch) for f in fs])
+        for f, h in zip(fs, hs):
+            handles[f] = h
+            mark('a', f)
+        if early_chain:
+            advance(False)
     if not exchange_contexts:
         with lane_a():
-            for a, b in mine:                                      # ---- phase A: no communication, no state
-                for f in range(a, b):
-                    lrs, refs = get_window(f)
-                    handles[f] = executor.phase_a(lrs, refs, f, window_is_hinted(f, reset_branch))
-                    mark('a', f)
+            for op in group_lane_ops([('a1', f) for a, b in mine for f in range(a, b)], group):   # ---- phase A: no communication, no state
+                if op[0] == 'ag':
+                    run_group(op[1], get_window)
+                else:
+                    lrs, refs = get_window(op[1])
+                    handles[op[1]] = executor.phase_a(lrs, refs, op[1], window_is_hinted(op[1], reset_branch))
+                    mark('a', op[1])
+                    if early_chain:
+                        advance(False)
     else:
         plan = ContextPlan(nframes, world, blocks, reset_branch, frame_num)
         grp = context_group()
@@ -634,9 +792,11 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
         strict = getattr(executor, 'strict_contexts', lambda on: None)
         strict(True)                                               # a context that is missing is a bug, not something to recompute
         with lane_a():
-            for op in plan.program(rank):
+            for op in group_lane_ops(plan.program(rank), group):
                 kind, x = op[0], op[1]
-                if kind == 'prep':
+                if kind == 'ag':
+                    run_group(x, lambda f: wins[f])
+                elif kind == 'prep':
                     executor.prepare_context(x, frame_in[x][0], frame_in[x][1])
                 elif kind == 'post_recv':
                     with comm_lane():
@@ -658,37 +818,27 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
                     lrs, refs = wins[x]
                     handles[x] = executor.phase_a(lrs, refs, x, window_is_hinted(x, reset_branch))
                     mark('a', x)
+                    if early_chain:
+                        advance(False)
         assert not rx
-    tim['issue_a'] = time.perf_counter() - t0
-    split = hasattr(executor, 'phase_b1')
-    # the hand-off in two messages (the receiver's step starts on the small one): executors that offer it, with the B1 / B2 split
-    two_msg = split and bool(getattr(executor, 'split_handoff', False))
-    for a, b in mine:                                              # ---- the chain: one block at a time, in frame order
-        nxt_rank = owner_of.get(b)                                 # owner of the block that follows in chain order
-        handoff_out = nxt_rank is not None and nxt_rank != rank and needs_handoff(b, reset_branch)
-        with lane_b():
-            t1 = time.perf_counter()
-            if needs_handoff(a, reset_branch):
-                if owner_of[a - 1] != rank:
-                    _import(executor, owner_of[a - 1], channels, device, split=two_msg)
-                first = False
-            else:
-                first = True
-            tim['recv_wait'] += time.perf_counter() - t1
-            t2 = time.perf_counter()
-            if split:
-                for f in range(a, b):                              # B1 chain: forward-branch steps only
-                    wait('a', f)
-                    handles[f] = executor.phase_b1(handles[f], first)
-                    mark('b1', f)
+    tim['issue_a'] = time.perf_counter() - t0 - tim['issue_b1'] - tim['issue_b2']
+    if split:
+        advance(True)                                              # ---- the rest of the chain (blocking receives), then every B2 left
+    else:
+        for a, b in mine:                                          # ---- the chain: one block at a time, in frame order
+            nxt_rank = owner_of.get(b)                             # owner of the block that follows in chain order
+            handoff_out = nxt_rank is not None and nxt_rank != rank and needs_handoff(b, reset_branch)
+            with lane_b():
+                t1 = time.perf_counter()
+                if needs_handoff(a, reset_branch):
+                    if owner_of[a - 1] != rank:
+                        _import(executor, owner_of[a - 1], channels, device, split=False)
                     first = False
-                if handoff_out:                                    # the next block's chain starts as soon as this one ends
-                    if two_msg:
-                        pending.extend(_send_split(executor, nxt_rank, device, keep))
-                    else:
-                        pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
-                    tim['handoff_messages'] += 1
-            else:
+                else:
+                    first = True
+                tim['recv_wait'] += time.perf_counter() - t1
+                t2 = time.perf_counter()
+
                 def start_send():    # called by phase_b of the block's LAST frame as soon as its carried state is final
                     pending.append(send_state(_export(executor), nxt_rank, device, async_op=True))
                 early = handoff_out and getattr(executor, 'supports_after_state', False)
@@ -708,20 +858,7 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
                     if not early:
                         send_state(_export(executor), nxt_rank, device)
                     tim['handoff_messages'] += 1
-            tim['issue_b1'] += time.perf_counter() - t2
-    t3 = time.perf_counter()
-    if split:
-        with lane_a():
-            for a, b in mine:                                      # ---- B2: upsamplers, off the chain
-                for f in range(a, b):
-                    wait('b1', f)
-                    h = handles.pop(f)
-                    keep.append(h)                                 # (two lanes: the handle's tensors stay allocated until the
-                    out = executor.phase_b2(h)                     #  final synchronisation -- they are read on both streams)
-                    results[f] = out
-                    if on_result is not None:
-                        on_result(f, out)
-    tim['issue_b2'] = time.perf_counter() - t3
+                tim['issue_b1'] += time.perf_counter() - t2
     for wk in pending:
         if wk is not None:
             wk.wait()
@@ -738,7 +875,7 @@ class EngineExecutor(object):
     supports_after_state = True
 
     def __init__(self, net, device, h, w, nframes, frame_num, keep_on_device=True, pipelined=True, inputs_materialised=False,
-                 split_handoff=True):
+                 split_handoff=True, split_phase_a=True):
         self.net, self.dev, self.h, self.w, self.nframes, self.t = net, device, h, w, nframes, frame_num
         self.keep = keep_on_device
         self.eng = net.Network.ensure_engines(1, device)[0]
@@ -754,11 +891,18 @@ class EngineExecutor(object):
         # per-frame events -- B1(f) runs as soon as phase A of ITS frame is done and the state has arrived
         self._lanes = None
         self._marks = {}
+        self._marks_preset = set()
         self._ctx_spec = None
+        # round 6: phase-A groups with the preparation on lane a and the backward chains (+ the upsamplers) on a third lane, like a
+        # frame group's P | M sections (REFVSR_SHARD_SPLIT_A=0: the whole phase A on lane a, the A/B)
+        import os as _os
+        self.split_phase_a = bool(split_phase_a) and _os.environ.get('REFVSR_SHARD_SPLIT_A', '1') != '0' and self.eng.group_ok()
 
     def _streams(self):
+        """(lane a = P: per-frame preparation, flows, context messages | lane b = F: the B1 chain + hand-off | comm | lane c = M: the
+        backward chains of the phase-A groups + the upsamplers) -- the stream layout of a frame group (P | F | M)."""
         if self._lanes is None:
-            self._lanes = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            self._lanes = tuple(torch.cuda.Stream(device=self.dev) for _ in range(4))
             self.begin_run()
         return self._lanes
 
@@ -806,7 +950,13 @@ class EngineExecutor(object):
     def lane_b(self):
         return torch.cuda.stream(self._streams()[1])
 
+    def lane_c(self):
+        """Where the upsamplers (B2) go: behind the backward chains on M when the phase-A groups are split over P | M, else lane a."""
+        return torch.cuda.stream(self._streams()[3 if self.split_phase_a else 0])
+
     def mark(self, what, f):
+        if what == 'a' and (what, f) in self._marks_preset:       # a split phase-A group: the handle's own event on M is the mark
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
         self._marks[(what, f)] = ev
@@ -830,6 +980,20 @@ class EngineExecutor(object):
     def phase_a(self, lrs, refs, f, hint):
         return self.net.Network.phase_a(lrs[None].to(self.dev), refs[None].to(self.dev), frame_ids=self._ids(f), first_hint=hint)
 
+    def phase_a_group(self, windows, fs, hints):
+        """phase_a of several local windows in one pass (run_wavefront(group=)): windows [(lrs, refs)], fs their frame indices."""
+        streams = None
+        if self.split_phase_a:
+            lanes = self._streams()
+            streams = (lanes[3], (lanes[1],))
+        hs = self.net.Network.phase_a_group([w_[0].to(self.dev) for w_ in windows], [w_[1].to(self.dev) for w_ in windows],
+                                            [self._ids(f) for f in fs], hints, streams)
+        for f, h in zip(fs, hs):
+            if h[0].get('ready') is not None:
+                self._marks[('a', f)] = h[0]['ready']
+                self._marks_preset.add(('a', f))
+        return hs
+
     def phase_b(self, handles, first, after_state=None):
         return self._out(self.net.Network.phase_b(handles, first, after_state=after_state)['result'][0])
 
@@ -846,6 +1010,7 @@ class EngineExecutor(object):
             for s_ in self._lanes:
                 cur.wait_stream(s_)
         self._marks.clear()
+        self._marks_preset.clear()
 
     def state_nbytes(self):
         return self.eng.state_nbytes(self.h, self.w)

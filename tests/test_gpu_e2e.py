@@ -422,6 +422,57 @@ def test_two_phase_forward_is_bit_identical(dev):
                 assert torch.equal(got, want[f]), '%s: two-phase frame %d differs (hinted=%s)' % (name, f, hinted)
 
 
+def test_phase_a_group_equals_phase_a(dev):
+    """Engine.phase_a_group (round 6: phase A of several windows of a clip in one pass -- batched SPyNet, the backward branches as
+    multi-map launches; what shard.run_wavefront(group=) runs on lane a) returns the handles phase_a returns: the upsampled frames
+    of (group A | B1 chain | B2) equal forward() bit for bit -- consecutive windows, windows that are NOT consecutive (a rank's share
+    of a block-cyclic partition), groups with a hinted restart window inside, partial groups, 24 and 48 channels."""
+    from refvsr_amd.synth import make_clip, window_indices
+    for name, t, size, reset, plan in [
+            ('config_RefVSR_small_L1', 5, (64, 96), 4, [[0, 1, 2, 3], [4, 5, 6, 7], [8]]),
+            ('config_RefVSR_small_L1', 5, (64, 96), None, [[0, 2, 4, 6], [1, 3], [5, 7, 8]]),
+            ('config_RefVSR_small_MFID', 3, (32, 48), 3, [[0, 1, 2], [3, 4, 5, 6]]),
+            ('config_RefVSR_MFID', 3, (40, 56), None, [[0, 1, 2, 3], [4, 5]])]:
+        nfr = max(f for g in plan for f in g) + 1
+        lr, rf, _ = make_clip(nfr, size[0], size[1], seed=13)
+        lr, rf = lr.to(dev), rf.to(dev)
+        wins = [window_indices(f, nfr, t) for f in range(nfr)]
+        ref_net, _, _ = make_net(name, t, dev, reset=reset, save_sample=False)
+        want = [ref_net(lr[w][None], rf[w][None], f == 0)['result'].clone() for f, w in enumerate(wins)]
+        for split in (False, True):
+            # split: the sharded executor's stream layout -- preparation + flows on the current stream (here a side stream P), the
+            # backward chains on M, the B1 chain on a third stream behind the handles' `ready` events, the upsamplers on M
+            net, _, _ = make_net(name, t, dev, reset=reset, save_sample=False)
+            assert net.Network.ensure_engines(1, dev)[0].group_ok()
+            P, M, Fs = (torch.cuda.Stream(dev) for _ in range(3))
+            for st in (P, M, Fs):
+                st.wait_stream(torch.cuda.current_stream(dev))
+            hs = {}
+            with torch.cuda.stream(P if split else torch.cuda.current_stream(dev)):
+                for g in plan:
+                    hints = [f == 0 or bool(reset and f % reset == 0) for f in g]
+                    out = net.Network.phase_a_group([lr[wins[f]] for f in g], [rf[wins[f]] for f in g], [wins[f] for f in g], hints,
+                                                    (M, (Fs,)) if split else None)
+                    assert len(out) == len(g) and all((h[0].get('ready') is not None) == split for h in out)
+                    hs.update(dict(zip(g, out)))
+            done = {}
+            with torch.cuda.stream(Fs if split else torch.cuda.current_stream(dev)):
+                for f in range(nfr):
+                    if split:
+                        Fs.wait_event(hs[f][0]['ready'])
+                    net.Network.phase_b1(hs[f], f == 0)
+                    done[f] = torch.cuda.Event()
+                    done[f].record()
+            with torch.cuda.stream(M if split else torch.cuda.current_stream(dev)):
+                got = []
+                for f in range(nfr):
+                    torch.cuda.current_stream(dev).wait_event(done[f])
+                    got.append(net.Network.phase_b2(hs[f])['result'])
+            torch.cuda.synchronize()
+            for f in range(nfr):
+                assert torch.equal(got[f], want[f]), '%s: frame %d of the grouped phase A differs (groups %s, split=%s)' % (name, f, plan, split)
+
+
 def test_streams_are_deterministic(dev):
     """Race detector: the same stream run ten times (default two-stream mode, clip edges with replicated frames,
     reset rollover; S and HD configurations) must give the same bits every time -- an unsynchronised cross-stream
@@ -819,6 +870,13 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
         tim = {}                     # B1 chain on the second HIP stream behind per-frame events (the two-lane schedule)
         res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=shard.partition_cyclic(6, world, 1), timings=tim)
         assert tim['blocks'] == 3 and tim['handoff_messages'] == (3 if rank == 0 else 2)
+    elif wavefront in ('grouped', 'grouped_exchange'):
+        # round 6: lane a in phase-A groups (Engine.phase_a_group), the chain's local segments issued between the groups; two contiguous
+        # shards of three frames = one group each, with / without the context exchange
+        tim = {}
+        res = shard.run_wavefront(ex, get, 6, 3, cfg.reset_branch, cfg.mid_channels, 'cpu', parts=shard.partition(6, world), timings=tim,
+                                  exchange_contexts=(wavefront == 'grouped_exchange'), group=4)
+        assert tim['blocks'] == 1
     elif wavefront in ('exchange_cyclic', 'exchange_balanced'):
         # every per-frame context prepared by ONE rank and sent to the other (run_wavefront(exchange_contexts=True)): block-cyclic
         # blocks of one frame (contexts travel in both directions of the pair, two per window) / two contiguous shards
@@ -846,6 +904,8 @@ def _shard_worker(rank, world, port, reset, aligned, q, wavefront=False, name='c
                                                           ('keep', False, True, 'config_RefVSR_small_MFID'),
                                                           (None, False, 'cyclic', 'config_RefVSR_small_L1'),
                                                           (None, False, 'exchange_cyclic', 'config_RefVSR_small_L1'),
+                                                          (None, False, 'grouped', 'config_RefVSR_small_L1'),
+                                                          (4, False, 'grouped_exchange', 'config_RefVSR_small_MFID'),
                                                           (4, False, 'exchange_balanced', 'config_RefVSR_small_MFID')])
 def test_two_process_sharding_matches_sequential(dev, reset, aligned, wavefront, name):
     """Frame sharding across two ranks (state hand-off as ONE packed fp16 buffer, the exchange-free reset-aligned
@@ -1124,6 +1184,33 @@ def test_bench_gpus_2_self_launches_and_reports_the_sharded_clip(dev):
     assert d['wavefront']['frames_equal'] is True and d['wavefront']['backend'].startswith('gloo')
     assert d['weak_scaling_shards']['scaling'] == 'weak' and d['weak_scaling_shards']['value'] > 0
     assert abs(d['value'] - 12.0 / d['wavefront']['seconds']) < 2e-2 * d['value']          # (the compact line rounds the seconds)
+
+
+def test_bench_gpus_2_configs3_at_its_size_all_frames_equal(dev):
+    """BASELINE configs[3] at its own size inside the test run: `python bench.py --gpus 2` with the 64-frame
+    270 x 480 clip of config_RefVSR_small_MFID sharded over two ranks (they share this box's one GPU and talk over gloo; phase A in
+    groups of four windows, contexts exchanged, state hand-off) -- and ALL 64 frames compared with the single-rank run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    env['REFVSR_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--clip', '64', '--clip-check', '64',
+                        '--repeats', '1', '--warm-seconds', '0.05', '--no-kernels', '--full-json', '/tmp/bench_n2_configs3_full.json'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    wf = d['wavefront']
+    report('configs[3] at its size, two ranks on one GPU (gloo)', frames_per_s=wf['value'], seconds=wf['seconds'],
+           one_rank_same_clip_frames_per_s=wf.get('one_rank_same_clip_frames_per_s'), speedup_vs_n1_headline=wf.get('speedup_vs_n1_headline'))
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['config']['timed_frames'] == 64
+    assert wf['frames_equal'] is True and wf['frames_checked_against_single_rank_run'] == 64 and wf['phase_a_group'] == 4
+    assert '270x480' in d['config']['workload'] and 'RefVSR_small_MFID' in d['config']['workload']
 
 
 def _exchange_t5_worker(rank, world, port, q):

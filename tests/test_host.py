@@ -773,14 +773,17 @@ def test_conv48_two_source_blob_is_two_channel_half_blobs():
                 assert np.abs(got - want[24 * z:24 * z + 24, oy, ox]).max() < 2e-5, (z, oy, ox)
 
 
-def _context_protocol_completes(plan, in_order_transport):
+def _context_protocol_completes(plan, in_order_transport, group=1):
     """Replays ContextPlan.program of every rank.  in_order_transport=False: gloo -- the host blocks in wait_recv until the peer has
     ISSUED the matching send (messages of one direction of a pair match in posting order).  True: RCCL -- nothing blocks the host;
     lane a is an in-order stream [prep | send (the pair stream waits for lane a up to here) | wait_recv | a1], every rank pair has ONE
     in-order stream per side holding its sends and receives in issue order, and an operation runs only when it is at the head on
     BOTH sides.  Returns (completed, per-rank trace of 'a1' windows with the contexts available then)."""
     world, nfr = plan.world, plan.nframes
-    prog = {r: plan.program(r) for r in range(world)}
+    from refvsr_amd import shard as _shard
+    # group > 1: what run_wavefront(group=) executes -- runs of windows as one ('ag', members) op, everything between them issued first
+    prog = {r: _shard.group_lane_ops(plan.program(r), group) for r in range(world)}
+    members = lambda op: op[1] if op[0] == 'ag' else (op[1],)
     if not in_order_transport:
         pc = {r: 0 for r in range(world)}
         sent = {}                                  # (src, dst) -> list of frames in send order
@@ -807,12 +810,13 @@ def _context_protocol_completes(plan, in_order_transport):
                         assert s_[k] == op[1], 'message order of the pair differs between its ends'
                         have[r].add(op[1])
                     else:
-                        assert all(i in have[r] for i in plan.needed[op[1]]), 'window %d lacks a context' % op[1]
+                        for f_ in members(op):
+                            assert all(i in have[r] for i in plan.needed[f_]), 'window %d lacks a context' % f_
                     pc[r] += 1
                     progress = True
         return all(pc[r] == len(prog[r]) for r in range(world))
     # stream semantics
-    lane = {r: [op for op in prog[r] if op[0] in ('prep', 'send', 'wait_recv', 'a1')] for r in range(world)}
+    lane = {r: [op for op in prog[r] if op[0] in ('prep', 'send', 'wait_recv', 'a1', 'ag')] for r in range(world)}
     if in_order_transport == 'one stream per rank':
         # eager-initialised ProcessGroupNCCL: unbatched send / recv of a group are serialised with ALL its other operations -- one
         # FIFO per rank over all peers; an operation runs when it and its match are at the heads of both FIFOs
@@ -873,7 +877,8 @@ def _context_protocol_completes(plan, in_order_transport):
                         break
                     have[r].add(op[1])
                 else:
-                    assert all(i in have[r] for i in plan.needed[op[1]]), 'window %d lacks a context' % op[1]
+                    for f_ in members(op):
+                        assert all(i in have[r] for i in plan.needed[f_]), 'window %d lacks a context' % f_
                 lp[r] += 1
                 progress = True
         for (r, peer), ops_ in pair.items():
@@ -928,6 +933,48 @@ def test_context_plan_covers_every_window_and_never_deadlocks():
     # (all context operations of a rank serialised on ONE stream -- what an eagerly initialised ProcessGroupNCCL does to unbatched
     #  send / recv; bench.py initialises lazily, one communicator and stream per rank pair -- must complete as well)
     assert cases > 1000 and serial_ok == cases
+
+
+def test_grouped_lane_programs_keep_the_protocol():
+    """run_wavefront(group=G): runs of up to G windows of a rank become one phase-A group (multi-map launches), everything that stood
+    between them -- preparations, sends, receives -- is issued before the group.  The grouped programs hold every op of the plain ones,
+    keep the order of the messages, find every context and complete under the three transport semantics."""
+    from refvsr_amd import shard
+    assert shard.group_lane_ops([('a1', 0), ('prep', 3), ('a1', 1), ('wait_recv', 4, 1), ('a1', 2), ('a1', 5), ('a1', 6)], 3) == \
+        [('prep', 3), ('wait_recv', 4, 1), ('ag', (0, 1, 2)), ('ag', (5, 6))]
+    assert shard.group_lane_ops([('a1', 0), ('a1', 1)], 1) == [('a1', 0), ('a1', 1)]
+    assert shard.group_time(4, 4, 4.0, 5.5) == 4.0 and shard.group_time(1, 4, 4.0, 5.5) == 5.5 and shard.group_time(2, 4, 4.0, 5.5) == 5.0
+    cases = 0
+    for world in (2, 3, 8):
+        for nfr in (world + 1, 13, 64):
+            for reset in (None, 9):
+                for t in (3, 5):
+                    fams = [shard.partition(nfr, world), shard.partition_cyclic(nfr, world, 1), shard.partition_cyclic(nfr, world, 3),
+                            shard.partition_cyclic_growing(nfr, world, 5.3, 1.04, 7.2)]
+                    if reset:
+                        fams.append(shard.partition_hybrid(nfr, world, reset))
+                    for parts in fams:
+                        plan = shard.ContextPlan(nfr, world, parts, reset, t)
+                        for G in (2, 4):
+                            for r in range(world):
+                                plain, grouped = plan.program(r), shard.group_lane_ops(plan.program(r), G)
+                                flat = [('a1', f) for op in grouped if op[0] == 'ag' for f in op[1]]
+                                assert flat == [op for op in plain if op[0] == 'a1'] and all(len(op[1]) <= G for op in grouped if op[0] == 'ag')
+                                assert [op for op in grouped if op[0] != 'ag'] == [op for op in plain if op[0] != 'a1']
+                            assert _context_protocol_completes(plan, False, G), ('gloo', world, nfr, reset, t, G, parts)
+                            assert _context_protocol_completes(plan, True, G), ('rccl', world, nfr, reset, t, G, parts)
+                            assert _context_protocol_completes(plan, 'one stream per rank', G), ('serial', world, nfr, reset, t, G, parts)
+                            cases += 1
+    assert cases >= 300
+    # the model: a group costs its members' time at the group rate and finishes them together; grouping never changes the work of a rank
+    ta, ta1, tb1, tb2 = 4.2, 5.4, 0.9, 0.45
+    hyb = shard.partition_hybrid(64, 8, 9)
+    ex = dict(t_prep=2.2, t_ctx=0.1, t_cold_x=0.5)
+    s1, span1 = shard.predicted_speedup(64, 8, hyb, 9, ta1, tb1, tb2, 0.1, 4.0, True, ex)
+    s4, span4 = shard.predicted_speedup(64, 8, hyb, 9, ta, tb1, tb2, 0.1, 4.0, True, ex, group=4, t_a_single=ta1)
+    assert span4 < span1 and span4 >= 9 * (ta + tb1 + tb2) - 1e-6           # never below the largest shard's own work at the group rate
+    one = shard.predicted_speedup(64, 1, [(0, 64)], 9, ta, tb1, tb2, group=4, t_a_single=ta1)[0]
+    assert abs(one - 1.0) < 0.02
 
 
 def test_context_exchange_model():

@@ -84,6 +84,12 @@ class _ExecLanes(_Exec):
         h['_frame'] = f
         return h
 
+    def phase_a_group(self, windows, fs, hints):
+        """run_wavefront(group=): several windows per lane-a op (the engine runs their backward branches as multi-map launches; the
+        oracle walks them one by one -- the protocol around them is what is under test)."""
+        self.groups = getattr(self, 'groups', []) + [tuple(fs)]
+        return [self.phase_a(w_[0], w_[1], f, h) for w_, f, h in zip(windows, fs, hints)]
+
     def phase_b1(self, handle, first):
         assert self.lane == 'b' and self.log and self.log[-1][:3] == ('wait', 'a', handle['_frame'])
         return _Exec.phase_b1(self, handle, first)
@@ -227,14 +233,18 @@ def _worker(rank, world, port, reset, aligned, q, wavefront=False, nframes=6, na
         res = shard.run_wavefront(_ExecLanes(cfg, sd), get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim)
         assert tim['blocks'] == 1 and tim['handoff_messages'] == (1 if rank + 1 < world else 0)
     elif isinstance(wavefront, str) and wavefront.startswith('exchange'):   # per-frame contexts prepared once and exchanged
+        G = 1
+        if '@g' in wavefront:                              # '...@gN': lane a in phase-A groups of up to N windows (round 6)
+            wavefront, g_ = wavefront.split('@g')
+            G = int(g_)
         fam = wavefront.split('_', 1)[1]
         parts = {'cyclic': lambda: shard.partition_cyclic(nframes, world, 2), 'hybrid': lambda: shard.partition_hybrid(nframes, world, reset),
                  'balanced': lambda: shard.partition(nframes, world),
                  'growing': lambda: shard.partition_cyclic_growing(nframes, world, 5.3, 1.0, 7.2)}[fam]()
         ex = _ExecCtx(cfg, sd, nframes, 3)
         tim = {}
-        res = shard.run_wavefront(ex, get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim, exchange_contexts=True)
-        info = {'prepared': ex.prepared_here, 'imported': ex.imported_here, 'messages': tim['context_messages']}
+        res = shard.run_wavefront(ex, get, nframes, 3, reset, cfg.mid_channels, 'cpu', parts=parts, timings=tim, exchange_contexts=True, group=G)
+        info = {'prepared': ex.prepared_here, 'imported': ex.imported_here, 'messages': tim['context_messages'], 'groups': getattr(ex, 'groups', [])}
     elif wavefront == 'two_message':                       # the hand-off as two messages, the second awaited inside the step
         ex = _ExecSplit(cfg, sd)
         C, hh = cfg.mid_channels, 16
@@ -389,6 +399,20 @@ def test_context_exchange_world8_partitions():
     for fam in ('exchange_cyclic', 'exchange_growing'):
         got, infos = _run(reset=None, aligned=False, wavefront=fam, world=8, nframes=26)
         _check_exchange(got, infos, 26, 8)
+
+
+def test_phase_a_groups_world2_and_world8():
+    """run_wavefront(group=G) with the context exchange: lane a issues phase A in groups of up to G local windows (Engine.phase_a_group
+    on the GPU), the chain's local segments and their upsamplers are issued between the groups (the early chain), blocks behind a
+    remote hand-off after lane a.  Two ranks, block-cyclic blocks of 2 with a group size that straddles blocks; eight ranks on
+    BASELINE configs[3] in miniature (reset-aligned hybrid: six chains without any hand-off).  Bit-identical to the sequential stream,
+    every context prepared once, groups as group_lane_ops forms them."""
+    got, infos = _run(reset=None, aligned=False, wavefront='exchange_cyclic@g3', world=2, nframes=9)
+    _check_exchange(got, infos, 9, 2)
+    assert infos[0]['groups'] == [(0, 1, 4), (5, 8)] and infos[1]['groups'] == [(2, 3, 6), (7,)]
+    got, infos = _run(reset='keep', aligned=False, wavefront='exchange_hybrid@g4', world=8, nframes=64, name='config_RefVSR_small_MFID')
+    _check_exchange(got, infos, 64, 8)
+    assert infos[0]['groups'] == [(0, 1, 2, 3), (4, 5, 6, 7), (8,)] and infos[7]['groups'] == [(59, 60, 61, 62), (63,)]
 
 
 def test_two_message_handoff():
