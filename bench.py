@@ -748,9 +748,16 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     return out
 
 
-def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3):
-    """The K timed steps with host-resident inputs and outputs (see the call site).  Returns the `pcie_inclusive` object of the line."""
+def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3, result_dtype='float32', frames_once=False):
+    """The K timed steps with host-resident inputs and outputs (see the call site).  Returns the `pcie_inclusive` object of the line.
+    result_dtype: config.result_dtype for these passes ('uint8': the output head stores rint(255 v), REFVSR_RESULT_U8 -- the bytes the
+    reference's PNG writer makes of the fp32 frame on the CPU -- and a quarter of the bytes goes device -> host)."""
+    # frames_once: a streaming caller's loader -- every frame of the clip crosses PCIe ONCE (3.1 MB per output frame instead of the
+    # 15.6 MB of whole windows, whose frames overlap t - 1 to t) into a device-side table and the windows are gathered there
     nfr = args.warmup + args.steps
+    eng_ = net.Network.ensure_engines(1, dev)[0]
+    prev_dtype, eng_.result_dtype = eng_.result_dtype, result_dtype
+    table = {}
     h_lr, h_rf = all_lr.cpu().pin_memory(), all_rf.cpu().pin_memory()               # [nfr, t, 3, h, w] fp32, as the reference's loader makes them
     h_out = [None]                                                                   # [nfr, 3, s h, s w] pinned, sized by the first result
     cp = torch.cuda.Stream(dev)
@@ -761,8 +768,18 @@ def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3
         while f < f1:
             n = min(G, f1 - f)
             with torch.cuda.stream(cp):
-                lr_d = h_lr[f:f + n].to(dev, non_blocking=True)
-                rf_d = h_rf[f:f + n].to(dev, non_blocking=True)
+                if frames_once:
+                    for b in range(n):
+                        for j, i in enumerate(wins[f + b]):
+                            if i not in table:
+                                table[i] = (h_lr[f + b, j].to(dev, non_blocking=True), h_rf[f + b, j].to(dev, non_blocking=True))
+                    lr_d = torch.stack([torch.stack([table[i][0] for i in wins[f + b]], 0) for b in range(n)], 0)
+                    rf_d = torch.stack([torch.stack([table[i][1] for i in wins[f + b]], 0) for b in range(n)], 0)
+                    for i in [k for k in table if k < wins[f][0]]:
+                        del table[i]
+                else:
+                    lr_d = h_lr[f:f + n].to(dev, non_blocking=True)
+                    rf_d = h_rf[f:f + n].to(dev, non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record(cp)
             ids = [[start + i for i in wins[f + b]] for b in range(n)]
@@ -771,7 +788,7 @@ def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3
             else:
                 res = [net(lr_d, rf_d, f == 0, frame_ids=ids[0], input_ready=ready)['result']]
             if h_out[0] is None:
-                h_out[0] = torch.empty((nfr,) + tuple(res[0].shape[-3:]), dtype=torch.float32).pin_memory()
+                h_out[0] = torch.empty((nfr,) + tuple(res[0].shape[-3:]), dtype=res[0].dtype).pin_memory()
             for b in range(n):
                 h_out[0][f + b].copy_(res[b].reshape(h_out[0].shape[1:]), non_blocking=True)
             f += n
@@ -780,6 +797,7 @@ def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3
     for rep in range(passes + 1):
         net.Network.reset()
         net.Network.set_pipelined(True)
+        table.clear()
         run(0, args.warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -787,14 +805,16 @@ def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3
         torch.cuda.synchronize()
         if rep:                                                                      # (pass 0: untimed)
             secs.append(time.perf_counter() - t0)
-    assert bool(torch.isfinite(h_out[0][args.warmup:]).all())
+    eng_.result_dtype = prev_dtype
+    assert bool(torch.isfinite(h_out[0][args.warmup:].float()).all())
     secs.sort()
     el = secs[len(secs) // 2]
     win_mb = 2 * h_lr[0].numel() * 4 / 1e6
     return {'value': args.steps / el, 'unit': 'frames/s', 'ms_per_step': 1e3 * el / args.steps, 'samples': [round(args.steps / s, 2) for s in secs],
-            'h2d_mb_per_frame': round(win_mb, 2), 'd2h_mb_per_frame': round(h_out[0][0].numel() * 4 / 1e6, 2), 'frames_per_call': G,
+            'h2d_mb_per_frame': round(win_mb, 2), 'd2h_mb_per_frame': round(h_out[0][0].numel() * h_out[0].element_size() / 1e6, 2), 'frames_per_call': G,
+            'result_dtype': result_dtype,
             'note': 'windows and results in pinned host memory: every call copies its whole windows (t LR + t reference frames, fp32) host -> device '
-                    'on a copy stream and its results (fp32) device -> host; host clock to the last result in host memory'}
+                    'on a copy stream and its results (%s) device -> host; host clock to the last result in host memory' % result_dtype}
 
 
 def _r(v, nd=4):
@@ -812,8 +832,9 @@ def compact_line(line, limit=5600):
     cfg_.pop('precision', None)
     out['config'] = cfg_
     out['samples'] = line.get('samples')
-    out['roofline'] = pick(line.get('roofline'), ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'maps_per_launch',
-                                                  'mean_launch_ms', 'launches_timed', 'flops_per_launch', 'error'))
+    out['roofline'] = pick(line.get('roofline'), ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'governing', 'mfma_frac', 'mfma_issued_frac',
+                                                  'hbm_frac', 'arithmetic_intensity', 'algorithmic_bytes_per_launch', 'traffic', 'traffic_static',
+                                                  'maps_per_launch', 'mean_launch_ms', 'launches_timed', 'flops_per_launch', 'error'))
     out['cpu_baseline'] = pick(line.get('cpu_baseline'), ('value', 'unit', 'cores', 'kind', 'sample', 'seconds_per_frame', 'gpu_over_cpu', 'error'))
     if out['cpu_baseline'] and 'sample' in out['cpu_baseline']:
         out['cpu_baseline']['sample'] = str(out['cpu_baseline']['sample'])[:200]
@@ -821,6 +842,10 @@ def compact_line(line, limit=5600):
     out['one_frame_per_call'] = pick(line.get('one_frame_per_call'), ('value', 'unit', 'samples'))
     out['first_frame_ms'] = _r(line.get('first_frame_ms'), 2)
     out['pcie_inclusive'] = pick(line.get('pcie_inclusive'), ('value', 'unit', 'samples', 'h2d_mb_per_frame', 'd2h_mb_per_frame', 'error'))
+    if isinstance((line.get('pcie_inclusive') or {}).get('result_uint8'), dict):
+        out['pcie_inclusive']['result_uint8'] = pick(line['pcie_inclusive']['result_uint8'], ('value', 'd2h_mb_per_frame'))
+        if isinstance(line['pcie_inclusive'].get('result_uint8_frames_once'), dict):
+            out['pcie_inclusive']['result_uint8_frames_once'] = pick(line['pcie_inclusive']['result_uint8_frames_once'], ('value', 'h2d_mb_per_frame'))
     out['roofline_match_top2'] = pick(line.get('roofline_match_top2'), ('achieved', 'frac', 'mean_launch_ms', 'traffic'))
     out['whole_path'] = pick(line.get('whole_path'), ('algorithmic_tflop_per_frame', 'achieved_tflops_per_gpu', 'frac_of_f16_mfma_peak',
                                                       'frac_of_f16_mfma_peak_on_survey_figure'))
@@ -1222,6 +1247,13 @@ def main():
     if rank == 0 and world == 1 and pipelined and not args.no_dropin:
         try:
             pcie = pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev)
+            # ... and with config.result_dtype = 'uint8' (round 6): the output head stores the 8-bit frame itself
+            u8 = pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, result_dtype='uint8')
+            pcie['result_uint8'] = {k: u8[k] for k in ('value', 'unit', 'samples', 'd2h_mb_per_frame')}
+            # ... and with every frame crossing PCIe once (a streaming loader: device-side frame table, windows gathered on the device)
+            u8o = pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, result_dtype='uint8', frames_once=True)
+            pcie['result_uint8_frames_once'] = {k: u8o[k] for k in ('value', 'unit', 'samples', 'd2h_mb_per_frame')}
+            pcie['result_uint8_frames_once']['h2d_mb_per_frame'] = round(2 * all_lr[0, 0].numel() * 4 / 1e6, 2)
         except Exception as e:  # noqa: BLE001  (an extra figure must never take the headline number down)
             pcie = {'error': repr(e)[:300]}
         net.Network.set_pipelined(False)
@@ -1286,14 +1318,33 @@ def main():
                     traffic = tj.get('resblock LR x%d maps' % maps_per_launch) if maps_per_launch > 1 else tj.get('resblock LR')
                     if traffic is None and maps_per_launch > 1 and tj.get('resblock LR'):
                         traffic = tj['resblock LR'] * maps_per_launch
-                    tsrc = 'profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
+                    tsrc = 'STATIC: profiles/pmc_kernels.json of commit 5a591e3 (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_kernels.py; kernel unchanged since), not measured in this run'
                 except Exception:  # noqa: BLE001
                     traffic = None
+            # Both roofs.  Algorithmic bytes per launch = every map read once + written once (fp16 HWC, 48 bytes per
+            # pixel each way) + one weight blob; arithmetic intensity = useful FLOPs / those bytes; the roof that GOVERNS is the HBM one
+            # when the intensity lies below the ridge (peak FLOP/s / peak bytes/s = 312 FLOP/byte), else the MFMA one.  `achieved` /
+            # `peak` / `frac` are those of the governing roof, the other roof's fraction is beside it.
+            abytes = maps_per_launch * 2.0 * H * W_ * 48 + 43264
+            ai = flops / abytes
+            ridge = PEAK_F16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            hbm_gbs = abytes / (per_launch_ms * 1e-3) / 1e9
+            governing = 'hbm' if ai < ridge else 'mfma'
+            issued = 798.0 * 16384 / (2 * 2.0 * 9 * C_ * C_ * 256)
             rb_line = {'kernel': 'resblock24_kernel (fused conv3x3-ReLU-conv3x3+residual, 24 channels, LR map %dx%d%s)' %
-                                 (H, W_, ', %d maps per launch' % maps_per_launch if maps_per_launch > 1 else ''), 'bound': 'mfma',
+                                 (H, W_, ', %d maps per launch' % maps_per_launch if maps_per_launch > 1 else ''), 'bound': governing,
                        'maps_per_launch': maps_per_launch,
-                       'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
-                       'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': sum(n for _, n in runs),
+                       'achieved': hbm_gbs if governing == 'hbm' else ach, 'peak': PEAK_HBM_GBS if governing == 'hbm' else PEAK_F16_TFLOPS,
+                       'unit': 'GB/s' if governing == 'hbm' else 'TFLOP/s',
+                       'frac': (hbm_gbs / PEAK_HBM_GBS) if governing == 'hbm' else ach / PEAK_F16_TFLOPS,
+                       'governing': '%s (arithmetic intensity %.0f FLOP/byte %s the ridge %.0f)' % (governing, ai, '<' if ai < ridge else '>=', ridge),
+                       'mfma_frac': ach / PEAK_F16_TFLOPS, 'mfma_tflops': ach, 'mfma_issued_frac': issued * ach / PEAK_F16_TFLOPS,
+                       'hbm_frac': hbm_gbs / PEAK_HBM_GBS, 'hbm_gbs': hbm_gbs, 'algorithmic_bytes_per_launch': abytes, 'arithmetic_intensity': ai,
+                       'traffic': traffic, 'traffic_source': tsrc, 'traffic_static': None if traffic is None else True,
+                       'traffic_over_algorithmic': None if traffic is None else traffic / abytes,
+                       'launches_timed': sum(n for _, n in runs),
+                       'launches_timed_in': 'one more pass of the SAME calls with every internal section on one stream (in the timed passes the '
+                                            'events around a run also bracket the other streams\' kernels)',
                        'mean_launch_ms': per_launch_ms, 'flops_per_launch': flops,
                        'issued_over_useful_flops': 798.0 * 16384 / (2 * 2.0 * 9 * C_ * C_ * 256),
                        'note': 'useful FLOPs (2 x 9 x 24 x 24 x 2 convs per pixel); the kernel issues 2.46x that on the matrix pipe: x2 hi + lo '
@@ -1310,12 +1361,16 @@ def main():
             if os.path.exists(pj) and (n_lr, n_ref) == (129600, 32400):   # HBM bytes per launch from the PMC passes; not live
                 try:
                     traffic = json.load(open(pj))['traffic_bytes_per_launch']
-                    tsrc = 'profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)'
+                    tsrc = 'STATIC: profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; kernel unchanged since), not measured in this run'
                 except Exception:  # noqa: BLE001
                     traffic = None
+            mbytes = (n_lr + n_ref) * 304.0 + n_lr * 16.0            # fp16 rows of 152 halfs, read once; top-2 (index, value) written
             line['roofline_match_top2'] = {'kernel': 'match_top2_kernel (fused cosine GEMM + column top-2)', 'bound': 'mfma',
                                            'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
-                                           'traffic': traffic, 'traffic_source': tsrc, 'launches_timed': len(ms),
+                                           'governing': 'mfma (arithmetic intensity %.0f FLOP/byte >> the ridge %.0f)' % (flops / mbytes, PEAK_F16_TFLOPS * 1e3 / PEAK_HBM_GBS),
+                                           'mfma_frac': ach / PEAK_F16_TFLOPS, 'hbm_frac': mbytes / (mean_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                           'traffic': traffic, 'traffic_source': tsrc, 'traffic_static': None if traffic is None else True,
+                                           'launches_timed': len(ms), 'launches_timed_in': 'the timed passes themselves (one launch per frame, events around it)',
                                            'mean_launch_ms': mean_ms, 'flops_per_launch': flops}
         else:
             line['roofline_match_top2'] = None

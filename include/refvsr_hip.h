@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define REFVSR_ABI_VERSION 13  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
+#define REFVSR_ABI_VERSION 14  /* 2: K-block order of packed conv weights (refvsr_amd/packing.py:kslot);
                                   3: exact matching (match_refine flagging, match_exact), lean ResBlock;
                                   4: hi + lo patch rows (match_patches rows_lo), split-fp16 match_exact;
                                   5: compile-time-specialised 24-channel ResBlock (resblock24 blob);
@@ -41,7 +41,9 @@ extern "C" {
                                       (169 vs 176 frames/s, profiles/r03_fused_warp_ab.txt);
                                   12: refvsr_resblock48_chain_batch (the multi-map form of the 48-channel block);
                                   13: CU partitions: refvsr_stream_create_cu_range / refvsr_stream_set_cu_budget /
-                                      refvsr_stream_destroy / refvsr_num_cus */
+                                      refvsr_stream_destroy / refvsr_num_cus;
+                                  14: result formats of the output head (REFVSR_RESULT_*): refvsr_conv_last_fmt,
+                                      refvsr_conv_hr_last_fmt, refvsr_convert_result */
 
 int refvsr_abi_version(void);
 /* REFVSR_MAX_MAPS of the built library (a value, not a status): bindings check their own copy against it at load time. */
@@ -226,6 +228,18 @@ int refvsr_conv_last(const void* src, int c, int h, int w, const void* blob, con
  * (refvsr_amd/packing.py:pack_conv_hr_last); base_lr / out as in refvsr_conv_last. */
 int refvsr_conv_hr_last(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
                         float* out, void* stream);
+/* Result formats of the output head (ABI 14; extension -- the reference returns fp32 and its consumers quantise on the CPU:
+ * evaluation/eval_qual_quan.py:117-119 hands cv2.imwrite `output * 255`, i.e. saturate_cast<uchar> = round to nearest even).
+ * The _fmt forms of the two head launches store the planar [3][h][w] result as fp32 (== the plain forms), fp16, or uint8 =
+ * rint(255 v) of the clamped fp32 value -- the bytes the reference's PNG writer produces -- so that 1/2 or 1/4 of the bytes cross
+ * PCIe; refvsr_convert_result does the same conversion on an fp32 result (the generic head of configurations without a fused one). */
+enum { REFVSR_RESULT_F32 = 0, REFVSR_RESULT_F16 = 1, REFVSR_RESULT_U8 = 2 };
+int refvsr_conv_last_fmt(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
+                         void* out, int out_fmt, void* stream);
+int refvsr_conv_hr_last_fmt(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
+                            void* out, int out_fmt, void* stream);
+int refvsr_convert_result(const float* src, size_t n, int out_fmt, void* out, void* stream);
+
 /* The confidence fusions in ONE launch (ABI 10): conf_fusion / conf_fusion2 / conf_fusion_BWFW of RefVSR.py:47-52, called at
  * :130, :141-142 and :107-109 as  conv_{16->C}(lrelu(conv_{2->16}(cat[conf_a, conf_b])))  on the LR grid (up = 1) and on
  * clamp(F.interpolate(cat[conf_a, conf_b], scale_factor=2, mode='bicubic'), 0, 1) (up = 2).  conf_a / conf_b: planar fp32

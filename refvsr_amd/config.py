@@ -90,6 +90,7 @@ def base_config(project='', mode='', config_='', data='', LRS='', batch_size=8):
     c.compute_dtype = 'f16'     # storage/MFMA operand type of feature maps on the GPU
     c.overlap_streams = True    # forward-branch step on a side HIP stream, concurrent with the new frame's preparation
     c.fuse_resblocks = True     # conv-act-conv+residual pairs in one launch where the LDS budget allows
+    c.result_dtype = 'float32'  # 'float16' | 'uint8': the output head stores rint(255 v) itself (extension; host consumers quantise anyway)
     return c
 
 

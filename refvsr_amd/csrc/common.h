@@ -212,6 +212,15 @@ __device__ __forceinline__ float rv_bicubic_at(const float* __restrict__ s, int 
     return acc;
 }
 
+// ---- result formats of the output head (ABI 14, REFVSR_RESULT_*): one value v in [0, 1] of the planar [3][h][w] result at element e.
+// U8 = what the reference's consumers make of the fp32 frame on the CPU (evaluation/eval_qual_quan.py:117-119: cv2.imwrite of
+// output * 255 = saturate_cast<uchar>, round to nearest even): rint(v * 255) in fp32, the same two roundings.
+__device__ __forceinline__ void rv_store_result(void* out, const size_t e, const float v, const int fmt) {
+    if (fmt == REFVSR_RESULT_F32) reinterpret_cast<float*>(out)[e] = v;
+    else if (fmt == REFVSR_RESULT_F16) reinterpret_cast<f16*>(out)[e] = (f16)v;
+    else reinterpret_cast<unsigned char*>(out)[e] = (unsigned char)__float2int_rn(v * 255.0f);
+}
+
 // ---- K-block order of the MFMA convolutions (shared with refvsr_amd/packing.py:kslot) --------------------------
 // A K-block is one 16-byte channel group `cg` of one tap (ty, tx).  A wave's ds_read_b128 of the B operand is
 // served in four groups of 16 lanes, each mixing TWO adjacent K-blocks (q = 0|1 or 2|3, MI355X_MICROARCH.md

@@ -52,6 +52,7 @@ struct C24Args {
     // COUT = 3 (refvsr_conv_last): `out` is planar fp32 [3][h][w]; base_lr: the LR centre frame, planar fp32 [3][bh][bw], whose
     // bicubic up-sampling (clamped to [0, 1]) is added before the final clamp
     const float* base_lr; int bh, bw; float base_step;
+    int out_fmt;                                 // COUT = 3: REFVSR_RESULT_* of `out`
     // Multi-map launches (refvsr_*_batch, ABI 11): batch > 1 maps of one geometry share the launch and the weight fill; flat tile
     // index t = b * tpm + (tile of map b); map b's operands come from the tables (entry 0 == the scalar fields above, which stay
     // the "operand present" flags).  Not for the HALF variant.
@@ -438,7 +439,6 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
             // (ds_bpermute), evaluates ITS channel's bicubic sample (rv_bicubic_at: resize_kernel<BICUBIC>'s FMA chains) and stores one
             // value: 48 lanes x 4 bytes = three 64-byte row segments per group
             const size_t plane_o = (size_t)p.h * p.w, plane_b = (size_t)p.bh * p.bw;
-            float* op = reinterpret_cast<float*>(outp);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const f32x4 y = acc[0][t];
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(WPS, W
                 const int oy = ty0 + RW(t), ox = tx0 + CG(t) * 16 + lpe;
                 if (q < 3 && oy < p.h && ox < p.w) {
                     const float b = fminf(fmaxf(rv_bicubic_at(p.base_lr + q * plane_b, p.bh, p.bw, oy, ox, p.base_step, p.base_step), 0.0f), 1.0f);
-                    op[q * plane_o + (size_t)oy * p.w + ox] = fminf(fmaxf(v + b, 0.0f), 1.0f);
+                    rv_store_result(outp, q * plane_o + (size_t)oy * p.w + ox, fminf(fmaxf(v + b, 0.0f), 1.0f), p.out_fmt);
                 }
             }
         } else if constexpr (SHUF != 0) {
@@ -749,13 +749,20 @@ extern "C" int refvsr_conf_alpha_batch(const float* const* conf_a, const float* 
 // + refvsr_conv_mfma's planar mode: the 3-channel base never exists in HBM, one MFMA per K-step instead of two 16-row tiles.
 extern "C" int refvsr_conv_last_supported(int c) { return c == 24 || c == 48; }
 extern "C" int refvsr_conv_last_blob_bytes(int c) { return refvsr_conv_last_supported(c) ? c24_steps(c / 8) * 1024 + 128 : -1; }
+extern "C" int refvsr_conv_last_fmt(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
+                                    void* out, int out_fmt, void* stream);
 extern "C" int refvsr_conv_last(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
                                 float* out, void* stream) {
+    return refvsr_conv_last_fmt(src, c, h, w, blob, base_lr, bh, bw, out, REFVSR_RESULT_F32, stream);
+}
+extern "C" int refvsr_conv_last_fmt(const void* src, int c, int h, int w, const void* blob, const float* base_lr, int bh, int bw,
+                                    void* out, int out_fmt, void* stream) {
+    RV_CHECK(out_fmt >= REFVSR_RESULT_F32 && out_fmt <= REFVSR_RESULT_U8, "conv_last: unknown result format %d", out_fmt);
     RV_CHECK(refvsr_conv_last_supported(c), "conv_last: %d input channels not supported (24 | 48)", c);
     RV_CHECK(base_lr && bh > 0 && bw > 0 && h % bh == 0 && w % bw == 0 && h / bh == w / bw, "conv_last: base frame %dx%d does not divide the output %dx%d", bh, bw, h, w);
     C24Args a;
     if (c24_fill(a, "conv_last", c, src, nullptr, 0, h, w, blob, 1.0f, nullptr, nullptr, 1.0f, out)) return 1;
-    a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h;
+    a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h; a.out_fmt = out_fmt;
     hipStream_t st = (hipStream_t)stream;
     if (c == 24) return launch_c24<3, 3, 0, 8, 8, 4>(a, st);
     return launch_c24<3, 6, 0, 8, 8, 4>(a, st);

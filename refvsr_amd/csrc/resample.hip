@@ -484,3 +484,38 @@ extern "C" int refvsr_spynet_level_input(const float* ref, const float* supp, co
     RV_CHECK(ref && supp, "spynet_level_input: bad args");
     return refvsr_spynet_level_input_batch(&ref, &supp, 1, flow_prev, h, w, out8, flow_up, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// fp32 result -> fp16 | uint8 (REFVSR_RESULT_*, ABI 14): the conversion of the fused output heads (rv_store_result) for results that
+// come out of the generic head
+// ------------------------------------------------------------------------------------------------
+__global__ void convert_result_kernel(const float* __restrict__ src, size_t n, int fmt, void* __restrict__ out) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i0);
+        const float c[4] = {fminf(fmaxf(v.x, 0.f), 1.f), fminf(fmaxf(v.y, 0.f), 1.f), fminf(fmaxf(v.z, 0.f), 1.f), fminf(fmaxf(v.w, 0.f), 1.f)};
+        if (fmt == REFVSR_RESULT_F16) {
+            union { f16 h[4]; uint2 u; } o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.h[k] = (f16)c[k];
+            *reinterpret_cast<uint2*>(reinterpret_cast<f16*>(out) + i0) = o.u;
+        } else {
+            union { unsigned char b[4]; unsigned u; } o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.b[k] = (unsigned char)__float2int_rn(c[k] * 255.0f);
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(out) + i0) = o.u;
+        }
+    } else {
+        for (size_t i = i0; i < n; ++i) rv_store_result(out, i, fminf(fmaxf(src[i], 0.f), 1.f), fmt);
+    }
+}
+
+extern "C" int refvsr_convert_result(const float* src, size_t n, int out_fmt, void* out, void* stream) {
+    RV_CHECK(src && out && n > 0, "convert_result: bad args");
+    RV_CHECK(out_fmt == REFVSR_RESULT_F16 || out_fmt == REFVSR_RESULT_U8, "convert_result: format must be REFVSR_RESULT_F16 | REFVSR_RESULT_U8");
+    RV_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 7) == 0, "convert_result: src must be 16-byte, out 8-byte aligned");
+    const size_t nq = (n + 3) / 4;
+    hipLaunchKernelGGL(convert_result_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n, out_fmt, out);
+    RV_LAUNCH_CHECK();
+    return 0;
+}

@@ -64,6 +64,7 @@ struct RB24Args {
     int probe_iter;                      // which tile iteration of the workgroup is stamped
     // HEAD kernels (refvsr_conv_hr_last): `out` is planar fp32 [3][h][w]; base_lr = the LR centre frame, planar fp32 [3][bh][bw]
     const float* base_lr; int bh, bw; float base_step;
+    int out_fmt;                         // HEAD kernels: REFVSR_RESULT_* of `out` (planar [3][h][w])
     // Multi-map launches (refvsr_resblock24_chain_batch): batch > 1 maps of one geometry share the launch and the weight fill; the
     // flat tile index t = b * tpm + (tile of map b), map b reads bsrc[b] and writes bout[b].  batch <= 1: src / out above.
     int batch, tpm;
@@ -443,7 +444,6 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
             // clamp( conv_last + bias + clamp01(bicubic(lr_centre)), 0, 1 ) -> planar fp32: after the fold lane (0, n) holds the
             // three channel sums of pixel n, lane (q, n), q < 3, takes channel q and evaluates ITS channel's bicubic sample
             const size_t plane_o = (size_t)p.h * p.w, plane_b = (size_t)p.bh * p.bw;
-            float* op = reinterpret_cast<float*>(outp);
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
                 const f32x4 y = c0[t];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
                 const int oy = ty0 + oy0 + (t >> 1), ox = tx0 + (t & 1) * 16 + lpe;
                 if (q < 3 && oy < p.h && ox < p.w) {
                     const float b = fminf(fmaxf(rv_bicubic_at(p.base_lr + q * plane_b, p.bh, p.bw, oy, ox, p.base_step, p.base_step), 0.0f), 1.0f);
-                    op[q * plane_o + (size_t)oy * p.w + ox] = fminf(fmaxf(v + b, 0.0f), 1.0f);
+                    rv_store_result(outp, q * plane_o + (size_t)oy * p.w + ox, fminf(fmaxf(v + b, 0.0f), 1.0f), p.out_fmt);
                 }
             }
         } else if constexpr (STORE == 0) {
@@ -633,9 +633,18 @@ extern "C" int refvsr_resblock24_chain_batch(const void* const* src, int batch, 
 // src: fp16 HWC [h][w][24]; blob: REFVSR_RESBLOCK24_BLOB_BYTES in the block layout with conv1 = conv_hr and conv2's fragment slot
 // (s, 0) = [rows 0-2: hi(W_last), rows 8-10: lo(W_last)], slots (s, 1), (s, 2) zero, b1 = conv_hr's bias, b2 = [b_last, 0 ...]
 // (refvsr_amd/packing.py:pack_conv_hr_last).  The HR intermediate map (100 MB at 1080 x 1920) stays in LDS.
+extern "C" int refvsr_conv_hr_last_fmt(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
+                                       void* out, int out_fmt, void* stream);
 extern "C" int refvsr_conv_hr_last(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
                                    float* out, void* stream) {
+    return refvsr_conv_hr_last_fmt(src, h, w, blob, act_slope, base_lr, bh, bw, out, REFVSR_RESULT_F32, stream);
+}
+// ... with the result stored as fp32 | fp16 | uint8 = rint(255 v) (REFVSR_RESULT_*; ABI 14): host-side consumers quantise the frame to
+// 8 bits anyway (evaluation/eval_qual_quan.py:117-119), a quarter of the bytes leaves the device
+extern "C" int refvsr_conv_hr_last_fmt(const void* src, int h, int w, const void* blob, float act_slope, const float* base_lr, int bh, int bw,
+                                       void* out, int out_fmt, void* stream) {
     RV_CHECK(src && out && blob && base_lr && h > 0 && w > 0, "conv_hr_last: bad args");
+    RV_CHECK(out_fmt >= REFVSR_RESULT_F32 && out_fmt <= REFVSR_RESULT_U8, "conv_hr_last: unknown result format %d", out_fmt);
     RV_CHECK(((uintptr_t)blob & 15) == 0, "conv_hr_last: blob must be 16-byte aligned");
     RV_CHECK(act_slope > 0.f && act_slope <= 1.f, "conv_hr_last: activation slope must lie in (0, 1]");
     RV_CHECK(bh > 0 && bw > 0 && h % bh == 0 && w % bw == 0 && h / bh == w / bw, "conv_hr_last: base frame %dx%d does not divide the output %dx%d", bh, bw, h, w);
@@ -645,7 +654,7 @@ extern "C" int refvsr_conv_hr_last(const void* src, int h, int w, const void* bl
     memset(&a, 0, sizeof(a));
     a.h = h; a.w = w; a.act_slope = act_slope;
     a.src = (const unsigned char*)src; a.out = (unsigned char*)out; a.blob = (const unsigned char*)blob;
-    a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h;
+    a.base_lr = base_lr; a.bh = bh; a.bw = bw; a.base_step = (float)bh / (float)h; a.out_fmt = out_fmt;
     hipStream_t st = (hipStream_t)stream;
     const int nt8 = rv_cdiv(w, RB_TW) * rv_cdiv(h, 8);
     const int waves = g_rb24_waves == 8 || g_rb24_waves == 16 ? g_rb24_waves : (nt8 >= 4 * rv_stream_cus(st) ? 16 : 8);

@@ -222,6 +222,10 @@ class Engine(object):
         # P (per-frame preparation + flows); the caller's stream only receives the result
         self.pipelined = bool(getattr(config, 'pipelined', False))
         self._zero_maps = {}
+        # result format (round 6, extension; default 'float32' = the reference's): 'float16' | 'uint8' -- the output head stores
+        # rint(255 v) itself (REFVSR_RESULT_U8: the bytes eval_qual_quan.py:117-119 writes to the PNG), a quarter of the bytes to copy
+        self.result_dtype = str(getattr(config, 'result_dtype', None) or 'float32').replace('torch.', '')
+        ops.result_format(self.result_dtype)
         self._pipe = None
         # stream layout of the pipelined mode when nothing is configured: 'pf_m' for one forward() per frame (round 4); an engine that
         # is driven through forward_group switches to 'pfm' (P | F | M) at its first group: with the backward branches batched the
@@ -828,7 +832,7 @@ class Engine(object):
             if blob is None:
                 from .packing import pack_conv_hr_last
                 blob = self.W.chains['conv_hr_last_blob'] = pack_conv_hr_last(*self.cw('conv_hr').raw, *self.cw('conv_last').raw).to(out.device).contiguous()
-            return ops.conv_hr_last(blob, out, lr_center, act=0.1)
+            return ops.conv_hr_last(blob, out, lr_center, act=0.1, result_dtype=self.result_dtype)
         out = ops.conv(self.cw('conv_hr'), out, act=0.1)
         if self.fuse_head and ops.conv_last_ok(self.C, out.shape[0], out.shape[1]):
             # conv_last + the bicubic base + the clamps in one launch: the base map is evaluated per output value
@@ -836,9 +840,9 @@ class Engine(object):
             if blob is None:
                 from .packing import pack_conv_last
                 blob = self.W.chains['conv_last_blob'] = pack_conv_last(*self.cw('conv_last').raw).to(out.device).contiguous()
-            return ops.conv_last(blob, out, lr_center)
+            return ops.conv_last(blob, out, lr_center, result_dtype=self.result_dtype)
         base = ops.bicubic_scale(lr_center, self.cfg.scale, clamp01=True)
-        return ops.conv(self.cw('conv_last'), out, planar_out=True, res_planar=base, clamp=(0.0, 1.0))
+        return ops.convert_result(ops.conv(self.cw('conv_last'), out, planar_out=True, res_planar=base, clamp=(0.0, 1.0)), self.result_dtype)
 
     # ------------------------------------------------------------------ window bookkeeping
     def _frames(self, lrs, refs, frame_ids=None):

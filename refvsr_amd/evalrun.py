@@ -51,10 +51,14 @@ def read_frame(path):
 
 def write_frame(path, img, quality=None):
     from PIL import Image
-    a = (img.detach().float().cpu().clamp(0, 1).numpy().transpose(1, 2, 0) * 255.0)
-    # cv2.imwrite converts a float image with convertTo(CV_8U) = saturate_cast<uchar>: round to nearest, saturate
-    # (eval_qual_quan.py:117-119 hands it output*255 as float)
-    im = Image.fromarray(np.rint(a).clip(0, 255).astype(np.uint8))
+    if img.dtype == torch.uint8:
+        # config.result_dtype = 'uint8': the output head stored rint(255 x) itself (REFVSR_RESULT_U8) -- the bytes computed below
+        im = Image.fromarray(img.detach().cpu().numpy().transpose(1, 2, 0))
+    else:
+        a = (img.detach().float().cpu().clamp(0, 1).numpy().transpose(1, 2, 0) * 255.0)
+        # cv2.imwrite converts a float image with convertTo(CV_8U) = saturate_cast<uchar>: round to nearest, saturate
+        # (eval_qual_quan.py:117-119 hands it output*255 as float)
+        im = Image.fromarray(np.rint(a).clip(0, 255).astype(np.uint8))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     im.save(path, **({'quality': quality} if quality else {}))
 
@@ -156,7 +160,9 @@ def evaluate(config, net=None, log=print):
     st = {'clip_p': 0.0, 'clip_s': 0.0, 'clip_t': 0.0, 'clip_n': 0, 'first_line': True, 'prev': None}
 
     def emit(it, out, lr_c, dt):
-        out_cpu = out[0].float().cpu()
+        out_raw = out[0].cpu()
+        # (result_dtype 'uint8' / 'float16', extensions: the scores are then those of the quantised frame; the PNG bytes are the same)
+        out_cpu = out_raw.float() / 255.0 if out_raw.dtype == torch.uint8 else out_raw.float()
         p = s = 0.0
         if not getattr(E, 'qualitative_only', False):
             gt = it['HR_UW']
@@ -179,7 +185,7 @@ def evaluate(config, net=None, log=print):
             for fmt in ('png', 'jpg'):
                 base = os.path.join(out_root, fmt)
                 write_frame(os.path.join(base, 'input', it['video_name'], '%s.%s' % (stem, fmt)), lr_c)
-                write_frame(os.path.join(base, 'output', it['video_name'], '%s.%s' % (stem, fmt)), out_cpu)
+                write_frame(os.path.join(base, 'output', it['video_name'], '%s.%s' % (stem, fmt)), out_raw if out_raw.dtype == torch.uint8 else out_cpu)
         st['clip_p'] += p
         st['clip_s'] += s
         st['clip_t'] += dt
@@ -284,8 +290,12 @@ def build_config(argv=None):
     ap.add_argument('-ss', '--save_sample', action='store_true')
     ap.add_argument('--frame_group', type=int, default=1, help='extension: consecutive frames of a clip per network call (1 = the reference loop; 4 = '
                                                                 'multi-map launches of the backward branches, same results)')
+    ap.add_argument('--result_dtype', default='float32', choices=['float32', 'float16', 'uint8'],
+                    help="extension: what the output head stores ('uint8' = rint(255 x), the bytes of the written PNG; the scores are then "
+                         "those of the quantised frame)")
     args, _ = ap.parse_known_args(argv)
     cfg = get_config(args.project, args.mode, args.config, args.data)
+    cfg.result_dtype = args.result_dtype
     if args.network:
         cfg.network = args.network
     if args.frame_num:

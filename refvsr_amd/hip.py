@@ -11,8 +11,9 @@ LIB_PATH = os.path.join(_HERE, 'librefvsr_hip.so')
 
 OUT_NHWC16, OUT_NHWC16_SHUFFLE2, OUT_PLANAR32 = 0, 1, 2
 RS_BICUBIC, RS_BILINEAR, RS_BILINEAR_AC, RS_NEAREST = 0, 1, 2, 3
+RESULT_F32, RESULT_F16, RESULT_U8 = 0, 1, 2
 MATCH_KP, MATCH_ROWCHUNK, MATCH_COLBLOCK = 152, 256, 512
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_MAPS = 4
 RESBLOCK24_BLOB_BYTES = 43264
 RESBLOCK48_BLOB_BYTES = 172544
@@ -96,6 +97,9 @@ SIGNATURES = {
     'refvsr_conv_last_supported': [_I],          # returns 0 / 1
     'refvsr_conv_last_blob_bytes': [_I],         # returns the size
     'refvsr_conv_last': [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
+    'refvsr_conv_last_fmt': [_P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P],
+    'refvsr_conv_hr_last_fmt': [_P, _I, _I, _P, _F, _P, _I, _I, _P, _I, _P],
+    'refvsr_convert_result': [_P, _Z, _I, _P, _P],
     'refvsr_conf_alpha': [_P, _P, _I, _I, _I, _P, _P, _F, _P, _I, _F, _P, _P, _P],
     'refvsr_spynet_level_input_batch': [_P, _P, _I, _P, _I, _I, _P, _P, _P],
     # multi-map launches (ABI 11): host arrays of `batch` device pointers

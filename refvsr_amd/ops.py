@@ -433,28 +433,53 @@ def conf_alpha(conf_a, conf_b, up, w0, b0, cw, slope0=0.2, slope1=0.2, want_max=
     return (alpha, cmax) if want_max else alpha
 
 
-def conv_last(blob, src, base_lr):
-    """refvsr_conv_last: clamp(conv3x3_{C->3}(src) + bias + clamp01(bicubic(base_lr)), 0, 1) -> planar fp32 [3, h, w] in one launch.
+RESULT_DTYPES = {'float32': (torch.float32, hip.RESULT_F32), 'float16': (torch.float16, hip.RESULT_F16), 'uint8': (torch.uint8, hip.RESULT_U8)}
+
+
+def result_format(name):
+    """(torch dtype, REFVSR_RESULT_*) of config.result_dtype ('float32' | 'float16' | 'uint8'; None = 'float32')."""
+    key = str(name or 'float32').replace('torch.', '')
+    if key not in RESULT_DTYPES:
+        raise ValueError("result_dtype must be 'float32', 'float16' or 'uint8', got %r" % (name,))
+    return RESULT_DTYPES[key]
+
+
+def convert_result(x, result_dtype):
+    """fp32 result in [0, 1] -> fp16 | uint8 = rint(255 x) (refvsr_convert_result: what the fused heads store directly)."""
+    dt, fmt = result_format(result_dtype)
+    if fmt == hip.RESULT_F32:
+        return x
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=dt, device=x.device)
+    hip.check(hip.lib().refvsr_convert_result(_ptr(x), x.numel(), fmt, _ptr(out), _stream()), 'convert_result')
+    return out
+
+
+def conv_last(blob, src, base_lr, result_dtype=None):
+    """refvsr_conv_last: clamp(conv3x3_{C->3}(src) + bias + clamp01(bicubic(base_lr)), 0, 1) -> planar [3, h, w] in one launch (fp32, or
+    result_dtype = 'float16' | 'uint8': REFVSR_RESULT_*).
     blob: packing.pack_conv_last on the device; src nhwc16 [h, w, C]; base_lr planar fp32 [3, h / s, w / s]."""
     _nhwc(src)
     _planar(base_lr, 3)
     h, w, c = src.shape
     bh, bw = base_lr.shape[1:]
-    out = torch.empty((3, h, w), dtype=torch.float32, device=src.device)
-    hip.check(hip.lib().refvsr_conv_last(_ptr(src), c, h, w, _ptr(blob), _ptr(base_lr), bh, bw, _ptr(out), _stream()), 'conv_last')
+    dt, fmt = result_format(result_dtype)
+    out = torch.empty((3, h, w), dtype=dt, device=src.device)
+    hip.check(hip.lib().refvsr_conv_last_fmt(_ptr(src), c, h, w, _ptr(blob), _ptr(base_lr), bh, bw, _ptr(out), fmt, _stream()), 'conv_last')
     return out
 
 
-def conv_hr_last(blob, src, base_lr, act=0.1):
-    """refvsr_conv_hr_last: clamp(conv_last(lrelu(conv_hr(src))) + clamp01(bicubic(base_lr)), 0, 1) -> planar fp32 [3, h, w], one launch
-    (mid_channels = 24).  blob: packing.pack_conv_hr_last on the device."""
+def conv_hr_last(blob, src, base_lr, act=0.1, result_dtype=None):
+    """refvsr_conv_hr_last: clamp(conv_last(lrelu(conv_hr(src))) + clamp01(bicubic(base_lr)), 0, 1) -> planar [3, h, w], one launch
+    (mid_channels = 24; fp32, or result_dtype = 'float16' | 'uint8').  blob: packing.pack_conv_hr_last on the device."""
     _nhwc(src)
     _planar(base_lr, 3)
     h, w, c = src.shape
     assert c == 24 and blob.numel() == hip.RESBLOCK24_BLOB_BYTES
     bh, bw = base_lr.shape[1:]
-    out = torch.empty((3, h, w), dtype=torch.float32, device=src.device)
-    hip.check(hip.lib().refvsr_conv_hr_last(_ptr(src), h, w, _ptr(blob), act, _ptr(base_lr), bh, bw, _ptr(out), _stream()), 'conv_hr_last')
+    dt, fmt = result_format(result_dtype)
+    out = torch.empty((3, h, w), dtype=dt, device=src.device)
+    hip.check(hip.lib().refvsr_conv_hr_last_fmt(_ptr(src), h, w, _ptr(blob), act, _ptr(base_lr), bh, bw, _ptr(out), fmt, _stream()), 'conv_hr_last')
     return out
 
 

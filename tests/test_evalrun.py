@@ -103,6 +103,27 @@ def test_cli_end_to_end_on_gpu(dataset, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_result_dtype_uint8_writes_the_same_png_bytes(dataset, tmp_path):
+    """`--result_dtype uint8` (round 6): the output head stores rint(255 x) on the GPU, a quarter of the bytes crosses PCIe -- the PNG
+    files are byte-identical to the float32 run's (whose quantisation happens on the CPU, like eval_qual_quan.py:117-119)."""
+    from refvsr_amd import evalrun, get_config, make_state_dict
+    sd = make_state_dict(get_config('p', 'm', 'config_RefVSR_small_L1'), 1234)
+    ck = str(tmp_path / 'RefVSR_small_L1.pytorch')
+    torch.save(sd, ck)
+    res = {}
+    for dt in ('float32', 'uint8'):
+        cfg = _cfg(dataset, str(tmp_path / ('out_' + dt)), ['--ckpt_abs_name', ck, '--result_dtype', dt])
+        res[dt] = evalrun.evaluate(cfg, log=lambda *_: None)
+    assert res['float32']['frames'] == res['uint8']['frames'] == 6
+    for clip in ('0001', '0002'):
+        for fr in ('0000', '0001', '0002'):
+            a = open(os.path.join(res['float32']['output_root'], 'png', 'output', clip, fr + '.png'), 'rb').read()
+            b = open(os.path.join(res['uint8']['output_root'], 'png', 'output', clip, fr + '.png'), 'rb').read()
+            assert a == b, 'PNG %s/%s differs' % (clip, fr)
+    assert max(abs(p - q) for p, q in zip(res['float32']['psnr'], res['uint8']['psnr'])) < 0.05     # (scores of the 8-bit frame)
+
+
+@pytest.mark.gpu
 def test_cli_frame_groups_equal_the_reference_loop(dataset_long, tmp_path):
     """`--frame_group 4`: the CLI hands the network four consecutive windows of a clip per call (SRNet.forward_group) -- PSNR / SSIM
     of every frame, the score-file structure and the written PNGs equal the one-frame-per-call loop's."""

@@ -473,6 +473,38 @@ def test_phase_a_group_equals_phase_a(dev):
                 assert torch.equal(got[f], want[f]), '%s: frame %d of the grouped phase A differs (groups %s, split=%s)' % (name, f, plan, split)
 
 
+@pytest.mark.parametrize('name,size', [('config_RefVSR_small_L1', (64, 96)), ('config_RefVSR_MFID', (40, 56)), ('config_RefVSR_IR_L1', (64, 64))])
+def test_result_dtype_option(dev, name, size):
+    """config.result_dtype (round 6, extension; default float32 = the reference): 'uint8' = rint(255 x) of the fp32 result -- the bytes
+    the reference's consumer writes (evaluation/eval_qual_quan.py:117-119: cv2.imwrite(output * 255) = round to nearest even, saturate)
+    -- and 'float16' = the fp32 result rounded once, stored by the output head itself (the fused 24-channel tail, refvsr_conv_last for
+    48 channels, refvsr_convert_result behind the generic head of RefVSR_IR)."""
+    from refvsr_amd.synth import make_clip, window_indices
+    from refvsr_amd import ops
+    t, nfr = (5, 3) if 'IR' in name else (3, 3)                # (RefVSR_IR needs 64 x 64 frames and a window of five)
+    lr, rf, _ = make_clip(nfr, size[0], size[1], seed=21)
+    lr, rf = lr.to(dev), rf.to(dev)
+    outs = {}
+    for dt in ('float32', 'float16', 'uint8'):
+        from refvsr_amd import SRNet, get_config, make_state_dict
+        cfg = get_config('p', 'm', name)
+        cfg.frame_num, cfg.save_sample, cfg.result_dtype = t, False, dt
+        net = SRNet(cfg).to(dev).eval()
+        net.load_state_dict(make_state_dict(cfg, 1234))
+        outs[dt] = [net(lr[window_indices(f, nfr, t)][None], rf[window_indices(f, nfr, t)][None], f == 0)['result'].clone() for f in range(nfr)]
+    for f in range(nfr):
+        x = outs['float32'][f]
+        assert x.dtype == torch.float32 and outs['float16'][f].dtype == torch.float16 and outs['uint8'][f].dtype == torch.uint8
+        assert torch.equal(outs['float16'][f], x.half())
+        want = torch.from_numpy(np.rint(x.cpu().numpy() * np.float32(255.0)).clip(0, 255).astype(np.uint8))
+        assert torch.equal(outs['uint8'][f].cpu(), want), '%s frame %d: %d bytes differ' % (name, f, int((outs['uint8'][f].cpu() != want).sum()))
+    x = torch.rand(3, 37, 53, device=dev)                      # the stand-alone conversion, ragged size (tail path)
+    assert torch.equal(ops.convert_result(x, 'float16'), x.half())
+    assert torch.equal(ops.convert_result(x, 'uint8').cpu(), torch.from_numpy(np.rint(x.cpu().numpy() * np.float32(255.0)).astype(np.uint8)))
+    with pytest.raises(ValueError):
+        ops.result_format('int8')
+
+
 def test_streams_are_deterministic(dev):
     """Race detector: the same stream run ten times (default two-stream mode, clip edges with replicated frames,
     reset rollover; S and HD configurations) must give the same bits every time -- an unsynchronised cross-stream
