@@ -194,7 +194,6 @@ class Engine(object):
         self.rb48 = (bool(getattr(config, 'fuse_resblocks', True)) and not env_flag('REFVSR_NO_FUSE')
                      and not env_flag('REFVSR_NO_RB48'))                 # A/B knob: C = 48 blocks as two refvsr_conv48 launches (round 3)
         self.rb48_max_pixels = int(os.environ.get('REFVSR_RB48_MAX_PIXELS', str(540 * 960)))
-        self.pipe_restart = not env_flag('REFVSR_SERIAL_RESTART')         # A/B knob: roll-over restarts of a pipelined stream drain it and run on M (round 4)
         self.rb48_multimap = not env_flag('REFVSR_NO_RB48_MULTIMAP')      # A/B knob: frame groups of C = 48 run their blocks map by map
         # SPyNet levels up to this many pixels run their streamed convs with 16 output channels per workgroup (A/B knob; 0 = never)
         self.spynet_mt1_pixels = int(os.environ.get('REFVSR_SPYNET_MT1_PIXELS', str(72 * 120)))
@@ -917,8 +916,6 @@ class Engine(object):
                             141-155 frames/s (BENCH_r03: 140.9; profiles/r03_one_vs_two_m_streams.txt).  The fast mode of round 3 was
                             the one in which F and P happened to share a hardware queue, i.e. exactly this layout.
           'pfm'             round 3: P, F, M on three streams (kept for the A/B and the slow-mode reproduction)
-          'p_fm'            F on M's stream (one conv chain at a time; measured slower: the backward branch + forward step + upsampler
-                            in series are longer than a frame)
           'one'             P, F and M on ONE stream (measurement aid: bench.py times the multi-map launches of a group in it)
         Wider models (C = 48 / 36) additionally alternate two M streams (for mid_channels = 24 two M streams measured equal to one,
         209.5 / 210.2 vs 209.1 / 209.6 frames/s, profiles/r04_two_m_and_mfid_layout_ab.txt: no switch)."""
@@ -934,8 +931,8 @@ class Engine(object):
         layout = str(getattr(self.cfg, 'pipe_layout', None) or os.environ.get('REFVSR_PIPE_LAYOUT') or self._layout_default or
                      ('pfm' if (self.C == 24 and self.group_ok()) else 'pf_m'))
         if True:
-            if layout not in ('pf_m', 'pfm', 'p_fm', 'one'):
-                raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | p_fm | one, got %r' % layout)
+            if layout not in ('pf_m', 'pfm', 'one'):                 # ('p_fm', F on M's stream, measured slower in rounds 4-5: removed in round 6)
+                raise ValueError('REFVSR_PIPE_LAYOUT must be pf_m | pfm | one, got %r' % layout)
             two = self.C != 24
             split = str(getattr(self.cfg, 'cu_split', None) or os.environ.get('REFVSR_CU_SPLIT') or '')
             if split and layout in ('pfm', 'pf_m'):
@@ -954,50 +951,17 @@ class Engine(object):
                 two = False                           # around a run of launches then bracket nothing but that run
             m2 = torch.cuda.Stream(device=dev) if two else m
             p_ = m if layout == 'one' else torch.cuda.Stream(device=dev)
-            f_ = p_ if layout in ('pf_m', 'one') else (m if layout == 'p_fm' else torch.cuda.Stream(device=dev))
+            f_ = p_ if layout in ('pf_m', 'one') else torch.cuda.Stream(device=dev)
             self._pipe = [m, m2, f_, p_]
             self.pipe_layout = layout
             self._pipe_calls = 0
         return self._pipe
 
-    @torch.no_grad()
-    def _forward_pipelined(self, lrs, refs, is_first_frame, want_vis, frame_ids, input_ready=None):
-        """Same computation as _forward_seq, spread over three internal streams so that consecutive calls overlap:
-        P prepares the window's new frame and its flows while M is still walking the previous call's backward branch
-        and F its forward-branch step.  Dependencies are carried by HIP events (per-frame `ready`, per-flow, per-call
-        forward-branch result); every tensor that crosses streams is recorded on its consumers so the caching
-        allocator cannot recycle it early; the host may run at most two calls ahead of the GPU."""
-        t, _, h, w = lrs.shape
-        ctr, C, dev = t // 2, self.C, lrs.device
-        caller = torch.cuda.current_stream()
-        M0, M1, F_, P = self._pipe_streams(dev)
-        # the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch carries
-        # state): calls may alternate between two M streams; for mid_channels = 24 M0 is M1 by default (see _pipe_streams)
-        M, Mo = (M0, M1) if (self._pipe_calls & 1) == 0 else (M1, M0)
-        self._pipe_calls += 1
-        # the host may run at most pipe_depth calls ahead of the GPU (each call in flight holds its intermediates: ~0.3 GB at 270p).
-        # Depth 3 since round 4: with 2 the host had ~2.4 ms of slack when it issued a call (2.9 ms of host work per call against
-        # 5.3 ms of GPU work) and a 6 ms hiccup of the host -- a GC pass, a descheduled thread -- reached the GPU as a gap
-        # (profiles/r04_stream_layout_ab.txt: passes of 175 instead of 187 frames/s with unstretched stream sections).
-        while len(self._inflight) >= self.pipe_depth:
-            self._inflight.popleft().synchronize()
-        # reset_branch roll-over of a RUNNING stream (RefVSR.py:168-170): the call differs from a steady one only in its forward branch --
-        # t // 2 + 1 steps from zeros over the window's first frames instead of one step from the carried state (their contexts and flows
-        # are cached) -- so it stays on the three streams (`restart`): no drain of the calls in flight, no serial pass on M, no refill of the
-        # pipeline behind it (round 5, late: the serial restart cost a group-mode stream a tenth of its rate at reset_branch = 9).  A caller's
-        # first frame, a stream without a state and the gradio mode take the reference order on M as before.
-        restart = bool(not is_first_frame and self.fw_feat is not None and self.max_frame_itr_num is not None and
-                       self.frame_itr_num == self.max_frame_itr_num and not bool(self.cfg.EVAL.is_gradio) and self.pipe_restart)
-        if self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num and not restart:
-            is_first_frame = True
-        streams = []
-        for st in (M0, M1, F_, P):
-            if all(st is not s_ for s_ in streams):
-                streams.append(st)
-        # inputs: the internal streams read lrs / refs.  input_ready = 'materialised' (the caller asserts the tensors are final,
-        # e.g. a pre-loaded clip): no wait.  An event / stream: the internal streams wait for it (a producer on a copy stream keeps
-        # the calls pipelined).  None: wait for the caller's stream as it stands -- always safe, but the caller's stream also
-        # carries the wait for the previous call's result, so consecutive calls then overlap only inside a call.
+    def _pipe_inputs(self, tensors, input_ready, streams, caller):
+        """When the internal streams may read the inputs of a pipelined call.  input_ready = 'materialised' (the caller asserts the
+        tensors are final, e.g. a pre-loaded clip): no wait.  An event / stream: the internal streams wait for it (a producer on a copy
+        stream keeps the calls pipelined).  None: wait for the caller's stream as it stands -- always safe, but the caller's stream also
+        carries the wait for the previous call's result, so consecutive calls then overlap only inside a call."""
         if input_ready is None:
             input_ready = torch.cuda.Event()
             input_ready.record(caller)
@@ -1009,111 +973,48 @@ class Engine(object):
                     st.wait_event(input_ready)
         elif input_ready != 'materialised':
             raise ValueError("input_ready must be None, 'materialised', a torch.cuda.Event or a torch.cuda.Stream")
-        for st in streams:
-            lrs.record_stream(st)
-            refs.record_stream(st)
-        sev = self.stream_events                     # bench.py: per-call (start, end) HIP events of the P / F / M sections
-        mark = (lambda st: None) if sev is None else _timed_event
-        tev = {}
-        if is_first_frame or self.fw_feat is None or bool(self.cfg.EVAL.is_gradio):
-            # restart of the forward branch: run the reference order on M, after everything in flight
-            for st in (P, F_, Mo):
-                M.wait_stream(st)
-            with ops.on_stream(M):
-                out, vis = self._forward_seq(lrs, refs, is_first_frame, want_vis, frame_ids)
-            for st in (F_, P, Mo):
-                st.wait_stream(M)
-        else:
-            self._check_window(lrs, refs)
-            assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
-            share = (M0, M1, F_, P)
-            # ---- P: everything that is a function of single frames / frame pairs
-            with ops.on_stream(P):
-                tev['P0'] = mark(P)
-                n_ctx = next(_uid)
-                fr = self._frames(lrs, refs, frame_ids)            # new frames are cloned here, on P
-                for f in fr:
-                    if f.uid > n_ctx:
-                        for st in share:
-                            f.lr.record_stream(st)
-                            f.ref.record_stream(st)
-                for i in range(0 if restart else ctr, t):        # (restart: the forward branch walks the first frames too -- cached)
-                    f = fr[i]
-                    if f.conf is None:
-                        self.pyramid(f)
-                        self.prepare_frame(f)
-                        if i == t - 1 and self.bw_head_blocks >= 0:
-                            zf = self._zeros((h, w, self._state_cs()), torch.float16, dev)
-                            f.bw_head = (self.bw_head_blocks, self.resblocks(f.lr8, zf, 'backward_resblocks', stop=self.bw_head_blocks))
-                            for st in share:
-                                f.bw_head[1].record_stream(st)
-                        for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
-                            for st in share:
-                                x.record_stream(st)
-                        f.ready = torch.cuda.Event()
-                        f.ready.record()
-                    else:
-                        if f.pyr is None:
-                            self.pyramid(f)
-                        if f.ready is None:      # prepared on M by a first-frame call: make it safe on F and P too
-                            for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
-                                for st in share:
-                                    x.record_stream(st)
-                # the window's new flows in one batched SPyNet pass: the backward flows and the forward flow of this call
-                need = [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
-                if restart:
-                    need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]           # forward flows of the first frames (cached pairs cost nothing)
-                self.flows(need, share)
-                bw_flows = {i: self.flow(fr[i], fr[i + 1], share) for i in range(ctr, t - 1)}
-                tev['P1'] = mark(P)
-            # ---- F: forward-branch step (state of the previous call, cached frames)
-            with ops.on_stream(F_):
-                tev['F0'] = mark(F_)
-                for f in (fr[:ctr + 2] if restart else (fr[ctr], fr[ctr + 1])):
-                    if f.ready is not None:
-                        F_.wait_event(f.ready)
-                for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
-                    x.record_stream(F_)
-                flow_f = lambda a, b: self.flow(fr[a], fr[b], share)
-                fw = self._forward_branch(fr, flow_f, t, h, w, restart)
-                for x in fw:
-                    x.record_stream(M0)
-                    x.record_stream(M1)
-                ev_fw = torch.cuda.Event(enable_timing=sev is not None)
-                ev_fw.record()
-                tev['F1'] = ev_fw
-            # ---- M: backward branch + upsampler
-            with ops.on_stream(M):
-                tev['M0'] = mark(M)
-                cs_ = self._state_cs()
-                feat = self._zeros((h, w, cs_), torch.float16, dev)
-                feat_up = self._zeros((2 * h, 2 * w, cs_), torch.float16, dev)
-                conf = self._zeros((1, h, w), torch.float32, dev)
-                for i in range(t - 1, ctr - 1, -1):
-                    if fr[i].ready is not None:
-                        M.wait_event(fr[i].ready)
-                    fl = None
-                    if i < t - 1:
-                        fl = self.flow(fr[i], fr[i + 1], share)          # cached by P above: waits on its event
-                    feat, feat_up, conf = self._prop_step(fr[i], 'backward_resblocks', feat, feat_up, conf, fl)
-                M.wait_event(ev_fw)
-                out = self.compute_up(feat_up, fw[1], conf, fw[2], fr[ctr].lr)
-                vis = None
-                if want_vis:
-                    vis = collections.OrderedDict()
-                    vis['conf_map'] = fr[ctr].conf
-                    vis['conf_map_prop'] = ops.max2(conf, fw[2])
-                    vis['conf_map_prop_backward'] = conf
-                    vis['conf_map_prop_forward'] = fw[2]
-            del bw_flows
-            if restart:                                                             # RefVSR.py:292-295
-                self.frame_itr_num = 0
-            self.frame_itr_num += 1
-        done = torch.cuda.Event(enable_timing=sev is not None)
+        for x in tensors:
+            for st in streams:
+                x.record_stream(st)
+
+    @torch.no_grad()
+    def _forward_pipelined(self, lrs, refs, is_first_frame, want_vis, frame_ids, input_ready=None):
+        """Same computation as _forward_seq, spread over the internal streams so that consecutive calls overlap: P prepares the
+        window's new frame and its flows while M is still walking the previous call's backward branch and F its forward-branch step.
+        Round 6: a steady call IS a frame group of one window (_forward_group_pipelined: one implementation of the P | F | M schedule
+        for one window per call, B windows per call and -- forward_multi -- n samples per call); only calls that restart the forward
+        branch from a caller's first frame (or without a carried state, or in the gradio mode) take the reference order on M here."""
+        dev = lrs.device
+        # reset_branch roll-over of a RUNNING stream (RefVSR.py:168-170): the call differs from a steady one only in its forward branch --
+        # t // 2 + 1 steps from zeros over the window's first frames instead of one step from the carried state (their contexts and flows
+        # are cached) -- so it stays on the three streams (`rst` in _forward_group_pipelined): no drain of the calls in flight, no serial
+        # pass on M, no refill of the pipeline behind it.  A caller's first frame, a stream without a state and the gradio mode take the
+        # reference order on M.
+        steady = bool(not is_first_frame and self.fw_feat is not None and not bool(self.cfg.EVAL.is_gradio))
+        if steady:
+            outs, vis = self._forward_group_pipelined([(lrs, refs, frame_ids)], input_ready, want_vis)
+            return outs[0], vis
+        caller = torch.cuda.current_stream()
+        M0, M1, F_, P = self._pipe_streams(dev)
+        M, Mo = (M0, M1) if (self._pipe_calls & 1) == 0 else (M1, M0)
+        self._pipe_calls += 1
+        while len(self._inflight) >= self.pipe_depth:
+            self._inflight.popleft().synchronize()
+        streams = []
+        for st in (M0, M1, F_, P):
+            if all(st is not s_ for s_ in streams):
+                streams.append(st)
+        self._pipe_inputs((lrs, refs), input_ready, streams, caller)
+        # restart of the forward branch: run the reference order on M, after everything in flight
+        for st in (P, F_, Mo):
+            M.wait_stream(st)
+        with ops.on_stream(M):
+            out, vis = self._forward_seq(lrs, refs, True if (self.max_frame_itr_num is not None and self.frame_itr_num == self.max_frame_itr_num)
+                                         else is_first_frame, want_vis, frame_ids)
+        for st in (F_, P, Mo):
+            st.wait_stream(M)
+        done = torch.cuda.Event()
         done.record(M)
-        if sev is not None and tev:
-            tev['M1'] = done
-            sev.append(tev)
         caller.wait_event(done)
         out.record_stream(caller)
         if vis:
@@ -1267,14 +1168,12 @@ class Engine(object):
                 # the longest run of steady windows from i on (the iteration counter advances by one per window)
                 j = i
                 if self.group_ok() and self.pipelined and self.fw_feat is not None and not (i == 0 and is_first_frame):
-                    # (a roll-over window stays inside the group: only its forward branch is the long one, `restart` in
-                    #  _forward_group_pipelined; with REFVSR_SERIAL_RESTART=1 it ends the run and goes through forward() alone)
-                    while (j < len(wins) and j - i < ops.hip.MAX_MAPS and
-                           (self.pipe_restart or self.max_frame_itr_num is None or
-                            self._itr_after(j - i) != self.max_frame_itr_num)):
+                    # (a roll-over window stays inside the group: only its forward branch is the long one, `rst` in
+                    #  _forward_group_pipelined)
+                    while j < len(wins) and j - i < ops.hip.MAX_MAPS:
                         j += 1
                 if j - i >= 2:
-                    res = self._forward_group_pipelined(wins[i:j], input_ready)
+                    res, _ = self._forward_group_pipelined(wins[i:j], input_ready)
                     outs[i:j] = res
                     i = j
                 else:
@@ -1283,7 +1182,12 @@ class Engine(object):
                     i += 1
         return outs
 
-    def _forward_group_pipelined(self, wins, input_ready):
+    def _forward_group_pipelined(self, wins, input_ready, want_vis=False):
+        """B >= 1 steady windows of this stream on the internal streams (the ONE implementation of the P | F | M schedule, round 6):
+        P prepares the windows' new frames and flows, F walks the B forward-branch steps frame by frame, M the B backward branches --
+        multi-map launches for B >= 2, the single-map launch list for B = 1 (one forward() per frame: the first layers of its backward
+        branch, a function of the new frame alone, run with the frame's preparation on P: `bw_head_blocks`) -- then the upsamplers.
+        Returns (results, vis of the single window or None)."""
         B = len(wins)
         t, _, h, w = wins[0][0].shape
         ctr, dev = t // 2, wins[0][0].device
@@ -1296,31 +1200,23 @@ class Engine(object):
         rst = [bool(self.max_frame_itr_num is not None and self._itr_after(b) == self.max_frame_itr_num) for b in range(B)]
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
-        M = M0          # (two M streams alternating between groups: 210.5 vs 220.4 frames/s, profiles/r05_group_knobs_ab.txt)
+        # B = 1: the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch carries
+        # state): calls alternate between the two M streams of the wider models (mid_channels = 24: M0 is M1, see _pipe_streams).
+        # Groups stay on one (two M streams alternating between groups: 210.5 vs 220.4 frames/s, profiles/r05_group_knobs_ab.txt)
+        M = M0 if (B > 1 or (self._pipe_calls & 1) == 0) else M1
         self._pipe_calls += 1
         self._await_fw_up(self.fw_feat_up)
-        while len(self._inflight) >= max(1, self.pipe_depth - 1):          # (a group in flight holds B calls' worth of intermediates)
+        # the host may run at most pipe_depth calls ahead of the GPU (each call in flight holds its intermediates: ~0.3 GB at 270p; a
+        # group holds B calls' worth).  Depth 3 since round 4: with 2 the host had ~2.4 ms of slack when it issued a call and a 6 ms
+        # hiccup of the host reached the GPU as a gap (profiles/r04_stream_layout_ab.txt)
+        while len(self._inflight) >= (self.pipe_depth if B == 1 else max(1, self.pipe_depth - 1)):
             self._inflight.popleft().synchronize()
         streams = []
         for st in (M0, M1, F_, P):
             if all(st is not s_ for s_ in streams):
                 streams.append(st)
-        if input_ready is None:
-            input_ready = torch.cuda.Event()
-            input_ready.record(caller)
-        if not isinstance(input_ready, str):
-            for st in streams:
-                if isinstance(input_ready, torch.cuda.Stream):
-                    st.wait_stream(input_ready)
-                else:
-                    st.wait_event(input_ready)
-        elif input_ready != 'materialised':
-            raise ValueError("input_ready must be None, 'materialised', a torch.cuda.Event or a torch.cuda.Stream")
-        for lrs, refs, _ in wins:
-            for st in streams:
-                lrs.record_stream(st)
-                refs.record_stream(st)
-        sev = self.stream_events
+        self._pipe_inputs([x for lrs, refs, _ in wins for x in (lrs, refs)], input_ready, streams, caller)
+        sev = self.stream_events                     # bench.py: per-call (start, end) HIP events of the P / F / M sections
         mark = (lambda st: None) if sev is None else _timed_event
         tev = {'n': B}
         share = (M0, M1, F_, P)
@@ -1329,11 +1225,11 @@ class Engine(object):
             for x in [f.lr, f.ref, f.lr8, f.conf, f.idx, f.aligned, f.aligned_up] + list(f.pyr):
                 for st in share:
                     x.record_stream(st)
-        # ---- P: everything that is a function of single frames / frame pairs, for all windows of the group
+        # ---- P: everything that is a function of single frames / frame pairs, for all windows of the call
         with ops.on_stream(P):
             tev['P0'] = mark(P)
             n_ctx = next(_uid)
-            frs = self._frames_group(wins)
+            frs = self._frames_group(wins)                        # new frames are cloned here, on P
             for fr in frs:
                 for f in fr:
                     if f.uid > n_ctx:
@@ -1346,6 +1242,12 @@ class Engine(object):
                     if f.conf is None:
                         self.pyramid(f)
                         self.prepare_frame(f)
+                        if B == 1 and i == t - 1 and self.bw_head_blocks >= 0:
+                            # (a group's own preparation computes no backward head: its whole first step is cheaper as multi-map launches)
+                            zf = self._zeros((h, w, self._state_cs()), torch.float16, dev)
+                            f.bw_head = (self.bw_head_blocks, self.resblocks(f.lr8, zf, 'backward_resblocks', stop=self.bw_head_blocks))
+                            for st in share:
+                                f.bw_head[1].record_stream(st)
                         publish(f)
                         f.ready = torch.cuda.Event()
                         f.ready.record()
@@ -1354,12 +1256,13 @@ class Engine(object):
                             self.pyramid(f)
                         if f.ready is None:          # prepared on M by a first-frame call: make it safe on the other streams too
                             publish(f)
+            # the call's new flows in batched SPyNet passes: the backward flows and the forward flow of every window
             need = []
             for b, fr in enumerate(frs):
                 need += [(fr[i], fr[i + 1]) for i in range(ctr, t - 1)] + [(fr[ctr + 1], fr[ctr])]
                 if rst[b]:
-                    need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]
-            self.flows(need, share)
+                    need += [(fr[i], fr[i - 1]) for i in range(1, ctr + 1)]           # forward flows of the first frames (cached pairs cost nothing)
+            held = self.flows(need, share)                        # (kept until the end of the issue: the cache may trim them)
             tev['P1'] = mark(P)
         # ---- F: the forward-branch steps, one frame after the other (the carried state)
         fws, ev_fw = [], []
@@ -1380,8 +1283,8 @@ class Engine(object):
                 fws.append(fw)
                 ev_fw.append(e)
             tev['F1'] = ev_fw[-1]
-        # ---- M: the B backward branches step by step as multi-map launches, then the upsamplers
-        outs = []
+        # ---- M: the B backward branches step by step (B >= 2: multi-map launches), then the upsamplers
+        outs, vis = [], None
         with ops.on_stream(M):
             tev['M0'] = mark(M)
             cs_ = self._state_cs()
@@ -1396,11 +1299,22 @@ class Engine(object):
                 fls = None
                 if i < t - 1:
                     fls = [self.flow(fr[i], fr[i + 1], share) for fr in frs]         # cached by P above: waits on its event
-                feats, feat_ups, confs = self._prop_step_b(fs, 'backward_resblocks', feats, feat_ups, confs, fls)
+                if B == 1:
+                    f1, u1, c1 = self._prop_step(fs[0], 'backward_resblocks', feats[0], feat_ups[0], confs[0], None if fls is None else fls[0])
+                    feats, feat_ups, confs = [f1], [u1], [c1]
+                else:
+                    feats, feat_ups, confs = self._prop_step_b(fs, 'backward_resblocks', feats, feat_ups, confs, fls)
             for b, fr in enumerate(frs):
                 M.wait_event(ev_fw[b])
                 outs.append(self.compute_up(feat_ups[b], fws[b][1], confs[b], fws[b][2], fr[ctr].lr))
-        self.frame_itr_num = self._itr_after(B)                       # (+ B, through the roll-overs inside the group)
+            if want_vis and B == 1:
+                vis = collections.OrderedDict()
+                vis['conf_map'] = frs[0][ctr].conf
+                vis['conf_map_prop'] = ops.max2(confs[0], fws[0][2])
+                vis['conf_map_prop_backward'] = confs[0]
+                vis['conf_map_prop_forward'] = fws[0][2]
+        del held
+        self.frame_itr_num = self._itr_after(B)                       # (+ B, through the roll-overs inside the group; RefVSR.py:292-295)
         done = torch.cuda.Event(enable_timing=sev is not None)
         done.record(M)
         if sev is not None:
@@ -1409,8 +1323,11 @@ class Engine(object):
         caller.wait_event(done)
         for o in outs:
             o.record_stream(caller)
+        if vis:
+            for v in vis.values():
+                v.record_stream(caller)
         self._inflight.append(done)
-        return outs
+        return outs, vis
 
     # ------------------------------------------------------------------ n > 1: the samples of a batch as multi-map launches (round 5)
     # The n samples of a call (lrs [n,t,3,h,w], RefVSR.py:151) are n independent streams over identical weights: in steady state the

@@ -362,9 +362,9 @@ def test_pipelined_mode_is_bit_identical(dev):
     ref_net, _, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
     want = [ref_net(wl[f], wr[f], f == 0)['result'].clone() for f in range(nfr)]
     # every stream layout (round 4 default 'pf_m': preparation + forward step on one stream, backward branch + upsampler on the
-    # other; 'pfm': round 3's three streams; 'p_fm') x every way of saying when the inputs are final
+    # other; 'pfm': three streams) x every way of saying when the inputs are final
     side = torch.cuda.Stream(device=dev)
-    for rep, (layout, ready) in enumerate([('pf_m', 'materialised'), ('pf_m', None), ('pfm', 'materialised'), ('p_fm', 'materialised'),
+    for rep, (layout, ready) in enumerate([('pf_m', 'materialised'), ('pf_m', None), ('pfm', 'materialised'), ('pfm', None),
                                            ('pf_m', 'event'), ('pf_m', 'stream')]):
         net, cfg_, _ = make_net('config_RefVSR_small_L1', t, dev, reset=4, save_sample=False)
         cfg_.pipe_layout = layout
