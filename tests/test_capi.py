@@ -156,3 +156,19 @@ def test_multimap_entry_points_validate_before_device_work(libpath):
     expect(h.refvsr_warp_nhwc16_up2_batch(five, 5, 8, 8, 24, five, 8, 8, five, None), '(map, flow) pairs per launch')
     expect(h.refvsr_warp_planar_batch(arr(at(0), P(0)), 2, 1, 8, 8, s2, 8, 8, o2, None), 'null pointer (pair 1)')
 
+
+
+def test_cu_budget_argument_checks_and_constants(libpath):
+    """ABI 13 / 14 host-side contracts that need no GPU: REFVSR_MAX_MAPS of the library equals the binding's copy (checked at load
+    time too), the CU-budget setter validates before any device work, the result-format enum of the header equals the binding's."""
+    from refvsr_amd import hip
+    h = hip.lib()
+    assert h.refvsr_max_maps() == hip.MAX_MAPS == 4
+    src = open(os.path.join(ROOT, 'include', 'refvsr_hip.h')).read()
+    assert re.search(r'REFVSR_RESULT_F32 = 0, REFVSR_RESULT_F16 = 1, REFVSR_RESULT_U8 = 2', src)
+    assert (hip.RESULT_F32, hip.RESULT_F16, hip.RESULT_U8) == (0, 1, 2)
+    assert h.refvsr_stream_set_cu_budget(ctypes.c_void_p(0x1000), 12) != 0 and b'multiple of 8' in h.refvsr_last_error()
+    assert h.refvsr_stream_set_cu_budget(ctypes.c_void_p(0x1000), -8) != 0
+    assert h.refvsr_stream_set_cu_budget(ctypes.c_void_p(0x1000), 0) == 0        # forgetting an unknown stream is not an error
+    assert h.refvsr_convert_result(None, 16, hip.RESULT_U8, None, None) != 0 and b'bad args' in h.refvsr_last_error()
+    assert h.refvsr_stream_destroy(None) != 0

@@ -331,6 +331,49 @@ def test_conv_mfma_persistent_tile_walk(dev, cap):
         assert err < 1e-3
 
 
+def test_cu_masked_streams_do_not_change_results(dev):
+    """CU partitions (ABI 13): a stream bound to CUs [first, first + n) -- refvsr_stream_create_cu_range over
+    hipExtStreamCreateWithCUMask -- on which the persistent launchers size their grids for n CUs: the fused block chain (single- and
+    four-map launches), a resident and a streamed conv and the matching GEMM give the results of the default stream, bit for bit,
+    on two disjoint partitions at once and on a partition of 8 CUs (one per XCD)."""
+    g = torch.Generator().manual_seed(31)
+    C, n, h, w = 24, 6, 70, 100
+    raw = []
+    for _ in range(n):
+        ws = [torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5 * 0.5 for _ in range(2)]
+        raw.append(((ws[0], torch.randn(C, generator=g) * 0.1), (ws[1], torch.randn(C, generator=g) * 0.1)))
+    ch = ops.Resblock24Chain(raw, dev)
+    xs = [ops.pack_nhwc16(torch.randn(C, h, w, generator=g).to(dev)) for _ in range(4)]
+    cw7 = ops.ConvWeights(pack_conv(torch.randn(32, 64, 7, 7, generator=g) * 0.02, torch.zeros(32), [64], False), dev)     # streamed weights
+    x64 = ops.pack_nhwc16(torch.randn(64, 40, 56, generator=g).to(dev))
+    lr_rows, _ = ops.match_patches(torch.randn(16, 32, 48, generator=g).to(dev), 512)
+    ref_rows, _ = ops.match_patches(torch.randn(16, 16, 24, generator=g).to(dev), 256)
+
+    def work():
+        return (ops.resblock24_chain(ch, xs[0], 0.0), ops.resblock24_chain_b(ch, xs, 0.2), ops.conv(cw7, x64, act=0.0),
+                ops.match_top2(ref_rows, 16 * 24, lr_rows, 32 * 48, 1))
+    want = work()
+    total = ops.num_cus()
+    assert total % 8 == 0 and total >= 64
+    half = total // 2 // 8 * 8
+    sa, sb, s8 = ops.CuStream(0, half, dev), ops.CuStream(half, total - half, dev), ops.CuStream(8, 8, dev)
+    outs = []
+    for st in (sa, sb, s8):
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with ops.on_stream(st):
+            outs.append(work())
+    torch.cuda.synchronize()
+    for got in outs:
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        assert torch.equal(got[3][0], want[3][0]) and torch.equal(got[3][1], want[3][1])
+    lib = hip.lib()
+    import ctypes as C_
+    assert lib.refvsr_stream_set_cu_budget(C_.c_void_p(sa.cuda_stream), 12) != 0                  # not a multiple of 8
+    assert lib.refvsr_stream_set_cu_budget(C_.c_void_p(sa.cuda_stream), total + 8) != 0
+    out = C_.c_void_p(0)
+    assert lib.refvsr_stream_create_cu_range(4, 8, C_.byref(out)) != 0 and b'multiple-of-8' in lib.refvsr_last_error()
+
+
 def test_conv_mfma_gather_mode_strided(dev):
     """5x5 stride-4 / stride-8 offset predictors of the HD configs (alignment.py:20): the staged tile cannot fit
     LDS, the kernel switches to gathering B fragments from global memory."""
