@@ -763,25 +763,33 @@ def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3
     cp = torch.cuda.Stream(dev)
     G = max(1, G)
 
+    def load(f, f1):
+        """Host -> device copies of the windows of the call that starts at frame f, on the copy stream; returns what the call needs."""
+        n = min(G, f1 - f)
+        with torch.cuda.stream(cp):
+            if frames_once:
+                for b in range(n):
+                    for j, i in enumerate(wins[f + b]):
+                        if i not in table:
+                            table[i] = (h_lr[f + b, j].to(dev, non_blocking=True), h_rf[f + b, j].to(dev, non_blocking=True))
+                lr_d = torch.stack([torch.stack([table[i][0] for i in wins[f + b]], 0) for b in range(n)], 0)
+                rf_d = torch.stack([torch.stack([table[i][1] for i in wins[f + b]], 0) for b in range(n)], 0)
+                for i in [k for k in table if k < wins[f][0]]:
+                    del table[i]
+            else:
+                lr_d = h_lr[f:f + n].to(dev, non_blocking=True)
+                rf_d = h_rf[f:f + n].to(dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(cp)
+        return n, lr_d, rf_d, ready
+
     def run(f0, f1):
+        # a double-buffered loader: the copies of call k + 1 are issued BEFORE call k (they never queue behind a wait for a result)
         f = f0
+        nxt = load(f, f1)
         while f < f1:
-            n = min(G, f1 - f)
-            with torch.cuda.stream(cp):
-                if frames_once:
-                    for b in range(n):
-                        for j, i in enumerate(wins[f + b]):
-                            if i not in table:
-                                table[i] = (h_lr[f + b, j].to(dev, non_blocking=True), h_rf[f + b, j].to(dev, non_blocking=True))
-                    lr_d = torch.stack([torch.stack([table[i][0] for i in wins[f + b]], 0) for b in range(n)], 0)
-                    rf_d = torch.stack([torch.stack([table[i][1] for i in wins[f + b]], 0) for b in range(n)], 0)
-                    for i in [k for k in table if k < wins[f][0]]:
-                        del table[i]
-                else:
-                    lr_d = h_lr[f:f + n].to(dev, non_blocking=True)
-                    rf_d = h_rf[f:f + n].to(dev, non_blocking=True)
-                ready = torch.cuda.Event()
-                ready.record(cp)
+            n, lr_d, rf_d, ready = nxt
+            nxt = load(f + n, f1) if f + n < f1 else None
             ids = [[start + i for i in wins[f + b]] for b in range(n)]
             if n >= 2:
                 res = net.forward_group(lr_d, rf_d, ids, is_first_frame=(f == 0), input_ready=ready)['result']

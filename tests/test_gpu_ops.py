@@ -336,6 +336,8 @@ def test_cu_masked_streams_do_not_change_results(dev):
     hipExtStreamCreateWithCUMask -- on which the persistent launchers size their grids for n CUs: the fused block chain (single- and
     four-map launches), a resident and a streamed conv and the matching GEMM give the results of the default stream, bit for bit,
     on two disjoint partitions at once and on a partition of 8 CUs (one per XCD)."""
+    from refvsr_amd import hip, ops
+    from refvsr_amd.packing import pack_conv
     g = torch.Generator().manual_seed(31)
     C, n, h, w = 24, 6, 70, 100
     raw = []
