@@ -1326,7 +1326,7 @@ def main():
                     traffic = tj.get('resblock LR x%d maps' % maps_per_launch) if maps_per_launch > 1 else tj.get('resblock LR')
                     if traffic is None and maps_per_launch > 1 and tj.get('resblock LR'):
                         traffic = tj['resblock LR'] * maps_per_launch
-                    tsrc = 'STATIC: profiles/pmc_kernels.json of commit 5a591e3 (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_kernels.py; kernel unchanged since), not measured in this run'
+                    tsrc = 'STATIC: profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE in separate passes on tools/pmc_kernels.py; re-measured on the round-6 tree, tools/gpu_runs/r6_call8.sh, raw counters profiles/r06_pmc_kernels_*.csv), not measured in this run'
                 except Exception:  # noqa: BLE001
                     traffic = None
             # Both roofs.  Algorithmic bytes per launch = every map read once + written once (fp16 HWC, 48 bytes per
@@ -1369,7 +1369,7 @@ def main():
             if os.path.exists(pj) and (n_lr, n_ref) == (129600, 32400):   # HBM bytes per launch from the PMC passes; not live
                 try:
                     traffic = json.load(open(pj))['traffic_bytes_per_launch']
-                    tsrc = 'STATIC: profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; kernel unchanged since), not measured in this run'
+                    tsrc = 'STATIC: profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; re-measured on the round-6 tree, tools/gpu_runs/r6_call8.sh), not measured in this run'
                 except Exception:  # noqa: BLE001
                     traffic = None
             mbytes = (n_lr + n_ref) * 304.0 + n_lr * 16.0            # fp16 rows of 152 halfs, read once; top-2 (index, value) written

@@ -22,6 +22,8 @@ frame_itr_num -- RefVSR.py:96-101,279-283).  The backward branch restarts from z
 export_state/import_state), so the protocols are tested on CPU with the gloo backend and the oracle as
 executor, and on one GPU with two processes and the real engine.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -895,8 +897,7 @@ class EngineExecutor(object):
         self._ctx_spec = None
         # round 6: phase-A groups with the preparation on lane a and the backward chains (+ the upsamplers) on a third lane, like a
         # frame group's P | M sections (REFVSR_SHARD_SPLIT_A=0: the whole phase A on lane a, the A/B)
-        import os as _os
-        self.split_phase_a = bool(split_phase_a) and _os.environ.get('REFVSR_SHARD_SPLIT_A', '1') != '0' and self.eng.group_ok()
+        self.split_phase_a = bool(split_phase_a) and os.environ.get('REFVSR_SHARD_SPLIT_A', '1') != '0' and self.eng.group_ok()
 
     def _streams(self):
         """(lane a = P: per-frame preparation, flows, context messages | lane b = F: the B1 chain + hand-off | comm | lane c = M: the
