@@ -189,6 +189,44 @@ def test_refvsr_ir_pipelined_equals_sequential(dev):
         assert net.Network.frame_itr_num == seq.Network.frame_itr_num
 
 
+def test_refvsr_ir_never_takes_the_group_or_multi_path(dev):
+    """frame groups, phase-A groups and the n > 1 multi-map path are schedules of RefVSR's propagation -- an IR engine must
+    not take them whatever its mid_channels (a 24- or 48-channel IR config used to pass Engine.group_ok's channel test).
+    EngineIR.group_ok() is False; forward_group, phase_a_group and an n = 2 call run EngineIR.forward per window / sample and equal
+    the per-frame calls."""
+    from refvsr_amd import SRNet, get_config, make_state_dict
+    from refvsr_amd.synth import make_clip, window_indices
+    nfr, t = 5, 5
+    lr, rf, _ = make_clip(nfr, 64, 64, seed=33)
+    lr, rf = lr.to(dev), rf.to(dev)
+    wins = [window_indices(f, nfr, t) for f in range(nfr)]
+    for C in (24, 36):
+        cfg = get_config('p', 'm', 'config_RefVSR_IR_L1')
+        cfg.frame_num, cfg.save_sample, cfg.mid_channels = t, False, C
+        sd = make_state_dict(cfg, 1234)
+        nets = []
+        for _ in range(2):
+            n_ = SRNet(cfg).to(dev).eval()
+            n_.load_state_dict(sd)
+            nets.append(n_)
+        ref_net, net = nets
+        want = [ref_net(lr[w][None], rf[w][None], f == 0, frame_ids=w)['result'].clone() for f, w in enumerate(wins)]
+        net.Network.set_pipelined(True)
+        eng = net.Network.ensure_engines(1, dev)[0]
+        assert type(eng).__name__ == 'EngineIR' and eng.group_ok() is False
+        got = [net(lr[wins[0]][None], rf[wins[0]][None], True, frame_ids=wins[0])['result']]
+        got += list(net.forward_group(torch.stack([lr[w] for w in wins[1:]], 0), torch.stack([rf[w] for w in wins[1:]], 0), wins[1:])['result'])
+        torch.cuda.synchronize()
+        for f in range(nfr):
+            assert torch.equal(got[f], want[f]), 'IR C=%d frame %d through forward_group differs' % (C, f)
+        # n = 2 samples: the per-sample loop, not forward_multi
+        two = net.Network
+        two.reset()
+        x2, r2 = torch.stack([lr[wins[0]], lr[wins[0]]], 0), torch.stack([rf[wins[0]], rf[wins[0]]], 0)
+        out2 = net(x2, r2, True, frame_ids=wins[0])['result']
+        assert torch.equal(out2[0], want[0][0]) and torch.equal(out2[1], want[0][0])
+
+
 def test_refvsr_ir_padded_size_against_live_oracle(dev):
     """RefVSR_IR at 66x70 (neither side a multiple of 4): the EDVR extractor's reflect padding to 68x72 and the crop of its
     features (RefVSR_IR.py:171-217) -- the path the 270x480 bench line of this model runs -- against the live oracle:
