@@ -674,16 +674,25 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                 dist.recv(tiny, a_, group=grp)
                 dist.send(tiny, a_, group=grp)
         torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    tim = {}
-    res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=blocks, timings=tim,
-                              exchange_contexts=exch is not None, group=G)
-    torch.cuda.synchronize()
-    dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # Two passes of the same sharded clip (round 6): the first, untimed for `value`, warms what the phase measurements cannot -- the
+    # caching allocator keeps its pools PER STREAM and the executor's four lanes are new streams: the first pass grows their pools
+    # with hipMalloc calls (device-synchronising, milliseconds each) inside a ~50 ms run.  Both passes start from a reset module
+    # (cold start of the CLIP -- first frame, empty window cache -- is part of the workload in both); the first one's time is kept.
+    el_pass = []
+    for rep in range(2):
+        net.Network.reset()
+        res = None
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        tim = {}
+        res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, comm_dev, parts=blocks, timings=tim,
+                                  exchange_contexts=exch is not None, group=G)
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el_pass.append(float(el.item()))
     # per-frame checksums of every rank -> rank 0, compared with rank 0's own sequential run of the first frames
     sums = torch.zeros(nfr, 2, dtype=torch.float64, device=comm_dev)
     for f, r in res.items():
@@ -720,6 +729,8 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
                                       'what': 'the same clip on ONE GPU through forward_group (frame groups of 4, three streams), measured by rank 0 '
                                               'before the sharded run while the other ranks wait'},
                'speedup_vs_n1_headline': one_rank_s / float(el.item()),
+               'first_pass_seconds': el_pass[0],
+               'passes': 'two passes of the same clip from a reset module; value = the second (the first grows the per-stream allocator pools of the lanes)',
                'workload': '%s, %d-frame clip %dx%d -> %dx%d, frame_num=5, reset_branch=%d, sharded by frame index over %d ranks '
                            '(BASELINE configs[3])' % (name, nfr, h, w, 4 * h, 4 * w, cfg.reset_branch, world),
                'value': nfr / float(el.item()), 'unit': 'frames/s', 'seconds': float(el.item()), 'scaling': 'strong',
