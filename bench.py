@@ -484,14 +484,14 @@ def one_rank_clip_seconds(net, cfg, dev, h, w, nfr, t=5, group=PHASE_GROUP, reps
             N.set_pipelined(True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            o = net(all_lr[0:1], all_rf[0:1], True, frame_ids=wins[0], input_ready='materialised')['result']
-            f = 1
+            f = 0
             while f < nfr:
                 n = min(G, nfr - f)
                 if n >= 2:
-                    o = net.forward_group(all_lr[f:f + n], all_rf[f:f + n], [wins[f + b] for b in range(n)], input_ready='materialised')['result'][-1]
+                    o = net.forward_group(all_lr[f:f + n], all_rf[f:f + n], [wins[f + b] for b in range(n)], is_first_frame=(f == 0),
+                                          input_ready='materialised')['result'][-1]
                 else:
-                    o = net(all_lr[f:f + 1], all_rf[f:f + 1], False, frame_ids=wins[f], input_ready='materialised')['result']
+                    o = net(all_lr[f:f + 1], all_rf[f:f + 1], f == 0, frame_ids=wins[f], input_ready='materialised')['result']
                 f += n
             torch.cuda.synchronize()
             el = time.perf_counter() - t0

@@ -982,17 +982,16 @@ class Engine(object):
         """Same computation as _forward_seq, spread over the internal streams so that consecutive calls overlap: P prepares the
         window's new frame and its flows while M is still walking the previous call's backward branch and F its forward-branch step.
         Round 6: a steady call IS a frame group of one window (_forward_group_pipelined: one implementation of the P | F | M schedule
-        for one window per call, B windows per call and -- forward_multi -- n samples per call); only calls that restart the forward
-        branch from a caller's first frame (or without a carried state, or in the gradio mode) take the reference order on M here."""
+        for one window per call, B windows per call and -- forward_multi -- n samples per call); only the gradio mode and a call without
+        a carried state that is not a first frame (an error of the caller, reported by _forward_seq) take the reference order on M."""
         dev = lrs.device
-        # reset_branch roll-over of a RUNNING stream (RefVSR.py:168-170): the call differs from a steady one only in its forward branch --
-        # t // 2 + 1 steps from zeros over the window's first frames instead of one step from the carried state (their contexts and flows
-        # are cached) -- so it stays on the three streams (`rst` in _forward_group_pipelined): no drain of the calls in flight, no serial
-        # pass on M, no refill of the pipeline behind it.  A caller's first frame, a stream without a state and the gradio mode take the
-        # reference order on M.
-        steady = bool(not is_first_frame and self.fw_feat is not None and not bool(self.cfg.EVAL.is_gradio))
-        if steady:
-            outs, vis = self._forward_group_pipelined([(lrs, refs, frame_ids)], input_ready, want_vis)
+        # A window whose forward branch restarts -- a reset_branch roll-over of a running stream (RefVSR.py:168-170) and, since round 6,
+        # a caller's FIRST FRAME -- differs from a steady one only in its forward branch: t // 2 + 1 steps from zeros over the window's
+        # first frames instead of one step from the carried state.  It stays on the three streams (`rst` in _forward_group_pipelined): no
+        # drain of the calls in flight, no serial pass on M, no refill of the pipeline behind it (a first frame used to cost 11.5 ms of
+        # serial launches on M at 270p; a clip's first call now overlaps like any other).
+        if not bool(self.cfg.EVAL.is_gradio) and (is_first_frame or self.fw_feat is not None):
+            outs, vis = self._forward_group_pipelined([(lrs, refs, frame_ids)], input_ready, want_vis, first=bool(is_first_frame))
             return outs[0], vis
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
@@ -1151,13 +1150,15 @@ class Engine(object):
     def forward_group(self, wins, is_first_frame=False, input_ready=None):
         """B consecutive windows of this stream in one call: wins = [(lrs [t,3,h,w], refs, frame_ids)] in stream order, every window
         as forward(lrs, refs, is_first, frame_ids=ids) would get it (is_first_frame applies to wins[0]).  Returns [result planar
-        [3,s h,s w]] per window -- bit-identical to the B forward() calls.  Steady-state runs of >= 2 windows execute as a group
-        (multi-map launches on the internal streams: needs set_pipelined(True); a reset_branch roll-over window stays in its group, only
-        its forward branch is the long one); a caller's first frame, a stream without a carried state and engines without the group
-        schedule run one forward() each.
+        [3,s h,s w]] per window -- bit-identical to the B forward() calls.  Runs of >= 2 windows execute as a group (multi-map launches
+        on the internal streams: needs set_pipelined(True); a reset_branch roll-over window and -- round 6 -- a caller's first frame stay
+        in their group, only their forward branch is the long one); a stream without a carried state, the gradio mode and engines
+        without the group schedule run one forward() each.
         input_ready: as in forward() (None | 'materialised' | event | stream), for all windows of the call."""
         outs = [None] * len(wins)
         i = 0
+        if is_first_frame:
+            self.id_cache, self.flow_cache = {}, {}               # a new clip: ids of the previous one must not match (as in forward())
         if self.group_ok() and self.pipelined:
             # before the first internal stream exists: an engine driven through forward_group runs P | F | M from its first call on
             # (a rebuild later would leave the first set of streams behind, and with more streams than hardware queues the
@@ -1167,13 +1168,14 @@ class Engine(object):
             while i < len(wins):
                 # the longest run of steady windows from i on (the iteration counter advances by one per window)
                 j = i
-                if self.group_ok() and self.pipelined and self.fw_feat is not None and not (i == 0 and is_first_frame):
+                head = bool(i == 0 and is_first_frame)              # (round 6: a first frame is a member of its group like a roll-over)
+                if (self.group_ok() and self.pipelined and not bool(self.cfg.EVAL.is_gradio) and (self.fw_feat is not None or head)):
                     # (a roll-over window stays inside the group: only its forward branch is the long one, `rst` in
                     #  _forward_group_pipelined)
                     while j < len(wins) and j - i < ops.hip.MAX_MAPS:
                         j += 1
                 if j - i >= 2:
-                    res, _ = self._forward_group_pipelined(wins[i:j], input_ready)
+                    res, _ = self._forward_group_pipelined(wins[i:j], input_ready, first=head)
                     outs[i:j] = res
                     i = j
                 else:
@@ -1182,22 +1184,29 @@ class Engine(object):
                     i += 1
         return outs
 
-    def _forward_group_pipelined(self, wins, input_ready, want_vis=False):
+    def _forward_group_pipelined(self, wins, input_ready, want_vis=False, first=False):
         """B >= 1 steady windows of this stream on the internal streams (the ONE implementation of the P | F | M schedule, round 6):
         P prepares the windows' new frames and flows, F walks the B forward-branch steps frame by frame, M the B backward branches --
         multi-map launches for B >= 2, the single-map launch list for B = 1 (one forward() per frame: the first layers of its backward
         branch, a function of the new frame alone, run with the frame's preparation on P: `bw_head_blocks`) -- then the upsamplers.
-        Returns (results, vis of the single window or None)."""
+        first: wins[0] is a caller's first frame (RefVSR.py:257-258,292-295): its forward branch starts from zeros like a roll-over's, the
+        iteration counter restarts.  Returns (results, vis of the single window or None)."""
         B = len(wins)
         t, _, h, w = wins[0][0].shape
         ctr, dev = t // 2, wins[0][0].device
         for lrs, refs, _ in wins:
             self._check_window(lrs, refs)
             assert tuple(lrs.shape) == (t, 3, h, w)
-        assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
-        # windows of the group at which the forward branch restarts (reset_branch roll-over): their backward branches are chains like the
-        # others', their forward branch is the long one (from zeros over the window's first frames)
+        if first:
+            # the counter as the roll-over logic wants it: the first window restarts (RefVSR.py:292-295: frame_itr_num = 0, then + 1)
+            self.frame_itr_num = self.max_frame_itr_num if self.max_frame_itr_num is not None else 0
+        else:
+            assert tuple(self.fw_feat.shape[:2]) == (h, w), 'frame size changed without is_first_frame=True'
+        # windows of the group at which the forward branch restarts (reset_branch roll-over, a caller's first frame): their backward
+        # branches are chains like the others', their forward branch is the long one (from zeros over the window's first frames)
         rst = [bool(self.max_frame_itr_num is not None and self._itr_after(b) == self.max_frame_itr_num) for b in range(B)]
+        if first:
+            rst[0] = True
         caller = torch.cuda.current_stream()
         M0, M1, F_, P = self._pipe_streams(dev)
         # B = 1: the backward branch + upsampler of consecutive calls are independent of each other (only the forward branch carries
@@ -1273,7 +1282,8 @@ class Engine(object):
                     if f.ready is not None:
                         F_.wait_event(f.ready)
                 for x in (self.fw_feat, self.fw_feat_up, self.fw_conf, self.fw_flow):
-                    x.record_stream(F_)
+                    if x is not None:                             # (None: a first frame without a previous clip)
+                        x.record_stream(F_)
                 fw = self._forward_branch(fr, (lambda a, b_, fr=fr: self.flow(fr[a], fr[b_], share)), t, h, w, rst[b])
                 for x in fw:
                     x.record_stream(M0)
