@@ -512,47 +512,34 @@ def one_rank_clip_seconds(net, cfg, dev, h, w, nfr, t=5, group=PHASE_GROUP, reps
 
 
 def one_rank_wavefront_seconds(net, cfg, dev, h, w, nfr, t=5, group=PHASE_GROUP, reps=2):
-    """Wall seconds of shard.run_wavefront over the whole clip with ONE rank (a world-1 gloo group made here when the process has
-    none): the sharded executor itself -- phase-A groups on P | M, the B1 chain on its own lane, upsamplers behind the chains -- with
-    no partner to wait for.  Against one_rank_clip_seconds it says what the executor costs over the single-GPU fast path; against
+    """Wall seconds of shard.run_wavefront over the whole clip with ONE rank (no process group needed): the sharded executor itself
+    -- phase-A groups on P | M, the B1 chain on its own lane, upsamplers behind the chains -- with no partner to wait for.  Against one_rank_clip_seconds it says what the executor costs over the single-GPU fast path; against
     the phase sum it gives the overlap of the lanes, which the makespan model (one task at a time per rank) does not have."""
-    import torch.distributed as dist
     from refvsr_amd import shard
     from refvsr_amd.synth import make_clip, window_indices
-    made = False
-    if not dist.is_initialized():
-        import socket
-        sk = socket.socket()
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-        sk.close()
-        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
-        made = True
-    try:
-        lr, rf, _ = make_clip(nfr, h, w, seed=0, want_gt=False)
-        lr, rf = lr.to(dev), rf.to(dev)
-        win = {f: (lr[torch.tensor(window_indices(f, nfr, t), device=dev)].contiguous(), rf[torch.tensor(window_indices(f, nfr, t), device=dev)].contiguous())
-               for f in range(nfr)}
-        ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
-        G = max(1, int(group)) if ex.eng.group_ok() else 1
-        best = None
-        for rep in range(reps + 1):
-            net.Network.reset()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, torch.device('cpu'), parts=[(0, nfr)], group=G)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            assert len(res) == nfr and bool(torch.isfinite(res[nfr - 1]).all())
-            del res
-            if rep > 0:
-                best = el if best is None else min(best, el)
-        net.Network.set_pipelined(False)
+    # (run_wavefront needs no process group for one rank -- and creating a gloo group here would print its banner on STDOUT, ahead of
+    #  the one JSON line the driver parses)
+    lr, rf, _ = make_clip(nfr, h, w, seed=0, want_gt=False)
+    lr, rf = lr.to(dev), rf.to(dev)
+    win = {f: (lr[torch.tensor(window_indices(f, nfr, t), device=dev)].contiguous(), rf[torch.tensor(window_indices(f, nfr, t), device=dev)].contiguous())
+           for f in range(nfr)}
+    ex = shard.EngineExecutor(net, dev, h, w, nfr, t)
+    G = max(1, int(group)) if ex.eng.group_ok() else 1
+    best = None
+    for rep in range(reps + 1):
         net.Network.reset()
-        return best
-    finally:
-        if made:
-            dist.destroy_process_group()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = shard.run_wavefront(ex, lambda f: win[f], nfr, t, cfg.reset_branch, cfg.mid_channels, torch.device('cpu'), parts=[(0, nfr)], group=G)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert len(res) == nfr and bool(torch.isfinite(res[nfr - 1]).all())
+        del res
+        if rep > 0:
+            best = el if best is None else min(best, el)
+    net.Network.set_pipelined(False)
+    net.Network.reset()
+    return best
 
 
 def wavefront_model_single_gpu(args, dev, h, w):

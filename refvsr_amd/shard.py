@@ -677,7 +677,8 @@ def _run_wavefront(executor, get_window, nframes, frame_num, reset_branch, chann
     'issue_a' / 'recv_wait' / 'issue_b1' / 'issue_b2' host seconds, 'handoff_messages' sent, 'blocks' local blocks,
     'context_messages' sent, 'context_wait' host seconds blocked waiting for contexts."""
     import time
-    rank, world = dist.get_rank(), dist.get_world_size()
+    # (no process group: ONE rank walking the clip through the executor -- bench.py's one-rank figure; nothing is sent or received)
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     blocks = as_blocks(parts if parts is not None else partition(nframes, world), world)
     mine = [(a, b) for a, b, r in blocks if r == rank]
     owner_of = {}

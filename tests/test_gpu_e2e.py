@@ -1256,6 +1256,31 @@ def test_bench_gpus_2_self_launches_and_reports_the_sharded_clip(dev):
     assert abs(d['value'] - 12.0 / d['wavefront']['seconds']) < 2e-2 * d['value']          # (the compact line rounds the seconds)
 
 
+def test_bench_n1_prints_exactly_one_stdout_line(dev):
+    """The driver parses ONE JSON line from `python bench.py`'s stdout.  Round 6 briefly broke that at N = 1: the one-rank executor leg
+    made a world-1 gloo group, whose C++ banner goes to stdout ahead of the line.  The default command (270 x 480, so that the
+    wavefront-model legs run; the slow extra legs switched off) must print the line and nothing else, and the line must carry the
+    round-6 fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '8', '--warmup', '3', '--repeats', '1', '--warm-seconds', '0.05',
+                        '--no-other-configs', '--no-cpu-baseline', '--no-kernels', '--full-json', '/tmp/bench_n1_full.json'],
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith('{'), r.stdout[:600]
+    d = json.loads(out_lines[0])
+    assert d['n_gpus'] == 1 and d['config']['headline_mode'] == 'frame groups' and d['roofline']['bound'] in ('hbm', 'mfma')
+    assert {'mfma_frac', 'hbm_frac', 'governing', 'traffic_static'} <= set(d['roofline'])
+    assert 'restarts_vs_n1_fast_path' in d['wavefront_model_predicted_speedup']['8']
+    assert d['pcie_inclusive']['result_uint8']['value'] > 0
+
+
 def test_bench_gpus_2_configs3_at_its_size_all_frames_equal(dev):
     """BASELINE configs[3] at its own size inside the test run: `python bench.py --gpus 2` with the 64-frame
     270 x 480 clip of config_RefVSR_small_MFID sharded over two ranks (they share this box's one GPU and talk over gloo; phase A in
