@@ -119,7 +119,7 @@ def queued_launch_us(fn, iters, blocker):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def kernel_rooflines(cfg, eng, h, w, dev):
+def kernel_rooflines(cfg, eng, h, w, dev, live_traffic=None):
     """Per-kernel achieved rates on this GPU, in isolation (after the timed region; never part of `value`)."""
     from refvsr_amd import ops
     C = cfg.mid_channels
@@ -133,9 +133,9 @@ def kernel_rooflines(cfg, eng, h, w, dev):
     lr = torch.rand(3, h, w, generator=g).to(dev)
     big_a, big_b = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
     blocker = lambda: torch.mm(big_a, big_b)          # ~1 ms of GPU time to queue the measured launches behind
-    traffic = {}
+    traffic = dict(live_traffic or {})
     pj = os.path.join(ROOT, 'profiles', 'pmc_kernels.json')
-    if os.path.exists(pj):
+    if not traffic and os.path.exists(pj):
         try:
             traffic = json.load(open(pj)).get('traffic_bytes_per_launch', {})
         except Exception:  # noqa: BLE001
@@ -752,6 +752,39 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     return out
 
 
+def live_pmc_traffic(timeout_s=150.0):
+    """HBM bytes per launch measured IN THIS RUN (round 6): the two counter passes MI355X_MICROARCH.md prescribes --
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate child processes, no tracing beside the counters -- on
+    tools/pmc_kernels.py (the launches of the `kernels` object + match_top2 + the multi-map block launches at 270 x 480), condensed by
+    tools/pmc_to_json.py (FETCH_SIZE x 2 for 16-byte coalesced reads on gfx950, KiB units).  Returns (pmc_kernels dict, pmc_match_top2
+    dict) or raises; ~10 s per pass.  The profiler attaches to CHILD processes: nothing of this process is traced."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        raise RuntimeError('rocprofv3 not found')
+    tools = os.path.join(ROOT, 'tools')
+    work = tempfile.mkdtemp(prefix='refvsr_pmc_', dir='/tmp')
+    env = dict(os.environ)
+    env['TMPDIR'] = '/tmp'
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            r = subprocess.run([exe, '--pmc', ctr, '--output-format', 'csv', '-d', os.path.join(work, ctr), '-o', 'k', '--', sys.executable,
+                                os.path.join(tools, 'pmc_kernels.py')], cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                raise RuntimeError('rocprofv3 --pmc %s failed (rc=%d): %s' % (ctr, r.returncode, (r.stderr or r.stdout)[-200:]))
+        r = subprocess.run([sys.executable, os.path.join(tools, 'pmc_to_json.py'), os.path.join(work, 'FETCH_SIZE'), os.path.join(work, 'WRITE_SIZE'), work],
+                           cwd='/tmp', env=env, capture_output=True, text=True, timeout=60)
+        if r.returncode != 0:
+            raise RuntimeError('pmc_to_json failed: %s' % r.stderr[-200:])
+        return json.load(open(os.path.join(work, 'pmc_kernels.json'))), json.load(open(os.path.join(work, 'pmc_match_top2.json')))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def pcie_inclusive_pass(net, args, all_lr, all_rf, wins, start, G, dev, passes=3, result_dtype='float32', frames_once=False):
     """The K timed steps with host-resident inputs and outputs (see the call site).  Returns the `pcie_inclusive` object of the line.
     result_dtype: config.result_dtype for these passes ('uint8': the output head stores rint(255 v), REFVSR_RESULT_U8 -- the bytes the
@@ -977,6 +1010,7 @@ def main():
     ap.add_argument('--verbose-line', action='store_true', help='print the complete record on stdout instead of the compact line')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second timed pass through the unmodified call surface')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline measurements')
+    ap.add_argument('--no-live-pmc', action='store_true', help='take `traffic` from profiles/pmc_*.json instead of two rocprofv3 --pmc child passes in this run')
     ap.add_argument('--no-wavefront', action='store_true', help='N > 1: skip the sharded-clip leg with the state hand-off')
     ap.add_argument('--clip', type=int, default=64, help='N > 1: frames of the sharded clip (BASELINE configs[3]: 64)')
     ap.add_argument('--clip-check', type=int, default=12, help='frames of the sharded clip re-run on one rank and compared')
@@ -1270,6 +1304,16 @@ def main():
             pcie = {'error': repr(e)[:300]}
         net.Network.set_pipelined(False)
 
+    # `traffic` of the two roofline kernels measured in THIS run (round 6): two rocprofv3 --pmc child passes (counters only, the GPU is
+    # idle meanwhile); any failure -- no rocprofv3, a refused counter, a timeout -- falls back to the committed profiles/pmc_*.json
+    live_pmc, live_pmc_err = None, None
+    if rank == 0 and world == 1 and not args.no_live_pmc and (H, W_) == (270, 480) and args.config == 'config_RefVSR_small_L1':
+        try:
+            torch.cuda.synchronize()
+            live_pmc = live_pmc_traffic()
+        except Exception as e:  # noqa: BLE001  (an extra figure must never take the headline number down)
+            live_pmc, live_pmc_err = None, repr(e)[:200]
+
     line = None
     if rank == 0:
         fps = world * args.steps / elapsed
@@ -1324,7 +1368,12 @@ def main():
             ach = flops / (per_launch_ms * 1e-3) / 1e12
             traffic, tsrc = None, None
             pj = os.path.join(ROOT, 'profiles', 'pmc_kernels.json')
-            if os.path.exists(pj) and (H, W_) == (270, 480):
+            if live_pmc is not None and (H, W_) == (270, 480):
+                tj = live_pmc[0].get('traffic_bytes_per_launch', {})
+                traffic = tj.get('resblock LR x%d maps' % maps_per_launch) if maps_per_launch > 1 else tj.get('resblock LR')
+                tsrc = ('LIVE: two rocprofv3 --pmc child passes of this run (FETCH_SIZE, WRITE_SIZE: separate processes, counters only) on '
+                        'tools/pmc_kernels.py; FETCH_SIZE x 2 (gfx950, 16-byte coalesced reads) + WRITE_SIZE, KiB units')
+            if traffic is None and os.path.exists(pj) and (H, W_) == (270, 480):
                 try:
                     tj = json.load(open(pj)).get('traffic_bytes_per_launch', {})
                     traffic = tj.get('resblock LR x%d maps' % maps_per_launch) if maps_per_launch > 1 else tj.get('resblock LR')
@@ -1352,7 +1401,7 @@ def main():
                        'governing': '%s (arithmetic intensity %.0f FLOP/byte %s the ridge %.0f)' % (governing, ai, '<' if ai < ridge else '>=', ridge),
                        'mfma_frac': ach / PEAK_F16_TFLOPS, 'mfma_tflops': ach, 'mfma_issued_frac': issued * ach / PEAK_F16_TFLOPS,
                        'hbm_frac': hbm_gbs / PEAK_HBM_GBS, 'hbm_gbs': hbm_gbs, 'algorithmic_bytes_per_launch': abytes, 'arithmetic_intensity': ai,
-                       'traffic': traffic, 'traffic_source': tsrc, 'traffic_static': None if traffic is None else True,
+                       'traffic': traffic, 'traffic_source': tsrc, 'traffic_static': None if traffic is None else not str(tsrc).startswith('LIVE'),
                        'traffic_over_algorithmic': None if traffic is None else traffic / abytes,
                        'launches_timed': sum(n for _, n in runs),
                        'launches_timed_in': 'one more pass of the SAME calls with every internal section on one stream (in the timed passes the '
@@ -1370,7 +1419,10 @@ def main():
             ach = flops / (mean_ms * 1e-3) / 1e12
             traffic, tsrc = None, None
             pj = os.path.join(ROOT, 'profiles', 'pmc_match_top2.json')
-            if os.path.exists(pj) and (n_lr, n_ref) == (129600, 32400):   # HBM bytes per launch from the PMC passes; not live
+            if live_pmc is not None and (n_lr, n_ref) == (129600, 32400):
+                traffic = live_pmc[1].get('traffic_bytes_per_launch')
+                tsrc = 'LIVE: two rocprofv3 --pmc child passes of this run (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE)'
+            if traffic is None and os.path.exists(pj) and (n_lr, n_ref) == (129600, 32400):   # HBM bytes per launch from the committed PMC passes
                 try:
                     traffic = json.load(open(pj))['traffic_bytes_per_launch']
                     tsrc = 'STATIC: profiles/pmc_match_top2.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; re-measured on the round-6 tree, tools/gpu_runs/r6_call8.sh), not measured in this run'
@@ -1381,12 +1433,14 @@ def main():
                                            'achieved': ach, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_TFLOPS,
                                            'governing': 'mfma (arithmetic intensity %.0f FLOP/byte >> the ridge %.0f)' % (flops / mbytes, PEAK_F16_TFLOPS * 1e3 / PEAK_HBM_GBS),
                                            'mfma_frac': ach / PEAK_F16_TFLOPS, 'hbm_frac': mbytes / (mean_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                           'traffic': traffic, 'traffic_source': tsrc, 'traffic_static': None if traffic is None else True,
+                                           'traffic': traffic, 'traffic_source': tsrc, 'traffic_static': None if traffic is None else not str(tsrc).startswith('LIVE'),
                                            'launches_timed': len(ms), 'launches_timed_in': 'the timed passes themselves (one launch per frame, events around it)',
                                            'mean_launch_ms': mean_ms, 'flops_per_launch': flops}
         else:
             line['roofline_match_top2'] = None
         line['roofline'] = rb_line if rb_line is not None else line['roofline_match_top2']
+        if live_pmc_err and isinstance(line['roofline'], dict):
+            line['roofline']['live_pmc_error'] = live_pmc_err
         line['first_frame_ms'] = first_ms
         line['pcie_inclusive'] = pcie
         sv = SURVEY_DEDUP_TFLOP.get(args.config) if (H, W_, T) == (270, 480, 5) else None
@@ -1399,7 +1453,7 @@ def main():
             'frac_of_f16_mfma_peak_on_survey_figure': (sv * fps / world / PEAK_F16_TFLOPS) if sv else None}
         if not args.no_kernels:
             try:
-                line['kernels'] = kernel_rooflines(cfg, eng, H, W_, dev)
+                line['kernels'] = kernel_rooflines(cfg, eng, H, W_, dev, None if live_pmc is None else live_pmc[0].get('traffic_bytes_per_launch'))
             except Exception as e:  # noqa: BLE001
                 line['kernels'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_wavefront and (H, W_) == (270, 480):
