@@ -26,7 +26,8 @@ What the line carries beside the contract fields:
   roofline           -- the TIME-dominant kernel (the fused 24-channel ResBlock, a third of the device time, MFMA-bound): useful FLOPs
                         per launch / mean launch duration from HIP events around every run of blocks in one more pass of the same calls
                         with every internal section on ONE stream; in group mode the launches of record are the multi-map launches
-                        (`maps_per_launch`); `traffic` = HBM bytes per launch from the PMC passes (profiles/pmc_kernels.json);
+                        (`maps_per_launch`); `traffic` = HBM bytes per launch from two rocprofv3 --pmc child passes of THIS run (FETCH_SIZE,
+                        WRITE_SIZE; fallback: profiles/pmc_kernels.json, then `traffic_static` is true); both roofs are stated;
                         configurations whose blocks do not run on that kernel (C = 48 / 36) report the matching kernel here
   roofline_match_top2 -- the fused matching GEMM + arg-max (one launch per frame): algorithmic FLOPs per launch / mean duration from HIP
                         events around every launch inside the timed region
