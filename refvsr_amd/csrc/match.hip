@@ -140,7 +140,16 @@ __global__ void match_refine_kernel(const float* __restrict__ lf, int h, int w, 
     float best = -INFINITY;
     int bi = 0x7fffffff;
     const int n_ref = hr * wr;
+    // (round 6) With the fp16 scores at hand a candidate whose score lies 2 x `margin` or more below the best fp16 score cannot be the
+    // exact maximum under the error bound the flagging below rests on (|exact - fp16| <= margin per score: its exact value is at most
+    // top16 - margin, the top candidate's at least that) -- so its exact value is not evaluated: most columns have a clear winner and
+    // gather ONE reference patch instead of two.  Same winner, same value (the winner's own fp32 expression), bit for bit:
+    // tests/test_gpu_ops.py::test_match_*, the full-size index-map fixtures.
+    float top16 = -INFINITY;
+    if (cand_val)
+        for (int k = 0; k < ncand; ++k) top16 = fmaxf(top16, cand_val[(size_t)p * ncand + k]);
     for (int k = 0; k < ncand; ++k) {
+        if (cand_val && !(cand_val[(size_t)p * ncand + k] > top16 - 2.0f * margin)) continue;
         int r = cand[(size_t)p * ncand + k];
         r = min(max(r, 0), n_ref - 1);
         const int ry = r / wr, rx = r - ry * wr;
