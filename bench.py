@@ -753,7 +753,7 @@ def run_wavefront_leg(args, rank, world, dev, backend, h, w):
     return out
 
 
-def live_pmc_traffic(timeout_s=150.0):
+def live_pmc_traffic(timeout_s=90.0):
     """HBM bytes per launch measured IN THIS RUN (round 6): the two counter passes MI355X_MICROARCH.md prescribes --
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate child processes, no tracing beside the counters -- on
     tools/pmc_kernels.py (the launches of the `kernels` object + match_top2 + the multi-map block launches at 270 x 480), condensed by
@@ -765,6 +765,11 @@ def live_pmc_traffic(timeout_s=150.0):
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if exe is None:
         raise RuntimeError('rocprofv3 not found')
+    nested = [k for k in os.environ if k.startswith(('ROCPROFILER_', 'ROCPROF_', 'ROCP_')) or (k == 'LD_PRELOAD' and 'rocprof' in os.environ[k])]
+    if nested:
+        # this process is itself being profiled (e.g. `rocprofv3 --kernel-trace -- python bench.py`): a profiler inside a profiled
+        # process tree would inherit the outer tool's environment -- the committed counter files serve instead
+        raise RuntimeError('already running under a profiler (%s): live counter passes skipped' % ', '.join(sorted(nested)[:3]))
     tools = os.path.join(ROOT, 'tools')
     work = tempfile.mkdtemp(prefix='refvsr_pmc_', dir='/tmp')
     env = dict(os.environ)
