@@ -1016,6 +1016,7 @@ def main():
     ap.add_argument('--verbose-line', action='store_true', help='print the complete record on stdout instead of the compact line')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second timed pass through the unmodified call surface')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline measurements')
+    ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)     # test aid: process group + sharded-clip leg with ONE rank (RCCL on a 1-GPU box)
     ap.add_argument('--no-live-pmc', action='store_true', help='take `traffic` from profiles/pmc_*.json instead of two rocprofv3 --pmc child passes in this run')
     ap.add_argument('--no-wavefront', action='store_true', help='N > 1: skip the sharded-clip leg with the state hand-off')
     ap.add_argument('--clip', type=int, default=64, help='N > 1: frames of the sharded clip (BASELINE configs[3]: 64)')
@@ -1064,8 +1065,17 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    # --force-dist (test aid): the process group and the sharded-clip leg also for ONE rank -- on a 1-GPU box that is the only way to
+    # run the nccl (= RCCL) branch of this script at all: device-side all_reduce / barrier, communicator set-up, comm_dev = the GPU
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1 and 'MASTER_PORT' not in os.environ:
+            import socket
+            s_ = socket.socket()
+            s_.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
+            s_.close()
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     from refvsr_amd import SRNet, get_config, make_state_dict
@@ -1480,7 +1490,7 @@ def main():
                     line['other_configs'][key] = other_config_leg(nm, hh, ww, st, wu, dev)
                 except Exception as e:  # noqa: BLE001
                     line['other_configs'][key] = {'error': repr(e)[:300]}
-    if world > 1 and not args.no_wavefront:
+    if dist_on and not args.no_wavefront:
         # The extra leg must never take the headline number down: if it has not returned within the deadline (a hung
         # send / recv, a rank that died) every rank leaves through a watchdog, rank 0 after printing the line.
         import threading
@@ -1523,7 +1533,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         emit(line, args)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

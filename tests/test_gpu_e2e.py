@@ -1281,6 +1281,32 @@ def test_bench_n1_prints_exactly_one_stdout_line(dev):
     assert d['pcie_inclusive']['result_uint8']['value'] > 0
 
 
+def test_bench_sharded_clip_leg_under_rccl_with_one_rank(dev):
+    """The nccl (= RCCL) branch of bench.py had never executed on this pool's 1-GPU boxes (RCCL refuses two ranks on one device, so the
+    two-rank runs use gloo).  `--force-dist` (test aid) brings up the process group with ONE rank on the real backend and runs the
+    sharded-clip leg through it: communicator set-up, device-side all_reduce / barrier, comm_dev = the GPU, the executor's lanes, the two
+    passes, the frame check -- everything but a message between two GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'REFVSR_DIST_BACKEND', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--force-dist', '--steps', '4', '--warmup', '2', '--size', '64x96', '--clip', '14',
+                        '--clip-check', '14', '--repeats', '1', '--warm-seconds', '0.05', '--no-kernels', '--no-other-configs', '--no-cpu-baseline',
+                        '--no-live-pmc', '--full-json', '/tmp/bench_rccl1_full.json'],
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    wf = d['wavefront']
+    assert wf.get('error') is None, wf
+    assert wf['backend'].startswith('nccl') and wf['ranks_seen'] == 1 and wf['frames_equal'] is True
+    assert wf['frames_checked_against_single_rank_run'] == 14 and wf['value'] > 0
+
+
 def test_bench_gpus_2_configs3_at_its_size_all_frames_equal(dev):
     """BASELINE configs[3] at its own size inside the test run: `python bench.py --gpus 2` with the 64-frame
     270 x 480 clip of config_RefVSR_small_MFID sharded over two ranks (they share this box's one GPU and talk over gloo; phase A in
